@@ -1,0 +1,388 @@
+"""ctypes binding for the CPU oracle (oracle/q3_oracle.c).  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, _HERE)
+import build as _build  # noqa: E402
+
+_CFG_FIELDS = [
+    ("hidden", C.c_int32), ("n_layers", C.c_int32), ("n_heads", C.c_int32), ("n_kv_heads", C.c_int32),
+    ("head_dim", C.c_int32), ("ffn", C.c_int32), ("vocab", C.c_int32),
+    ("rope_theta", C.c_float), ("rms_eps", C.c_float),
+    ("cp_layers", C.c_int32), ("cp_heads", C.c_int32), ("cp_kv_heads", C.c_int32), ("cp_head_dim", C.c_int32),
+    ("cp_ffn", C.c_int32), ("n_groups", C.c_int32), ("sub_vocab", C.c_int32),
+    ("cp_rope_theta", C.c_float), ("cp_rms_eps", C.c_float),
+    ("text_vocab", C.c_int32), ("text_hidden", C.c_int32),
+    ("cd_codebook", C.c_int32), ("cd_hidden", C.c_int32), ("cd_layers", C.c_int32), ("cd_heads", C.c_int32),
+    ("cd_head_dim", C.c_int32), ("cd_ffn", C.c_int32), ("cd_window", C.c_int32),
+    ("cd_rope_theta", C.c_float), ("cd_rms_eps", C.c_float),
+    ("cd_n_up", C.c_int32), ("cd_up_ratios", C.c_int32 * 4),
+    ("cd_decoder_dim", C.c_int32), ("cd_n_blocks", C.c_int32), ("cd_up_rates", C.c_int32 * 8),
+    ("cd_tconv_trim", C.c_int32),
+    ("codec_eos", C.c_int32), ("suppress_begin", C.c_int32), ("suppress_end", C.c_int32),
+]
+
+
+class Config(C.Structure):
+    _fields_ = _CFG_FIELDS
+
+    def to_dict(self):
+        d = {}
+        for n, _ in _CFG_FIELDS:
+            v = getattr(self, n)
+            d[n] = list(v) if hasattr(v, "__len__") else v
+        return d
+
+    @classmethod
+    def from_dict(cls, d):
+        c = cls()
+        for n, t in _CFG_FIELDS:
+            v = d[n]
+            if hasattr(t, "_length_"):
+                arr = t()
+                for i, x in enumerate(v):
+                    arr[i] = x
+                setattr(c, n, arr)
+            else:
+                setattr(c, n, v)
+        return c
+
+
+class Sampling(C.Structure):
+    # src/tts_onnx.h:99-105
+    _fields_ = [("temperature", C.c_float), ("top_p", C.c_float), ("top_k", C.c_int32),
+                ("repetition_penalty", C.c_float), ("max_new_tokens", C.c_int32)]
+
+    def __init__(self, temperature=0.8, top_p=0.95, top_k=50, repetition_penalty=1.0, max_new_tokens=2048):
+        super().__init__(temperature, top_p, top_k, repetition_penalty, max_new_tokens)
+
+
+def config_06b():
+    """Qwen3-TTS-0.6B dims: src/tts_onnx.h:31-37 + [HINT] dims from SURVEY.md section 8."""
+    return Config.from_dict(dict(
+        hidden=1024, n_layers=28, n_heads=16, n_kv_heads=8, head_dim=128, ffn=3072, vocab=3072,
+        rope_theta=1e6, rms_eps=1e-6,
+        cp_layers=5, cp_heads=16, cp_kv_heads=8, cp_head_dim=128, cp_ffn=3072, n_groups=16, sub_vocab=2048,
+        cp_rope_theta=1e6, cp_rms_eps=1e-6,
+        text_vocab=151936, text_hidden=2048,
+        cd_codebook=2048, cd_hidden=1024, cd_layers=8, cd_heads=16, cd_head_dim=64, cd_ffn=3072, cd_window=72,
+        cd_rope_theta=10000.0, cd_rms_eps=1e-5,
+        cd_n_up=2, cd_up_ratios=[2, 2, 0, 0], cd_decoder_dim=1536, cd_n_blocks=4,
+        cd_up_rates=[8, 5, 4, 3, 0, 0, 0, 0], cd_tconv_trim=0,
+        codec_eos=2150, suppress_begin=2048, suppress_end=3072))
+
+
+def config_tiny():
+    """Small config with the same structure; every kernel path is exercised in seconds on CPU."""
+    return Config.from_dict(dict(
+        hidden=64, n_layers=2, n_heads=4, n_kv_heads=2, head_dim=16, ffn=96, vocab=96,
+        rope_theta=1e6, rms_eps=1e-6,
+        cp_layers=2, cp_heads=4, cp_kv_heads=2, cp_head_dim=16, cp_ffn=96, n_groups=16, sub_vocab=64,
+        cp_rope_theta=1e6, cp_rms_eps=1e-6,
+        text_vocab=152000, text_hidden=32,
+        cd_codebook=64, cd_hidden=32, cd_layers=2, cd_heads=2, cd_head_dim=16, cd_ffn=48, cd_window=4,
+        cd_rope_theta=10000.0, cd_rms_eps=1e-5,
+        cd_n_up=2, cd_up_ratios=[2, 2, 0, 0], cd_decoder_dim=64, cd_n_blocks=4,
+        cd_up_rates=[8, 5, 4, 3, 0, 0, 0, 0], cd_tconv_trim=0,
+        codec_eos=70, suppress_begin=64, suppress_end=96))
+
+
+def tensor_specs(cfg):
+    """(name, shape, kind) for every tensor of the model.  kind: 'w' matrix, 'norm' (ones-centred),
+    'b' bias, 'scale' LayerScale/gamma, 'snake' alpha/beta."""
+    c = cfg
+    H = c.hidden
+    out = []
+
+    def layers(prefix, n, Hh, nq, nkv, d, ffn, qk, ls):
+        for i in range(n):
+            p = f"{prefix}.layers.{i}."
+            out.append((p + "input_norm", (Hh,), "norm"))
+            out.append((p + "q_proj", (nq * d, Hh), "w"))
+            out.append((p + "k_proj", (nkv * d, Hh), "w"))
+            out.append((p + "v_proj", (nkv * d, Hh), "w"))
+            out.append((p + "o_proj", (Hh, nq * d), "w"))
+            if qk:
+                out.append((p + "q_norm", (d,), "norm"))
+                out.append((p + "k_norm", (d,), "norm"))
+            out.append((p + "post_norm", (Hh,), "norm"))
+            out.append((p + "gate_proj", (ffn, Hh), "w"))
+            out.append((p + "up_proj", (ffn, Hh), "w"))
+            out.append((p + "down_proj", (Hh, ffn), "w"))
+            if ls:
+                out.append((p + "attn_scale", (Hh,), "scale"))
+                out.append((p + "mlp_scale", (Hh,), "scale"))
+
+    layers("talker", c.n_layers, H, c.n_heads, c.n_kv_heads, c.head_dim, c.ffn, True, False)
+    out.append(("talker.norm", (H,), "norm"))
+    out.append(("talker.codec_head", (c.vocab, H), "w"))
+    out.append(("talker.codec_embed", (c.vocab, H), "w"))
+    out.append(("text.embed", (c.text_vocab, c.text_hidden), "w"))
+    out.append(("text.fc1.w", (c.text_hidden, c.text_hidden), "w"))
+    out.append(("text.fc1.b", (c.text_hidden,), "b"))
+    out.append(("text.fc2.w", (H, c.text_hidden), "w"))
+    out.append(("text.fc2.b", (H,), "b"))
+    layers("cp", c.cp_layers, H, c.cp_heads, c.cp_kv_heads, c.cp_head_dim, c.cp_ffn, True, False)
+    out.append(("cp.norm", (H,), "norm"))
+    for j in range(c.n_groups - 1):
+        out.append((f"cp.head.{j}", (c.sub_vocab, H), "w"))
+    for j in range(c.n_groups - 1):
+        out.append((f"cp.embed.{j}", (c.sub_vocab, H), "w"))
+    CH = c.cd_hidden
+    layers("cd", c.cd_layers, CH, c.cd_heads, c.cd_heads, c.cd_head_dim, c.cd_ffn, False, True)
+    out.append(("cd.norm", (CH,), "norm"))
+    out.append(("cd.code_embed", (c.n_groups * c.cd_codebook, CH), "w"))
+    for s in range(c.cd_n_up):
+        f = c.cd_up_ratios[s]
+        p = f"cd.up.{s}."
+        out.append((p + "tconv.w", (CH, CH, f), "w"))
+        out.append((p + "tconv.b", (CH,), "b"))
+        out.append((p + "cnx.dw.w", (CH, 1, 7), "w"))
+        out.append((p + "cnx.dw.b", (CH,), "b"))
+        out.append((p + "cnx.ln.w", (CH,), "norm"))
+        out.append((p + "cnx.ln.b", (CH,), "b"))
+        out.append((p + "cnx.pw1.w", (4 * CH, CH), "w"))
+        out.append((p + "cnx.pw1.b", (4 * CH,), "b"))
+        out.append((p + "cnx.pw2.w", (CH, 4 * CH), "w"))
+        out.append((p + "cnx.pw2.b", (CH,), "b"))
+        out.append((p + "cnx.gamma", (CH,), "scale"))
+    D = c.cd_decoder_dim
+    out.append(("cd.dec.conv_in.w", (D, CH, 7), "w"))
+    out.append(("cd.dec.conv_in.b", (D,), "b"))
+    for i in range(c.cd_n_blocks):
+        cin, cout, r = D >> i, D >> (i + 1), c.cd_up_rates[i]
+        p = f"cd.dec.blocks.{i}."
+        out.append((p + "snake.alpha", (cin,), "snake"))
+        out.append((p + "snake.beta", (cin,), "snake"))
+        out.append((p + "tconv.w", (cin, cout, 2 * r), "w"))
+        out.append((p + "tconv.b", (cout,), "b"))
+        for u in range(3):
+            q = p + f"res.{u}."
+            out.append((q + "act1.alpha", (cout,), "snake"))
+            out.append((q + "act1.beta", (cout,), "snake"))
+            out.append((q + "conv1.w", (cout, cout, 7), "w"))
+            out.append((q + "conv1.b", (cout,), "b"))
+            out.append((q + "act2.alpha", (cout,), "snake"))
+            out.append((q + "act2.beta", (cout,), "snake"))
+            out.append((q + "conv2.w", (cout, cout, 1), "w"))
+            out.append((q + "conv2.b", (cout,), "b"))
+    OD = D >> c.cd_n_blocks
+    out.append(("cd.dec.snake_out.alpha", (OD,), "snake"))
+    out.append(("cd.dec.snake_out.beta", (OD,), "snake"))
+    out.append(("cd.dec.conv_out.w", (1, OD, 7), "w"))
+    out.append(("cd.dec.conv_out.b", (1,), "b"))
+    return out
+
+
+def bf16_round(a):
+    """Round fp32 -> nearest-even bf16, returned as fp32 (values exactly representable in bf16)."""
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    u = a.view(np.uint32).astype(np.uint64)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+    return u.astype(np.uint32).view(np.float32).reshape(a.shape)
+
+
+def random_weights(cfg, seed=0, text_rows=None):
+    """Seeded numpy weights (bf16-representable fp32) for small configs.  Matrix std is
+    1/sqrt(fan_in) so activations stay O(1) through every stack."""
+    rng = np.random.default_rng(seed)
+    w = {}
+    for name, shape, kind in tensor_specs(cfg):
+        if kind == "w":
+            fan_in = int(np.prod(shape[1:])) if len(shape) > 1 else shape[0]
+            if name.endswith("tconv.w"):
+                fan_in = shape[0] * max(1, shape[2] // 2) if shape[2] > 2 else shape[0]
+            if name in ("talker.codec_embed", "text.embed", "cd.code_embed") or name.startswith("cp.embed"):
+                a = rng.standard_normal(shape, dtype=np.float32)
+            else:
+                a = rng.standard_normal(shape, dtype=np.float32) / np.sqrt(fan_in)
+        elif kind == "norm":
+            a = 1.0 + 0.1 * rng.standard_normal(shape, dtype=np.float32)
+        elif kind == "b":
+            a = 0.1 * rng.standard_normal(shape, dtype=np.float32)
+        elif kind == "scale":
+            a = 0.5 + 0.1 * rng.standard_normal(shape, dtype=np.float32)
+        else:  # snake
+            a = 0.3 * rng.standard_normal(shape, dtype=np.float32)
+        w[name] = bf16_round(a)
+    return w
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        so = _build.build()
+        L = C.CDLL(so)
+        L.q3o_create.restype = C.c_void_p
+        L.q3o_create.argtypes = [C.POINTER(Config), C.c_int]
+        L.q3o_destroy.argtypes = [C.c_void_p]
+        L.q3o_last_error.restype = C.c_char_p
+        L.q3o_set_tensor.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64]
+        L.q3o_tensor_numel.restype = C.c_int64
+        L.q3o_tensor_numel.argtypes = [C.c_void_p, C.c_char_p]
+        L.q3o_set_threads.argtypes = [C.c_int]
+        L.q3o_text_project.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.q3o_codec_embed.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.q3o_cp_embed.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
+        L.q3o_prefill.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.q3o_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.q3o_code_predictor.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.q3o_vocoder.restype = C.c_int64
+        L.q3o_vocoder.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64]
+        L.q3o_vocoder_len.restype = C.c_int64
+        L.q3o_vocoder_len.argtypes = [C.POINTER(Config), C.c_int]
+        L.q3o_vocoder_tap.restype = C.c_int64
+        L.q3o_vocoder_tap.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64]
+        L.q3o_rng_uniform.restype = C.c_float
+        L.q3o_rng_uniform.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]
+        L.q3o_sample.restype = C.c_int64
+        L.q3o_sample.argtypes = [C.c_void_p, C.c_int, C.POINTER(Sampling), C.c_float]
+        L.q3o_softmax.argtypes = [C.c_void_p, C.c_int]
+        L.q3o_top_k_filter.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.q3o_top_p_filter.argtypes = [C.c_void_p, C.c_int, C.c_float]
+        L.q3o_build_prompt.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
+        L.q3o_trailing.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.q3o_generate.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(Sampling), C.c_uint64, C.c_uint32,
+                                   C.c_int, C.c_int, C.c_void_p]
+        L.q3o_synthesize_tokens.restype = C.c_int64
+        L.q3o_synthesize_tokens.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(Sampling), C.c_uint64,
+                                            C.c_uint32, C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(C.c_int)]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Oracle:
+    def __init__(self, cfg, max_ctx=256, weights=None):
+        self.L = lib()
+        self.cfg = cfg
+        self.max_ctx = max_ctx
+        self.h = self.L.q3o_create(C.byref(cfg), max_ctx)
+        if weights is not None:
+            self.load(weights)
+
+    def close(self):
+        if self.h:
+            self.L.q3o_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc < 0:
+            raise RuntimeError(self.L.q3o_last_error().decode())
+        return rc
+
+    def set_tensor(self, name, arr):
+        a = np.ascontiguousarray(arr, dtype=np.float32)
+        self._check(self.L.q3o_set_tensor(self.h, name.encode(), _p(a), a.size))
+
+    def load(self, weights):
+        for k, v in weights.items():
+            self.set_tensor(k, v)
+
+    def text_project(self, ids):
+        ids = np.ascontiguousarray(ids, dtype=np.int64)
+        out = np.empty((ids.size, self.cfg.hidden), np.float32)
+        self._check(self.L.q3o_text_project(self.h, _p(ids), ids.size, _p(out)))
+        return out
+
+    def codec_embed(self, ids):
+        ids = np.ascontiguousarray(ids, dtype=np.int64)
+        out = np.empty((ids.size, self.cfg.hidden), np.float32)
+        self._check(self.L.q3o_codec_embed(self.h, _p(ids), ids.size, _p(out)))
+        return out
+
+    def cp_embed(self, tok, step):
+        out = np.empty(self.cfg.hidden, np.float32)
+        self._check(self.L.q3o_cp_embed(self.h, int(tok), int(step), _p(out)))
+        return out
+
+    def prefill(self, embeds):
+        e = np.ascontiguousarray(embeds, dtype=np.float32)
+        S = e.shape[0]
+        logits = np.empty((S, self.cfg.vocab), np.float32)
+        lh = np.empty(self.cfg.hidden, np.float32)
+        self._check(self.L.q3o_prefill(self.h, _p(e), S, _p(logits), _p(lh)))
+        return logits, lh
+
+    def decode(self, embed):
+        e = np.ascontiguousarray(embed, dtype=np.float32)
+        logits = np.empty(self.cfg.vocab, np.float32)
+        lh = np.empty(self.cfg.hidden, np.float32)
+        self._check(self.L.q3o_decode(self.h, _p(e), _p(logits), _p(lh)))
+        return logits, lh
+
+    def code_predictor(self, seq, step):
+        s = np.ascontiguousarray(seq, dtype=np.float32)
+        logits = np.empty(self.cfg.sub_vocab, np.float32)
+        self._check(self.L.q3o_code_predictor(self.h, _p(s), s.shape[0], int(step), _p(logits)))
+        return logits
+
+    def vocoder_len(self, F):
+        return int(self.L.q3o_vocoder_len(C.byref(self.cfg), F))
+
+    def vocoder(self, codes):
+        c = np.ascontiguousarray(codes, dtype=np.int64)
+        F = c.shape[0]
+        n = self.vocoder_len(F)
+        pcm = np.empty(n, np.float32)
+        got = self._check(self.L.q3o_vocoder(self.h, _p(c), F, _p(pcm), n))
+        assert got == n, (got, n)
+        return pcm
+
+    def vocoder_tap(self, codes, stage, cap):
+        c = np.ascontiguousarray(codes, dtype=np.int64)
+        out = np.empty(cap, np.float32)
+        n = self._check(self.L.q3o_vocoder_tap(self.h, _p(c), c.shape[0], stage, _p(out), cap))
+        return out[:n]
+
+    def sample(self, logits, sp, u):
+        a = np.ascontiguousarray(logits, dtype=np.float32)
+        return int(self.L.q3o_sample(_p(a), a.size, C.byref(sp), C.c_float(u)))
+
+    def build_prompt(self, ids, lang=0, speaker=None):
+        ids = np.ascontiguousarray(ids, dtype=np.int64)
+        prompt = np.zeros((16, self.cfg.hidden), np.float32)
+        S = C.c_int(0)
+        sp = None
+        if speaker is not None:
+            sp = np.ascontiguousarray(speaker, dtype=np.float32)
+        self._check(self.L.q3o_build_prompt(self.h, _p(ids), ids.size, lang, _p(sp) if sp is not None else None,
+                                            _p(prompt), C.byref(S)))
+        return prompt[:S.value].copy()
+
+    def trailing(self):
+        pad = np.empty(self.cfg.hidden, np.float32)
+        n = self.L.q3o_trailing(self.h, None, 0, _p(pad))
+        rows = np.empty((n, self.cfg.hidden), np.float32)
+        self.L.q3o_trailing(self.h, _p(rows), n, _p(pad))
+        return rows, pad
+
+    def generate(self, prompt, sp, seed=0, stream=0, cp_cached=True, ignore_eos=False):
+        p = np.ascontiguousarray(prompt, dtype=np.float32)
+        codes = np.zeros((sp.max_new_tokens, self.cfg.n_groups), np.int64)
+        F = self._check(self.L.q3o_generate(self.h, _p(p), p.shape[0], C.byref(sp), seed, stream,
+                                            int(cp_cached), int(ignore_eos), _p(codes)))
+        return codes[:F].copy()
+
+
+def rng_uniform(seed, stream, frame, group):
+    return float(lib().q3o_rng_uniform(seed, stream, frame, group))
