@@ -1,0 +1,133 @@
+/*
+ * q3tts.h — C-ABI of libq3tts_hip.so: the MI355X (gfx950) replacement for the seven ONNX Runtime
+ * sessions of leaxer-ai/leaxer-qwen3-tts.
+ *
+ * The reference has no plugin/FFI layer; its narrowest seam is the private run_* family of
+ * TTSEngine (reference src/tts_onnx.h:196-212, src/tts_onnx.cpp:545-776), each a named-tensor
+ * ONNX Runtime Session::Run over host vectors.  Every entry point below cites the run_* call it
+ * replaces.  Conventions: int return (0 ok, <0 error; message via q3tts_last_error), no exceptions
+ * cross the ABI, plain pointers and sizes only.  "_host" entry points take HOST pointers exactly
+ * like the reference's run_* (inputs caller-owned, outputs copied out); the batched generation
+ * entry points keep everything (KV cache, logits, codes) resident in HBM.  A handle is not
+ * thread-safe: one in-flight call per handle, like one TTSEngine (tts_onnx.h:182-186).
+ */
+#ifndef Q3TTS_H
+#define Q3TTS_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Model dimensions.  The reference hard-codes the 0.6B talker dims (tts_onnx.h:31-37); the rest
+ * are properties of the opaque graphs ([HINT]).  Runtime-configurable so the
+ * same library serves the 1.7B export and the tiny test configs. */
+typedef struct q3tts_config {
+    int32_t hidden, n_layers, n_heads, n_kv_heads, head_dim, ffn, vocab;
+    float rope_theta, rms_eps;
+    int32_t cp_layers, cp_heads, cp_kv_heads, cp_head_dim, cp_ffn, n_groups, sub_vocab;
+    float cp_rope_theta, cp_rms_eps;
+    int32_t text_vocab, text_hidden;
+    int32_t cd_codebook, cd_hidden, cd_layers, cd_heads, cd_head_dim, cd_ffn, cd_window;
+    float cd_rope_theta, cd_rms_eps;
+    int32_t cd_n_up;
+    int32_t cd_up_ratios[4];
+    int32_t cd_decoder_dim;
+    int32_t cd_n_blocks;
+    int32_t cd_up_rates[8];
+    int32_t cd_tconv_trim; /* 0: trim k-s on both sides, 1: right side only */
+    int32_t codec_eos, suppress_begin, suppress_end; /* tts_onnx.h:51, tts_onnx.cpp:803-807 */
+} q3tts_config;
+
+/* SamplingParams, reference src/tts_onnx.h:99-105 (repetition_penalty is never read there) */
+typedef struct q3tts_sampling {
+    float temperature, top_p;
+    int32_t top_k;
+    float repetition_penalty;
+    int32_t max_new_tokens;
+} q3tts_sampling;
+
+typedef struct q3tts_engine q3tts_engine;
+
+/* flags for q3tts_create */
+#define Q3TTS_FLAG_NO_GRAPH 1u   /* launch the decode step eagerly instead of replaying a hipGraph */
+
+/* ---- lifecycle (replaces TTSEngine ctor / load_model, tts_onnx.cpp:84-232) ---- */
+int q3tts_default_config(const char* name /* "0.6b" */, q3tts_config* out);
+q3tts_engine* q3tts_create(const q3tts_config* cfg, int device, int max_batch, int max_ctx, uint32_t flags);
+void q3tts_destroy(q3tts_engine* e);
+const char* q3tts_last_error(q3tts_engine* e); /* e may be NULL: error of the last failed create */
+
+/* ---- weights: tensors by name (names = the oracle's / DESIGN.md section 3) ---- */
+int q3tts_num_tensors(q3tts_engine* e);
+int q3tts_tensor_info(q3tts_engine* e, int index, char* name, int name_cap, int64_t* shape4, int* ndim);
+int q3tts_set_tensor_host(q3tts_engine* e, const char* name, const float* data, int64_t numel);
+int q3tts_get_tensor_host(q3tts_engine* e, const char* name, float* out, int64_t numel);
+/* seeded on-device synthetic weights (integer hash -> Irwin-Hall normal, bf16-representable) */
+int q3tts_fill_synthetic(q3tts_engine* e, uint64_t seed);
+/* call after the last set_tensor / fill: builds RoPE tables, packed conv weights, tts_pad row */
+int q3tts_finalize(q3tts_engine* e);
+
+/* ---- session-shaped entry points, host I/O, one per reference run_* ---- */
+/* run_text_project, tts_onnx.cpp:545-559: ids[n] -> out[n][hidden] */
+int q3tts_text_project_host(q3tts_engine* e, const int64_t* ids, int n, float* out);
+/* run_codec_embed / run_codec_embed_batch, tts_onnx.cpp:561-590 */
+int q3tts_codec_embed_host(q3tts_engine* e, const int64_t* ids, int n, float* out);
+/* run_code_predictor_embed, tts_onnx.cpp:592-613 */
+int q3tts_cp_embed_host(q3tts_engine* e, int64_t id, int generation_step, float* out);
+/* run_prefill, tts_onnx.cpp:615-665: embeds[S][hidden] -> logits[S][vocab], last_hidden[hidden];
+ * the KV cache of `slot` is reset and stays device-resident (replaces KVCache, tts_onnx.h:108-115) */
+int q3tts_talker_prefill_host(q3tts_engine* e, int slot, const float* embeds, int S, float* logits, float* last_hidden);
+/* run_decode, tts_onnx.cpp:667-732: one token appended to `slot` */
+int q3tts_talker_decode_host(q3tts_engine* e, int slot, const float* embed, float* logits, float* last_hidden);
+/* run_code_predictor, tts_onnx.cpp:734-757: seq[n][hidden], head #generation_step on the last row */
+int q3tts_code_predictor_host(q3tts_engine* e, const float* seq, int n, int generation_step, float* logits);
+/* run_vocoder, tts_onnx.cpp:759-776: codes[F][n_groups] (frame-major) -> pcm; *out_len = lengths[0] */
+int q3tts_codec_decode_host(q3tts_engine* e, const int64_t* codes, int F, float* pcm, int64_t cap, int64_t* out_len);
+int64_t q3tts_codec_decode_len(const q3tts_config* cfg, int F);
+/* sample_token, tts_onnx.cpp:878-905, on device; u in [0,1) replaces the mt19937 draw.
+ * suppress != 0 applies the special-token suppression of tts_onnx.cpp:803-807 first. */
+int q3tts_sample_host(q3tts_engine* e, const float* logits, int n, const q3tts_sampling* p, float u, int suppress, int64_t* token);
+float q3tts_rng_uniform(uint64_t seed, uint32_t stream, uint32_t frame, uint32_t group);
+
+/* ---- host logic of the path, mirrored (build_prompt_embeddings, tts_onnx.cpp:442-539) ---- */
+/* lang: 0 Auto, 1 English, 2 Chinese, 3 Japanese, 4 Korean.  prompt[<=16][hidden], *S rows;
+ * trailing[cap_rows][hidden] receives trailing_text_hidden_, *n_trailing its row count. */
+int q3tts_build_prompt_host(q3tts_engine* e, const int64_t* ids, int n_ids, int lang, const float* speaker,
+                            float* prompt, int* S, float* trailing, int cap_rows, int* n_trailing);
+
+/* ---- fused, batched generation (generate_codes + predict_subcodes, tts_onnx.cpp:782-872) ---- */
+/* Admit an utterance into `slot`: uploads prompt + trailing rows, runs prefill, arms the slot.
+ * stream_id selects the RNG stream; ignore_eos keeps EOS suppressed (fixed-length benchmark mode). */
+int q3tts_slot_begin(q3tts_engine* e, int slot, const float* prompt, int S, const float* trailing, int n_trailing,
+                     const q3tts_sampling* p, uint64_t seed, uint32_t stream_id, int ignore_eos);
+/* Advance every armed slot by n_steps frames (one hipGraph replay per frame).  Returns the number
+ * of slots still active, <0 on error. */
+int q3tts_decode_steps(q3tts_engine* e, int n_steps);
+int q3tts_slot_status(q3tts_engine* e, int slot, int* n_frames, int* finished);
+/* codes[cap_frames][n_groups], int64 like the reference (tts_onnx.cpp:421-427) */
+int q3tts_slot_codes_host(q3tts_engine* e, int slot, int64_t* codes, int cap_frames);
+/* vocoder over the slot's device-resident codes */
+int q3tts_slot_codec_decode_host(q3tts_engine* e, int slot, float* pcm, int64_t cap, int64_t* out_len);
+int q3tts_slot_release(q3tts_engine* e, int slot);
+
+/* synthesize_tokens (tts_onnx.cpp:405-436) for a batch: utterance u has token ids
+ * ids[offsets[u] .. offsets[u+1]).  pcm_out[u] receives up to pcm_cap samples, pcm_len[u] the
+ * sample count, n_frames[u] the frames generated; codes_out (optional) [n_utt][max_new][n_groups]. */
+int q3tts_synthesize_batch_host(q3tts_engine* e, int n_utt, const int64_t* ids, const int32_t* offsets, int lang,
+                                const q3tts_sampling* p, uint64_t seed, int ignore_eos,
+                                float* const* pcm_out, int64_t pcm_cap, int64_t* pcm_len, int32_t* n_frames,
+                                int64_t* codes_out);
+
+/* ---- measurement hooks (bench.py) ---- */
+/* device time in ms of the last q3tts_decode_steps call, from HIP events on the engine's stream */
+int q3tts_last_decode_ms(q3tts_engine* e, float* ms, int* steps);
+/* device time in ms of the last codec decode */
+int q3tts_last_codec_ms(q3tts_engine* e, float* ms);
+/* algorithmic bytes one decode step streams (weights + KV at the slots' current contexts) */
+int q3tts_decode_step_bytes(q3tts_engine* e, double* weight_bytes, double* kv_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,62 @@
+"""Build libq3tts_hip.so (gfx950) in-tree with hipcc.  No JIT cache: the .so ships with the repo
+snapshot to the GPU box.  `python leaxer-qwen3-tts_amd/build.py [--force]`."""
+import hashlib
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "build")
+LIB = os.path.join(HERE, "libq3tts_hip.so")
+SOURCES = ["q3_decode_kernels.hip", "q3_codec_kernels.hip", "q3_engine.cpp", "q3_codec.cpp", "q3_capi.cpp"]
+HEADERS = ["q3_common.h", "q3_engine.h", os.path.join("..", "..", "include", "q3tts.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall", "-Wno-unused-function",
+         "-Wno-unused-variable", "-Wno-unused-but-set-variable"]
+
+
+def _digest(paths):
+    h = hashlib.sha1(" ".join(FLAGS).encode())
+    for p in paths:
+        with open(p, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def _compile(src, hdr_digest, force):
+    path = os.path.join(CSRC, src)
+    obj = os.path.join(OBJ, src + ".o")
+    tag = obj + ".tag"
+    dg = _digest([path]) + hdr_digest
+    if not force and os.path.exists(obj) and os.path.exists(tag) and open(tag).read() == dg:
+        return obj, False
+    cmd = ["hipcc"] + FLAGS + ["-x", "hip", "-c", path, "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed for %s:\n%s" % (src, r.stderr[-6000:]))
+    with open(tag, "w") as f:
+        f.write(dg)
+    return obj, True
+
+
+def build(force=False, verbose=False):
+    os.makedirs(OBJ, exist_ok=True)
+    srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    hdr_digest = _digest([os.path.join(CSRC, h) for h in HEADERS])
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        res = list(ex.map(lambda s: _compile(s, hdr_digest, force), srcs))
+    objs = [o for o, _ in res]
+    if any(ch for _, ch in res) or not os.path.exists(LIB):
+        cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB + ".tmp"] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n" + r.stderr[-4000:])
+        os.replace(LIB + ".tmp", LIB)
+        if verbose:
+            print("linked", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,233 @@
+// q3_capi.cpp — extern "C" surface declared in include/q3tts.h.  No exception crosses the ABI.
+#include <cstring>
+#include <vector>
+
+#include "q3_engine.h"
+
+using q3::Engine;
+
+struct q3tts_engine {
+    Engine* e = nullptr;
+    std::string err;
+};
+static std::string g_create_err;
+
+#define Q3_API_BEGIN(h)                                       \
+    if (!(h) || !(h)->e) return -1;                           \
+    try {                                                     \
+        (void)hipSetDevice((h)->e->device);
+#define Q3_API_END(h)                                         \
+    }                                                         \
+    catch (const q3::Error& ex) { (h)->err = ex.msg; return -1; } \
+    catch (const std::exception& ex) { (h)->err = ex.what(); return -1; } \
+    catch (...) { (h)->err = "unknown error"; return -1; }
+
+extern "C" {
+
+int q3tts_default_config(const char* name, q3tts_config* o) {
+    if (!o || !name) return -1;
+    if (strcmp(name, "0.6b") != 0 && strcmp(name, "0.6B") != 0) return -1;
+    memset(o, 0, sizeof *o);
+    // talker dims: reference src/tts_onnx.h:31-37; the rest [HINT]
+    o->hidden = 1024; o->n_layers = 28; o->n_heads = 16; o->n_kv_heads = 8; o->head_dim = 128; o->ffn = 3072; o->vocab = 3072;
+    o->rope_theta = 1e6f; o->rms_eps = 1e-6f;
+    o->cp_layers = 5; o->cp_heads = 16; o->cp_kv_heads = 8; o->cp_head_dim = 128; o->cp_ffn = 3072; o->n_groups = 16; o->sub_vocab = 2048;
+    o->cp_rope_theta = 1e6f; o->cp_rms_eps = 1e-6f;
+    o->text_vocab = 151936; o->text_hidden = 2048;
+    o->cd_codebook = 2048; o->cd_hidden = 1024; o->cd_layers = 8; o->cd_heads = 16; o->cd_head_dim = 64; o->cd_ffn = 3072; o->cd_window = 72;
+    o->cd_rope_theta = 10000.0f; o->cd_rms_eps = 1e-5f;
+    o->cd_n_up = 2; o->cd_up_ratios[0] = 2; o->cd_up_ratios[1] = 2;
+    o->cd_decoder_dim = 1536; o->cd_n_blocks = 4;
+    o->cd_up_rates[0] = 8; o->cd_up_rates[1] = 5; o->cd_up_rates[2] = 4; o->cd_up_rates[3] = 3;
+    o->cd_tconv_trim = 0;
+    o->codec_eos = 2150; o->suppress_begin = 2048; o->suppress_end = 3072;
+    return 0;
+}
+
+q3tts_engine* q3tts_create(const q3tts_config* cfg, int device, int max_batch, int max_ctx, uint32_t flags) {
+    if (!cfg) { g_create_err = "null config"; return nullptr; }
+    try {
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) throw q3::Error("no HIP device: libq3tts_hip needs an MI355X (gfx950); there is no CPU fallback");
+        if (device < 0 || device >= n) throw q3::Error("device index out of range");
+        q3tts_engine* h = new q3tts_engine;
+        h->e = new Engine(*cfg, device, max_batch, max_ctx, flags);
+        return h;
+    } catch (const q3::Error& ex) { g_create_err = ex.msg; }
+    catch (const std::exception& ex) { g_create_err = ex.what(); }
+    catch (...) { g_create_err = "unknown error"; }
+    return nullptr;
+}
+
+void q3tts_destroy(q3tts_engine* h) {
+    if (!h) return;
+    delete h->e;
+    delete h;
+}
+
+const char* q3tts_last_error(q3tts_engine* h) { return h ? h->err.c_str() : g_create_err.c_str(); }
+
+int q3tts_num_tensors(q3tts_engine* h) { return h && h->e ? (int)h->e->tensors.size() : -1; }
+
+int q3tts_tensor_info(q3tts_engine* h, int i, char* name, int cap, int64_t* shape4, int* ndim) {
+    Q3_API_BEGIN(h)
+    if (i < 0 || i >= (int)h->e->tensors.size()) throw q3::Error("tensor index out of range");
+    const q3::Tensor& t = h->e->tensors[i];
+    if (name && cap > 0) { strncpy(name, t.name.c_str(), cap - 1); name[cap - 1] = 0; }
+    if (shape4) for (int k = 0; k < 4; ++k) shape4[k] = t.shape[k];
+    if (ndim) *ndim = t.ndim;
+    return 0;
+    Q3_API_END(h)
+}
+
+int q3tts_set_tensor_host(q3tts_engine* h, const char* name, const float* data, int64_t n) {
+    Q3_API_BEGIN(h) h->e->set_tensor(name, data, n); return 0; Q3_API_END(h)
+}
+int q3tts_get_tensor_host(q3tts_engine* h, const char* name, float* out, int64_t n) {
+    Q3_API_BEGIN(h) h->e->get_tensor(name, out, n); return 0; Q3_API_END(h)
+}
+int q3tts_fill_synthetic(q3tts_engine* h, uint64_t seed) {
+    Q3_API_BEGIN(h) h->e->fill_synthetic(seed); return 0; Q3_API_END(h)
+}
+int q3tts_finalize(q3tts_engine* h) {
+    Q3_API_BEGIN(h) h->e->finalize(); return 0; Q3_API_END(h)
+}
+
+int q3tts_text_project_host(q3tts_engine* h, const int64_t* ids, int n, float* out) {
+    Q3_API_BEGIN(h) h->e->text_project(ids, n, out); return 0; Q3_API_END(h)
+}
+int q3tts_codec_embed_host(q3tts_engine* h, const int64_t* ids, int n, float* out) {
+    Q3_API_BEGIN(h) h->e->codec_embed(ids, n, out); return 0; Q3_API_END(h)
+}
+int q3tts_cp_embed_host(q3tts_engine* h, int64_t id, int step, float* out) {
+    Q3_API_BEGIN(h) h->e->cp_embed(id, step, out); return 0; Q3_API_END(h)
+}
+int q3tts_talker_prefill_host(q3tts_engine* h, int slot, const float* embeds, int S, float* logits, float* last_hidden) {
+    Q3_API_BEGIN(h) h->e->talker_prefill(slot, embeds, S, logits, last_hidden); return 0; Q3_API_END(h)
+}
+int q3tts_talker_decode_host(q3tts_engine* h, int slot, const float* embed, float* logits, float* last_hidden) {
+    Q3_API_BEGIN(h) h->e->talker_decode(slot, embed, logits, last_hidden); return 0; Q3_API_END(h)
+}
+int q3tts_code_predictor_host(q3tts_engine* h, const float* seq, int n, int step, float* logits) {
+    Q3_API_BEGIN(h) h->e->code_predictor(seq, n, step, logits); return 0; Q3_API_END(h)
+}
+int q3tts_codec_decode_host(q3tts_engine* h, const int64_t* codes, int F, float* pcm, int64_t cap, int64_t* out_len) {
+    Q3_API_BEGIN(h)
+    const int64_t n = h->e->codec_decode_host(codes, F, pcm, cap);
+    if (out_len) *out_len = n;
+    return 0;
+    Q3_API_END(h)
+}
+
+int64_t q3tts_codec_decode_len(const q3tts_config* c, int F) {
+    int64_t T = F;
+    for (int s = 0; s < c->cd_n_up; ++s) T *= c->cd_up_ratios[s];
+    for (int i = 0; i < c->cd_n_blocks; ++i) {
+        const int r = c->cd_up_rates[i], k = 2 * r, pad = k - r;
+        const int left = c->cd_tconv_trim == 0 ? pad : 0;
+        T = (T - 1) * r + k - left - pad;
+    }
+    return T;
+}
+
+int q3tts_sample_host(q3tts_engine* h, const float* logits, int n, const q3tts_sampling* p, float u, int suppress, int64_t* token) {
+    Q3_API_BEGIN(h) h->e->sample(logits, n, *p, u, suppress, token); return 0; Q3_API_END(h)
+}
+
+static uint64_t mix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+float q3tts_rng_uniform(uint64_t seed, uint32_t stream, uint32_t frame, uint32_t group) {
+    uint64_t k = mix64(seed ^ mix64(((uint64_t)stream << 32) | frame));
+    k = mix64(k + group);
+    return (float)(k >> 40) * (1.0f / 16777216.0f);
+}
+
+int q3tts_build_prompt_host(q3tts_engine* h, const int64_t* ids, int n_ids, int lang, const float* speaker,
+                            float* prompt, int* S, float* trailing, int cap_rows, int* n_trailing) {
+    Q3_API_BEGIN(h) h->e->build_prompt(ids, n_ids, lang, speaker, prompt, S, trailing, cap_rows, n_trailing); return 0; Q3_API_END(h)
+}
+
+int q3tts_slot_begin(q3tts_engine* h, int slot, const float* prompt, int S, const float* trailing, int n_trailing,
+                     const q3tts_sampling* p, uint64_t seed, uint32_t stream_id, int ignore_eos) {
+    Q3_API_BEGIN(h) h->e->slot_begin(slot, prompt, S, trailing, n_trailing, *p, seed, stream_id, ignore_eos); return 0; Q3_API_END(h)
+}
+int q3tts_decode_steps(q3tts_engine* h, int n_steps) {
+    Q3_API_BEGIN(h) return h->e->decode_steps(n_steps); Q3_API_END(h)
+}
+int q3tts_slot_status(q3tts_engine* h, int slot, int* n_frames, int* finished) {
+    Q3_API_BEGIN(h) h->e->slot_status(slot, n_frames, finished); return 0; Q3_API_END(h)
+}
+int q3tts_slot_codes_host(q3tts_engine* h, int slot, int64_t* codes, int cap_frames) {
+    Q3_API_BEGIN(h) h->e->slot_codes(slot, codes, cap_frames); return 0; Q3_API_END(h)
+}
+int q3tts_slot_codec_decode_host(q3tts_engine* h, int slot, float* pcm, int64_t cap, int64_t* out_len) {
+    Q3_API_BEGIN(h)
+    const int64_t n = h->e->slot_codec_decode(slot, pcm, cap);
+    if (out_len) *out_len = n;
+    return 0;
+    Q3_API_END(h)
+}
+int q3tts_slot_release(q3tts_engine* h, int slot) {
+    Q3_API_BEGIN(h) h->e->slot_release(slot); return 0; Q3_API_END(h)
+}
+
+// synthesize_tokens (reference src/tts_onnx.cpp:405-436) over a batch of independent utterances:
+// waves of up to max_batch slots; prompt assembly -> prefill -> fused decode -> vocoder.
+int q3tts_synthesize_batch_host(q3tts_engine* h, int n_utt, const int64_t* ids, const int32_t* offsets, int lang,
+                                const q3tts_sampling* p, uint64_t seed, int ignore_eos,
+                                float* const* pcm_out, int64_t pcm_cap, int64_t* pcm_len, int32_t* n_frames,
+                                int64_t* codes_out) {
+    Q3_API_BEGIN(h)
+    Engine& e = *h->e;
+    const int H = e.c.hidden, G = e.c.n_groups;
+    std::vector<float> prompt((size_t)16 * H), trailing((size_t)e.max_trailing * H);
+    for (int u0 = 0; u0 < n_utt; u0 += e.B) {
+        const int nb = std::min(e.B, n_utt - u0);
+        for (int b = 0; b < e.B; ++b) e.slot_release(b);
+        for (int b = 0; b < nb; ++b) {
+            const int u = u0 + b;
+            int S = 0, nt = 0;
+            e.build_prompt(ids + offsets[u], offsets[u + 1] - offsets[u], lang, nullptr, prompt.data(), &S, trailing.data(), e.max_trailing, &nt);
+            e.slot_begin(b, prompt.data(), S, trailing.data(), nt, *p, seed, (uint32_t)u, ignore_eos);
+        }
+        int left = p->max_new_tokens;
+        while (left > 0) {
+            const int chunk = std::min(left, 32);
+            const int active = e.decode_steps(chunk);
+            left -= chunk;
+            if (active == 0) break;
+        }
+        for (int b = 0; b < nb; ++b) {
+            const int u = u0 + b;
+            int nf = 0;
+            e.slot_status(b, &nf, nullptr);
+            if (n_frames) n_frames[u] = nf;
+            if (codes_out) e.slot_codes(b, codes_out + (size_t)u * p->max_new_tokens * G, p->max_new_tokens);
+            const int64_t n = e.slot_codec_decode(b, pcm_out ? pcm_out[u] : nullptr, pcm_cap);
+            if (pcm_len) pcm_len[u] = n;
+        }
+        for (int b = 0; b < nb; ++b) e.slot_release(b);
+    }
+    return 0;
+    Q3_API_END(h)
+}
+
+int q3tts_last_decode_ms(q3tts_engine* h, float* ms, int* steps) {
+    Q3_API_BEGIN(h)
+    if (ms) *ms = h->e->last_decode_ms;
+    if (steps) *steps = h->e->last_decode_steps;
+    return 0;
+    Q3_API_END(h)
+}
+int q3tts_last_codec_ms(q3tts_engine* h, float* ms) {
+    Q3_API_BEGIN(h) if (ms) *ms = h->e->last_codec_ms; return 0; Q3_API_END(h)
+}
+int q3tts_decode_step_bytes(q3tts_engine* h, double* wb, double* kvb) {
+    Q3_API_BEGIN(h) h->e->step_bytes(wb, kvb); return 0; Q3_API_END(h)
+}
+
+} // extern "C"

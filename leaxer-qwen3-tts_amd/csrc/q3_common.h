@@ -1,0 +1,164 @@
+// q3_common.h — shared declarations of libq3tts_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+#include "../../include/q3tts.h"
+
+typedef uint16_t bf16_t; // raw bf16 bits
+
+#define Q3_HIP_CHECK(expr)                                                                         \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess) throw q3::Error(std::string(#expr) + ": " + hipGetErrorString(_e));  \
+    } while (0)
+
+namespace q3 {
+
+struct Error {
+    std::string msg;
+    explicit Error(std::string m) : msg(std::move(m)) {}
+};
+
+// fp32 -> bf16, round-to-nearest-even (inputs are finite weights)
+inline bf16_t f32_to_bf16(float f) {
+    uint32_t u;
+    __builtin_memcpy(&u, &f, 4);
+    u = (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+    return (bf16_t)u;
+}
+inline float bf16_to_f32(bf16_t b) {
+    uint32_t u = (uint32_t)b << 16;
+    float f;
+    __builtin_memcpy(&f, &u, 4);
+    return f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// kernel argument blocks + launchers (q3_decode_kernels.hip)
+// ------------------------------------------------------------------------------------------------
+
+enum GemvEpi { EPI_STORE = 0, EPI_RESIDUAL = 1, EPI_SWIGLU = 2, EPI_BIAS = 3, EPI_BIAS_SILU = 4 };
+
+// out[m][n] = epi( sum_k xin[m][k] * W[n][k] ),  W row-major bf16 [N][K] (nn.Linear.weight layout)
+struct GemvArgs {
+    const bf16_t* W = nullptr;   // [N][K]
+    const bf16_t* W2 = nullptr;  // EPI_SWIGLU: up_proj rows (W = gate_proj)
+    const float* x = nullptr;    // [M][ldx]
+    int ldx = 0;
+    const float* gamma = nullptr; // non-null: fused RMSNorm of x rows (gamma[K], eps)
+    float eps = 0.f;
+    float* xn_out = nullptr;      // optional: normalised rows written by block 0 (ld_xn)
+    int ld_xn = 0;
+    const float* bias = nullptr;  // EPI_BIAS / EPI_BIAS_SILU
+    const float* res = nullptr;   // EPI_RESIDUAL (may alias out)
+    int ldres = 0;
+    float* out = nullptr;
+    int ldo = 0;
+    int M = 0, N = 0, K = 0;
+    int epi = EPI_STORE;
+    bool nt = false;              // non-temporal weight loads (streamed-once weights)
+};
+void launch_gemv(const GemvArgs& a, hipStream_t s);
+
+// Decode-time attention over a paged fp32 KV cache with the new tokens' q/k-norm + RoPE + append fused.
+struct AttnArgs {
+    const float* qkv = nullptr; // [nb*n_new][ld_qkv]: q heads | k heads | v heads (raw projections)
+    int ld_qkv = 0;
+    float* out = nullptr;       // [nb*n_new][nq*d]
+    int ld_out = 0;
+    float* kcache = nullptr;    // [page][layer][kvh][page_tokens][d]
+    float* vcache = nullptr;
+    const int* page_table = nullptr; // [slot][pages_per_slot]
+    int pages_per_slot = 0, page_shift = 0;
+    int layer = 0, n_layers = 0;
+    const float* q_norm = nullptr; // [d] or null
+    const float* k_norm = nullptr;
+    float eps = 0.f;
+    const float* rope_cos = nullptr; // [max_pos][d/2]
+    const float* rope_sin = nullptr;
+    const int* pos_dev = nullptr;    // per-slot position of new token 0 (device) or null -> pos_scalar
+    int pos_scalar = 0;
+    int slot_offset = 0, nb = 0, n_new = 0;
+    int nq = 0, nkv = 0, d = 0;
+    float scale = 0.f;
+    int window = 0;
+    int new_from_raw = 1; // 1: new tokens' K/V come from qkv (and are appended); 0: everything is in the cache, q pre-roped
+};
+void launch_attn(const AttnArgs& a, hipStream_t s);
+
+struct SlotState { // device-resident per-slot generation state
+    int32_t n_frames;     // frames recorded so far
+    int32_t finished;     // 1 after EOS / max_frames
+    int32_t active;       // slot armed
+    int32_t prompt_len;
+    int32_t trailing_len;
+    int32_t max_frames;
+    int32_t top_k;
+    int32_t ignore_eos;
+    float temperature, top_p;
+    uint32_t stream_id;
+    uint32_t pad0;
+    uint64_t seed;
+};
+
+struct SampleArgs {
+    const float* logits = nullptr; // [nb][ld]
+    int ld = 0, V = 0, nb = 0;
+    int sup_begin = 0, sup_end = 0, eos_id = -1; // suppress [sup_begin,sup_end) except eos_id (group 0 only)
+    int group = 0, n_groups = 0;
+    SlotState* st = nullptr;       // [nb]; null -> standalone mode (params below, token_out)
+    float temperature = 1.f, top_p = 1.f;
+    int top_k = 0;
+    float u = 0.f;
+    int suppress = 0;
+    int64_t* token_out = nullptr;
+    // fused epilogue (generation mode)
+    const bf16_t* embed = nullptr; // [V][H] embedding table of the sampled codebook
+    int H = 0;
+    float* x_next = nullptr;       // row b*ld_xnext: embedding of the sampled token (next predictor input)
+    int ld_xnext = 0;
+    float* sum = nullptr;          // [nb][H] running fp32 sum of the frame's 16 embeddings
+    float* x_talk = nullptr;       // [nb][H], last group only: sum + text row | tts_pad
+    const float* trailing = nullptr; // [nb][max_trailing][H]
+    int max_trailing = 0;
+    const float* tts_pad = nullptr;  // [H]
+    int32_t* codes = nullptr;      // [nb][max_frames_cap][n_groups]
+    int max_frames_cap = 0;
+    int32_t* talker_pos = nullptr; // [nb], last group only: position of the token the talker decodes next
+};
+void launch_sample(const SampleArgs& a, hipStream_t s);
+
+void launch_gather_rows_bf16(const bf16_t* table, int H, const int64_t* ids_dev, int n, float* out, int ldo, hipStream_t s);
+void launch_fill_synth(void* dst, int is_bf16, int64_t n, uint64_t key, float mean, float stddev, hipStream_t s);
+void launch_copy_rows(const float* src, int lds, float* dst, int ldd, int rows, int cols, hipStream_t s);
+void launch_count_active(const SlotState* st, int nb, int32_t* out, hipStream_t s);
+
+// ------------------------------------------------------------------------------------------------
+// codec decoder launchers (q3_codec_kernels.hip)
+// ------------------------------------------------------------------------------------------------
+struct ConvArgs { // out[t][co] = bias[co] + sum_{tap,ci} W[tap][co][ci] * pre(in[src_t(t,tap)][ci])  (+ residual)
+    const float* in = nullptr; int T_in = 0, C_in = 0;
+    float* out = nullptr;      int T_out = 0, C_out = 0;
+    const float* W = nullptr;  // [taps][C_out][C_in] fp32
+    const float* bias = nullptr;
+    int taps = 1, dil = 1;
+    int transposed = 0, stride = 1, left = 0; // transposed: out index j=jo+left gets in[t] via tap j - t*stride
+    const float* snake_alpha = nullptr; // non-null: SnakeBeta applied to the input on load
+    const float* snake_beta = nullptr;
+    const float* res = nullptr;  // optional residual added in the epilogue (same shape as out)
+    const float* res_scale = nullptr; // optional per-channel scale on the conv result before the residual add
+    int act = 0;                 // 0 none, 1 GELU(erf), 2 SiLU on (acc + bias)
+    const float* mul = nullptr;  // optional elementwise multiplier of the activated result (SwiGLU up branch)
+    int clamp = 0;               // clamp to [-1, 1]
+};
+void launch_conv(const ConvArgs& a, hipStream_t s);
+void launch_code_embed_mean(const float* table, const int32_t* codes, int F, int G, int codebook, int C, float* out, hipStream_t s);
+void launch_rmsnorm_rows(const float* x, const float* w, float eps, int rows, int C, float* out, hipStream_t s);
+void launch_rope_store(float* qkv, int ld, int T, int nq, int nkv, int d, const float* cs, const float* sn,
+                       float* kc, float* vc, hipStream_t s);
+void launch_dwconv_ln(const float* x, int T, int C, const float* dw_w, const float* dw_b, const float* ln_w,
+                      const float* ln_b, float* out, hipStream_t s);
+
+} // namespace q3

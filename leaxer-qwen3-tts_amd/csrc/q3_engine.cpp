@@ -1,0 +1,663 @@
+// q3_engine.cpp — device-resident engine: weight registry, workspaces, paged KV cache, the
+// per-frame launch sequence (captured into a hipGraph), and the mirrored host logic of the
+// reference's generation path (src/tts_onnx.cpp:442-539, 782-872).
+#include "q3_engine.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+namespace q3 {
+
+// ---- host-logic constants, reference src/tts_onnx.h:40-62 ----
+static const int64_t TTS_BOS = 151672, TTS_EOS = 151673, TTS_PAD = 151671;
+static const int64_t CODEC_BOS = 2149, CODEC_PAD = 2148, CODEC_THINK = 2154, CODEC_NOTHINK = 2155;
+static const int64_t CODEC_THINK_BOS = 2156, CODEC_THINK_EOS = 2157, LANG_ENGLISH = 2050;
+
+static uint64_t mix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+static uint64_t fnv1a(const std::string& s) {
+    uint64_t h = 1469598103934665603ull;
+    for (unsigned char ch : s) { h ^= ch; h *= 1099511628211ull; }
+    return h;
+}
+
+void* Engine::dmalloc(size_t bytes) {
+    void* p = nullptr;
+    if (bytes == 0) bytes = 16;
+    Q3_HIP_CHECK(hipMalloc(&p, bytes));
+    allocs.push_back(p);
+    return p;
+}
+void Engine::sync() { Q3_HIP_CHECK(hipStreamSynchronize(stream)); }
+
+Tensor& Engine::T(const std::string& n) {
+    auto it = tindex.find(n);
+    if (it == tindex.end()) throw Error("unknown tensor '" + n + "'");
+    return tensors[it->second];
+}
+
+// ------------------------------------------------------------------------------------------------
+// construction: tensor registry (names/shapes shared with the oracle and DESIGN.md section 3)
+// ------------------------------------------------------------------------------------------------
+Engine::Engine(const q3tts_config& cfg, int device_, int max_batch, int max_ctx_, uint32_t flags_)
+    : c(cfg), device(device_), B(max_batch), max_ctx(max_ctx_), flags(flags_) {
+    if (B < 1 || B > 1024) throw Error("max_batch out of range");
+    if (c.hidden % 8 || c.ffn % 8 || c.text_hidden % 8 || c.cp_ffn % 8) throw Error("hidden/ffn sizes must be multiples of 8");
+    if (c.vocab > 4096 || c.sub_vocab > 4096) throw Error("codec vocabularies larger than 4096 are not supported");
+    if (c.n_groups < 2 || c.n_groups > 32) throw Error("n_groups out of range");
+    Q3_HIP_CHECK(hipSetDevice(device));
+    Q3_HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    Q3_HIP_CHECK(hipEventCreate(&ev0));
+    Q3_HIP_CHECK(hipEventCreate(&ev1));
+
+    auto add = [&](const std::string& name, std::vector<int64_t> shape, int kind, bool bf, void* dev = nullptr, float sstd = 0.02f) {
+        Tensor t;
+        t.name = name; t.ndim = (int)shape.size(); t.kind = kind; t.bf16 = bf; t.numel = 1; t.synth_std = sstd;
+        for (int i = 0; i < t.ndim; ++i) { t.shape[i] = shape[i]; t.numel *= shape[i]; }
+        t.dev = dev ? dev : dmalloc((size_t)t.numel * (bf ? 2 : 4));
+        tindex[name] = (int)tensors.size();
+        tensors.push_back(t);
+    };
+    auto add_layers = [&](const std::string& prefix, int n, int H, int nq, int nkv, int d, int ffn, bool qk, bool ls, bool bf) {
+        const size_t es = bf ? 2 : 4;
+        for (int i = 0; i < n; ++i) {
+            const std::string p = prefix + ".layers." + std::to_string(i) + ".";
+            add(p + "input_norm", {H}, TK_NORM, false);
+            char* fused = (char*)dmalloc((size_t)(nq + 2 * nkv) * d * H * es); // q|k|v rows contiguous: one GEMV
+            add(p + "q_proj", {(int64_t)nq * d, H}, TK_W, bf, fused);
+            add(p + "k_proj", {(int64_t)nkv * d, H}, TK_W, bf, fused + (size_t)nq * d * H * es);
+            add(p + "v_proj", {(int64_t)nkv * d, H}, TK_W, bf, fused + (size_t)(nq + nkv) * d * H * es);
+            add(p + "o_proj", {H, (int64_t)nq * d}, TK_W, bf);
+            if (qk) { add(p + "q_norm", {d}, TK_NORM, false); add(p + "k_norm", {d}, TK_NORM, false); }
+            add(p + "post_norm", {H}, TK_NORM, false);
+            add(p + "gate_proj", {ffn, H}, TK_W, bf);
+            add(p + "up_proj", {ffn, H}, TK_W, bf);
+            add(p + "down_proj", {H, ffn}, TK_W, bf);
+            if (ls) { add(p + "attn_scale", {H}, TK_SCALE, false); add(p + "mlp_scale", {H}, TK_SCALE, false); }
+        }
+    };
+    const int H = c.hidden;
+    add_layers("talker", c.n_layers, H, c.n_heads, c.n_kv_heads, c.head_dim, c.ffn, true, false, true);
+    add("talker.norm", {H}, TK_NORM, false);
+    add("talker.codec_head", {c.vocab, H}, TK_W, true);
+    add("talker.codec_embed", {c.vocab, H}, TK_W, true);
+    add("text.embed", {c.text_vocab, c.text_hidden}, TK_W, true);
+    add("text.fc1.w", {c.text_hidden, c.text_hidden}, TK_W, true);
+    add("text.fc1.b", {c.text_hidden}, TK_BIAS, false);
+    add("text.fc2.w", {H, c.text_hidden}, TK_W, true);
+    add("text.fc2.b", {H}, TK_BIAS, false);
+    add_layers("cp", c.cp_layers, H, c.cp_heads, c.cp_kv_heads, c.cp_head_dim, c.cp_ffn, true, false, true);
+    add("cp.norm", {H}, TK_NORM, false);
+    for (int j = 0; j < c.n_groups - 1; ++j) add("cp.head." + std::to_string(j), {c.sub_vocab, H}, TK_W, true);
+    for (int j = 0; j < c.n_groups - 1; ++j) add("cp.embed." + std::to_string(j), {c.sub_vocab, H}, TK_W, true);
+    const int CH = c.cd_hidden;
+    add_layers("cd", c.cd_layers, CH, c.cd_heads, c.cd_heads, c.cd_head_dim, c.cd_ffn, false, true, false);
+    add("cd.norm", {CH}, TK_NORM, false);
+    add("cd.code_embed", {(int64_t)c.n_groups * c.cd_codebook, CH}, TK_W, false);
+    for (int s = 0; s < c.cd_n_up; ++s) {
+        const int f = c.cd_up_ratios[s];
+        const std::string p = "cd.up." + std::to_string(s) + ".";
+        add(p + "tconv.w", {CH, CH, f}, TK_W, false);
+        add(p + "tconv.b", {CH}, TK_BIAS, false);
+        add(p + "cnx.dw.w", {CH, 1, 7}, TK_W, false);
+        add(p + "cnx.dw.b", {CH}, TK_BIAS, false);
+        add(p + "cnx.ln.w", {CH}, TK_NORM, false);
+        add(p + "cnx.ln.b", {CH}, TK_BIAS, false);
+        add(p + "cnx.pw1.w", {4 * CH, CH}, TK_W, false);
+        add(p + "cnx.pw1.b", {4 * CH}, TK_BIAS, false);
+        add(p + "cnx.pw2.w", {CH, 4 * CH}, TK_W, false);
+        add(p + "cnx.pw2.b", {CH}, TK_BIAS, false);
+        add(p + "cnx.gamma", {CH}, TK_SCALE, false);
+    }
+    const int D = c.cd_decoder_dim;
+    add("cd.dec.conv_in.w", {D, CH, 7}, TK_W, false);
+    add("cd.dec.conv_in.b", {D}, TK_BIAS, false);
+    for (int i = 0; i < c.cd_n_blocks; ++i) {
+        const int cin = D >> i, cout = D >> (i + 1), r = c.cd_up_rates[i];
+        const std::string p = "cd.dec.blocks." + std::to_string(i) + ".";
+        add(p + "snake.alpha", {cin}, TK_SNAKE, false);
+        add(p + "snake.beta", {cin}, TK_SNAKE, false);
+        add(p + "tconv.w", {cin, cout, 2 * r}, TK_W, false);
+        add(p + "tconv.b", {cout}, TK_BIAS, false);
+        for (int u = 0; u < 3; ++u) {
+            const std::string q = p + "res." + std::to_string(u) + ".";
+            add(q + "act1.alpha", {cout}, TK_SNAKE, false);
+            add(q + "act1.beta", {cout}, TK_SNAKE, false);
+            add(q + "conv1.w", {cout, cout, 7}, TK_W, false);
+            add(q + "conv1.b", {cout}, TK_BIAS, false);
+            add(q + "act2.alpha", {cout}, TK_SNAKE, false);
+            add(q + "act2.beta", {cout}, TK_SNAKE, false);
+            add(q + "conv2.w", {cout, cout, 1}, TK_W, false);
+            add(q + "conv2.b", {cout}, TK_BIAS, false);
+        }
+    }
+    const int OD = D >> c.cd_n_blocks;
+    add("cd.dec.snake_out.alpha", {OD}, TK_SNAKE, false);
+    add("cd.dec.snake_out.beta", {OD}, TK_SNAKE, false);
+    add("cd.dec.conv_out.w", {1, OD, 7}, TK_W, false, nullptr, 0.002f);
+    add("cd.dec.conv_out.b", {1}, TK_BIAS, false);
+
+    // ---- workspaces ----
+    rows_max = std::max(2 * B, 16);
+    max_trailing = 1024;
+    max_frames_cap = max_ctx;
+    const int QKV = (c.n_heads + 2 * c.n_kv_heads) * c.head_dim, QKVp = (c.cp_heads + 2 * c.cp_kv_heads) * c.cp_head_dim;
+    const int AO = std::max(c.n_heads * c.head_dim, c.cp_heads * c.cp_head_dim);
+    auto fm = [&](size_t n) { float* p = (float*)dmalloc(n * sizeof(float)); Q3_HIP_CHECK(hipMemsetAsync(p, 0, n * sizeof(float), stream)); return p; };
+    x_talk = fm((size_t)B * H);
+    qkv = fm((size_t)rows_max * std::max(QKV, QKVp));
+    attn = fm((size_t)rows_max * AO);
+    act = fm((size_t)rows_max * std::max(c.ffn, c.cp_ffn));
+    logits_t = fm((size_t)B * c.vocab);
+    logits_cp = fm((size_t)B * c.sub_vocab);
+    x_cp = fm((size_t)B * 2 * H);
+    x_cp1 = fm((size_t)B * H);
+    sum = fm((size_t)B * H);
+    xp = fm((size_t)16 * H);
+    hn = fm((size_t)16 * H);
+    logits_p = fm((size_t)16 * std::max(c.vocab, c.sub_vocab));
+    trailing_d = fm((size_t)B * max_trailing * H);
+    tts_pad_d = fm(H);
+    text_tmp = fm((size_t)16 * c.text_hidden);
+    text_tmp2 = fm((size_t)16 * c.text_hidden);
+    ids_d = (int64_t*)dmalloc(64 * sizeof(int64_t));
+    tok_d = (int64_t*)dmalloc(sizeof(int64_t));
+    codes_d = (int32_t*)dmalloc((size_t)B * max_frames_cap * c.n_groups * sizeof(int32_t));
+    codes_scratch_d = (int32_t*)dmalloc((size_t)max_frames_cap * c.n_groups * sizeof(int32_t));
+    talker_pos_d = (int32_t*)dmalloc((size_t)B * sizeof(int32_t));
+    Q3_HIP_CHECK(hipMemsetAsync(talker_pos_d, 0, (size_t)B * sizeof(int32_t), stream));
+    st_d = (SlotState*)dmalloc((size_t)B * sizeof(SlotState));
+    st_h.assign(B, SlotState{});
+    Q3_HIP_CHECK(hipMemsetAsync(st_d, 0, (size_t)B * sizeof(SlotState), stream));
+    active_d = (int32_t*)dmalloc(sizeof(int32_t));
+    Q3_HIP_CHECK(hipHostMalloc((void**)&active_h, sizeof(int32_t)));
+
+    // ---- paged KV caches (fp32), identity page allocation: slot b owns pages [b*pps, (b+1)*pps) ----
+    auto setup_stack = [&](DecStack& S, int Hh, int L, int nq, int nkv, int d, int ffn, float eps, int shift, int ctx, float theta, bool nt) {
+        S.H = Hh; S.L = L; S.nq = nq; S.nkv = nkv; S.d = d; S.ffn = ffn; S.eps = eps; S.page_shift = shift; S.nt = nt;
+        const int ptok = 1 << shift;
+        S.pages_per_slot = (ctx + ptok - 1) / ptok;
+        const size_t n = (size_t)B * S.pages_per_slot * L * nkv * ptok * d;
+        S.kc = (float*)dmalloc(n * sizeof(float));
+        S.vc = (float*)dmalloc(n * sizeof(float));
+        std::vector<int> pt((size_t)B * S.pages_per_slot);
+        for (size_t i = 0; i < pt.size(); ++i) pt[i] = (int)i;
+        S.page_table = (int*)dmalloc(pt.size() * sizeof(int));
+        Q3_HIP_CHECK(hipMemcpy(S.page_table, pt.data(), pt.size() * sizeof(int), hipMemcpyHostToDevice));
+        // RoPE tables with the oracle's formula (fp32 libm): inv = 1/powf(theta, 2i/d); ang = pos*inv
+        const int half = d / 2, npos = S.pages_per_slot * ptok;
+        std::vector<float> cs((size_t)npos * half), sn((size_t)npos * half);
+        for (int p = 0; p < npos; ++p)
+            for (int i = 0; i < half; ++i) {
+                const float inv = 1.0f / powf(theta, (float)(2 * i) / (float)d);
+                const float ang = (float)p * inv;
+                cs[(size_t)p * half + i] = cosf(ang);
+                sn[(size_t)p * half + i] = sinf(ang);
+            }
+        S.rope_cos = (float*)dmalloc(cs.size() * sizeof(float));
+        S.rope_sin = (float*)dmalloc(sn.size() * sizeof(float));
+        Q3_HIP_CHECK(hipMemcpy(S.rope_cos, cs.data(), cs.size() * sizeof(float), hipMemcpyHostToDevice));
+        Q3_HIP_CHECK(hipMemcpy(S.rope_sin, sn.data(), sn.size() * sizeof(float), hipMemcpyHostToDevice));
+    };
+    setup_stack(talker, H, c.n_layers, c.n_heads, c.n_kv_heads, c.head_dim, c.ffn, c.rms_eps, 6, max_ctx, c.rope_theta, true);
+    setup_stack(cp, H, c.cp_layers, c.cp_heads, c.cp_kv_heads, c.cp_head_dim, c.cp_ffn, c.cp_rms_eps, 5, 32, c.cp_rope_theta, false);
+    sync();
+}
+
+Engine::~Engine() {
+    (void)hipSetDevice(device);
+    if (stream) (void)hipStreamSynchronize(stream);
+    for (auto& kv : graphs) (void)hipGraphExecDestroy(kv.second);
+    codec_free();
+    for (void* p : allocs) (void)hipFree(p);
+    if (active_h) (void)hipHostFree(active_h);
+    if (ev0) (void)hipEventDestroy(ev0);
+    if (ev1) (void)hipEventDestroy(ev1);
+    if (stream) (void)hipStreamDestroy(stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// weights
+// ------------------------------------------------------------------------------------------------
+void Engine::set_tensor(const std::string& name, const float* data, int64_t n) {
+    Tensor& t = T(name);
+    if (t.numel != n) throw Error("tensor '" + name + "': expected " + std::to_string(t.numel) + " elements, got " + std::to_string(n));
+    if (t.bf16) {
+        std::vector<bf16_t> tmp((size_t)n);
+        for (int64_t i = 0; i < n; ++i) tmp[(size_t)i] = f32_to_bf16(data[i]);
+        Q3_HIP_CHECK(hipMemcpy(t.dev, tmp.data(), (size_t)n * 2, hipMemcpyHostToDevice));
+    } else {
+        Q3_HIP_CHECK(hipMemcpy(t.dev, data, (size_t)n * 4, hipMemcpyHostToDevice));
+    }
+    finalized = false;
+}
+
+void Engine::get_tensor(const std::string& name, float* out, int64_t n) {
+    Tensor& t = T(name);
+    if (t.numel != n) throw Error("tensor '" + name + "': expected " + std::to_string(t.numel) + " elements, got " + std::to_string(n));
+    sync();
+    if (t.bf16) {
+        std::vector<bf16_t> tmp((size_t)n);
+        Q3_HIP_CHECK(hipMemcpy(tmp.data(), t.dev, (size_t)n * 2, hipMemcpyDeviceToHost));
+        for (int64_t i = 0; i < n; ++i) out[i] = bf16_to_f32(tmp[(size_t)i]);
+    } else {
+        Q3_HIP_CHECK(hipMemcpy(out, t.dev, (size_t)n * 4, hipMemcpyDeviceToHost));
+    }
+}
+
+// SURVEY.md section 8d synthetic weights: matrices N(0, 0.02^2) bf16-representable, norm gains 1,
+// SnakeBeta alpha = beta = 0, LayerScale / ConvNeXt gamma 0.01, biases N(0, 0.02^2).
+void Engine::fill_synthetic(uint64_t seed) {
+    for (Tensor& t : tensors) {
+        float mean = 0.f, sd = 0.f;
+        switch (t.kind) {
+        case TK_W: sd = t.synth_std; break;
+        case TK_NORM: mean = 1.f; break;
+        case TK_BIAS: sd = 0.02f; break;
+        case TK_SCALE: mean = 0.01f; break;
+        default: break;
+        }
+        launch_fill_synth(t.dev, t.bf16 ? 1 : 0, t.numel, mix64(seed ^ fnv1a(t.name)), mean, sd, stream);
+    }
+    sync();
+    finalized = false;
+}
+
+void Engine::finalize() {
+    auto fp = [&](const std::string& n) { return (const float*)T(n).dev; };
+    auto bp = [&](const std::string& n) { return (const bf16_t*)T(n).dev; };
+    auto fill_stack = [&](DecStack& S, const std::string& prefix) {
+        S.layers.resize(S.L);
+        for (int i = 0; i < S.L; ++i) {
+            const std::string p = prefix + ".layers." + std::to_string(i) + ".";
+            DecLayerW& w = S.layers[i];
+            w.in_norm = fp(p + "input_norm"); w.post_norm = fp(p + "post_norm");
+            w.q_norm = fp(p + "q_norm"); w.k_norm = fp(p + "k_norm");
+            w.qkv = bp(p + "q_proj"); w.o = bp(p + "o_proj");
+            w.gate = bp(p + "gate_proj"); w.up = bp(p + "up_proj"); w.down = bp(p + "down_proj");
+        }
+    };
+    fill_stack(talker, "talker");
+    fill_stack(cp, "cp");
+    talker_norm = fp("talker.norm"); codec_head = bp("talker.codec_head"); codec_embed_w = bp("talker.codec_embed");
+    text_embed = bp("text.embed"); fc1_w = bp("text.fc1.w"); fc2_w = bp("text.fc2.w"); fc1_b = fp("text.fc1.b"); fc2_b = fp("text.fc2.b");
+    cp_norm = fp("cp.norm");
+    cp_head.clear(); cp_embed_w.clear();
+    for (int j = 0; j < c.n_groups - 1; ++j) { cp_head.push_back(bp("cp.head." + std::to_string(j))); cp_embed_w.push_back(bp("cp.embed." + std::to_string(j))); }
+    codec_finalize();
+    finalized = true;
+    // tts_pad_embed_ = text_project(TTS_PAD) (tts_onnx.cpp:459-463), model-wide constant kept on device
+    if (TTS_PAD < c.text_vocab) {
+        std::vector<float> pad(c.hidden);
+        int64_t id = TTS_PAD;
+        text_project(&id, 1, pad.data());
+        Q3_HIP_CHECK(hipMemcpy(tts_pad_d, pad.data(), pad.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    for (auto& kv : graphs) (void)hipGraphExecDestroy(kv.second);
+    graphs.clear();
+}
+
+// ------------------------------------------------------------------------------------------------
+// decoder stack: five launches per layer
+// ------------------------------------------------------------------------------------------------
+void Engine::run_layers(const DecStack& W, float* x, int ldx, int nb, int n_new, int slot_offset, const int* pos_dev, int pos_scalar) {
+    const int M = nb * n_new, QKV = (W.nq + 2 * W.nkv) * W.d, AO = W.nq * W.d;
+    for (int l = 0; l < W.L; ++l) {
+        const DecLayerW& w = W.layers[l];
+        GemvArgs g;
+        g.W = w.qkv; g.x = x; g.ldx = ldx; g.gamma = w.in_norm; g.eps = W.eps; g.out = qkv; g.ldo = QKV;
+        g.M = M; g.N = QKV; g.K = W.H; g.epi = EPI_STORE; g.nt = W.nt;
+        launch_gemv(g, stream);
+        AttnArgs a;
+        a.qkv = qkv; a.ld_qkv = QKV; a.out = attn; a.ld_out = AO; a.kcache = W.kc; a.vcache = W.vc;
+        a.page_table = W.page_table; a.pages_per_slot = W.pages_per_slot; a.page_shift = W.page_shift;
+        a.layer = l; a.n_layers = W.L; a.q_norm = w.q_norm; a.k_norm = w.k_norm; a.eps = W.eps;
+        a.rope_cos = W.rope_cos; a.rope_sin = W.rope_sin; a.pos_dev = pos_dev; a.pos_scalar = pos_scalar;
+        a.slot_offset = slot_offset; a.nb = nb; a.n_new = n_new; a.nq = W.nq; a.nkv = W.nkv; a.d = W.d;
+        a.scale = 1.0f / sqrtf((float)W.d); a.window = 0; a.new_from_raw = 1;
+        launch_attn(a, stream);
+        GemvArgs o;
+        o.W = w.o; o.x = attn; o.ldx = AO; o.res = x; o.ldres = ldx; o.out = x; o.ldo = ldx;
+        o.M = M; o.N = W.H; o.K = AO; o.epi = EPI_RESIDUAL; o.nt = W.nt;
+        launch_gemv(o, stream);
+        GemvArgs f;
+        f.W = w.gate; f.W2 = w.up; f.x = x; f.ldx = ldx; f.gamma = w.post_norm; f.eps = W.eps; f.out = act; f.ldo = W.ffn;
+        f.M = M; f.N = W.ffn; f.K = W.H; f.epi = EPI_SWIGLU; f.nt = W.nt;
+        launch_gemv(f, stream);
+        GemvArgs d;
+        d.W = w.down; d.x = act; d.ldx = W.ffn; d.res = x; d.ldres = ldx; d.out = x; d.ldo = ldx;
+        d.M = M; d.N = W.H; d.K = W.ffn; d.epi = EPI_RESIDUAL; d.nt = W.nt;
+        launch_gemv(d, stream);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// session-shaped ops
+// ------------------------------------------------------------------------------------------------
+void Engine::text_project(const int64_t* ids, int n, float* out) {
+    if (!finalized) throw Error("weights not finalized");
+    const int TH = c.text_hidden, H = c.hidden;
+    for (int i0 = 0; i0 < n; i0 += 16) {
+        const int m = std::min(16, n - i0);
+        for (int i = 0; i < m; ++i) if (ids[i0 + i] < 0 || ids[i0 + i] >= c.text_vocab) throw Error("text id out of range");
+        Q3_HIP_CHECK(hipMemcpyAsync(ids_d, ids + i0, (size_t)m * sizeof(int64_t), hipMemcpyHostToDevice, stream));
+        launch_gather_rows_bf16(text_embed, TH, ids_d, m, text_tmp, TH, stream);
+        GemvArgs a;
+        a.W = fc1_w; a.x = text_tmp; a.ldx = TH; a.bias = fc1_b; a.out = text_tmp2; a.ldo = TH; a.M = m; a.N = TH; a.K = TH; a.epi = EPI_BIAS_SILU;
+        launch_gemv(a, stream);
+        GemvArgs b;
+        b.W = fc2_w; b.x = text_tmp2; b.ldx = TH; b.bias = fc2_b; b.out = xp; b.ldo = H; b.M = m; b.N = H; b.K = TH; b.epi = EPI_BIAS;
+        launch_gemv(b, stream);
+        Q3_HIP_CHECK(hipMemcpyAsync(out + (size_t)i0 * H, xp, (size_t)m * H * sizeof(float), hipMemcpyDeviceToHost, stream));
+        sync();
+    }
+}
+
+void Engine::codec_embed(const int64_t* ids, int n, float* out) {
+    if (!finalized) throw Error("weights not finalized");
+    const int H = c.hidden;
+    for (int i0 = 0; i0 < n; i0 += 16) {
+        const int m = std::min(16, n - i0);
+        for (int i = 0; i < m; ++i) if (ids[i0 + i] < 0 || ids[i0 + i] >= c.vocab) throw Error("codec id out of range");
+        Q3_HIP_CHECK(hipMemcpyAsync(ids_d, ids + i0, (size_t)m * sizeof(int64_t), hipMemcpyHostToDevice, stream));
+        launch_gather_rows_bf16(codec_embed_w, H, ids_d, m, xp, H, stream);
+        Q3_HIP_CHECK(hipMemcpyAsync(out + (size_t)i0 * H, xp, (size_t)m * H * sizeof(float), hipMemcpyDeviceToHost, stream));
+        sync();
+    }
+}
+
+void Engine::cp_embed(int64_t id, int step, float* out) {
+    if (!finalized) throw Error("weights not finalized");
+    if (step < 0 || step >= c.n_groups - 1 || id < 0 || id >= c.sub_vocab) throw Error("cp_embed out of range");
+    Q3_HIP_CHECK(hipMemcpyAsync(ids_d, &id, sizeof(int64_t), hipMemcpyHostToDevice, stream));
+    launch_gather_rows_bf16(cp_embed_w[step], c.hidden, ids_d, 1, xp, c.hidden, stream);
+    Q3_HIP_CHECK(hipMemcpyAsync(out, xp, (size_t)c.hidden * sizeof(float), hipMemcpyDeviceToHost, stream));
+    sync();
+}
+
+void Engine::talker_prefill(int slot, const float* embeds, int S, float* logits, float* last_hidden) {
+    if (!finalized) throw Error("weights not finalized");
+    if (slot < 0 || slot >= B) throw Error("slot out of range");
+    if (S < 1 || S > 16) throw Error("prefill length must be 1..16 rows");
+    const int H = c.hidden, V = c.vocab;
+    Q3_HIP_CHECK(hipMemcpyAsync(xp, embeds, (size_t)S * H * sizeof(float), hipMemcpyHostToDevice, stream));
+    run_layers(talker, xp, H, 1, S, slot, nullptr, 0);
+    GemvArgs g; // final norm + codec head on every row; normalised rows kept for last_hidden
+    g.W = codec_head; g.x = xp; g.ldx = H; g.gamma = talker_norm; g.eps = c.rms_eps; g.xn_out = hn; g.ld_xn = H;
+    g.out = logits_p; g.ldo = V; g.M = S; g.N = V; g.K = H; g.epi = EPI_STORE; g.nt = true;
+    launch_gemv(g, stream);
+    // arm the fused path: logits of the last row -> logits_t[slot], last_hidden -> x_cp[slot][0]
+    launch_copy_rows(logits_p + (size_t)(S - 1) * V, V, logits_t + (size_t)slot * V, V, 1, V, stream);
+    launch_copy_rows(hn + (size_t)(S - 1) * H, H, x_cp + (size_t)slot * 2 * H, H, 1, H, stream);
+    st_h[slot].prompt_len = S;
+    st_h[slot].n_frames = 0;
+    int32_t pos = S;
+    Q3_HIP_CHECK(hipMemcpyAsync(talker_pos_d + slot, &pos, sizeof(int32_t), hipMemcpyHostToDevice, stream));
+    if (logits) Q3_HIP_CHECK(hipMemcpyAsync(logits, logits_p, (size_t)S * V * sizeof(float), hipMemcpyDeviceToHost, stream));
+    if (last_hidden) Q3_HIP_CHECK(hipMemcpyAsync(last_hidden, hn + (size_t)(S - 1) * H, (size_t)H * sizeof(float), hipMemcpyDeviceToHost, stream));
+    sync();
+}
+
+void Engine::talker_decode(int slot, const float* embed, float* logits, float* last_hidden) {
+    if (!finalized) throw Error("weights not finalized");
+    if (slot < 0 || slot >= B) throw Error("slot out of range");
+    const int H = c.hidden, V = c.vocab;
+    int32_t pos = 0;
+    Q3_HIP_CHECK(hipMemcpy(&pos, talker_pos_d + slot, sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (pos >= max_ctx) throw Error("KV cache full");
+    Q3_HIP_CHECK(hipMemcpyAsync(xp, embed, (size_t)H * sizeof(float), hipMemcpyHostToDevice, stream));
+    run_layers(talker, xp, H, 1, 1, slot, nullptr, pos);
+    GemvArgs g;
+    g.W = codec_head; g.x = xp; g.ldx = H; g.gamma = talker_norm; g.eps = c.rms_eps; g.xn_out = hn; g.ld_xn = H;
+    g.out = logits_p; g.ldo = V; g.M = 1; g.N = V; g.K = H; g.epi = EPI_STORE; g.nt = true;
+    launch_gemv(g, stream);
+    launch_copy_rows(logits_p, V, logits_t + (size_t)slot * V, V, 1, V, stream);
+    launch_copy_rows(hn, H, x_cp + (size_t)slot * 2 * H, H, 1, H, stream);
+    pos += 1;
+    Q3_HIP_CHECK(hipMemcpyAsync(talker_pos_d + slot, &pos, sizeof(int32_t), hipMemcpyHostToDevice, stream));
+    if (logits) Q3_HIP_CHECK(hipMemcpyAsync(logits, logits_p, (size_t)V * sizeof(float), hipMemcpyDeviceToHost, stream));
+    if (last_hidden) Q3_HIP_CHECK(hipMemcpyAsync(last_hidden, hn, (size_t)H * sizeof(float), hipMemcpyDeviceToHost, stream));
+    sync();
+}
+
+void Engine::code_predictor(const float* seq, int n, int step, float* logits) {
+    if (!finalized) throw Error("weights not finalized");
+    if (n < 1 || n > 16 || step < 0 || step >= c.n_groups - 1) throw Error("code_predictor arguments out of range");
+    const int H = c.hidden, SV = c.sub_vocab;
+    Q3_HIP_CHECK(hipMemcpyAsync(xp, seq, (size_t)n * H * sizeof(float), hipMemcpyHostToDevice, stream));
+    run_layers(cp, xp, H, 1, n, 0, nullptr, 0); // full causal re-run over the n rows (reference call pattern)
+    GemvArgs g;
+    g.W = cp_head[step]; g.x = xp + (size_t)(n - 1) * H; g.ldx = H; g.gamma = cp_norm; g.eps = c.cp_rms_eps;
+    g.out = logits_p; g.ldo = SV; g.M = 1; g.N = SV; g.K = H; g.epi = EPI_STORE;
+    launch_gemv(g, stream);
+    Q3_HIP_CHECK(hipMemcpyAsync(logits, logits_p, (size_t)SV * sizeof(float), hipMemcpyDeviceToHost, stream));
+    sync();
+}
+
+void Engine::sample(const float* logits, int n, const q3tts_sampling& p, float u, int suppress, int64_t* tok) {
+    if (n < 1 || n > 4096) throw Error("sample: n out of range");
+    Q3_HIP_CHECK(hipMemcpyAsync(logits_p, logits, (size_t)n * sizeof(float), hipMemcpyHostToDevice, stream));
+    SampleArgs a;
+    a.logits = logits_p; a.ld = n; a.V = n; a.nb = 1; a.sup_begin = c.suppress_begin; a.sup_end = c.suppress_end; a.eos_id = c.codec_eos;
+    a.temperature = p.temperature; a.top_p = p.top_p; a.top_k = p.top_k; a.u = u; a.suppress = suppress; a.token_out = tok_d;
+    launch_sample(a, stream);
+    Q3_HIP_CHECK(hipMemcpyAsync(tok, tok_d, sizeof(int64_t), hipMemcpyDeviceToHost, stream));
+    sync();
+}
+
+// build_prompt_embeddings, reference src/tts_onnx.cpp:442-539 (row layout; fp32 adds on the host
+// exactly as the reference does them, network calls on the device)
+void Engine::build_prompt(const int64_t* ids, int n_ids, int lang, const float* speaker, float* prompt, int* S,
+                          float* trailing, int cap_rows, int* n_trailing) {
+    const int H = c.hidden;
+    if (n_ids < 6) throw Error("token sequence too short: need [IM_START, ASSISTANT, TTS_BOS, text..., TTS_EOS, IM_END]");
+    std::vector<float> tts(3 * (size_t)H);
+    const int64_t tts_ids[3] = { TTS_BOS, TTS_EOS, TTS_PAD };
+    text_project(tts_ids, 3, tts.data());                       // :459-463
+    const float *tts_bos = tts.data(), *tts_eos = tts.data() + H, *tts_pad = tts.data() + 2 * H;
+    std::vector<int64_t> cpf;
+    if (lang == 0) cpf = { CODEC_NOTHINK, CODEC_THINK_BOS, CODEC_THINK_EOS };                      // :467-469
+    else cpf = { CODEC_THINK, CODEC_THINK_BOS, LANG_ENGLISH + (lang - 1), CODEC_THINK_EOS };       // :470-474
+    cpf.push_back(CODEC_PAD); cpf.push_back(CODEC_BOS);                                            // :475-476
+    const int ncp = (int)cpf.size();
+    std::vector<float> ce((size_t)(ncp + 1) * H);
+    codec_embed(cpf.data(), ncp, ce.data());                                                       // :478
+    if (speaker) { // speaker row inserted before the last (BOS) row, :481-490
+        memmove(ce.data() + (size_t)ncp * H, ce.data() + (size_t)(ncp - 1) * H, (size_t)H * sizeof(float));
+        memcpy(ce.data() + (size_t)(ncp - 1) * H, speaker, (size_t)H * sizeof(float));
+    }
+    int row = 0;
+    text_project(ids, 3, prompt);                                                                  // :493-494
+    row = 3;
+    const int pad_count = ncp - 2 + (speaker ? 1 : 0);                                             // :497-498
+    for (int i = 0; i <= pad_count; ++i, ++row) {                                                  // :506-512
+        const float* t = i < pad_count ? tts_pad : tts_bos;
+        for (int j = 0; j < H; ++j) prompt[(size_t)row * H + j] = t[j] + ce[(size_t)i * H + j];
+    }
+    const int text_start = 3, text_end = n_ids - 2;                                                // :515-516
+    std::vector<float> ft(H);
+    text_project(ids + text_start, 1, ft.data());                                                  // :518
+    for (int j = 0; j < H; ++j) prompt[(size_t)row * H + j] = ft[j] + ce[(size_t)(pad_count + 1) * H + j]; // :519-520
+    ++row;
+    *S = row;
+    int nt = text_end - (text_start + 1);
+    if (nt < 0) nt = 0;
+    if (nt + 1 > cap_rows) throw Error("text too long for the trailing buffer");
+    if (nt > 0) text_project(ids + text_start + 1, nt, trailing);                                  // :531-534 (row-wise identical to per-token calls)
+    memcpy(trailing + (size_t)nt * H, tts_eos, (size_t)H * sizeof(float));                         // :535
+    *n_trailing = nt + 1;                                                                          // :536
+}
+
+// ------------------------------------------------------------------------------------------------
+// fused generation: one frame = sampler + (n_groups-1) predictor passes + talker decode
+// ------------------------------------------------------------------------------------------------
+void Engine::record_step(int nb) {
+    const int H = c.hidden, V = c.vocab, SV = c.sub_vocab, G = c.n_groups;
+    SampleArgs s0;
+    s0.logits = logits_t; s0.ld = V; s0.V = V; s0.nb = nb; s0.sup_begin = c.suppress_begin; s0.sup_end = c.suppress_end; s0.eos_id = c.codec_eos;
+    s0.group = 0; s0.n_groups = G; s0.st = st_d; s0.embed = codec_embed_w; s0.H = H;
+    s0.x_next = x_cp + H; s0.ld_xnext = 2 * H; s0.sum = sum; s0.x_talk = x_talk; s0.trailing = trailing_d; s0.max_trailing = max_trailing;
+    s0.tts_pad = tts_pad_d; s0.codes = codes_d; s0.max_frames_cap = max_frames_cap; s0.talker_pos = talker_pos_d;
+    launch_sample(s0, stream);                                  // code0 (tts_onnx.cpp:803-812)
+    for (int j = 0; j < G - 1; ++j) {                           // predict_subcodes (:851-872), KV-cached
+        float* xin = j == 0 ? x_cp : x_cp1;
+        if (j == 0) run_layers(cp, x_cp, H, nb, 2, 0, nullptr, 0);        // rows [last_hidden, embed(code0)]
+        else run_layers(cp, x_cp1, H, nb, 1, 0, nullptr, j + 1);
+        GemvArgs g;
+        g.W = cp_head[j]; g.x = j == 0 ? xin + H : xin; g.ldx = j == 0 ? 2 * H : H; g.gamma = cp_norm; g.eps = c.cp_rms_eps;
+        g.out = logits_cp; g.ldo = SV; g.M = nb; g.N = SV; g.K = H; g.epi = EPI_STORE;
+        launch_gemv(g, stream);
+        SampleArgs s = s0;
+        s.logits = logits_cp; s.ld = SV; s.V = SV; s.group = j + 1; s.embed = cp_embed_w[j];
+        s.x_next = j + 1 < G - 1 ? x_cp1 : nullptr; s.ld_xnext = H;
+        launch_sample(s, stream);
+    }
+    run_layers(talker, x_talk, H, nb, 1, 0, talker_pos_d, 0);  // run_decode (:845)
+    GemvArgs g;
+    g.W = codec_head; g.x = x_talk; g.ldx = H; g.gamma = talker_norm; g.eps = c.rms_eps; g.xn_out = x_cp; g.ld_xn = 2 * H;
+    g.out = logits_t; g.ldo = V; g.M = nb; g.N = V; g.K = H; g.epi = EPI_STORE; g.nt = true;
+    launch_gemv(g, stream);
+}
+
+int Engine::nb_in_use() const {
+    int nb = 0;
+    for (int b = 0; b < B; ++b) if (st_h[b].active) nb = b + 1;
+    return nb;
+}
+
+void Engine::slot_begin(int slot, const float* prompt, int S, const float* trailing, int n_trailing,
+                        const q3tts_sampling& p, uint64_t seed, uint32_t stream_id, int ignore_eos) {
+    if (slot < 0 || slot >= B) throw Error("slot out of range");
+    if (n_trailing < 0 || n_trailing > max_trailing) throw Error("too many trailing text rows");
+    if (p.max_new_tokens < 1 || S + p.max_new_tokens > max_ctx) throw Error("prompt + max_new_tokens exceeds max_ctx");
+    const int H = c.hidden;
+    talker_prefill(slot, prompt, S, nullptr, nullptr);
+    if (n_trailing > 0)
+        Q3_HIP_CHECK(hipMemcpyAsync(trailing_d + (size_t)slot * max_trailing * H, trailing, (size_t)n_trailing * H * sizeof(float), hipMemcpyHostToDevice, stream));
+    SlotState& s = st_h[slot];
+    s.n_frames = 0; s.finished = 0; s.active = 1; s.prompt_len = S; s.trailing_len = n_trailing; s.max_frames = p.max_new_tokens;
+    s.top_k = p.top_k; s.ignore_eos = ignore_eos; s.temperature = p.temperature; s.top_p = p.top_p; s.stream_id = stream_id; s.pad0 = 0; s.seed = seed;
+    Q3_HIP_CHECK(hipMemcpyAsync(st_d + slot, &s, sizeof(SlotState), hipMemcpyHostToDevice, stream));
+    sync();
+}
+
+int Engine::decode_steps(int n_steps) {
+    if (!finalized) throw Error("weights not finalized");
+    const int nb = nb_in_use();
+    if (nb == 0) return 0;
+    hipGraphExec_t exec = nullptr;
+    if (!(flags & Q3TTS_FLAG_NO_GRAPH)) {
+        auto it = graphs.find(nb);
+        if (it == graphs.end()) {
+            hipGraph_t graph = nullptr;
+            Q3_HIP_CHECK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+            try { record_step(nb); } catch (...) { (void)hipStreamEndCapture(stream, &graph); if (graph) (void)hipGraphDestroy(graph); throw; }
+            Q3_HIP_CHECK(hipStreamEndCapture(stream, &graph));
+            Q3_HIP_CHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+            Q3_HIP_CHECK(hipGraphDestroy(graph));
+            graphs[nb] = exec;
+        } else exec = it->second;
+    }
+    Q3_HIP_CHECK(hipEventRecord(ev0, stream));
+    for (int i = 0; i < n_steps; ++i) {
+        if (exec) Q3_HIP_CHECK(hipGraphLaunch(exec, stream));
+        else record_step(nb);
+    }
+    Q3_HIP_CHECK(hipEventRecord(ev1, stream));
+    launch_count_active(st_d, nb, active_d, stream);
+    Q3_HIP_CHECK(hipMemcpyAsync(active_h, active_d, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+    sync();
+    Q3_HIP_CHECK(hipEventElapsedTime(&last_decode_ms, ev0, ev1));
+    last_decode_steps = n_steps;
+    return *active_h;
+}
+
+void Engine::slot_status(int slot, int* n_frames, int* finished) {
+    if (slot < 0 || slot >= B) throw Error("slot out of range");
+    SlotState s;
+    Q3_HIP_CHECK(hipMemcpy(&s, st_d + slot, sizeof(SlotState), hipMemcpyDeviceToHost));
+    if (n_frames) *n_frames = s.n_frames;
+    if (finished) *finished = s.finished || s.n_frames >= s.max_frames;
+}
+
+void Engine::slot_codes(int slot, int64_t* codes, int cap_frames) {
+    int nf = 0;
+    slot_status(slot, &nf, nullptr);
+    const int n = std::min(nf, cap_frames), G = c.n_groups;
+    std::vector<int32_t> tmp((size_t)n * G);
+    if (n > 0) Q3_HIP_CHECK(hipMemcpy(tmp.data(), codes_d + (size_t)slot * max_frames_cap * G, tmp.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < tmp.size(); ++i) codes[i] = tmp[i];
+}
+
+void Engine::slot_release(int slot) {
+    if (slot < 0 || slot >= B) throw Error("slot out of range");
+    st_h[slot].active = 0;
+    Q3_HIP_CHECK(hipMemcpy(st_d + slot, &st_h[slot], sizeof(SlotState), hipMemcpyHostToDevice));
+}
+
+int64_t Engine::slot_codec_decode(int slot, float* pcm, int64_t cap) {
+    int nf = 0;
+    slot_status(slot, &nf, nullptr);
+    if (nf <= 0) return 0; // reference returns an empty vector when no frame was generated (tts_onnx.cpp:418)
+    float* pcm_d = nullptr;
+    Q3_HIP_CHECK(hipEventRecord(ev0, stream));
+    const int64_t n = codec_run(codes_d + (size_t)slot * max_frames_cap * c.n_groups, nf, &pcm_d);
+    Q3_HIP_CHECK(hipEventRecord(ev1, stream));
+    const int64_t m = std::min(n, cap);
+    if (m > 0 && pcm) Q3_HIP_CHECK(hipMemcpyAsync(pcm, pcm_d, (size_t)m * sizeof(float), hipMemcpyDeviceToHost, stream));
+    sync();
+    Q3_HIP_CHECK(hipEventElapsedTime(&last_codec_ms, ev0, ev1));
+    return n;
+}
+
+int64_t Engine::codec_decode_host(const int64_t* codes, int F, float* pcm, int64_t cap) {
+    if (!finalized) throw Error("weights not finalized");
+    if (F < 1 || F > max_frames_cap) throw Error("codec_decode: F out of range");
+    const int G = c.n_groups;
+    std::vector<int32_t> tmp((size_t)F * G);
+    for (size_t i = 0; i < tmp.size(); ++i) {
+        if (codes[i] < 0 || codes[i] >= c.cd_codebook) throw Error("codec_decode: code out of range");
+        tmp[i] = (int32_t)codes[i];
+    }
+    int32_t* cd = codes_scratch_d;
+    Q3_HIP_CHECK(hipMemcpyAsync(cd, tmp.data(), tmp.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+    float* pcm_d = nullptr;
+    Q3_HIP_CHECK(hipEventRecord(ev0, stream));
+    const int64_t n = codec_run(cd, F, &pcm_d);
+    Q3_HIP_CHECK(hipEventRecord(ev1, stream));
+    const int64_t m = std::min(n, cap);
+    if (m > 0 && pcm) Q3_HIP_CHECK(hipMemcpyAsync(pcm, pcm_d, (size_t)m * sizeof(float), hipMemcpyDeviceToHost, stream));
+    sync();
+    Q3_HIP_CHECK(hipEventElapsedTime(&last_codec_ms, ev0, ev1));
+    return n;
+}
+
+// Algorithmic bytes of one decode step: every talker weight once, every
+// predictor weight once per pass, plus the KV entries the attention kernels read.
+void Engine::step_bytes(double* wbytes, double* kvbytes) {
+    const double H = c.hidden;
+    auto layer = [&](int nq, int nkv, int d, int ffn) { return 2.0 * (H * (nq + 2.0 * nkv) * d + H * nq * d + 3.0 * H * ffn); };
+    double w = c.n_layers * layer(c.n_heads, c.n_kv_heads, c.head_dim, c.ffn) + 2.0 * H * c.vocab;
+    const int P = c.n_groups - 1;
+    w += P * (c.cp_layers * layer(c.cp_heads, c.cp_kv_heads, c.cp_head_dim, c.cp_ffn) + 2.0 * H * c.sub_vocab);
+    double kv = 0;
+    for (int b = 0; b < B; ++b) {
+        if (!st_h[b].active) continue;
+        int nf = 0;
+        slot_status(b, &nf, nullptr);
+        const double Tt = st_h[b].prompt_len + nf;
+        kv += Tt * c.n_layers * 2.0 * c.n_kv_heads * c.head_dim * 4.0;       // fp32 cache
+        double tp = 0;
+        for (int j = 0; j < P; ++j) tp += j + 2;
+        kv += tp * c.cp_layers * 2.0 * c.cp_kv_heads * c.cp_head_dim * 4.0;
+    }
+    *wbytes = w; *kvbytes = kv;
+}
+
+} // namespace q3

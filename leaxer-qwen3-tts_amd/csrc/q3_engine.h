@@ -1,0 +1,126 @@
+// q3_engine.h — the device-resident engine behind the C-ABI (include/q3tts.h).
+#pragma once
+#include <memory>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "q3_common.h"
+
+namespace q3 {
+
+enum TensorKind { TK_W = 0, TK_NORM = 1, TK_BIAS = 2, TK_SCALE = 3, TK_SNAKE = 4 };
+
+struct Tensor {
+    std::string name;
+    int64_t shape[4] = {0, 0, 0, 0};
+    int ndim = 0;
+    int kind = TK_W;
+    bool bf16 = false;  // storage: bf16 for talker / predictor / text matrices, fp32 otherwise
+    void* dev = nullptr; // may point into a fused parent allocation (qkv)
+    int64_t numel = 0;
+    float synth_std = 0.02f;
+};
+
+struct DecLayerW { // one decoder layer, bf16 matrices
+    const float *in_norm = nullptr, *post_norm = nullptr, *q_norm = nullptr, *k_norm = nullptr;
+    const bf16_t *qkv = nullptr, *o = nullptr, *gate = nullptr, *up = nullptr, *down = nullptr;
+};
+struct DecStack {
+    int H = 0, L = 0, nq = 0, nkv = 0, d = 0, ffn = 0;
+    float eps = 0.f;
+    std::vector<DecLayerW> layers;
+    float *kc = nullptr, *vc = nullptr; // paged cache
+    int* page_table = nullptr;
+    int pages_per_slot = 0, page_shift = 0;
+    float *rope_cos = nullptr, *rope_sin = nullptr;
+    bool nt = false; // weights streamed once per step -> non-temporal loads
+};
+
+struct CodecW; // q3_codec.cpp
+
+class Engine {
+public:
+    Engine(const q3tts_config& cfg, int device, int max_batch, int max_ctx, uint32_t flags);
+    ~Engine();
+
+    q3tts_config c;
+    int device, B, max_ctx;
+    uint32_t flags;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    // ---- weights ----
+    std::vector<Tensor> tensors;
+    std::unordered_map<std::string, int> tindex;
+    std::vector<void*> allocs;
+    bool finalized = false;
+    Tensor& T(const std::string& n);
+    void set_tensor(const std::string& name, const float* data, int64_t n);
+    void get_tensor(const std::string& name, float* out, int64_t n);
+    void fill_synthetic(uint64_t seed);
+    void finalize();
+
+    // ---- session-shaped ops (host I/O) ----
+    void text_project(const int64_t* ids, int n, float* out);
+    void codec_embed(const int64_t* ids, int n, float* out);
+    void cp_embed(int64_t id, int step, float* out);
+    void talker_prefill(int slot, const float* embeds, int S, float* logits, float* last_hidden);
+    void talker_decode(int slot, const float* embed, float* logits, float* last_hidden);
+    void code_predictor(const float* seq, int n, int step, float* logits);
+    void sample(const float* logits, int n, const q3tts_sampling& p, float u, int suppress, int64_t* tok);
+    void build_prompt(const int64_t* ids, int n_ids, int lang, const float* speaker, float* prompt, int* S,
+                      float* trailing, int cap_rows, int* n_trailing);
+    int64_t codec_decode_host(const int64_t* codes, int F, float* pcm, int64_t cap);
+
+    // ---- fused generation ----
+    void slot_begin(int slot, const float* prompt, int S, const float* trailing, int n_trailing,
+                    const q3tts_sampling& p, uint64_t seed, uint32_t stream_id, int ignore_eos);
+    int decode_steps(int n_steps);
+    void slot_status(int slot, int* n_frames, int* finished);
+    void slot_codes(int slot, int64_t* codes, int cap_frames);
+    int64_t slot_codec_decode(int slot, float* pcm, int64_t cap);
+    void slot_release(int slot);
+    void step_bytes(double* wbytes, double* kvbytes);
+
+    float last_decode_ms = 0.f;
+    int last_decode_steps = 0;
+    float last_codec_ms = 0.f;
+
+    // ---- codec decoder (q3_codec.cpp) ----
+    CodecW* codec = nullptr;
+    void codec_finalize();
+    int64_t codec_run(const int32_t* codes_dev, int F, float** pcm_dev); // returns sample count
+    void codec_free();
+
+    // ---- internals ----
+    DecStack talker, cp;
+    const float* talker_norm = nullptr; const bf16_t* codec_head = nullptr; const bf16_t* codec_embed_w = nullptr;
+    const bf16_t *text_embed = nullptr, *fc1_w = nullptr, *fc2_w = nullptr; const float *fc1_b = nullptr, *fc2_b = nullptr;
+    const float* cp_norm = nullptr;
+    std::vector<const bf16_t*> cp_head, cp_embed_w;
+
+    int rows_max = 0, max_trailing = 0, max_frames_cap = 0;
+    float *x_talk = nullptr, *qkv = nullptr, *attn = nullptr, *act = nullptr, *logits_t = nullptr, *logits_cp = nullptr;
+    float *x_cp = nullptr, *x_cp1 = nullptr, *sum = nullptr, *xp = nullptr, *hn = nullptr, *logits_p = nullptr;
+    float *trailing_d = nullptr, *tts_pad_d = nullptr, *text_tmp = nullptr, *text_tmp2 = nullptr;
+    int64_t* ids_d = nullptr;
+    int32_t* codes_d = nullptr;
+    int32_t* codes_scratch_d = nullptr;
+    int32_t* talker_pos_d = nullptr;
+    SlotState* st_d = nullptr;
+    std::vector<SlotState> st_h;
+    int32_t* active_d = nullptr;
+    int32_t* active_h = nullptr; // pinned
+    int64_t* tok_d = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::unordered_map<int, hipGraphExec_t> graphs; // keyed by nb
+
+    void* dmalloc(size_t bytes);
+    void run_layers(const DecStack& W, float* x, int ldx, int nb, int n_new, int slot_offset, const int* pos_dev, int pos_scalar);
+    void record_step(int nb);
+    int nb_in_use() const;
+    void sync();
+};
+
+} // namespace q3

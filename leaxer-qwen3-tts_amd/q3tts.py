@@ -1,0 +1,351 @@
+"""ctypes binding of libq3tts_hip.so (C-ABI: include/q3tts.h).
+
+Host-side mirror of the reference's TTSEngine run_* family (reference src/tts_onnx.h:196-212) plus
+the batched generation entry points.  There is NO CPU fallback: if the HIP library is missing or
+no MI355X is visible, construction raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libq3tts_hip.so")
+
+_CFG_FIELDS = [
+    ("hidden", C.c_int32), ("n_layers", C.c_int32), ("n_heads", C.c_int32), ("n_kv_heads", C.c_int32),
+    ("head_dim", C.c_int32), ("ffn", C.c_int32), ("vocab", C.c_int32),
+    ("rope_theta", C.c_float), ("rms_eps", C.c_float),
+    ("cp_layers", C.c_int32), ("cp_heads", C.c_int32), ("cp_kv_heads", C.c_int32), ("cp_head_dim", C.c_int32),
+    ("cp_ffn", C.c_int32), ("n_groups", C.c_int32), ("sub_vocab", C.c_int32),
+    ("cp_rope_theta", C.c_float), ("cp_rms_eps", C.c_float),
+    ("text_vocab", C.c_int32), ("text_hidden", C.c_int32),
+    ("cd_codebook", C.c_int32), ("cd_hidden", C.c_int32), ("cd_layers", C.c_int32), ("cd_heads", C.c_int32),
+    ("cd_head_dim", C.c_int32), ("cd_ffn", C.c_int32), ("cd_window", C.c_int32),
+    ("cd_rope_theta", C.c_float), ("cd_rms_eps", C.c_float),
+    ("cd_n_up", C.c_int32), ("cd_up_ratios", C.c_int32 * 4),
+    ("cd_decoder_dim", C.c_int32), ("cd_n_blocks", C.c_int32), ("cd_up_rates", C.c_int32 * 8),
+    ("cd_tconv_trim", C.c_int32),
+    ("codec_eos", C.c_int32), ("suppress_begin", C.c_int32), ("suppress_end", C.c_int32),
+]
+
+
+class Config(C.Structure):
+    _fields_ = _CFG_FIELDS
+
+    def to_dict(self):
+        d = {}
+        for n, _ in _CFG_FIELDS:
+            v = getattr(self, n)
+            d[n] = list(v) if hasattr(v, "__len__") else v
+        return d
+
+    @classmethod
+    def from_dict(cls, d):
+        c = cls()
+        for n, t in _CFG_FIELDS:
+            v = d[n]
+            if hasattr(t, "_length_"):
+                arr = t()
+                for i, x in enumerate(v):
+                    arr[i] = x
+                setattr(c, n, arr)
+            else:
+                setattr(c, n, v)
+        return c
+
+
+class Sampling(C.Structure):
+    """SamplingParams, reference src/tts_onnx.h:99-105."""
+    _fields_ = [("temperature", C.c_float), ("top_p", C.c_float), ("top_k", C.c_int32),
+                ("repetition_penalty", C.c_float), ("max_new_tokens", C.c_int32)]
+
+    def __init__(self, temperature=0.8, top_p=0.95, top_k=50, repetition_penalty=1.0, max_new_tokens=2048):
+        super().__init__(temperature, top_p, top_k, repetition_penalty, max_new_tokens)
+
+
+FLAG_NO_GRAPH = 1
+
+# every symbol include/q3tts.h declares
+EXPORTS = [
+    "q3tts_default_config", "q3tts_create", "q3tts_destroy", "q3tts_last_error", "q3tts_num_tensors",
+    "q3tts_tensor_info", "q3tts_set_tensor_host", "q3tts_get_tensor_host", "q3tts_fill_synthetic", "q3tts_finalize",
+    "q3tts_text_project_host", "q3tts_codec_embed_host", "q3tts_cp_embed_host", "q3tts_talker_prefill_host",
+    "q3tts_talker_decode_host", "q3tts_code_predictor_host", "q3tts_codec_decode_host", "q3tts_codec_decode_len",
+    "q3tts_sample_host", "q3tts_rng_uniform", "q3tts_build_prompt_host", "q3tts_slot_begin", "q3tts_decode_steps",
+    "q3tts_slot_status", "q3tts_slot_codes_host", "q3tts_slot_codec_decode_host", "q3tts_slot_release",
+    "q3tts_synthesize_batch_host", "q3tts_last_decode_ms", "q3tts_last_codec_ms", "q3tts_decode_step_bytes",
+]
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: build it with `python leaxer-qwen3-tts_amd/build.py` "
+                           "(there is no CPU fallback)")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
+    L.q3tts_default_config.argtypes = [C.c_char_p, C.POINTER(Config)]
+    L.q3tts_create.restype = vp
+    L.q3tts_create.argtypes = [C.POINTER(Config), i32, i32, i32, C.c_uint32]
+    L.q3tts_destroy.argtypes = [vp]
+    L.q3tts_last_error.restype = C.c_char_p
+    L.q3tts_last_error.argtypes = [vp]
+    L.q3tts_num_tensors.argtypes = [vp]
+    L.q3tts_tensor_info.argtypes = [vp, i32, C.c_char_p, i32, C.POINTER(i64), C.POINTER(i32)]
+    L.q3tts_set_tensor_host.argtypes = [vp, C.c_char_p, vp, i64]
+    L.q3tts_get_tensor_host.argtypes = [vp, C.c_char_p, vp, i64]
+    L.q3tts_fill_synthetic.argtypes = [vp, C.c_uint64]
+    L.q3tts_finalize.argtypes = [vp]
+    L.q3tts_text_project_host.argtypes = [vp, vp, i32, vp]
+    L.q3tts_codec_embed_host.argtypes = [vp, vp, i32, vp]
+    L.q3tts_cp_embed_host.argtypes = [vp, i64, i32, vp]
+    L.q3tts_talker_prefill_host.argtypes = [vp, i32, vp, i32, vp, vp]
+    L.q3tts_talker_decode_host.argtypes = [vp, i32, vp, vp, vp]
+    L.q3tts_code_predictor_host.argtypes = [vp, vp, i32, i32, vp]
+    L.q3tts_codec_decode_host.argtypes = [vp, vp, i32, vp, i64, C.POINTER(i64)]
+    L.q3tts_codec_decode_len.restype = i64
+    L.q3tts_codec_decode_len.argtypes = [C.POINTER(Config), i32]
+    L.q3tts_sample_host.argtypes = [vp, vp, i32, C.POINTER(Sampling), f32, i32, C.POINTER(i64)]
+    L.q3tts_rng_uniform.restype = f32
+    L.q3tts_rng_uniform.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]
+    L.q3tts_build_prompt_host.argtypes = [vp, vp, i32, i32, vp, vp, C.POINTER(i32), vp, i32, C.POINTER(i32)]
+    L.q3tts_slot_begin.argtypes = [vp, i32, vp, i32, vp, i32, C.POINTER(Sampling), C.c_uint64, C.c_uint32, i32]
+    L.q3tts_decode_steps.argtypes = [vp, i32]
+    L.q3tts_slot_status.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(i32)]
+    L.q3tts_slot_codes_host.argtypes = [vp, i32, vp, i32]
+    L.q3tts_slot_codec_decode_host.argtypes = [vp, i32, vp, i64, C.POINTER(i64)]
+    L.q3tts_slot_release.argtypes = [vp, i32]
+    L.q3tts_synthesize_batch_host.argtypes = [vp, i32, vp, vp, i32, C.POINTER(Sampling), C.c_uint64, i32,
+                                              vp, i64, vp, vp, vp]
+    L.q3tts_last_decode_ms.argtypes = [vp, C.POINTER(f32), C.POINTER(i32)]
+    L.q3tts_last_codec_ms.argtypes = [vp, C.POINTER(f32)]
+    L.q3tts_decode_step_bytes.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    _lib = L
+    return L
+
+
+def default_config(name="0.6b"):
+    c = Config()
+    if lib().q3tts_default_config(name.encode(), C.byref(c)) != 0:
+        raise ValueError(f"unknown config {name!r}")
+    return c
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Engine:
+    """One engine = one GPU, `max_batch` utterance slots, device-resident weights + KV cache."""
+
+    def __init__(self, cfg, device=0, max_batch=1, max_ctx=2304, flags=0):
+        self.L = lib()
+        self.cfg = cfg
+        self.max_batch = max_batch
+        self.max_ctx = max_ctx
+        self.h = self.L.q3tts_create(C.byref(cfg), device, max_batch, max_ctx, flags)
+        if not self.h:
+            raise RuntimeError("q3tts_create failed: " + self.L.q3tts_last_error(None).decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.q3tts_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc < 0:
+            raise RuntimeError(self.L.q3tts_last_error(self.h).decode())
+        return rc
+
+    # ---- weights ----
+    def tensor_infos(self):
+        out = []
+        name = C.create_string_buffer(128)
+        shape = (C.c_int64 * 4)()
+        nd = C.c_int(0)
+        for i in range(self.L.q3tts_num_tensors(self.h)):
+            self._ck(self.L.q3tts_tensor_info(self.h, i, name, 128, shape, C.byref(nd)))
+            out.append((name.value.decode(), tuple(shape[k] for k in range(nd.value))))
+        return out
+
+    def set_tensor(self, name, arr):
+        a = np.ascontiguousarray(arr, dtype=np.float32)
+        self._ck(self.L.q3tts_set_tensor_host(self.h, name.encode(), _p(a), a.size))
+
+    def get_tensor(self, name, shape):
+        out = np.empty(shape, np.float32)
+        self._ck(self.L.q3tts_get_tensor_host(self.h, name.encode(), _p(out), out.size))
+        return out
+
+    def load(self, weights):
+        for k, v in weights.items():
+            self.set_tensor(k, v)
+        self.finalize()
+
+    def fill_synthetic(self, seed=0):
+        self._ck(self.L.q3tts_fill_synthetic(self.h, seed))
+        self.finalize()
+
+    def finalize(self):
+        self._ck(self.L.q3tts_finalize(self.h))
+
+    # ---- session-shaped ----
+    def text_project(self, ids):
+        ids = np.ascontiguousarray(ids, dtype=np.int64)
+        out = np.empty((ids.size, self.cfg.hidden), np.float32)
+        self._ck(self.L.q3tts_text_project_host(self.h, _p(ids), ids.size, _p(out)))
+        return out
+
+    def codec_embed(self, ids):
+        ids = np.ascontiguousarray(ids, dtype=np.int64)
+        out = np.empty((ids.size, self.cfg.hidden), np.float32)
+        self._ck(self.L.q3tts_codec_embed_host(self.h, _p(ids), ids.size, _p(out)))
+        return out
+
+    def cp_embed(self, tok, step):
+        out = np.empty(self.cfg.hidden, np.float32)
+        self._ck(self.L.q3tts_cp_embed_host(self.h, int(tok), int(step), _p(out)))
+        return out
+
+    def prefill(self, embeds, slot=0):
+        e = np.ascontiguousarray(embeds, dtype=np.float32)
+        S = e.shape[0]
+        logits = np.empty((S, self.cfg.vocab), np.float32)
+        lh = np.empty(self.cfg.hidden, np.float32)
+        self._ck(self.L.q3tts_talker_prefill_host(self.h, slot, _p(e), S, _p(logits), _p(lh)))
+        return logits, lh
+
+    def decode(self, embed, slot=0):
+        e = np.ascontiguousarray(embed, dtype=np.float32)
+        logits = np.empty(self.cfg.vocab, np.float32)
+        lh = np.empty(self.cfg.hidden, np.float32)
+        self._ck(self.L.q3tts_talker_decode_host(self.h, slot, _p(e), _p(logits), _p(lh)))
+        return logits, lh
+
+    def code_predictor(self, seq, step):
+        s = np.ascontiguousarray(seq, dtype=np.float32)
+        logits = np.empty(self.cfg.sub_vocab, np.float32)
+        self._ck(self.L.q3tts_code_predictor_host(self.h, _p(s), s.shape[0], int(step), _p(logits)))
+        return logits
+
+    def codec_decode_len(self, F):
+        return int(self.L.q3tts_codec_decode_len(C.byref(self.cfg), F))
+
+    def codec_decode(self, codes):
+        c = np.ascontiguousarray(codes, dtype=np.int64)
+        n = self.codec_decode_len(c.shape[0])
+        pcm = np.empty(n, np.float32)
+        out_len = C.c_int64(0)
+        self._ck(self.L.q3tts_codec_decode_host(self.h, _p(c), c.shape[0], _p(pcm), n, C.byref(out_len)))
+        return pcm[: out_len.value]
+
+    def sample(self, logits, sp, u, suppress=False):
+        a = np.ascontiguousarray(logits, dtype=np.float32)
+        tok = C.c_int64(0)
+        self._ck(self.L.q3tts_sample_host(self.h, _p(a), a.size, C.byref(sp), C.c_float(u), int(suppress), C.byref(tok)))
+        return int(tok.value)
+
+    def build_prompt(self, ids, lang=0, speaker=None, cap_rows=1024):
+        ids = np.ascontiguousarray(ids, dtype=np.int64)
+        prompt = np.zeros((16, self.cfg.hidden), np.float32)
+        trailing = np.zeros((cap_rows, self.cfg.hidden), np.float32)
+        S, nt = C.c_int(0), C.c_int(0)
+        sp = np.ascontiguousarray(speaker, dtype=np.float32) if speaker is not None else None
+        self._ck(self.L.q3tts_build_prompt_host(self.h, _p(ids), ids.size, lang, _p(sp) if sp is not None else None,
+                                                _p(prompt), C.byref(S), _p(trailing), cap_rows, C.byref(nt)))
+        return prompt[: S.value].copy(), trailing[: nt.value].copy()
+
+    # ---- fused generation ----
+    def slot_begin(self, slot, prompt, trailing, sp, seed=0, stream_id=0, ignore_eos=False):
+        p = np.ascontiguousarray(prompt, dtype=np.float32)
+        t = np.ascontiguousarray(trailing, dtype=np.float32)
+        self._ck(self.L.q3tts_slot_begin(self.h, slot, _p(p), p.shape[0], _p(t), t.shape[0], C.byref(sp), seed,
+                                         stream_id, int(ignore_eos)))
+
+    def decode_steps(self, n):
+        return self._ck(self.L.q3tts_decode_steps(self.h, n))
+
+    def slot_status(self, slot):
+        nf, fin = C.c_int(0), C.c_int(0)
+        self._ck(self.L.q3tts_slot_status(self.h, slot, C.byref(nf), C.byref(fin)))
+        return nf.value, bool(fin.value)
+
+    def slot_codes(self, slot):
+        nf, _ = self.slot_status(slot)
+        codes = np.zeros((max(nf, 1), self.cfg.n_groups), np.int64)
+        self._ck(self.L.q3tts_slot_codes_host(self.h, slot, _p(codes), nf))
+        return codes[:nf]
+
+    def slot_codec_decode(self, slot):
+        nf, _ = self.slot_status(slot)
+        n = self.codec_decode_len(nf) if nf > 0 else 0
+        pcm = np.empty(max(n, 1), np.float32)
+        out_len = C.c_int64(0)
+        self._ck(self.L.q3tts_slot_codec_decode_host(self.h, slot, _p(pcm), n, C.byref(out_len)))
+        return pcm[: out_len.value]
+
+    def slot_release(self, slot):
+        self._ck(self.L.q3tts_slot_release(self.h, slot))
+
+    def generate(self, prompt, trailing, sp, seed=0, stream_id=0, ignore_eos=False, slot=0, chunk=32):
+        """generate_codes (reference src/tts_onnx.cpp:782-849) for one utterance on the fused path."""
+        self.slot_begin(slot, prompt, trailing, sp, seed, stream_id, ignore_eos)
+        left = sp.max_new_tokens
+        while left > 0:
+            n = min(chunk, left)
+            active = self.decode_steps(n)
+            left -= n
+            if active == 0:
+                break
+        codes = self.slot_codes(slot)
+        return codes
+
+    def synthesize_batch(self, token_lists, sp, lang=0, seed=0, ignore_eos=False, want_codes=True):
+        """synthesize_tokens (reference src/tts_onnx.cpp:405-436) for a batch of utterances."""
+        n = len(token_lists)
+        flat = np.ascontiguousarray(np.concatenate([np.asarray(t, np.int64) for t in token_lists]))
+        offs = np.zeros(n + 1, np.int32)
+        offs[1:] = np.cumsum([len(t) for t in token_lists])
+        cap = self.codec_decode_len(sp.max_new_tokens)
+        pcm = [np.zeros(cap, np.float32) for _ in range(n)]
+        ptrs = (C.c_void_p * n)(*[a.ctypes.data for a in pcm])
+        pcm_len = np.zeros(n, np.int64)
+        nfr = np.zeros(n, np.int32)
+        codes = np.zeros((n, sp.max_new_tokens, self.cfg.n_groups), np.int64) if want_codes else None
+        self._ck(self.L.q3tts_synthesize_batch_host(self.h, n, _p(flat), _p(offs), lang, C.byref(sp), seed, int(ignore_eos),
+                                                    C.cast(ptrs, C.c_void_p), cap, _p(pcm_len), _p(nfr),
+                                                    _p(codes) if want_codes else None))
+        outs = [pcm[i][: pcm_len[i]] for i in range(n)]
+        cl = [codes[i, : nfr[i]] for i in range(n)] if want_codes else None
+        return outs, cl, nfr
+
+    # ---- measurement ----
+    def last_decode_ms(self):
+        ms, st = C.c_float(0), C.c_int(0)
+        self._ck(self.L.q3tts_last_decode_ms(self.h, C.byref(ms), C.byref(st)))
+        return ms.value, st.value
+
+    def last_codec_ms(self):
+        ms = C.c_float(0)
+        self._ck(self.L.q3tts_last_codec_ms(self.h, C.byref(ms)))
+        return ms.value
+
+    def decode_step_bytes(self):
+        w, kv = C.c_double(0), C.c_double(0)
+        self._ck(self.L.q3tts_decode_step_bytes(self.h, C.byref(w), C.byref(kv)))
+        return w.value, kv.value
+
+
+def rng_uniform(seed, stream, frame, group):
+    return float(lib().q3tts_rng_uniform(seed, stream, frame, group))

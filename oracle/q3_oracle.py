@@ -80,9 +80,11 @@ def config_06b():
 
 
 def config_tiny():
-    """Small config with the same structure; every kernel path is exercised in seconds on CPU."""
+    """Small config with the same structure; every kernel path is exercised in seconds on CPU.
+    The codec vocabulary keeps the real control-token ids (2148..2157, tts_onnx.h:50-56) so prompt
+    assembly runs unchanged; code0 is confined to [0,64) + EOS so that EOS is actually reachable."""
     return Config.from_dict(dict(
-        hidden=64, n_layers=2, n_heads=4, n_kv_heads=2, head_dim=16, ffn=96, vocab=96,
+        hidden=64, n_layers=2, n_heads=4, n_kv_heads=2, head_dim=16, ffn=96, vocab=2176,
         rope_theta=1e6, rms_eps=1e-6,
         cp_layers=2, cp_heads=4, cp_kv_heads=2, cp_head_dim=16, cp_ffn=96, n_groups=16, sub_vocab=64,
         cp_rope_theta=1e6, cp_rms_eps=1e-6,
@@ -91,7 +93,7 @@ def config_tiny():
         cd_rope_theta=10000.0, cd_rms_eps=1e-5,
         cd_n_up=2, cd_up_ratios=[2, 2, 0, 0], cd_decoder_dim=64, cd_n_blocks=4,
         cd_up_rates=[8, 5, 4, 3, 0, 0, 0, 0], cd_tconv_trim=0,
-        codec_eos=70, suppress_begin=64, suppress_end=96))
+        codec_eos=2150, suppress_begin=64, suppress_end=2176))
 
 
 def tensor_specs(cfg):

@@ -1,0 +1,140 @@
+"""CPU-only tests: oracle host logic (sampler, prompt layout, generation loop), C-ABI surface.
+Expected values are derived by hand from the reference source (file:line cited inline)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import q3_oracle as qo
+from util import frame_tokens
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    cfg = qo.config_tiny()
+    o = qo.Oracle(cfg, max_ctx=128, weights=qo.random_weights(cfg, 0))
+    yield o
+    o.close()
+
+
+def test_top_k_keeps_ties():
+    # tts_onnx.cpp:922-926: threshold = k-th largest, only x < threshold is dropped
+    x = np.array([0.1, 2.0, 1.9, -1.0, 2.0, 0.5], np.float32)
+    qo.lib().q3o_top_k_filter(x.ctypes.data_as(ctypes.c_void_p), 6, 1)
+    assert np.isinf(x[[0, 2, 3, 5]]).all() and x[1] == 2.0 and x[4] == 2.0
+    y = np.array([3.0, 1.0, 2.0], np.float32)
+    qo.lib().q3o_top_k_filter(y.ctypes.data_as(ctypes.c_void_p), 3, 3)  # k >= n: untouched (:918)
+    assert np.array_equal(y, [3.0, 1.0, 2.0])
+
+
+def test_top_p_keeps_crossing_element():
+    # :939-944: the element whose cumulative sum first exceeds p is kept
+    p = np.array([0.5, 0.3, 0.15, 0.05], np.float32)
+    qo.lib().q3o_top_p_filter(p.ctypes.data_as(ctypes.c_void_p), 4, ctypes.c_float(0.6))
+    assert np.array_equal(p, np.array([0.5, 0.3, 0, 0], np.float32))
+    q = np.array([0.1, 0.2, 0.3, 0.4], np.float32)
+    qo.lib().q3o_top_p_filter(q.ctypes.data_as(ctypes.c_void_p), 4, ctypes.c_float(1.0))  # p >= 1: no-op (:930)
+    assert np.array_equal(q, np.array([0.1, 0.2, 0.3, 0.4], np.float32))
+
+
+def test_temperature_zero_is_not_greedy(oracle):
+    # :882 skips the division when temperature == 0, so sampling proceeds at T=1
+    lg = np.array([0.0, 1.0, 0.5, 0.2], np.float32)
+    sp = qo.Sampling(temperature=0.0, top_p=1.0, top_k=0)
+    picks = [oracle.sample(lg, sp, (i + 0.5) / 400) for i in range(400)]
+    counts = np.bincount(picks, minlength=4) / 400
+    expect = np.exp(lg) / np.exp(lg).sum()
+    assert np.abs(counts - expect).max() < 0.01
+    greedy = qo.Sampling(temperature=0.0, top_p=1.0, top_k=1)
+    assert all(oracle.sample(lg, greedy, u) == 1 for u in (0.0, 0.3, 0.999))
+
+
+def test_rng_uniform_range_and_determinism():
+    u = [qo.rng_uniform(7, 1, f, g) for f in range(50) for g in range(16)]
+    assert min(u) >= 0.0 and max(u) < 1.0 and len(set(u)) > 790
+    assert qo.rng_uniform(7, 1, 3, 4) == qo.rng_uniform(7, 1, 3, 4) != qo.rng_uniform(8, 1, 3, 4)
+
+
+def test_prompt_layout(oracle):
+    # tts_onnx.cpp:442-539: Auto -> 8 rows, explicit language -> 9, +1 with a speaker row
+    H = oracle.cfg.hidden
+    ids = frame_tokens([10, 20, 30, 40])
+    p = oracle.build_prompt(ids, 0)
+    assert p.shape == (8, H)
+    tts = oracle.text_project([151672, 151673, 151671])  # bos, eos, pad (:459-463)
+    role = oracle.text_project(ids[:3])
+    assert np.array_equal(p[:3], role)                                     # :493-494
+    trailing, pad = oracle.trailing()
+    assert np.array_equal(pad, tts[2])
+    assert trailing.shape == (4, H)                                        # 3 remaining text tokens + tts_eos (:531-536)
+    assert np.array_equal(trailing[-1], tts[1])
+    assert np.array_equal(trailing[0], oracle.text_project([20])[0])
+    assert oracle.build_prompt(ids, 1).shape == (9, H)
+    assert oracle.build_prompt(ids, 0, speaker=np.ones(H, np.float32)).shape == (9, H)
+
+
+def test_prompt_rows_are_sums(oracle):
+    o = oracle
+    H = o.cfg.hidden
+    ids = frame_tokens([10, 20, 30])
+    p = o.build_prompt(ids, 3)  # Japanese -> [THINK, THINK_BOS, 2052, THINK_EOS, PAD, BOS]
+    tts = o.text_project([151672, 151673, 151671])
+    ce = o.codec_embed([2154, 2156, 2052, 2157, 2148, 2149])
+    assert p.shape == (10 - 1, H)
+    for i in range(4):
+        assert np.array_equal(p[3 + i], tts[2] + ce[i])                    # tts_pad + codec row (:506-512)
+    assert np.array_equal(p[7], tts[0] + ce[4])                            # tts_bos + CODEC_PAD row
+    assert np.array_equal(p[8], o.text_project([10])[0] + ce[5])           # first text + CODEC_BOS (:515-520)
+
+
+def test_generate_cached_equals_uncached_and_eos(oracle):
+    ids = frame_tokens([1, 2, 3, 4, 5])
+    p = oracle.build_prompt(ids, 0)
+    sp = qo.Sampling(temperature=1.0, top_p=1.0, top_k=0, max_new_tokens=30)
+    a = oracle.generate(p, sp, seed=4, stream=0, cp_cached=True)
+    b = oracle.generate(p, sp, seed=4, stream=0, cp_cached=False)
+    assert np.array_equal(a, b)
+    assert (a[:, 0] < 64).all()                            # suppressed ids never sampled (:803-807)
+    assert (a[:, 0] != 2150).all()                           # EOS ends generation, never recorded (:812)
+    c = oracle.generate(p, sp, seed=4, stream=0, ignore_eos=True)
+    assert len(c) == 30 and len(a) < 30 and (c[:, 0] < 64).all()   # benchmark mode never stops early
+
+
+def test_vocoder_length_formula():
+    cfg = qo.config_06b()
+    # transformers Code2Wav trims k-s on both sides of every decoder transposed conv: F=1 -> 1365
+    assert qo.lib().q3o_vocoder_len(ctypes.byref(cfg), 1) == 1365
+    cfg.cd_tconv_trim = 1
+    assert qo.lib().q3o_vocoder_len(ctypes.byref(cfg), 3) == 3 * 1920
+
+
+def test_capi_exports_every_declared_symbol():
+    import q3tts
+    hdr = open(os.path.join(ROOT, "include", "q3tts.h")).read()
+    declared = set(re.findall(r"\b(q3tts_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(q3tts.EXPORTS), declared ^ set(q3tts.EXPORTS)
+    L = ctypes.CDLL(q3tts.LIB_PATH)
+    for name in declared:
+        assert hasattr(L, name), name
+
+
+def test_default_config_matches_reference_constants():
+    import q3tts
+    c = q3tts.default_config("0.6b")
+    # reference src/tts_onnx.h:31-37, :51
+    assert (c.hidden, c.n_layers, c.n_kv_heads, c.head_dim, c.vocab, c.n_groups, c.sub_vocab) == (1024, 28, 8, 128, 3072, 16, 2048)
+    assert c.codec_eos == 2150 and (c.suppress_begin, c.suppress_end) == (2048, 3072)
+    assert c.to_dict() == qo.config_06b().to_dict()
+
+
+def test_no_cpu_fallback():
+    import q3tts
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError, match="no HIP device|q3tts_create failed"):
+        q3tts.Engine(q3tts.default_config(), device=0)
