@@ -1,0 +1,190 @@
+"""bench.py — headline metric of BASELINE.json: real-time factor (24 kHz audio seconds / wall seconds)
+and codec-frames/sec of Qwen3-TTS-0.6B synthesis on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--frames F]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one pass of the whole hot path over one batch of B utterances per GPU: prompt assembly,
+talker prefill, F frames of [sampler + 15 code-predictor passes + talker decode] replayed from a
+hipGraph, then the 12 Hz codec decode to 24 kHz PCM.  Default workload = BASELINE.json configs[1]:
+0.6B, batch 1, sampled (temp 0.8 / top-k 50 / top-p 0.95), max-tokens 2048, 16-token prompt; weights
+are seeded synthetic (no checkpoint in the image), EOS is suppressed so every utterance runs the full
+2048 frames (random weights never learnt to stop).  Multi-GPU: utterances are independent, each rank
+runs its own batch on its own GPU (weak scaling); RCCL carries only the final gather of codes.
+
+Rank 0 prints ONE JSON line.  `roofline` is for the decode step (the hipGraph replayed per frame):
+algorithmic bytes / device time measured with HIP events on the engine's stream.
+`cpu_baseline` times the CPU oracle (a port of the reference's call pattern, fp32) on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in ("leaxer-qwen3-tts_amd", "oracle", "tests"):
+    sys.path.insert(0, os.path.join(ROOT, p))
+
+import numpy as np  # noqa: E402
+
+FRAME_SECONDS = 0.08  # 12.5 Hz codec frames
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def algorithmic_step_bytes(cfg, batch, avg_ctx):
+    """talker weights once + predictor weights once per pass (bf16) + bf16-equivalent
+    KV bytes the attention must read (B x T x 2 x L x n_kv x d x 2 B)."""
+    H = cfg.hidden
+
+    def layer(nq, nkv, d, ffn):
+        return 2.0 * (H * (nq + 2 * nkv) * d + H * nq * d + 3 * H * ffn)
+    w = cfg.n_layers * layer(cfg.n_heads, cfg.n_kv_heads, cfg.head_dim, cfg.ffn) + 2.0 * H * cfg.vocab
+    w += (cfg.n_groups - 1) * (cfg.cp_layers * layer(cfg.cp_heads, cfg.cp_kv_heads, cfg.cp_head_dim, cfg.cp_ffn)
+                               + 2.0 * H * cfg.sub_vocab)
+    kv = batch * avg_ctx * cfg.n_layers * 2.0 * cfg.n_kv_heads * cfg.head_dim * 2.0
+    return w + kv
+
+
+def cpu_baseline(eng, cfg, ids, sp_kwargs, frames):
+    """Times the CPU oracle (oracle/, fp32, OpenMP) on a bounded sample of the same workload: prompt
+    assembly + prefill + `frames` frames in the REFERENCE's call pattern (predictor re-run without a
+    KV cache, tts_onnx.cpp:862-868) + vocoder of those frames.  The oracle is only the checker /
+    baseline here; nothing measured as `value` touches it."""
+    import q3_oracle as qo
+    ocfg = qo.Config.from_dict(cfg.to_dict())
+    orc = qo.Oracle(ocfg, max_ctx=64)
+    for name, shape in eng.tensor_infos():
+        orc.set_tensor(name, eng.get_tensor(name, shape))
+    threads = orc.threads
+    sp = qo.Sampling(max_new_tokens=frames, **sp_kwargs)
+    t0 = time.perf_counter()
+    prompt = orc.build_prompt(ids, 0)
+    codes = orc.generate(prompt, sp, seed=3, stream=0, cp_cached=False, ignore_eos=True)
+    pcm = orc.vocoder(codes)
+    dt = time.perf_counter() - t0
+    orc.close()
+    return {"value": round(len(codes) * FRAME_SECONDS / dt, 5), "unit": "x real-time (audio s / wall s)", "cores": threads,
+            "kind": "port", "frames_per_s": round(len(codes) / dt, 3),
+            "sample": f"1 utterance, 16-token prompt, prefill + {len(codes)} frames (reference call pattern, no predictor KV cache) "
+                      f"+ vocoder of {len(codes)} frames ({len(pcm)} samples), fp32 oracle, {dt:.1f} s wall; "
+                      "reference ORT-CPU baseline unavailable (no onnxruntime / models in image)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=1, help="utterances per GPU per step (configs[1]: 1, configs[2]: 64)")
+    ap.add_argument("--frames", type=int, default=2048, help="max-tokens per utterance")
+    ap.add_argument("--greedy", action="store_true", help="top_k=1 instead of the sampled default")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=12)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    torch = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))  # RCCL on ROCm
+
+    import q3tts
+    cfg = q3tts.default_config("0.6b")
+    B, F = args.batch, args.frames
+    eng = q3tts.Engine(cfg, device=local_rank, max_batch=B, max_ctx=F + 32)
+    eng.fill_synthetic(seed=0)
+    sp_kwargs = dict(temperature=1.0, top_p=1.0, top_k=1) if args.greedy else dict(temperature=0.8, top_p=0.95, top_k=50)
+    sp = q3tts.Sampling(max_new_tokens=F, **sp_kwargs)
+    rng = np.random.default_rng(1 + rank)
+    IM_START, ASSISTANT, TTS_BOS, TTS_EOS, IM_END = 151644, 77091, 151672, 151673, 151645
+    toks = [np.array([IM_START, ASSISTANT, TTS_BOS] + list(rng.integers(0, 151643, 16)) + [TTS_EOS, IM_END], np.int64)
+            for _ in range(B)]
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def step(i):
+        pcm, codes, nfr = eng.synthesize_batch(toks, sp, lang=0, seed=100 + i, ignore_eos=True, want_codes=True)
+        if dist is not None:  # the only exchange on the path: gather of the generated codes (RCCL over xGMI)
+            t = torch.from_numpy(np.stack([c.astype(np.int32) for c in codes])).cuda()
+            out = [torch.empty_like(t) for _ in range(world)]
+            dist.all_gather(out, t)
+        return int(nfr.sum()), sum(len(p) for p in pcm)
+
+    for i in range(args.warmup):
+        step(-1 - i)
+    eng.counters(reset=True)
+    barrier()
+    t0 = time.perf_counter()
+    frames = samples = 0
+    for i in range(args.steps):
+        f, s = step(i)
+        frames += f
+        samples += s
+    barrier()
+    dt = time.perf_counter() - t0
+    ctr = eng.counters()
+
+    if dist is not None:
+        v = torch.tensor([dt, float(frames), float(samples)], dtype=torch.float64, device="cuda")
+        tmax = v.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(v, op=dist.ReduceOp.SUM)
+        dt = float(tmax[0])
+        frames, samples = int(v[1]), int(v[2])
+
+    if rank == 0:
+        step_ms = ctr["decode_ms"] / max(ctr["decode_steps"], 1)
+        abytes = algorithmic_step_bytes(cfg, B, 8 + F / 2.0)
+        achieved = abytes / (step_ms * 1e-3) / 1e9 if step_ms > 0 else 0.0
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "decode_step_traffic.json")
+        if os.path.exists(tf):
+            try:
+                traffic = json.load(open(tf)).get(f"b{B}")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "real-time factor (24 kHz audio sec / wall sec), Qwen3-TTS-0.6B",
+            "value": round(frames * FRAME_SECONDS / dt, 3),
+            "unit": "x real-time (audio s / wall s)",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16 weights, fp32 activations/accumulate (fp32 codec decoder)", "data": "synthetic",
+            "config": {"workload": f"Qwen3-TTS-0.6B, batch={B}/GPU, 16-token prompt, "
+                                   + ("greedy top_k=1" if args.greedy else "sampled temp=0.8 top-k=50 top-p=0.95")
+                                   + f", max-tokens={F} (EOS suppressed), synthetic seeded weights",
+                       "batch_per_gpu": B, "frames_per_utterance": F, "parallelism": f"dp{world} (independent utterances)"},
+            "codec_frames_per_s": round(frames / dt, 2),
+            "pcm_samples": samples,
+            "decode_ms_per_frame_step": round(step_ms, 4),
+            "codec_decode_ms_per_frame": round(ctr["codec_ms"] / max(ctr["codec_frames"], 1), 5),
+            "roofline": {"bound": "hbm", "kernel": "decode step (hipGraph: q3::k_gemv x" + str(5 * (cfg.n_layers + 15 * cfg.cp_layers) + 16)
+                                                   + " + k_attn + k_sample)",
+                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "algorithmic_bytes_per_launch": int(abytes), "launch_ms": round(step_ms, 4)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(eng, cfg, toks[0], sp_kwargs, args.cpu_frames)
+            except Exception as ex:  # the baseline is a reported extra, never the measurement
+                out["cpu_baseline"] = {"value": None, "unit": "x real-time (audio s / wall s)", "cores": os.cpu_count(), "kind": "port",
+                                       "sample": f"failed: {ex}"}
+        print(json.dumps(out), flush=True)
+    eng.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -124,6 +124,9 @@ int q3tts_synthesize_batch_host(q3tts_engine* e, int n_utt, const int64_t* ids, 
 int q3tts_last_decode_ms(q3tts_engine* e, float* ms, int* steps);
 /* device time in ms of the last codec decode */
 int q3tts_last_codec_ms(q3tts_engine* e, float* ms);
+/* accumulated device time since the last reset: decode steps (HIP events around the graph
+ * replays, on the engine's stream) and codec decodes */
+int q3tts_counters(q3tts_engine* e, double* decode_ms, int64_t* decode_steps, double* codec_ms, int64_t* codec_frames, int reset);
 /* algorithmic bytes one decode step streams (weights + KV at the slots' current contexts) */
 int q3tts_decode_step_bytes(q3tts_engine* e, double* weight_bytes, double* kv_bytes);
 

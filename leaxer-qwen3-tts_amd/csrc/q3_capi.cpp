@@ -226,6 +226,16 @@ int q3tts_last_decode_ms(q3tts_engine* h, float* ms, int* steps) {
 int q3tts_last_codec_ms(q3tts_engine* h, float* ms) {
     Q3_API_BEGIN(h) if (ms) *ms = h->e->last_codec_ms; return 0; Q3_API_END(h)
 }
+int q3tts_counters(q3tts_engine* h, double* dms, int64_t* dsteps, double* cms, int64_t* cframes, int reset) {
+    Q3_API_BEGIN(h)
+    if (dms) *dms = h->e->total_decode_ms;
+    if (dsteps) *dsteps = h->e->total_decode_steps;
+    if (cms) *cms = h->e->total_codec_ms;
+    if (cframes) *cframes = h->e->total_codec_frames;
+    if (reset) { h->e->total_decode_ms = 0; h->e->total_decode_steps = 0; h->e->total_codec_ms = 0; h->e->total_codec_frames = 0; }
+    return 0;
+    Q3_API_END(h)
+}
 int q3tts_decode_step_bytes(q3tts_engine* h, double* wb, double* kvb) {
     Q3_API_BEGIN(h) h->e->step_bytes(wb, kvb); return 0; Q3_API_END(h)
 }

@@ -1,8 +1,241 @@
-// q3_codec.cpp — 12 Hz codec decoder orchestration (placeholder until the kernels land)
+// q3_codec.cpp — orchestration of the 12 Hz codec decoder on the GPU: the reference's
+// run_vocoder / tokenizer12hz_decode.onnx session (src/tts_onnx.cpp:759-776).  [HINT] architecture:
+// transformers Qwen3OmniMoeCode2Wav (modeling_qwen3_omni_moe.py:3180-3697), pinned by
+// tests/golden/hf_code2wav.npz.  Whole-utterance decode like the reference (tts_onnx.cpp:430):
+// with 288 GB of HBM the largest activation (F=2048: 3.9 M samples x 96 ch fp32 = 1.5 GB) needs no
+// chunking.
+#include <cmath>
+#include <vector>
+
 #include "q3_engine.h"
+
 namespace q3 {
-struct CodecW {};
-void Engine::codec_finalize() {}
-void Engine::codec_free() {}
-int64_t Engine::codec_run(const int32_t*, int, float**) { throw Error("codec decoder not built yet"); }
+
+struct PackedConv { const float* w = nullptr; const float* b = nullptr; int cin = 0, cout = 0, k = 0; };
+struct SnakeP { const float *alpha = nullptr, *beta = nullptr; };
+
+struct CodecW {
+    struct Layer { const float *in_norm, *post_norm, *qkv, *o, *gate, *up, *down, *attn_scale, *mlp_scale; };
+    std::vector<Layer> layers;
+    const float *norm = nullptr, *code_embed = nullptr;
+    struct Up { PackedConv tconv; const float *dw_w, *dw_b, *ln_w, *ln_b, *pw1_w, *pw1_b, *pw2_w, *pw2_b, *gamma; };
+    std::vector<Up> up;
+    PackedConv conv_in, conv_out;
+    struct Res { SnakeP a1, a2; PackedConv c1, c2; };
+    struct Block { SnakeP act; PackedConv tconv; Res res[3]; };
+    std::vector<Block> blocks;
+    SnakeP snake_out;
+    std::vector<float*> packed; // owned
+    // run-time workspace
+    char* arena = nullptr; size_t arena_bytes = 0;
+    float *rope_cos = nullptr, *rope_sin = nullptr; int rope_P = 0;
+    int* page_table = nullptr;
+};
+
+void Engine::codec_free() {
+    if (!codec) return;
+    for (float* p : codec->packed) (void)hipFree(p);
+    if (codec->arena) (void)hipFree(codec->arena);
+    if (codec->rope_cos) (void)hipFree(codec->rope_cos);
+    if (codec->rope_sin) (void)hipFree(codec->rope_sin);
+    if (codec->page_table) (void)hipFree(codec->page_table);
+    delete codec;
+    codec = nullptr;
 }
+
+void Engine::codec_finalize() {
+    codec_free();
+    codec = new CodecW;
+    CodecW& W = *codec;
+    auto fp = [&](const std::string& n) { return (const float*)T(n).dev; };
+    auto pack = [&](const std::string& prefix, int cin, int cout, int k, bool transposed) {
+        float* out = nullptr;
+        Q3_HIP_CHECK(hipMalloc((void**)&out, (size_t)cin * cout * k * sizeof(float)));
+        W.packed.push_back(out);
+        launch_repack_conv(fp(prefix + ".w"), out, cin, cout, k, transposed ? 1 : 0, stream);
+        PackedConv p; p.w = out; p.b = fp(prefix + ".b"); p.cin = cin; p.cout = cout; p.k = k;
+        return p;
+    };
+    auto snake = [&](const std::string& prefix) { SnakeP s; s.alpha = fp(prefix + ".alpha"); s.beta = fp(prefix + ".beta"); return s; };
+    const int CH = c.cd_hidden, D = c.cd_decoder_dim;
+    for (int i = 0; i < c.cd_layers; ++i) {
+        const std::string p = "cd.layers." + std::to_string(i) + ".";
+        CodecW::Layer L;
+        L.in_norm = fp(p + "input_norm"); L.post_norm = fp(p + "post_norm"); L.qkv = fp(p + "q_proj"); L.o = fp(p + "o_proj");
+        L.gate = fp(p + "gate_proj"); L.up = fp(p + "up_proj"); L.down = fp(p + "down_proj");
+        L.attn_scale = fp(p + "attn_scale"); L.mlp_scale = fp(p + "mlp_scale");
+        W.layers.push_back(L);
+    }
+    W.norm = fp("cd.norm"); W.code_embed = fp("cd.code_embed");
+    for (int s = 0; s < c.cd_n_up; ++s) {
+        const std::string p = "cd.up." + std::to_string(s) + ".";
+        CodecW::Up u;
+        u.tconv = pack(p + "tconv", CH, CH, c.cd_up_ratios[s], true);
+        u.dw_w = fp(p + "cnx.dw.w"); u.dw_b = fp(p + "cnx.dw.b"); u.ln_w = fp(p + "cnx.ln.w"); u.ln_b = fp(p + "cnx.ln.b");
+        u.pw1_w = fp(p + "cnx.pw1.w"); u.pw1_b = fp(p + "cnx.pw1.b"); u.pw2_w = fp(p + "cnx.pw2.w"); u.pw2_b = fp(p + "cnx.pw2.b");
+        u.gamma = fp(p + "cnx.gamma");
+        W.up.push_back(u);
+    }
+    W.conv_in = pack("cd.dec.conv_in", CH, D, 7, false);
+    for (int i = 0; i < c.cd_n_blocks; ++i) {
+        const int cin = D >> i, cout = D >> (i + 1), r = c.cd_up_rates[i];
+        const std::string p = "cd.dec.blocks." + std::to_string(i) + ".";
+        CodecW::Block B;
+        B.act = snake(p + "snake");
+        B.tconv = pack(p + "tconv", cin, cout, 2 * r, true);
+        for (int u = 0; u < 3; ++u) {
+            const std::string q = p + "res." + std::to_string(u) + ".";
+            B.res[u].a1 = snake(q + "act1"); B.res[u].a2 = snake(q + "act2");
+            B.res[u].c1 = pack(q + "conv1", cout, cout, 7, false);
+            B.res[u].c2 = pack(q + "conv2", cout, cout, 1, false);
+        }
+        W.blocks.push_back(B);
+    }
+    W.snake_out = snake("cd.dec.snake_out");
+    W.conv_out = pack("cd.dec.conv_out", D >> c.cd_n_blocks, 1, 7, false);
+    int zero = 0;
+    Q3_HIP_CHECK(hipMalloc((void**)&W.page_table, sizeof(int)));
+    Q3_HIP_CHECK(hipMemcpy(W.page_table, &zero, sizeof(int), hipMemcpyHostToDevice));
+    sync();
+}
+
+static int tconv_out_len(const q3tts_config& c, int T, int k, int s, int* left_out) {
+    const int pad = k - s, left = c.cd_tconv_trim == 0 ? pad : 0;
+    if (left_out) *left_out = left;
+    return (T - 1) * s + k - left - pad;
+}
+
+int64_t Engine::codec_run(const int32_t* codes_dev, int F, float** pcm_dev) {
+    if (!codec) throw Error("codec decoder not finalized");
+    CodecW& W = *codec;
+    const int CH = c.cd_hidden, NH = c.cd_heads, HD = c.cd_head_dim, FF = c.cd_ffn, D = c.cd_decoder_dim;
+    if (NH * HD != CH) throw Error("codec: heads*head_dim must equal hidden");
+    int P = 1, pshift = 0;
+    while (P < F) { P <<= 1; ++pshift; }
+    if (W.rope_P < P) { // RoPE tables, oracle formula (fp32 libm)
+        if (W.rope_cos) (void)hipFree(W.rope_cos);
+        if (W.rope_sin) (void)hipFree(W.rope_sin);
+        const int half = HD / 2;
+        std::vector<float> cs((size_t)P * half), sn((size_t)P * half);
+        for (int p = 0; p < P; ++p)
+            for (int i = 0; i < half; ++i) {
+                const float inv = 1.0f / powf(c.cd_rope_theta, (float)(2 * i) / (float)HD);
+                const float ang = (float)p * inv;
+                cs[(size_t)p * half + i] = cosf(ang); sn[(size_t)p * half + i] = sinf(ang);
+            }
+        Q3_HIP_CHECK(hipMalloc((void**)&W.rope_cos, cs.size() * sizeof(float)));
+        Q3_HIP_CHECK(hipMalloc((void**)&W.rope_sin, sn.size() * sizeof(float)));
+        Q3_HIP_CHECK(hipMemcpy(W.rope_cos, cs.data(), cs.size() * sizeof(float), hipMemcpyHostToDevice));
+        Q3_HIP_CHECK(hipMemcpy(W.rope_sin, sn.data(), sn.size() * sizeof(float), hipMemcpyHostToDevice));
+        W.rope_P = P;
+    }
+
+    int64_t n_pcm = 0;
+    float* pcm = nullptr;
+    for (int pass = 0; pass < 2; ++pass) { // pass 0 sizes the arena, pass 1 launches
+        const bool plan = pass == 0;
+        size_t off = 0;
+        auto take = [&](size_t nfloat) -> float* {
+            const size_t bytes = (nfloat * sizeof(float) + 255) & ~(size_t)255;
+            float* p = plan ? nullptr : (float*)(W.arena + off);
+            off += bytes;
+            return p;
+        };
+        auto conv = [&](const ConvArgs& a) { if (!plan) launch_conv(a, stream); };
+        auto gemm = [&](const float* in, int T, int Cin, const float* Wm, const float* bias, int Cout, float* out) {
+            ConvArgs a; a.in = in; a.T_in = T; a.C_in = Cin; a.out = out; a.T_out = T; a.C_out = Cout; a.W = Wm; a.bias = bias;
+            return a;
+        };
+        // ---- code embedding mean + pre-transformer ----
+        float* h = take((size_t)F * CH);
+        float* hn = take((size_t)F * CH);
+        float* qkvb = take((size_t)F * 3 * CH);
+        float* att = take((size_t)F * CH);
+        float* ub = take((size_t)F * FF);
+        float* gb = take((size_t)F * FF);
+        float* kc = take((size_t)NH * P * HD);
+        float* vc = take((size_t)NH * P * HD);
+        if (!plan) launch_code_embed_mean(W.code_embed, codes_dev, F, c.n_groups, c.cd_codebook, CH, h, stream);
+        for (int l = 0; l < c.cd_layers; ++l) {
+            const CodecW::Layer& L = W.layers[l];
+            if (!plan) launch_rmsnorm_rows(h, L.in_norm, c.cd_rms_eps, F, CH, hn, stream);
+            conv(gemm(hn, F, CH, L.qkv, nullptr, 3 * CH, qkvb));
+            if (!plan) {
+                launch_rope_store(qkvb, 3 * CH, F, NH, NH, HD, W.rope_cos, W.rope_sin, kc, vc, P, stream);
+                AttnArgs a;
+                a.qkv = qkvb; a.ld_qkv = 3 * CH; a.out = att; a.ld_out = CH; a.kcache = kc; a.vcache = vc;
+                a.page_table = W.page_table; a.pages_per_slot = 1; a.page_shift = pshift; a.layer = 0; a.n_layers = 1;
+                a.pos_scalar = 0; a.slot_offset = 0; a.nb = 1; a.n_new = F; a.nq = NH; a.nkv = NH; a.d = HD;
+                a.scale = 1.0f / sqrtf((float)HD); a.window = c.cd_window; a.new_from_raw = 0;
+                launch_attn(a, stream);
+            }
+            { ConvArgs a = gemm(att, F, CH, L.o, nullptr, CH, h); a.res_scale = L.attn_scale; a.res = h; conv(a); }
+            if (!plan) launch_rmsnorm_rows(h, L.post_norm, c.cd_rms_eps, F, CH, hn, stream);
+            conv(gemm(hn, F, CH, L.up, nullptr, FF, ub));
+            { ConvArgs a = gemm(hn, F, CH, L.gate, nullptr, FF, gb); a.act = 2; a.mul = ub; conv(a); }
+            { ConvArgs a = gemm(gb, F, FF, L.down, nullptr, CH, h); a.res_scale = L.mlp_scale; a.res = h; conv(a); }
+        }
+        if (!plan) launch_rmsnorm_rows(h, W.norm, c.cd_rms_eps, F, CH, h, stream);
+        // ---- ConvNeXt upsampling stages ----
+        float* cur = h;
+        int Tc = F;
+        for (int s = 0; s < c.cd_n_up; ++s) {
+            const CodecW::Up& U = W.up[s];
+            const int f = c.cd_up_ratios[s];
+            int left = 0;
+            const int To = tconv_out_len(c, Tc, f, f, &left);
+            float* y = take((size_t)To * CH);
+            float* ln = take((size_t)To * CH);
+            float* a4 = take((size_t)To * 4 * CH);
+            { ConvArgs a; a.in = cur; a.T_in = Tc; a.C_in = CH; a.out = y; a.T_out = To; a.C_out = CH; a.W = U.tconv.w; a.bias = U.tconv.b;
+              a.taps = f; a.transposed = 1; a.stride = f; a.left = left; conv(a); }
+            if (!plan) launch_dwconv_ln(y, To, CH, U.dw_w, U.dw_b, U.ln_w, U.ln_b, ln, stream);
+            { ConvArgs a = gemm(ln, To, CH, U.pw1_w, U.pw1_b, 4 * CH, a4); a.act = 1; conv(a); }
+            { ConvArgs a = gemm(a4, To, 4 * CH, U.pw2_w, U.pw2_b, CH, y); a.res_scale = U.gamma; a.res = y; conv(a); }
+            cur = y; Tc = To;
+        }
+        // ---- SnakeBeta decoder: conv_in, 4 x (snake, transposed conv, 3 residual units), snake, conv_out ----
+        float* x = take((size_t)Tc * D);
+        float* sx = take((size_t)Tc * D);
+        { ConvArgs a; a.in = cur; a.T_in = Tc; a.C_in = CH; a.out = x; a.T_out = Tc; a.C_out = D; a.W = W.conv_in.w; a.bias = W.conv_in.b; a.taps = 7;
+          a.out2 = sx; a.snake_alpha = W.blocks[0].act.alpha; a.snake_beta = W.blocks[0].act.beta; conv(a); }
+        int C = D;
+        static const int dil[3] = { 1, 3, 9 };
+        for (int i = 0; i < c.cd_n_blocks; ++i) {
+            const CodecW::Block& B = W.blocks[i];
+            const int r = c.cd_up_rates[i], Co = C / 2;
+            int left = 0;
+            const int To = tconv_out_len(c, Tc, 2 * r, r, &left);
+            float* nx = take((size_t)To * Co);
+            float* ns = take((size_t)To * Co);
+            float* nt = take((size_t)To * Co);
+            { ConvArgs a; a.in = sx; a.T_in = Tc; a.C_in = C; a.out = nx; a.T_out = To; a.C_out = Co; a.W = B.tconv.w; a.bias = B.tconv.b;
+              a.taps = 2 * r; a.transposed = 1; a.stride = r; a.left = left;
+              a.out2 = ns; a.snake_alpha = B.res[0].a1.alpha; a.snake_beta = B.res[0].a1.beta; conv(a); }
+            for (int u = 0; u < 3; ++u) {
+                const CodecW::Res& R = B.res[u];
+                { ConvArgs a; a.in = ns; a.T_in = To; a.C_in = Co; a.out = nullptr; a.T_out = To; a.C_out = Co; a.W = R.c1.w; a.bias = R.c1.b;
+                  a.taps = 7; a.dil = dil[u]; a.out2 = nt; a.snake_alpha = R.a2.alpha; a.snake_beta = R.a2.beta; conv(a); }
+                const SnakeP nxt = u < 2 ? B.res[u + 1].a1 : (i + 1 < c.cd_n_blocks ? W.blocks[i + 1].act : W.snake_out);
+                { ConvArgs a; a.in = nt; a.T_in = To; a.C_in = Co; a.out = nx; a.T_out = To; a.C_out = Co; a.W = R.c2.w; a.bias = R.c2.b;
+                  a.taps = 1; a.res = nx; a.out2 = ns; a.snake_alpha = nxt.alpha; a.snake_beta = nxt.beta; conv(a); }
+            }
+            x = nx; sx = ns; Tc = To; C = Co;
+        }
+        pcm = take((size_t)Tc);
+        { ConvArgs a; a.in = sx; a.T_in = Tc; a.C_in = C; a.out = pcm; a.T_out = Tc; a.C_out = 1; a.W = W.conv_out.w; a.bias = W.conv_out.b;
+          a.taps = 7; a.clamp = 1; conv(a); }
+        n_pcm = Tc;
+        if (plan && off > W.arena_bytes) {
+            sync();
+            if (W.arena) (void)hipFree(W.arena);
+            W.arena = nullptr;
+            Q3_HIP_CHECK(hipMalloc((void**)&W.arena, off));
+            W.arena_bytes = off;
+        }
+    }
+    *pcm_dev = pcm;
+    return n_pcm;
+}
+
+} // namespace q3

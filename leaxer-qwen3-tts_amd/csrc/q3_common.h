@@ -138,26 +138,28 @@ void launch_count_active(const SlotState* st, int nb, int32_t* out, hipStream_t 
 // ------------------------------------------------------------------------------------------------
 // codec decoder launchers (q3_codec_kernels.hip)
 // ------------------------------------------------------------------------------------------------
-struct ConvArgs { // out[t][co] = bias[co] + sum_{tap,ci} W[tap][co][ci] * pre(in[src_t(t,tap)][ci])  (+ residual)
+struct ConvArgs { // out[t][co] = epi(bias[co] + sum_{tap,ci} W[tap][co][ci] * in[src_t(t,tap)][ci])
     const float* in = nullptr; int T_in = 0, C_in = 0;
-    float* out = nullptr;      int T_out = 0, C_out = 0;
+    float* out = nullptr;      int T_out = 0, C_out = 0; // out may be null when only out2 is wanted
     const float* W = nullptr;  // [taps][C_out][C_in] fp32
     const float* bias = nullptr;
     int taps = 1, dil = 1;
-    int transposed = 0, stride = 1, left = 0; // transposed: out index j=jo+left gets in[t] via tap j - t*stride
-    const float* snake_alpha = nullptr; // non-null: SnakeBeta applied to the input on load
-    const float* snake_beta = nullptr;
-    const float* res = nullptr;  // optional residual added in the epilogue (same shape as out)
-    const float* res_scale = nullptr; // optional per-channel scale on the conv result before the residual add
-    int act = 0;                 // 0 none, 1 GELU(erf), 2 SiLU on (acc + bias)
-    const float* mul = nullptr;  // optional elementwise multiplier of the activated result (SwiGLU up branch)
+    int transposed = 0, stride = 1, left = 0; // transposed: out index jo = m*stride + phase - left
+    int act = 0;                 // 0 none, 1 GELU(erf), 2 SiLU, applied to (acc + bias)
+    const float* mul = nullptr;  // optional elementwise multiplier after act (SwiGLU up branch)
+    const float* res_scale = nullptr; // optional per-channel scale (LayerScale / ConvNeXt gamma)
+    const float* res = nullptr;  // optional residual (same shape as out, may alias out)
     int clamp = 0;               // clamp to [-1, 1]
+    float* out2 = nullptr;       // optional second output: SnakeBeta(value) for the NEXT layer
+    const float* snake_alpha = nullptr;
+    const float* snake_beta = nullptr;
 };
 void launch_conv(const ConvArgs& a, hipStream_t s);
+void launch_repack_conv(const float* w, float* out, int cin, int cout, int k, int transposed, hipStream_t s);
 void launch_code_embed_mean(const float* table, const int32_t* codes, int F, int G, int codebook, int C, float* out, hipStream_t s);
 void launch_rmsnorm_rows(const float* x, const float* w, float eps, int rows, int C, float* out, hipStream_t s);
 void launch_rope_store(float* qkv, int ld, int T, int nq, int nkv, int d, const float* cs, const float* sn,
-                       float* kc, float* vc, hipStream_t s);
+                       float* kc, float* vc, int P, hipStream_t s);
 void launch_dwconv_ln(const float* x, int T, int C, const float* dw_w, const float* dw_b, const float* ln_w,
                       const float* ln_b, float* out, hipStream_t s);
 

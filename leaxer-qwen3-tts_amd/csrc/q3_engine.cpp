@@ -575,6 +575,7 @@ int Engine::decode_steps(int n_steps) {
     sync();
     Q3_HIP_CHECK(hipEventElapsedTime(&last_decode_ms, ev0, ev1));
     last_decode_steps = n_steps;
+    total_decode_ms += last_decode_ms; total_decode_steps += n_steps;
     return *active_h;
 }
 
@@ -613,6 +614,7 @@ int64_t Engine::slot_codec_decode(int slot, float* pcm, int64_t cap) {
     if (m > 0 && pcm) Q3_HIP_CHECK(hipMemcpyAsync(pcm, pcm_d, (size_t)m * sizeof(float), hipMemcpyDeviceToHost, stream));
     sync();
     Q3_HIP_CHECK(hipEventElapsedTime(&last_codec_ms, ev0, ev1));
+    total_codec_ms += last_codec_ms; total_codec_frames += nf;
     return n;
 }
 
@@ -635,6 +637,7 @@ int64_t Engine::codec_decode_host(const int64_t* codes, int F, float* pcm, int64
     if (m > 0 && pcm) Q3_HIP_CHECK(hipMemcpyAsync(pcm, pcm_d, (size_t)m * sizeof(float), hipMemcpyDeviceToHost, stream));
     sync();
     Q3_HIP_CHECK(hipEventElapsedTime(&last_codec_ms, ev0, ev1));
+    total_codec_ms += last_codec_ms; total_codec_frames += F;
     return n;
 }
 

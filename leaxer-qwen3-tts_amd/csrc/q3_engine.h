@@ -86,6 +86,8 @@ public:
     float last_decode_ms = 0.f;
     int last_decode_steps = 0;
     float last_codec_ms = 0.f;
+    double total_decode_ms = 0.0, total_codec_ms = 0.0;
+    int64_t total_decode_steps = 0, total_codec_frames = 0;
 
     // ---- codec decoder (q3_codec.cpp) ----
     CodecW* codec = nullptr;

@@ -75,6 +75,7 @@ EXPORTS = [
     "q3tts_sample_host", "q3tts_rng_uniform", "q3tts_build_prompt_host", "q3tts_slot_begin", "q3tts_decode_steps",
     "q3tts_slot_status", "q3tts_slot_codes_host", "q3tts_slot_codec_decode_host", "q3tts_slot_release",
     "q3tts_synthesize_batch_host", "q3tts_last_decode_ms", "q3tts_last_codec_ms", "q3tts_decode_step_bytes",
+    "q3tts_counters",
 ]
 
 _lib = None
@@ -124,6 +125,7 @@ def lib():
                                               vp, i64, vp, vp, vp]
     L.q3tts_last_decode_ms.argtypes = [vp, C.POINTER(f32), C.POINTER(i32)]
     L.q3tts_last_codec_ms.argtypes = [vp, C.POINTER(f32)]
+    L.q3tts_counters.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(C.c_double), C.POINTER(i64), i32]
     L.q3tts_decode_step_bytes.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     _lib = L
     return L
@@ -340,6 +342,12 @@ class Engine:
         ms = C.c_float(0)
         self._ck(self.L.q3tts_last_codec_ms(self.h, C.byref(ms)))
         return ms.value
+
+    def counters(self, reset=False):
+        dms, cms = C.c_double(0), C.c_double(0)
+        ds, cf = C.c_int64(0), C.c_int64(0)
+        self._ck(self.L.q3tts_counters(self.h, C.byref(dms), C.byref(ds), C.byref(cms), C.byref(cf), int(reset)))
+        return dict(decode_ms=dms.value, decode_steps=ds.value, codec_ms=cms.value, codec_frames=cf.value)
 
     def decode_step_bytes(self):
         w, kv = C.c_double(0), C.c_double(0)

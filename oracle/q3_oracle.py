@@ -220,9 +220,24 @@ def random_weights(cfg, seed=0, text_rows=None):
 _lib = None
 
 
+def default_threads(cfg=None):
+    """OpenMP threads for the oracle: the GPU boxes expose many more hardware threads than the
+    job's CPU share (16 per GPU), and tiny configs are dominated by fork/join cost."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    n = max(1, min(n, 16))
+    if cfg is not None and cfg.hidden <= 128:
+        n = 1
+    return n
+
+
 def lib():
     global _lib
     if _lib is None:
+        os.environ.setdefault("OMP_WAIT_POLICY", "passive")  # no spinning between the many small regions
+        os.environ.setdefault("OMP_NUM_THREADS", str(default_threads()))
         so = _build.build()
         L = C.CDLL(so)
         L.q3o_create.restype = C.c_void_p
@@ -273,6 +288,8 @@ class Oracle:
         self.cfg = cfg
         self.max_ctx = max_ctx
         self.h = self.L.q3o_create(C.byref(cfg), max_ctx)
+        self.threads = default_threads(cfg)
+        self.L.q3o_set_threads(self.threads)
         if weights is not None:
             self.load(weights)
 
