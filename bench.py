@@ -80,7 +80,7 @@ def main():
     ap.add_argument("--frames", type=int, default=2048, help="max-tokens per utterance")
     ap.add_argument("--greedy", action="store_true", help="top_k=1 instead of the sampled default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=12)
+    ap.add_argument("--cpu-frames", type=int, default=160)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))

@@ -31,11 +31,27 @@ def to_ocfg(cfg):
     return qo.Config.from_dict(cfg.to_dict())
 
 
+def calibrate_codec(w, ocfg, target_rms=0.2):
+    """Scale the codec decoder's last conv so the PCM sits well inside the clamp range: a saturated
+    output would hide errors (and blow up absolute ones)."""
+    probe = dict(w)
+    probe["cd.dec.conv_out.w"] = w["cd.dec.conv_out.w"] * np.float32(2.0 ** -20)
+    probe["cd.dec.conv_out.b"] = w["cd.dec.conv_out.b"] * np.float32(2.0 ** -20)
+    o = qo.Oracle(ocfg, max_ctx=16, weights=probe)
+    codes = np.random.default_rng(0).integers(0, ocfg.cd_codebook, (6, ocfg.n_groups)).astype(np.int64)
+    rms = float(np.sqrt(np.mean(o.vocoder(codes) ** 2)))
+    o.close()
+    k = np.float32(target_rms / max(rms, 1e-30) * 2.0 ** -20)
+    w["cd.dec.conv_out.w"] = qo.bf16_round(w["cd.dec.conv_out.w"] * k)
+    w["cd.dec.conv_out.b"] = qo.bf16_round(w["cd.dec.conv_out.b"] * k)
+    return w
+
+
 def tiny_pair(seed=0, max_batch=4, max_ctx=128, extra=None, flags=0):
     """(engine, oracle, weights) on config_tiny with identical bf16-representable weights."""
     import q3tts
     ocfg = qo.config_tiny()
-    w = qo.random_weights(ocfg, seed)
+    w = calibrate_codec(qo.random_weights(ocfg, seed), ocfg)
     if extra:
         w.update(extra)
     eng = q3tts.Engine(to_q3cfg(ocfg), device=0, max_batch=max_batch, max_ctx=max_ctx, flags=flags)
