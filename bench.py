@@ -80,6 +80,8 @@ def main():
     ap.add_argument("--frames", type=int, default=2048, help="max-tokens per utterance")
     ap.add_argument("--greedy", action="store_true", help="top_k=1 instead of the sampled default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay (rocprofv3 kernel tracing "
+                                                             "crashes inside hipGraphLaunch on this ROCm; same kernels either way)")
     ap.add_argument("--cpu-frames", type=int, default=160)
     args = ap.parse_args()
 
@@ -97,7 +99,7 @@ def main():
     import q3tts
     cfg = q3tts.default_config("0.6b")
     B, F = args.batch, args.frames
-    eng = q3tts.Engine(cfg, device=local_rank, max_batch=B, max_ctx=F + 32)
+    eng = q3tts.Engine(cfg, device=local_rank, max_batch=B, max_ctx=F + 32, flags=q3tts.FLAG_NO_GRAPH if args.no_graph else 0)
     eng.fill_synthetic(seed=0)
     sp_kwargs = dict(temperature=1.0, top_p=1.0, top_k=1) if args.greedy else dict(temperature=0.8, top_p=0.95, top_k=50)
     sp = q3tts.Sampling(max_new_tokens=F, **sp_kwargs)
