@@ -59,8 +59,16 @@ struct GemvArgs {
     int M = 0, N = 0, K = 0;
     int epi = EPI_STORE;
     bool nt = false;              // non-temporal weight loads (streamed-once weights)
+    // optional: x rows are the combination of split-T attention partials (o_proj prologue)
+    const float* po = nullptr;    // [(row*heads + h)*S + s][d] un-normalised sum(p*v)
+    const float* pm = nullptr;    // [(row*heads + h)*S + s] running max
+    const float* pl = nullptr;    // [(row*heads + h)*S + s] running sum
+    int pS = 0, pchunk = 0, pn_new = 1, pslot_offset = 0, pheads = 0, pd = 0;
+    const int* ppos_dev = nullptr;
+    int ppos_scalar = 0;
 };
 void launch_gemv(const GemvArgs& a, hipStream_t s);
+bool gemv_fast_path(const GemvArgs& a); // single-pass kernel available (M <= 2, K in {1024,2048,3072})
 
 // Decode-time attention over a paged fp32 KV cache with the new tokens' q/k-norm + RoPE + append fused.
 struct AttnArgs {
@@ -85,8 +93,13 @@ struct AttnArgs {
     float scale = 0.f;
     int window = 0;
     int new_from_raw = 1; // 1: new tokens' K/V come from qkv (and are appended); 0: everything is in the cache, q pre-roped
+    // split-T mode: n_splits workgroups per (kv head, new token, row), each over `chunk` tokens, write
+    // un-normalised partials instead of `out`; combined by the o_proj GEMV prologue or launch_attn_combine
+    int n_splits = 1, chunk = 1 << 30;
+    float* po = nullptr; float* pm = nullptr; float* pl = nullptr;
 };
 void launch_attn(const AttnArgs& a, hipStream_t s);
+void launch_attn_combine(const AttnArgs& a, hipStream_t s); // partials -> a.out
 
 struct SlotState { // device-resident per-slot generation state
     int32_t n_frames;     // frames recorded so far

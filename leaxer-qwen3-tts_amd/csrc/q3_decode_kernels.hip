@@ -192,7 +192,210 @@ static void gemv_r(const GemvArgs& a, hipStream_t s) {
     if (R == 2) gemv_epi<MT, 2>(a, grid, s); else gemv_epi<MT, 1>(a, grid, s);
 }
 
+
+// ================================================================================================
+// k_gemv1 — single-pass decode GEMV for M <= 2 rows and K = NCH*512: every weight load of the wave
+// (RW rows x NCH x 16 B/lane) is issued before anything else, the activation row is read once into
+// registers (its RMSNorm statistics come from those same registers), so the kernel is one memory
+// latency deep.  COMB: the activation rows are the combination of split-T attention partials.
+// ================================================================================================
+static __device__ __forceinline__ uint4 ldw_rt(const bf16_t* p, bool nt) {
+    u32x4 v;
+    if (nt) v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+    else v = *reinterpret_cast<const u32x4*>(p);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
+template <int MT, int NCH, int RW, int EPI, bool NORM, bool COMB>
+__global__ __launch_bounds__(256) void k_gemv1(GemvArgs a) {
+    constexpr int K = NCH * 512;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n0 = (blockIdx.x * 4 + wave) * RW;
+    const int N = a.N, M = a.M;
+    __shared__ float xs[COMB ? MT * K : 1];
+
+    // 1. weights: everything this wave will ever read, in flight at once
+    uint4 w[RW][NCH], w2[RW][NCH];
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+        const int n = n0 + r < N ? n0 + r : N - 1;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            w[r][c] = ldw_rt(a.W + (size_t)n * K + c * 512 + lane * 8, a.nt);
+            if (EPI == EPI_SWIGLU) w2[r][c] = ldw_rt(a.W2 + (size_t)n * K + c * 512 + lane * 8, a.nt);
+        }
+    }
+    // 2. activations
+    float xv[MT][NCH][8];
+    if (COMB) {
+        for (int k8 = threadIdx.x * 8; k8 < K; k8 += 2048) {
+            const int head = k8 / a.pd, e0 = k8 % a.pd;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                if (m < M) {
+                    const int bi = m / a.pn_new, inew = m % a.pn_new;
+                    const int pos = (a.ppos_dev ? a.ppos_dev[a.pslot_offset + bi] : a.ppos_scalar) + inew;
+                    int nact = pos / a.pchunk + 1;
+                    if (nact > a.pS) nact = a.pS;
+                    const size_t idx = ((size_t)m * a.pheads + head) * a.pS;
+                    float mx = -INFINITY;
+                    for (int sp = 0; sp < nact; ++sp) mx = fmaxf(mx, a.pm[idx + sp]);
+                    float L = 0.f, O[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    for (int sp = 0; sp < nact; ++sp) {
+                        const float wgt = expf(a.pm[idx + sp] - mx);
+                        L += wgt * a.pl[idx + sp];
+                        const float4 o0 = *reinterpret_cast<const float4*>(a.po + (idx + sp) * a.pd + e0);
+                        const float4 o1 = *reinterpret_cast<const float4*>(a.po + (idx + sp) * a.pd + e0 + 4);
+                        O[0] += wgt * o0.x; O[1] += wgt * o0.y; O[2] += wgt * o0.z; O[3] += wgt * o0.w;
+                        O[4] += wgt * o1.x; O[5] += wgt * o1.y; O[6] += wgt * o1.z; O[7] += wgt * o1.w;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) xs[m * K + k8 + j] = O[j] / L;
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const float4 x0 = *reinterpret_cast<const float4*>(&xs[m * K + c * 512 + lane * 8]);
+                const float4 x1 = *reinterpret_cast<const float4*>(&xs[m * K + c * 512 + lane * 8 + 4]);
+                xv[m][c][0] = x0.x; xv[m][c][1] = x0.y; xv[m][c][2] = x0.z; xv[m][c][3] = x0.w;
+                xv[m][c][4] = x1.x; xv[m][c][5] = x1.y; xv[m][c][6] = x1.z; xv[m][c][7] = x1.w;
+            }
+    } else {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const float* xr = a.x + (size_t)(m < M ? m : 0) * a.ldx + c * 512 + lane * 8;
+                const float4 x0 = *reinterpret_cast<const float4*>(xr);
+                const float4 x1 = *reinterpret_cast<const float4*>(xr + 4);
+                xv[m][c][0] = x0.x; xv[m][c][1] = x0.y; xv[m][c][2] = x0.z; xv[m][c][3] = x0.w;
+                xv[m][c][4] = x1.x; xv[m][c][5] = x1.y; xv[m][c][6] = x1.z; xv[m][c][7] = x1.w;
+            }
+    }
+    if (NORM) {
+        float g[NCH][8];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const float4 g0 = *reinterpret_cast<const float4*>(a.gamma + c * 512 + lane * 8);
+            const float4 g1 = *reinterpret_cast<const float4*>(a.gamma + c * 512 + lane * 8 + 4);
+            g[c][0] = g0.x; g[c][1] = g0.y; g[c][2] = g0.z; g[c][3] = g0.w; g[c][4] = g1.x; g[c][5] = g1.y; g[c][6] = g1.z; g[c][7] = g1.w;
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            float ss = 0.f;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) ss = fmaf(xv[m][c][j], xv[m][c][j], ss);
+            ss = wave_sum(ss);
+            const float inv = 1.0f / sqrtf(ss / (float)K + a.eps);
+#pragma unroll
+            for (int c = 0; c < NCH; ++c)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) xv[m][c][j] = g[c][j] * (xv[m][c][j] * inv);
+            if (a.xn_out != nullptr && blockIdx.x == 0 && wave == 0 && m < M) {
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    float* o = a.xn_out + (size_t)m * a.ld_xn + c * 512 + lane * 8;
+                    *reinterpret_cast<float4*>(o) = make_float4(xv[m][c][0], xv[m][c][1], xv[m][c][2], xv[m][c][3]);
+                    *reinterpret_cast<float4*>(o + 4) = make_float4(xv[m][c][4], xv[m][c][5], xv[m][c][6], xv[m][c][7]);
+                }
+            }
+        }
+    }
+    // 3. dot products
+    float mine = 0.f, mine2 = 0.f;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const uint32_t wu[4] = { w[r][c].x, w[r][c].y, w[r][c].z, w[r][c].w };
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { s1 = fmaf(xv[m][c][2 * j], bf_lo(wu[j]), s1); s1 = fmaf(xv[m][c][2 * j + 1], bf_hi(wu[j]), s1); }
+                if (EPI == EPI_SWIGLU) {
+                    const uint32_t vu[4] = { w2[r][c].x, w2[r][c].y, w2[r][c].z, w2[r][c].w };
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { s2 = fmaf(xv[m][c][2 * j], bf_lo(vu[j]), s2); s2 = fmaf(xv[m][c][2 * j + 1], bf_hi(vu[j]), s2); }
+                }
+            }
+            s1 = wave_sum(s1);
+            if (lane == m * RW + r) mine = s1;
+            if (EPI == EPI_SWIGLU) { s2 = wave_sum(s2); if (lane == m * RW + r) mine2 = s2; }
+        }
+    if (lane < MT * RW) {
+        const int m = lane / RW, r = lane % RW, n = n0 + r;
+        if (m < M && n < N) {
+            float o;
+            if (EPI == EPI_STORE) o = mine;
+            else if (EPI == EPI_RESIDUAL) o = a.res[(size_t)m * a.ldres + n] + mine;
+            else if (EPI == EPI_SWIGLU) o = silu_f(mine) * mine2;
+            else if (EPI == EPI_BIAS) o = mine + a.bias[n];
+            else o = silu_f(mine + a.bias[n]);
+            a.out[(size_t)m * a.ldo + n] = o;
+        }
+    }
+}
+
+static int gemv1_rw(const GemvArgs& a) {
+    int rw = a.N / 1024;
+    if (rw < 1) rw = 1;
+    if (rw > 4) rw = 4;
+    if (a.epi == EPI_SWIGLU && rw > 3) rw = 3;
+    return rw;
+}
+bool gemv_fast_path(const GemvArgs& a) {
+    if (a.M < 1 || a.M > 2) return false;
+    if (a.K != 1024 && a.K != 2048 && a.K != 3072) return false;
+    if (a.ldx % 4 != 0 && !a.po) return false;
+    const bool norm = a.gamma != nullptr, comb = a.po != nullptr;
+    if (comb && (norm || a.epi != EPI_RESIDUAL || a.pd % 8 != 0 || a.pheads * a.pd != a.K)) return false;
+    if (norm && a.epi != EPI_STORE && a.epi != EPI_SWIGLU) return false;
+    return true;
+}
+
+template <int MT, int NCH, int RW>
+static void gemv1_launch(const GemvArgs& a, int grid, hipStream_t s) {
+    const bool norm = a.gamma != nullptr, comb = a.po != nullptr;
+#define Q3_G1(EPI, NORM, COMB) hipLaunchKernelGGL((k_gemv1<MT, NCH, RW, EPI, NORM, COMB>), dim3(grid), dim3(256), 0, s, a)
+    if (comb) { Q3_G1(EPI_RESIDUAL, false, true); return; }
+    switch (a.epi) {
+    case EPI_STORE: if (norm) Q3_G1(EPI_STORE, true, false); else Q3_G1(EPI_STORE, false, false); break;
+    case EPI_SWIGLU: if (norm) Q3_G1(EPI_SWIGLU, true, false); else Q3_G1(EPI_SWIGLU, false, false); break;
+    case EPI_RESIDUAL: Q3_G1(EPI_RESIDUAL, false, false); break;
+    case EPI_BIAS: Q3_G1(EPI_BIAS, false, false); break;
+    default: Q3_G1(EPI_BIAS_SILU, false, false); break;
+    }
+#undef Q3_G1
+}
+template <int MT, int NCH>
+static void gemv1_rwsel(const GemvArgs& a, hipStream_t s) {
+    const int rw = gemv1_rw(a);
+    const int grid = (a.N + 4 * rw - 1) / (4 * rw);
+    if (rw == 1) gemv1_launch<MT, NCH, 1>(a, grid, s);
+    else if (rw == 2) gemv1_launch<MT, NCH, 2>(a, grid, s);
+    else if (rw == 3) gemv1_launch<MT, NCH, 3>(a, grid, s);
+    else gemv1_launch<MT, NCH, 4>(a, grid, s);
+}
+template <int MT>
+static void gemv1_nch(const GemvArgs& a, hipStream_t s) {
+    if (a.K == 1024) gemv1_rwsel<MT, 2>(a, s);
+    else if (a.K == 2048) gemv1_rwsel<MT, 4>(a, s);
+    else gemv1_rwsel<MT, 6>(a, s);
+}
+
 void launch_gemv(const GemvArgs& a0, hipStream_t s) {
+    if (gemv_fast_path(a0)) {
+        if (a0.M == 1) gemv1_nch<1>(a0, s); else gemv1_nch<2>(a0, s);
+        return;
+    }
+    if (a0.po) throw Error("gemv: attention-partials prologue needs the fast path (combine separately)");
     if (a0.K % 8 != 0 || a0.ldx % 4 != 0) throw Error("gemv: K must be a multiple of 8 and ldx of 4");
     if ((a0.epi == EPI_RESIDUAL || a0.epi == EPI_BIAS || a0.epi == EPI_BIAS_SILU) && a0.gamma) throw Error("gemv: norm+epilogue combination not built");
     if (a0.M <= 0 || a0.N <= 0) return;
@@ -211,17 +414,23 @@ void launch_gemv(const GemvArgs& a0, hipStream_t s) {
 }
 
 // ================================================================================================
-// k_attn — one workgroup per (kv head, new token, batch row)
+// k_attn — decode attention over the paged fp32 KV cache.  Workgroup = (kv head, new token x split,
+// batch row).  A split covers `chunk` cache tokens; 16 lane-groups of 16 lanes each own every 16th
+// token and keep a private online softmax; U tokens per group are loaded before any is consumed
+// (the first batch before the q/k RMSNorm+RoPE prologue), so a split is ~one memory latency deep.
+// Output: normalised rows (n_splits == 1, po == null) or un-normalised partials (m, l, sum p*v)
+// that the o_proj GEMV prologue / k_attn_combine merge.
 // ================================================================================================
 #define ATT_MAX_NEW 16
 #define ATT_MAX_GRP 4
 
-// D = head_dim; 16 lanes share a token, EPL = D/16 elements per lane
-template <int D>
+template <int D, int U, int G>
 __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
     constexpr int EPL = D / 16;
     constexpr int HALF = D / 2;
-    const int kvh = blockIdx.x, inew = blockIdx.y, bi = blockIdx.z;
+    const int kvh = blockIdx.x, bi = blockIdx.z;
+    const int S = a.n_splits;
+    const int inew = blockIdx.y / S, split = blockIdx.y % S;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int grp = a.nq / a.nkv;
     const int slot = a.slot_offset + bi;
@@ -230,11 +439,20 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
     const int pos = base + inew;
     const int page_tokens = 1 << a.page_shift;
 
-    __shared__ float q_s[ATT_MAX_GRP][D];
+    // token range of this split
+    int lo = split * a.chunk;
+    int hi = lo + a.chunk < pos + 1 ? lo + a.chunk : pos + 1;
+    if (a.window > 0 && pos - a.window + 1 > lo) lo = pos - a.window + 1;
+    if (lo >= hi) return; // empty split: the combiner derives the active split count from pos
+    const int n_cache = a.new_from_raw ? base : pos + 1;   // tokens < n_cache live in the cache
+    const int cend = hi < n_cache ? hi : n_cache;           // cache tokens [lo, cend)
+    const int nlo = lo > base ? lo : base;                  // new tokens [nlo, hi) come from qkv (new_from_raw)
+
+    __shared__ float q_s[G][D];
     __shared__ float knew[ATT_MAX_NEW][D];
     __shared__ float vnew[ATT_MAX_NEW][D];
-    __shared__ float cm[16][ATT_MAX_GRP], cl[16][ATT_MAX_GRP];
-    __shared__ float co[16][ATT_MAX_GRP][D];
+    __shared__ float cm[16][G], cl[16][G];
+    __shared__ float co[16][G][D];
 
     const int* pt = a.page_table + (size_t)slot * a.pages_per_slot;
     auto cache_off = [&](int t) -> size_t {
@@ -242,23 +460,49 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
         return ((((size_t)page * a.n_layers + a.layer) * a.nkv + kvh) * page_tokens + (t & (page_tokens - 1))) * D;
     };
 
-    // ---- 1. q heads of this group and the new tokens' keys: RMSNorm + RoPE; own K/V appended to the cache ----
-    const int nvec = a.new_from_raw ? grp + inew + 1 : grp;
+    const int tg = wave * 4 + (lane >> 4), sub = lane & 15;
+    float kr[U][EPL], vr[U][EPL];
+    auto load_batch = [&](int t0) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int t = t0 + 16 * u;
+            if (t < cend) {
+                const size_t off = cache_off(t) + sub * EPL;
+                if (EPL >= 4) {
+#pragma unroll
+                    for (int e = 0; e < EPL; e += 4) {
+                        const float4 k4 = *reinterpret_cast<const float4*>(a.kcache + off + e);
+                        const float4 v4 = *reinterpret_cast<const float4*>(a.vcache + off + e);
+                        kr[u][e] = k4.x; kr[u][e + 1] = k4.y; kr[u][e + 2] = k4.z; kr[u][e + 3] = k4.w;
+                        vr[u][e] = v4.x; vr[u][e + 1] = v4.y; vr[u][e + 2] = v4.z; vr[u][e + 3] = v4.w;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < EPL; ++e) { kr[u][e] = a.kcache[off + e]; vr[u][e] = a.vcache[off + e]; }
+                }
+            }
+        }
+    };
+    load_batch(lo + tg); // in flight while the prologue below runs
+
+    // ---- 1. q heads of this group and this split's new keys: RMSNorm + RoPE; own K/V appended to the cache ----
+    const int jlo = nlo - base;                    // first new token of this split
+    const int nnew = a.new_from_raw && hi > nlo ? hi - nlo : 0;
+    const int nvec = grp + nnew;
     for (int v = wave; v < nvec; v += 4) {
         const bool is_q = v < grp;
-        const int j = is_q ? inew : v - grp;                 // which new token the vector belongs to
+        const int j = is_q ? inew : jlo + (v - grp);
         const float* src = a.qkv + (size_t)(bi * a.n_new + j) * a.ld_qkv + (is_q ? (kvh * grp + v) * D : (a.nq + kvh) * D);
         const int p = base + j;
         float x0 = 0.f, x1 = 0.f;
         if (lane < HALF) { x0 = src[lane]; x1 = src[lane + HALF]; }
-        if (!a.new_from_raw) { // q was normalised + roped by k_rope_store
+        if (!a.new_from_raw) { // q was roped by k_rope_store
             if (lane < HALF) { q_s[v][lane] = x0; q_s[v][lane + HALF] = x1; }
             continue;
         }
         const float* nw = is_q ? a.q_norm : a.k_norm;
         if (nw != nullptr) {
             float ss = wave_sum(x0 * x0 + x1 * x1);
-            // oracle order: sum of squares, mean, +eps, 1/sqrt; then w * (x * r)
             float r = 1.0f / sqrtf(ss / (float)D + a.eps);
             if (lane < HALF) { x0 = nw[lane] * (x0 * r); x1 = nw[lane + HALF] * (x1 * r); }
         }
@@ -282,31 +526,17 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
     }
     __syncthreads();
 
-    // ---- 2. online softmax over the visible tokens; 16 token groups of 16 lanes ----
-    const int tg = wave * 4 + (lane >> 4), sub = lane & 15;
-    float qr[ATT_MAX_GRP][EPL], o[ATT_MAX_GRP][EPL], mrun[ATT_MAX_GRP], lrun[ATT_MAX_GRP];
+    // ---- 2. online softmax ----
+    float qr[G][EPL], o[G][EPL], mrun[G], lrun[G];
 #pragma unroll
-    for (int h = 0; h < ATT_MAX_GRP; ++h) {
+    for (int h = 0; h < G; ++h) {
         mrun[h] = -INFINITY; lrun[h] = 0.f;
 #pragma unroll
         for (int e = 0; e < EPL; ++e) { qr[h][e] = h < grp ? q_s[h][sub * EPL + e] : 0.f; o[h][e] = 0.f; }
     }
-    int t_lo = 0;
-    if (a.window > 0 && pos - a.window + 1 > 0) t_lo = pos - a.window + 1;
-    const int n_cache = a.new_from_raw ? base : pos + 1; // tokens < n_cache come from the cache
-    for (int t = t_lo + tg; t <= pos; t += 16) {
-        float kv[EPL], vv[EPL];
-        if (t < n_cache) {
-            const size_t off = cache_off(t) + sub * EPL;
+    auto consume = [&](const float (&kv)[EPL], const float (&vv)[EPL]) {
 #pragma unroll
-            for (int e = 0; e < EPL; ++e) { kv[e] = a.kcache[off + e]; vv[e] = a.vcache[off + e]; }
-        } else {
-            const int j = t - base;
-#pragma unroll
-            for (int e = 0; e < EPL; ++e) { kv[e] = knew[j][sub * EPL + e]; vv[e] = vnew[j][sub * EPL + e]; }
-        }
-#pragma unroll
-        for (int h = 0; h < ATT_MAX_GRP; ++h) {
+        for (int h = 0; h < G; ++h) {
             if (h < grp) {
                 float s = 0.f;
 #pragma unroll
@@ -315,17 +545,30 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
                 s *= a.scale;
                 const float mn = fmaxf(mrun[h], s);
                 const float corr = expf(mrun[h] - mn); // exp(-inf) = 0 on the first token
-                const float p = expf(s - mn);
-                lrun[h] = lrun[h] * corr + p;
+                const float pw = expf(s - mn);
+                lrun[h] = lrun[h] * corr + pw;
 #pragma unroll
-                for (int e = 0; e < EPL; ++e) o[h][e] = o[h][e] * corr + p * vv[e];
+                for (int e = 0; e < EPL; ++e) o[h][e] = o[h][e] * corr + pw * vv[e];
                 mrun[h] = mn;
             }
         }
+    };
+    for (int t0 = lo + tg; t0 < cend; t0 += 16 * U) {
+        if (t0 != lo + tg) load_batch(t0);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (t0 + 16 * u < cend) consume(kr[u], vr[u]);
+    }
+    for (int t = nlo + tg; t < hi && a.new_from_raw; t += 16) { // this split's new tokens (LDS)
+        const int j = t - base;
+        float kv[EPL], vv[EPL];
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) { kv[e] = knew[j][sub * EPL + e]; vv[e] = vnew[j][sub * EPL + e]; }
+        consume(kv, vv);
     }
     // ---- 3. combine the 16 token groups ----
 #pragma unroll
-    for (int h = 0; h < ATT_MAX_GRP; ++h) {
+    for (int h = 0; h < G; ++h) {
         if (h < grp) {
             if (sub == 0) { cm[tg][h] = mrun[h]; cl[tg][h] = lrun[h]; }
 #pragma unroll
@@ -345,7 +588,13 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
             L += w * cl[g][h];
             O += w * co[g][h][e];
         }
-        a.out[(size_t)row * a.ld_out + (kvh * grp + h) * D + e] = O / L;
+        const int head = kvh * grp + h;
+        if (a.po == nullptr) a.out[(size_t)row * a.ld_out + head * D + e] = O / L;
+        else {
+            const size_t pi = ((size_t)row * a.nq + head) * S + split;
+            a.po[pi * D + e] = O;
+            if (e == 0) { a.pm[pi] = mx; a.pl[pi] = L; }
+        }
     }
 }
 
@@ -353,27 +602,54 @@ void launch_attn(const AttnArgs& a, hipStream_t s) {
     const int grp = a.nq / a.nkv;
     if (grp < 1 || grp > ATT_MAX_GRP || a.nq % a.nkv) throw Error("attn: unsupported GQA group size");
     if (a.n_new > ATT_MAX_NEW && a.new_from_raw) throw Error("attn: too many new tokens per launch");
-    dim3 grid(a.nkv, a.n_new, a.nb);
-    if (a.d == 128) hipLaunchKernelGGL((k_attn<128>), grid, dim3(256), 0, s, a);
-    else if (a.d == 64) hipLaunchKernelGGL((k_attn<64>), grid, dim3(256), 0, s, a);
-    else if (a.d == 16) hipLaunchKernelGGL((k_attn<16>), grid, dim3(256), 0, s, a);
+    if (a.n_splits < 1 || (a.n_splits > 1 && (a.po == nullptr || a.window > 0))) throw Error("attn: split mode needs partial buffers and no window");
+    if ((size_t)a.n_new * a.n_splits > 65535) throw Error("attn: grid too large");
+    dim3 grid(a.nkv, a.n_new * a.n_splits, a.nb);
+#define Q3_ATT(D, U) do { if (grp == 1) hipLaunchKernelGGL((k_attn<D, U, 1>), grid, dim3(256), 0, s, a); \
+        else if (grp == 2) hipLaunchKernelGGL((k_attn<D, U, 2>), grid, dim3(256), 0, s, a); \
+        else hipLaunchKernelGGL((k_attn<D, U, 4>), grid, dim3(256), 0, s, a); } while (0)
+    if (a.d == 128) Q3_ATT(128, 8);
+    else if (a.d == 64) Q3_ATT(64, 8);
+    else if (a.d == 16) Q3_ATT(16, 4);
     else throw Error("attn: head_dim must be 16, 64 or 128");
+#undef Q3_ATT
+}
+
+// partials -> normalised rows (used when the consumer GEMV cannot take the fused prologue)
+__global__ __launch_bounds__(256) void k_attn_combine(AttnArgs a) {
+    const int row = blockIdx.x, bi = row / a.n_new, inew = row % a.n_new;
+    const int pos = (a.pos_dev ? a.pos_dev[a.slot_offset + bi] : a.pos_scalar) + inew;
+    int nact = pos / a.chunk + 1;
+    if (nact > a.n_splits) nact = a.n_splits;
+    for (int idx = threadIdx.x; idx < a.nq * a.d; idx += 256) {
+        const int head = idx / a.d, e = idx % a.d;
+        const size_t pi = ((size_t)row * a.nq + head) * a.n_splits;
+        float mx = -INFINITY;
+        for (int sp = 0; sp < nact; ++sp) mx = fmaxf(mx, a.pm[pi + sp]);
+        float L = 0.f, O = 0.f;
+        for (int sp = 0; sp < nact; ++sp) {
+            const float w = expf(a.pm[pi + sp] - mx);
+            L += w * a.pl[pi + sp];
+            O += w * a.po[(pi + sp) * a.d + e];
+        }
+        a.out[(size_t)row * a.ld_out + idx] = O / L;
+    }
+}
+void launch_attn_combine(const AttnArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(k_attn_combine, dim3(a.nb * a.n_new), dim3(256), 0, s, a);
 }
 
 // ================================================================================================
-// k_sample — temperature / top-k / top-p sampling (reference src/tts_onnx.cpp:878-950) on device,
-// one workgroup per batch row, V <= 4096.
+// k_sample — temperature / top-k / top-p sampling (reference src/tts_onnx.cpp:878-950) on device.
+// ONE WAVE per batch row: the whole vocabulary (<= 4096) sits in the wave's registers, every
+// reduction / scan is a cross-lane DPP sequence, so there is no block barrier chain; the epilogue
+// gathers the sampled token's embedding row and maintains the frame's running embedding sum
+// (tts_onnx.cpp:824-842), which keeps the generation loop free of host round trips.
 // ================================================================================================
 #define SAMP_MAXV 4096
-#define SAMP_PER (SAMP_MAXV / 256)
+#define SAMP_PER 64
 
 static __device__ __forceinline__ uint64_t mix64(uint64_t z) {
-    z += 0x9E3779B97F4A7C15ull;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return z ^ (z >> 31);
-}
-static __host__ __device__ __forceinline__ uint64_t mix64_hd(uint64_t z) {
     z += 0x9E3779B97F4A7C15ull;
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
@@ -389,45 +665,39 @@ static __device__ __forceinline__ uint32_t fkey(float f) {
     uint32_t u = __float_as_uint(f);
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
-
-static __device__ float block_sum(float v, float* red) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    v = wave_sum(v);
-    __syncthreads();
-    if (lane == 0) red[wave] = v;
-    __syncthreads();
-    return red[0] + red[1] + red[2] + red[3];
+static __device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
 }
-static __device__ float block_max(float v, float* red) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    v = wave_max(v);
-    __syncthreads();
-    if (lane == 0) red[wave] = v;
-    __syncthreads();
-    return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+// inclusive prefix sum across the wave (lane order)
+static __device__ __forceinline__ int wave_scan_i(int v, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(v, off, 64); if (lane >= off) v += t; }
+    return v;
+}
+static __device__ __forceinline__ float wave_scan_f(float v, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const float t = __shfl_up(v, off, 64); if (lane >= off) v += t; }
+    return v;
 }
 
-__global__ __launch_bounds__(256) void k_sample(SampleArgs a) {
-    const int b = blockIdx.x, tid = threadIdx.x;
+__global__ __launch_bounds__(64) void k_sample(SampleArgs a) {
+    const int b = blockIdx.x, lane = threadIdx.x;
     const int V = a.V;
-    __shared__ float red[4];
     __shared__ int hist[256];
-    __shared__ int scan[256];
     __shared__ int cand_idx[SAMP_MAXV];
     __shared__ float cand_p[SAMP_MAXV];
     __shared__ float sorted_p[SAMP_MAXV];
     __shared__ int sh_i[4];
-    __shared__ float sh_f[2];
 
     float temperature = a.temperature, top_p = a.top_p, u = a.u;
     int top_k = a.top_k, suppress = a.suppress, keep_eos = 1;
     int frame = 0;
     SlotState* st = a.st ? a.st + b : nullptr;
     if (st) {
-        if (!st->active) return;
-        if (a.group == 0 && !st->finished && st->n_frames >= st->max_frames) st->finished = 1; // tid-uniform value; benign race
-        __syncthreads();
-        if (st->finished) return;
+        if (!st->active || st->finished) return;
+        if (a.group == 0 && st->n_frames >= st->max_frames) { if (lane == 0) st->finished = 1; return; }
         temperature = st->temperature; top_p = st->top_p; top_k = st->top_k;
         frame = st->n_frames;
         u = rng_uniform_dev(st->seed, st->stream_id, (uint32_t)frame, (uint32_t)a.group);
@@ -435,13 +705,14 @@ __global__ __launch_bounds__(256) void k_sample(SampleArgs a) {
         keep_eos = !st->ignore_eos;
     }
 
-    // ---- load: thread owns indices [tid*PER, tid*PER+PER) so compaction preserves index order ----
-    const int PER = (V + 255) / 256;
+    // ---- load: lane owns indices [lane*PER, lane*PER+PER) so compaction preserves index order ----
+    const int PER = (V + 63) / 64;
     float x[SAMP_PER];
     const float* lg = a.logits + (size_t)b * a.ld;
+    float mx = -INFINITY;
 #pragma unroll
     for (int j = 0; j < SAMP_PER; ++j) {
-        const int i = tid * PER + j;
+        const int i = lane * PER + j;
         float v = -INFINITY;
         if (j < PER && i < V) {
             v = lg[i];
@@ -449,157 +720,187 @@ __global__ __launch_bounds__(256) void k_sample(SampleArgs a) {
             if (temperature > 0.0f && temperature != 1.0f) v = v / temperature;                              // :882-884
         }
         x[j] = v;
+        mx = fmaxf(mx, v);
     }
-    float mx = -INFINITY;
-#pragma unroll
-    for (int j = 0; j < SAMP_PER; ++j) mx = fmaxf(mx, x[j]);
-    mx = block_max(mx, red);
+    mx = wave_max(mx);
 
     // ---- top-k threshold = k-th largest value, ties kept (:917-927) ----
     float thr = -INFINITY;
     if (top_k > 0 && top_k < V) {
         if (top_k == 1) thr = mx;
-        else { // 4-pass MSB radix select on order-preserving keys
+        else { // 4-pass MSB radix select on order-preserving keys, LDS histogram, wave-level scans
             uint32_t prefix = 0, mask = 0;
             int remaining = top_k;
             for (int pass = 0; pass < 4; ++pass) {
                 const int shift = 24 - 8 * pass;
-                hist[tid] = 0;
+                hist[lane] = 0; hist[lane + 64] = 0; hist[lane + 128] = 0; hist[lane + 192] = 0;
                 __syncthreads();
 #pragma unroll
                 for (int j = 0; j < SAMP_PER; ++j) {
-                    const int i = tid * PER + j;
-                    if (j < PER && i < V) {
+                    if (j < PER && lane * PER + j < V) {
                         const uint32_t key = fkey(x[j]);
                         if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255], 1);
                     }
                 }
                 __syncthreads();
-                // suffix sums: scan[d] = #keys with digit >= d
-                scan[tid] = hist[tid];
-                __syncthreads();
-                for (int off = 1; off < 256; off <<= 1) {
-                    int v = scan[tid] + (tid + off < 256 ? scan[tid + off] : 0);
-                    __syncthreads();
-                    scan[tid] = v;
-                    __syncthreads();
-                }
-                // digit d is selected when scan[d] >= remaining > scan[d+1]
-                const int above = tid + 1 < 256 ? scan[tid + 1] : 0;
-                if (scan[tid] >= remaining && above < remaining) { sh_i[0] = tid; sh_i[1] = above; }
+                // lane owns digits 4*lane .. 4*lane+3; ge[d] = #keys with digit >= d
+                const int h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
+                const int tot = h0 + h1 + h2 + h3;
+                const int incl = wave_scan_i(tot, lane);                 // digits <= own block
+                const int all = __shfl(incl, 63, 64);
+                const int above = all - incl;                            // digits in higher lanes
+                const int ge3 = above + h3, ge2 = ge3 + h2, ge1 = ge2 + h1, ge0 = ge1 + h0;
+                // digit d is selected when ge[d] >= remaining > ge[d] - h[d]
+                if (ge3 >= remaining && above < remaining) { sh_i[0] = 4 * lane + 3; sh_i[1] = above; }
+                else if (ge2 >= remaining && ge3 < remaining) { sh_i[0] = 4 * lane + 2; sh_i[1] = ge3; }
+                else if (ge1 >= remaining && ge2 < remaining) { sh_i[0] = 4 * lane + 1; sh_i[1] = ge2; }
+                else if (ge0 >= remaining && ge1 < remaining) { sh_i[0] = 4 * lane; sh_i[1] = ge1; }
                 __syncthreads();
                 prefix |= (uint32_t)sh_i[0] << shift;
                 mask |= 255u << shift;
                 remaining -= sh_i[1];
                 __syncthreads();
             }
-            // prefix is the key of the k-th largest element
             const uint32_t ku = (prefix & 0x80000000u) ? (prefix & 0x7FFFFFFFu) : ~prefix;
             thr = __uint_as_float(ku);
         }
     }
 
-    // ---- ordered compaction of survivors (x >= thr and finite) ----
+    // ---- ordered compaction of survivors; softmax numerators exp(x - max) (:907-915) ----
     int cnt = 0;
 #pragma unroll
     for (int j = 0; j < SAMP_PER; ++j) cnt += (x[j] >= thr && x[j] != -INFINITY) ? 1 : 0;
-    scan[tid] = cnt;
-    __syncthreads();
-    for (int off = 1; off < 256; off <<= 1) { // inclusive prefix sum
-        int v = scan[tid] + (tid >= off ? scan[tid - off] : 0);
-        __syncthreads();
-        scan[tid] = v;
-        __syncthreads();
-    }
-    const int n_kept = scan[255];
-    int wpos = scan[tid] - cnt;
-    // softmax numerators (:907-915): exp(x - max); dropped entries contribute exp(-inf) = 0
+    const int incl = wave_scan_i(cnt, lane);
+    const int n_kept = __shfl(incl, 63, 64);
+    int wpos = incl - cnt;
     float esum = 0.f;
 #pragma unroll
     for (int j = 0; j < SAMP_PER; ++j) {
         if (x[j] >= thr && x[j] != -INFINITY) {
             const float e = expf(x[j] - mx);
-            cand_idx[wpos] = tid * PER + j;
+            cand_idx[wpos] = lane * PER + j;
             cand_p[wpos] = e;
             ++wpos;
             esum += e;
         }
     }
-    esum = block_sum(esum, red);
-    for (int c = tid; c < n_kept; c += 256) cand_p[c] = cand_p[c] / esum;
+    esum = wave_sum(esum);
     __syncthreads();
 
-    // ---- top-p (:929-950): sort descending (ties: lower index first), keep through the first cumsum > p ----
-    if (top_p < 1.0f) {
-        for (int c = tid; c < n_kept; c += 256) {
-            const float pc = cand_p[c];
+    int tok = 0;
+    if (n_kept <= 64) {
+        // ---- wave path: one candidate per lane, everything in registers ----
+        const bool have = lane < n_kept;
+        float p = have ? cand_p[lane] / esum : 0.f;
+        const int myidx = have ? cand_idx[lane] : 0;
+        if (top_p < 1.0f) { // :929-950 — rank by (p desc, index asc); keep through the first cumulative sum > top_p
             int rank = 0;
             for (int o2 = 0; o2 < n_kept; ++o2) {
-                const float po = cand_p[o2];
-                rank += (po > pc || (po == pc && o2 < c)) ? 1 : 0;
+                const float po = __shfl(p, o2, 64);
+                rank += (have && (po > p || (po == p && o2 < lane))) ? 1 : 0;
             }
-            sorted_p[rank] = pc;
-        }
-        __syncthreads();
-        if (tid == 0) {
-            float cum = 0.f;
-            int cutoff = n_kept;
-            for (int i = 0; i < n_kept; ++i) { cum += sorted_p[i]; if (cum > top_p) { cutoff = i + 1; break; } }
-            sh_i[2] = cutoff;
-        }
-        __syncthreads();
-        const int cutoff = sh_i[2];
-        // keep candidate c iff rank(c) < cutoff; recompute rank (n_kept is ~top_k)
-        float s2 = 0.f;
-        for (int c = tid; c < n_kept; c += 256) {
-            const float pc = cand_p[c];
-            int rank = 0;
+            float cum = 0.f; // sum of every candidate ranked at or before this one
             for (int o2 = 0; o2 < n_kept; ++o2) {
-                const float po = cand_p[o2];
-                rank += (po > pc || (po == pc && o2 < c)) ? 1 : 0;
+                const float po = __shfl(p, o2, 64);
+                const int ro = __shfl(rank, o2, 64);
+                if (ro <= rank) cum += po;
             }
-            sorted_p[c] = rank < cutoff ? pc : 0.f; // now indexed by candidate
+            int rcut = (have && cum > top_p) ? rank : 0x7FFFFFFF;
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) { const int t = __shfl_xor(rcut, off, 64); rcut = t < rcut ? t : rcut; }
+            if (!(have && rank <= rcut)) p = 0.f;
+            const float s2 = wave_sum(p);
+            if (s2 > 0.f) p = p / s2; // :893-898
         }
-        __syncthreads();
-        for (int c = tid; c < n_kept; c += 256) { cand_p[c] = sorted_p[c]; s2 += sorted_p[c]; }
-        s2 = block_sum(s2, red);
-        if (s2 > 0.f) for (int c = tid; c < n_kept; c += 256) cand_p[c] = cand_p[c] / s2; // :893-898
-        __syncthreads();
-    }
-
-    // ---- draw: inverse CDF in index order ----
-    if (tid == 0) {
-        float total = 0.f;
-        for (int c = 0; c < n_kept; ++c) total += cand_p[c];
+        // draw: inverse CDF in index order
+        const float total = wave_sum(p);
         const float target = u * total;
-        float cum = 0.f;
-        int pick = -1, last = -1;
-        for (int c = 0; c < n_kept; ++c) {
-            if (cand_p[c] > 0.f) { last = c; cum += cand_p[c]; if (cum > target) { pick = c; break; } }
+        const float cum = wave_scan_f(p, lane);
+        const unsigned long long hit = __ballot(p > 0.f && cum > target);
+        const unsigned long long pos_mask = __ballot(p > 0.f);
+        int pick;
+        if (hit) pick = __ffsll((long long)hit) - 1;
+        else pick = pos_mask ? 63 - __clzll((long long)pos_mask) : 0;
+        tok = __shfl(myidx, pick, 64);
+    } else {
+        // ---- general path (top_k == 0 or > 64, or many ties): LDS-resident candidates ----
+        for (int c = lane; c < n_kept; c += 64) cand_p[c] = cand_p[c] / esum;
+        __syncthreads();
+        if (top_p < 1.0f) {
+            for (int c = lane; c < n_kept; c += 64) {
+                const float pc = cand_p[c];
+                int rank = 0;
+                for (int o2 = 0; o2 < n_kept; ++o2) {
+                    const float po = cand_p[o2];
+                    rank += (po > pc || (po == pc && o2 < c)) ? 1 : 0;
+                }
+                sorted_p[rank] = pc;
+            }
+            __syncthreads();
+            if (lane == 0) {
+                float cum = 0.f;
+                int cutoff = n_kept;
+                for (int i = 0; i < n_kept; ++i) { cum += sorted_p[i]; if (cum > top_p) { cutoff = i + 1; break; } }
+                sh_i[2] = cutoff;
+            }
+            __syncthreads();
+            const int cutoff = sh_i[2];
+            const float pcut = sorted_p[cutoff - 1]; // probability of the last kept rank
+            // rank(c) < cutoff  <=>  p > pcut, or p == pcut and few enough equal-p candidates precede c
+            int n_gt = 0;
+            for (int c = lane; c < n_kept; c += 64) n_gt += cand_p[c] > pcut ? 1 : 0;
+            n_gt = wave_sum_i(n_gt);
+            const int n_eq_keep = cutoff - n_gt; // equal-p candidates kept, lowest indices first
+            __syncthreads();
+            if (lane == 0) {
+                int seen = 0;
+                for (int c = 0; c < n_kept; ++c) {
+                    const float pc = cand_p[c];
+                    if (pc > pcut) continue;
+                    if (pc == pcut && seen < n_eq_keep) { ++seen; continue; }
+                    cand_p[c] = 0.f;
+                }
+            }
+            __syncthreads();
+            float s2 = 0.f;
+            for (int c = lane; c < n_kept; c += 64) s2 += cand_p[c];
+            s2 = wave_sum(s2);
+            if (s2 > 0.f) for (int c = lane; c < n_kept; c += 64) cand_p[c] = cand_p[c] / s2;
+            __syncthreads();
         }
-        if (pick < 0) pick = last;
-        sh_i[3] = pick >= 0 ? cand_idx[pick] : 0;
+        if (lane == 0) {
+            float total = 0.f;
+            for (int c = 0; c < n_kept; ++c) total += cand_p[c];
+            const float target = u * total;
+            float cum = 0.f;
+            int pick = -1, last = -1;
+            for (int c = 0; c < n_kept; ++c) {
+                if (cand_p[c] > 0.f) { last = c; cum += cand_p[c]; if (cum > target) { pick = c; break; } }
+            }
+            if (pick < 0) pick = last;
+            sh_i[3] = pick >= 0 ? cand_idx[pick] : 0;
+        }
+        __syncthreads();
+        tok = sh_i[3];
     }
-    __syncthreads();
-    const int tok = sh_i[3];
 
-    if (!st) { if (tid == 0) a.token_out[b] = tok; return; }
+    if (!st) { if (lane == 0) a.token_out[b] = tok; return; }
 
     // ---- fused epilogue of the generation loop (tts_onnx.cpp:812-842, 864-868) ----
-    if (a.group == 0 && tok == a.eos_id) { if (tid == 0) st->finished = 1; return; } // :812 — no frame recorded
-    if (tid == 0) a.codes[((size_t)b * a.max_frames_cap + frame) * a.n_groups + a.group] = tok;
+    if (a.group == 0 && tok == a.eos_id) { if (lane == 0) st->finished = 1; return; } // :812 — no frame recorded
+    if (lane == 0) a.codes[((size_t)b * a.max_frames_cap + frame) * a.n_groups + a.group] = tok;
     const bf16_t* er = a.embed + (size_t)tok * a.H;
     const bool last_group = a.group == a.n_groups - 1;
     const float* text = nullptr;
     if (last_group) text = frame < st->trailing_len ? a.trailing + ((size_t)b * a.max_trailing + frame) * a.H : a.tts_pad; // :833-842
-    for (int h = tid; h < a.H; h += 256) {
+    for (int h = lane; h < a.H; h += 64) {
         const float e = __uint_as_float((uint32_t)er[h] << 16);
         if (a.x_next) a.x_next[(size_t)b * a.ld_xnext + h] = e;
         float sacc = a.group == 0 ? e : a.sum[(size_t)b * a.H + h] + e; // fp32, order code0, sub0..sub14 (:824-830)
         if (last_group) a.x_talk[(size_t)b * a.H + h] = sacc + text[h];
         else a.sum[(size_t)b * a.H + h] = sacc;
     }
-    if (last_group && tid == 0) {
+    if (last_group && lane == 0) {
         st->n_frames = frame + 1;
         a.talker_pos[b] = st->prompt_len + frame; // position of the token the talker decodes next
     }
@@ -607,7 +908,7 @@ __global__ __launch_bounds__(256) void k_sample(SampleArgs a) {
 
 void launch_sample(const SampleArgs& a, hipStream_t s) {
     if (a.V > SAMP_MAXV) throw Error("sample: vocabulary larger than 4096");
-    hipLaunchKernelGGL(k_sample, dim3(a.nb), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_sample, dim3(a.nb), dim3(64), 0, s, a);
 }
 
 // ================================================================================================

@@ -207,6 +207,15 @@ Engine::Engine(const q3tts_config& cfg, int device_, int max_batch, int max_ctx_
     };
     setup_stack(talker, H, c.n_layers, c.n_heads, c.n_kv_heads, c.head_dim, c.ffn, c.rms_eps, 6, max_ctx, c.rope_theta, true);
     setup_stack(cp, H, c.cp_layers, c.cp_heads, c.cp_kv_heads, c.cp_head_dim, c.cp_ffn, c.cp_rms_eps, 5, 32, c.cp_rope_theta, false);
+    // split-T attention: 128 cache tokens per workgroup (16 lane groups x 8 tokens in flight)
+    talker.chunk = 128;
+    talker.n_splits = (max_ctx + 127) / 128;
+    if (talker.n_splits > 64) { talker.n_splits = 64; talker.chunk = ((max_ctx + 63) / 64 + 127) / 128 * 128; }
+    for (DecStack* S : { &talker, &cp }) {
+        S->po = fm((size_t)rows_max * S->nq * S->n_splits * S->d);
+        S->pm = fm((size_t)rows_max * S->nq * S->n_splits);
+        S->pl = fm((size_t)rows_max * S->nq * S->n_splits);
+    }
     sync();
 }
 
@@ -321,10 +330,17 @@ void Engine::run_layers(const DecStack& W, float* x, int ldx, int nb, int n_new,
         a.rope_cos = W.rope_cos; a.rope_sin = W.rope_sin; a.pos_dev = pos_dev; a.pos_scalar = pos_scalar;
         a.slot_offset = slot_offset; a.nb = nb; a.n_new = n_new; a.nq = W.nq; a.nkv = W.nkv; a.d = W.d;
         a.scale = 1.0f / sqrtf((float)W.d); a.window = 0; a.new_from_raw = 1;
+        a.n_splits = W.n_splits; a.chunk = W.chunk; a.po = W.po; a.pm = W.pm; a.pl = W.pl;
         launch_attn(a, stream);
         GemvArgs o;
         o.W = w.o; o.x = attn; o.ldx = AO; o.res = x; o.ldres = ldx; o.out = x; o.ldo = ldx;
         o.M = M; o.N = W.H; o.K = AO; o.epi = EPI_RESIDUAL; o.nt = W.nt;
+        o.po = W.po; o.pm = W.pm; o.pl = W.pl; o.pS = W.n_splits; o.pchunk = W.chunk; o.pn_new = n_new; o.pslot_offset = slot_offset;
+        o.pheads = W.nq; o.pd = W.d; o.ppos_dev = pos_dev; o.ppos_scalar = pos_scalar;
+        if (!gemv_fast_path(o)) { // partials -> attn rows, then the generic GEMV
+            launch_attn_combine(a, stream);
+            o.po = nullptr; o.pm = nullptr; o.pl = nullptr;
+        }
         launch_gemv(o, stream);
         GemvArgs f;
         f.W = w.gate; f.W2 = w.up; f.x = x; f.ldx = ldx; f.gamma = w.post_norm; f.eps = W.eps; f.out = act; f.ldo = W.ffn;

@@ -35,6 +35,8 @@ struct DecStack {
     int pages_per_slot = 0, page_shift = 0;
     float *rope_cos = nullptr, *rope_sin = nullptr;
     bool nt = false; // weights streamed once per step -> non-temporal loads
+    int n_splits = 1, chunk = 1 << 30; // split-T attention
+    float *po = nullptr, *pm = nullptr, *pl = nullptr; // attention partials [rows][nq][n_splits]([d])
 };
 
 struct CodecW; // q3_codec.cpp

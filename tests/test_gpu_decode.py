@@ -180,3 +180,20 @@ def test_graph_and_eager_agree():
     assert np.array_equal(outs[0], outs[1])
     for o in (eng_g, eng_e, orc, orc2):
         o.close()
+
+
+def test_long_context_crosses_attention_splits():
+    """max_ctx 448 -> 4 attention splits of 128 tokens; 300 greedy frames walk across three split
+    boundaries (and several 64-token KV pages) and must stay bit-exact with the oracle."""
+    import q3tts
+    eng, orc, _ = tiny_pair(seed=11, max_batch=2, max_ctx=448)
+    sp = q3tts.Sampling(temperature=1.0, top_p=1.0, top_k=1, max_new_tokens=300)
+    ids = frame_tokens(list(range(40, 60)))
+    p, t = eng.build_prompt(ids, 0)
+    codes = eng.generate(p, t, sp, seed=8, stream_id=1, ignore_eos=True, slot=1)
+    ref = orc.generate(orc.build_prompt(ids, 0), to_osampling(sp), seed=8, stream=1, cp_cached=True, ignore_eos=True)
+    assert codes.shape == ref.shape == (300, eng.cfg.n_groups)
+    first_bad = np.argwhere((codes != ref).any(axis=1))
+    assert first_bad.size == 0, ("first diverging frame", int(first_bad[0]))
+    eng.close()
+    orc.close()

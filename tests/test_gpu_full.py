@@ -74,3 +74,26 @@ def test_codec_full_size(full):
     ref = orc.vocoder(codes)
     assert pcm.shape == ref.shape
     assert float(np.sqrt(np.mean((pcm - ref) ** 2))) < 1e-4
+
+
+def test_talker_decode_across_split_boundary_full_size(full):
+    """140 talker decode steps at 0.6B dims: the context crosses the first 128-token attention split."""
+    eng, orc = full
+    rng = np.random.default_rng(9)
+    x = (rng.standard_normal((8, 1024)) * 0.05).astype(np.float32)
+    lg, _ = eng.prefill(x)
+    lo, _ = orc.prefill(x)
+    assert np.abs(lg - lo).max() < 2e-4
+    big = qo.Oracle(orc.cfg, max_ctx=160)   # same weights, longer cache
+    for name, shape in eng.tensor_infos():
+        if name.startswith("talker."):
+            big.set_tensor(name, eng.get_tensor(name, shape))
+    big.prefill(x)
+    worst = 0.0
+    for i in range(140):
+        e = (rng.standard_normal(1024) * 0.05).astype(np.float32)
+        lg, lh = eng.decode(e)
+        lo, ho = big.decode(e)
+        worst = max(worst, float(np.abs(lg - lo).max()), float(np.abs(lh - ho).max()))
+    big.close()
+    assert worst < 3e-4, worst
