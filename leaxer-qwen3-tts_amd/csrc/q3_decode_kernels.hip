@@ -17,16 +17,50 @@
 
 namespace q3 {
 
-static __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+// Cross-lane reductions on the DPP path (no LDS round trip; __shfl_xor lowers to ds_bpermute + a full
+// lgkmcnt wait per step).  quad_perm / row_ror stay inside a 16-lane row; row_bcast15/31 carry the
+// row totals up to lane 63, which is broadcast through an SGPR.
+#define Q3_DPP_XOR1 0xB1   // quad_perm:[1,0,3,2]
+#define Q3_DPP_XOR2 0x4E   // quad_perm:[2,3,0,1]
+#define Q3_DPP_ROR4 0x124  // row_ror:4
+#define Q3_DPP_ROR8 0x128  // row_ror:8
+#define Q3_DPP_BCAST15 0x142
+#define Q3_DPP_BCAST31 0x143
+template <int CTRL, int ROW_MASK>
+static __device__ __forceinline__ float dpp_f(float oldv, float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, oldv), __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
+}
+template <int CTRL, int ROW_MASK>
+static __device__ __forceinline__ int dpp_i(int oldv, int v) {
+    return __builtin_amdgcn_update_dpp(oldv, v, CTRL, ROW_MASK, 0xF, false);
+}
+// sum over the 16 lanes of a DPP row (every lane of the row gets the total)
+static __device__ __forceinline__ float row_sum16(float v) {
+    v += dpp_f<Q3_DPP_XOR1, 0xF>(0.f, v);
+    v += dpp_f<Q3_DPP_XOR2, 0xF>(0.f, v);
+    v += dpp_f<Q3_DPP_ROR4, 0xF>(0.f, v);
+    v += dpp_f<Q3_DPP_ROR8, 0xF>(0.f, v);
     return v;
+}
+static __device__ __forceinline__ float wave_sum(float v) {
+    v = row_sum16(v);
+    v += dpp_f<Q3_DPP_BCAST15, 0xA>(0.f, v);
+    v += dpp_f<Q3_DPP_BCAST31, 0xC>(0.f, v);
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 static __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
-    return v;
+    v = fmaxf(v, dpp_f<Q3_DPP_XOR1, 0xF>(v, v));
+    v = fmaxf(v, dpp_f<Q3_DPP_XOR2, 0xF>(v, v));
+    v = fmaxf(v, dpp_f<Q3_DPP_ROR4, 0xF>(v, v));
+    v = fmaxf(v, dpp_f<Q3_DPP_ROR8, 0xF>(v, v));
+    v = fmaxf(v, dpp_f<Q3_DPP_BCAST15, 0xA>(v, v));
+    v = fmaxf(v, dpp_f<Q3_DPP_BCAST31, 0xC>(v, v));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
+static __device__ __forceinline__ float lane_bcast(float v, int src_lane /* wave-uniform */) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src_lane));
+}
+static __device__ __forceinline__ int lane_bcast_i(int v, int src_lane) { return __builtin_amdgcn_readlane(v, src_lane); }
 static __device__ __forceinline__ float bf_lo(uint32_t u) { return __uint_as_float(u << 16); }
 static __device__ __forceinline__ float bf_hi(uint32_t u) { return __uint_as_float(u & 0xFFFF0000u); }
 static __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
@@ -225,6 +259,15 @@ __global__ __launch_bounds__(256) void k_gemv1(GemvArgs a) {
             if (EPI == EPI_SWIGLU) w2[r][c] = ldw_rt(a.W2 + (size_t)n * K + c * 512 + lane * 8, a.nt);
         }
     }
+    __builtin_amdgcn_sched_barrier(0); // keep the weight loads ahead of everything below (hipcc sinks them otherwise)
+    // residual / bias operands of the epilogue: fetched now, not after the reduction
+    float epi_in = 0.f;
+    if (EPI == EPI_RESIDUAL || EPI == EPI_BIAS || EPI == EPI_BIAS_SILU) {
+        if (lane < MT * RW) {
+            const int m = lane / RW, n = n0 + lane % RW;
+            if (m < M && n < N) epi_in = EPI == EPI_RESIDUAL ? a.res[(size_t)m * a.ldres + n] : a.bias[n];
+        }
+    }
     // 2. activations
     float xv[MT][NCH][8];
     if (COMB) {
@@ -276,14 +319,17 @@ __global__ __launch_bounds__(256) void k_gemv1(GemvArgs a) {
                 xv[m][c][4] = x1.x; xv[m][c][5] = x1.y; xv[m][c][6] = x1.z; xv[m][c][7] = x1.w;
             }
     }
+    float g[NORM ? NCH : 1][8];
     if (NORM) {
-        float g[NCH][8];
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             const float4 g0 = *reinterpret_cast<const float4*>(a.gamma + c * 512 + lane * 8);
             const float4 g1 = *reinterpret_cast<const float4*>(a.gamma + c * 512 + lane * 8 + 4);
             g[c][0] = g0.x; g[c][1] = g0.y; g[c][2] = g0.z; g[c][3] = g0.w; g[c][4] = g1.x; g[c][5] = g1.y; g[c][6] = g1.z; g[c][7] = g1.w;
         }
+    }
+    __builtin_amdgcn_sched_barrier(0); // all loads of the kernel are in flight past this point
+    if (NORM) {
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             float ss = 0.f;
@@ -334,10 +380,10 @@ __global__ __launch_bounds__(256) void k_gemv1(GemvArgs a) {
         if (m < M && n < N) {
             float o;
             if (EPI == EPI_STORE) o = mine;
-            else if (EPI == EPI_RESIDUAL) o = a.res[(size_t)m * a.ldres + n] + mine;
+            else if (EPI == EPI_RESIDUAL) o = epi_in + mine;
             else if (EPI == EPI_SWIGLU) o = silu_f(mine) * mine2;
-            else if (EPI == EPI_BIAS) o = mine + a.bias[n];
-            else o = silu_f(mine + a.bias[n]);
+            else if (EPI == EPI_BIAS) o = mine + epi_in;
+            else o = silu_f(mine + epi_in);
             a.out[(size_t)m * a.ldo + n] = o;
         }
     }
@@ -541,7 +587,7 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
                 float s = 0.f;
 #pragma unroll
                 for (int e = 0; e < EPL; ++e) s = fmaf(qr[h][e], kv[e], s);
-                s += __shfl_xor(s, 8, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 1, 64);
+                s = row_sum16(s);
                 s *= a.scale;
                 const float mn = fmaxf(mrun[h], s);
                 const float corr = expf(mrun[h] - mn); // exp(-inf) = 0 on the first token
@@ -704,15 +750,16 @@ __global__ __launch_bounds__(64) void k_sample(SampleArgs a) {
         suppress = a.group == 0;
         keep_eos = !st->ignore_eos;
     }
+    const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
 
-    // ---- load: lane owns indices [lane*PER, lane*PER+PER) so compaction preserves index order ----
+    // ---- load (coalesced): lane owns indices j*64 + lane ----
     const int PER = (V + 63) / 64;
     float x[SAMP_PER];
     const float* lg = a.logits + (size_t)b * a.ld;
-    float mx = -INFINITY;
+    float lmax = -INFINITY;
 #pragma unroll
     for (int j = 0; j < SAMP_PER; ++j) {
-        const int i = lane * PER + j;
+        const int i = j * 64 + lane;
         float v = -INFINITY;
         if (j < PER && i < V) {
             v = lg[i];
@@ -720,15 +767,46 @@ __global__ __launch_bounds__(64) void k_sample(SampleArgs a) {
             if (temperature > 0.0f && temperature != 1.0f) v = v / temperature;                              // :882-884
         }
         x[j] = v;
-        mx = fmaxf(mx, v);
+        lmax = fmaxf(lmax, v);
     }
-    mx = wave_max(mx);
+    const float mx = wave_max(lmax);
 
     // ---- top-k threshold = k-th largest value, ties kept (:917-927) ----
     float thr = -INFINITY;
     if (top_k > 0 && top_k < V) {
-        if (top_k == 1) thr = mx;
-        else { // 4-pass MSB radix select on order-preserving keys, LDS histogram, wave-level scans
+        bool done = false;
+        if (top_k == 1) { thr = mx; done = true; }
+        else if (top_k <= 64) {
+            // The k-th largest of the 64 lane maxima is a lower bound L of the k-th largest overall, so
+            // only the few elements >= L can matter; rank those exactly.
+            int gt = 0, ge = 0;
+            for (int o2 = 0; o2 < 64; ++o2) { const float v = lane_bcast(lmax, o2); gt += v > lmax ? 1 : 0; ge += v >= lmax ? 1 : 0; }
+            const float L = wave_max((gt < top_k && top_k <= ge) ? lmax : -INFINITY);
+            int ns = 0;
+#pragma unroll
+            for (int j = 0; j < SAMP_PER; ++j) {
+                if (j < PER) {
+                    const bool sv = x[j] >= L && x[j] != -INFINITY;
+                    const unsigned long long m = __ballot(sv);
+                    if (sv) { const int ppos = ns + __popcll(m & lt_mask); if (ppos < 256) sorted_p[ppos] = x[j]; }
+                    ns += __popcll(m);
+                }
+            }
+            __syncthreads();
+            if (L != -INFINITY && ns >= top_k && ns <= 256) {
+                float cand = -INFINITY;
+                for (int i = lane; i < ns; i += 64) {
+                    const float vi = sorted_p[i];
+                    int g2 = 0, e2 = 0;
+                    for (int o2 = 0; o2 < ns; ++o2) { const float vo = sorted_p[o2]; g2 += vo > vi ? 1 : 0; e2 += vo >= vi ? 1 : 0; }
+                    if (g2 < top_k && top_k <= e2) cand = vi;
+                }
+                thr = wave_max(cand);
+                done = true;
+            }
+            __syncthreads();
+        }
+        if (!done) { // 4-pass MSB radix select on order-preserving keys (LDS histogram)
             uint32_t prefix = 0, mask = 0;
             int remaining = top_k;
             for (int pass = 0; pass < 4; ++pass) {
@@ -737,20 +815,18 @@ __global__ __launch_bounds__(64) void k_sample(SampleArgs a) {
                 __syncthreads();
 #pragma unroll
                 for (int j = 0; j < SAMP_PER; ++j) {
-                    if (j < PER && lane * PER + j < V) {
+                    if (j < PER && j * 64 + lane < V) {
                         const uint32_t key = fkey(x[j]);
                         if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255], 1);
                     }
                 }
                 __syncthreads();
-                // lane owns digits 4*lane .. 4*lane+3; ge[d] = #keys with digit >= d
                 const int h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
                 const int tot = h0 + h1 + h2 + h3;
-                const int incl = wave_scan_i(tot, lane);                 // digits <= own block
+                const int incl = wave_scan_i(tot, lane);
                 const int all = __shfl(incl, 63, 64);
-                const int above = all - incl;                            // digits in higher lanes
+                const int above = all - incl;
                 const int ge3 = above + h3, ge2 = ge3 + h2, ge1 = ge2 + h1, ge0 = ge1 + h0;
-                // digit d is selected when ge[d] >= remaining > ge[d] - h[d]
                 if (ge3 >= remaining && above < remaining) { sh_i[0] = 4 * lane + 3; sh_i[1] = above; }
                 else if (ge2 >= remaining && ge3 < remaining) { sh_i[0] = 4 * lane + 2; sh_i[1] = ge3; }
                 else if (ge1 >= remaining && ge2 < remaining) { sh_i[0] = 4 * lane + 1; sh_i[1] = ge2; }
@@ -766,22 +842,22 @@ __global__ __launch_bounds__(64) void k_sample(SampleArgs a) {
         }
     }
 
-    // ---- ordered compaction of survivors; softmax numerators exp(x - max) (:907-915) ----
-    int cnt = 0;
-#pragma unroll
-    for (int j = 0; j < SAMP_PER; ++j) cnt += (x[j] >= thr && x[j] != -INFINITY) ? 1 : 0;
-    const int incl = wave_scan_i(cnt, lane);
-    const int n_kept = __shfl(incl, 63, 64);
-    int wpos = incl - cnt;
+    // ---- index-ordered compaction of survivors; softmax numerators exp(x - max) (:907-915) ----
+    int n_kept = 0;
     float esum = 0.f;
 #pragma unroll
     for (int j = 0; j < SAMP_PER; ++j) {
-        if (x[j] >= thr && x[j] != -INFINITY) {
-            const float e = expf(x[j] - mx);
-            cand_idx[wpos] = lane * PER + j;
-            cand_p[wpos] = e;
-            ++wpos;
-            esum += e;
+        if (j < PER) {
+            const bool keep = x[j] >= thr && x[j] != -INFINITY;
+            const unsigned long long m = __ballot(keep);
+            if (keep) {
+                const int wpos = n_kept + __popcll(m & lt_mask);
+                const float e = expf(x[j] - mx);
+                cand_idx[wpos] = j * 64 + lane;
+                cand_p[wpos] = e;
+                esum += e;
+            }
+            n_kept += __popcll(m);
         }
     }
     esum = wave_sum(esum);
@@ -796,13 +872,13 @@ __global__ __launch_bounds__(64) void k_sample(SampleArgs a) {
         if (top_p < 1.0f) { // :929-950 — rank by (p desc, index asc); keep through the first cumulative sum > top_p
             int rank = 0;
             for (int o2 = 0; o2 < n_kept; ++o2) {
-                const float po = __shfl(p, o2, 64);
+                const float po = lane_bcast(p, o2);
                 rank += (have && (po > p || (po == p && o2 < lane))) ? 1 : 0;
             }
             float cum = 0.f; // sum of every candidate ranked at or before this one
             for (int o2 = 0; o2 < n_kept; ++o2) {
-                const float po = __shfl(p, o2, 64);
-                const int ro = __shfl(rank, o2, 64);
+                const float po = lane_bcast(p, o2);
+                const int ro = lane_bcast_i(rank, o2);
                 if (ro <= rank) cum += po;
             }
             int rcut = (have && cum > top_p) ? rank : 0x7FFFFFFF;
@@ -821,7 +897,7 @@ __global__ __launch_bounds__(64) void k_sample(SampleArgs a) {
         int pick;
         if (hit) pick = __ffsll((long long)hit) - 1;
         else pick = pos_mask ? 63 - __clzll((long long)pos_mask) : 0;
-        tok = __shfl(myidx, pick, 64);
+        tok = lane_bcast_i(myidx, pick);
     } else {
         // ---- general path (top_k == 0 or > 64, or many ties): LDS-resident candidates ----
         for (int c = lane; c < n_kept; c += 64) cand_p[c] = cand_p[c] / esum;
@@ -893,12 +969,38 @@ __global__ __launch_bounds__(64) void k_sample(SampleArgs a) {
     const bool last_group = a.group == a.n_groups - 1;
     const float* text = nullptr;
     if (last_group) text = frame < st->trailing_len ? a.trailing + ((size_t)b * a.max_trailing + frame) * a.H : a.tts_pad; // :833-842
-    for (int h = lane; h < a.H; h += 64) {
-        const float e = __uint_as_float((uint32_t)er[h] << 16);
-        if (a.x_next) a.x_next[(size_t)b * a.ld_xnext + h] = e;
-        float sacc = a.group == 0 ? e : a.sum[(size_t)b * a.H + h] + e; // fp32, order code0, sub0..sub14 (:824-830)
-        if (last_group) a.x_talk[(size_t)b * a.H + h] = sacc + text[h];
-        else a.sum[(size_t)b * a.H + h] = sacc;
+    // every load of the row first, then the stores (the pointers may alias as far as the compiler
+    // knows, which would otherwise serialise 16 load->store round trips)
+    constexpr int EP_MAX = 8; // H <= 2048
+    for (int h0 = 0; h0 < a.H; h0 += 256 * EP_MAX) {
+        float e[EP_MAX][4], sm[EP_MAX][4], tx[EP_MAX][4];
+#pragma unroll
+        for (int it = 0; it < EP_MAX; ++it) {
+            const int h = h0 + (it * 64 + lane) * 4;
+            if (h < a.H) {
+                const uint2 raw = *reinterpret_cast<const uint2*>(er + h);
+                e[it][0] = __uint_as_float(raw.x << 16); e[it][1] = __uint_as_float(raw.x & 0xFFFF0000u);
+                e[it][2] = __uint_as_float(raw.y << 16); e[it][3] = __uint_as_float(raw.y & 0xFFFF0000u);
+                if (a.group != 0) { const float4 v = *reinterpret_cast<const float4*>(a.sum + (size_t)b * a.H + h); sm[it][0] = v.x; sm[it][1] = v.y; sm[it][2] = v.z; sm[it][3] = v.w; }
+                if (last_group) { const float4 v = *reinterpret_cast<const float4*>(text + h); tx[it][0] = v.x; tx[it][1] = v.y; tx[it][2] = v.z; tx[it][3] = v.w; }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int it = 0; it < EP_MAX; ++it) {
+            const int h = h0 + (it * 64 + lane) * 4;
+            if (h < a.H) {
+                float o[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float sacc = a.group == 0 ? e[it][q] : sm[it][q] + e[it][q]; // fp32, order code0, sub0..sub14 (:824-830)
+                    o[q] = last_group ? sacc + tx[it][q] : sacc;
+                }
+                if (a.x_next) *reinterpret_cast<float4*>(a.x_next + (size_t)b * a.ld_xnext + h) = make_float4(e[it][0], e[it][1], e[it][2], e[it][3]);
+                if (last_group) *reinterpret_cast<float4*>(a.x_talk + (size_t)b * a.H + h) = make_float4(o[0], o[1], o[2], o[3]);
+                else *reinterpret_cast<float4*>(a.sum + (size_t)b * a.H + h) = make_float4(o[0], o[1], o[2], o[3]);
+            }
+        }
     }
     if (last_group && lane == 0) {
         st->n_frames = frame + 1;
