@@ -243,7 +243,8 @@ static __device__ __forceinline__ uint4 ldw_rt(const bf16_t* p, bool nt) {
 template <int MT, int NCH, int RW, int EPI, bool NORM, bool COMB>
 __global__ __launch_bounds__(256) void k_gemv1(GemvArgs a) {
     constexpr int K = NCH * 512;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // provably wave-uniform: row addresses stay scalar
     const int n0 = (blockIdx.x * 4 + wave) * RW;
     const int N = a.N, M = a.M;
     __shared__ float xs[COMB ? MT * K : 1];
@@ -281,16 +282,33 @@ __global__ __launch_bounds__(256) void k_gemv1(GemvArgs a) {
                     int nact = pos / a.pchunk + 1;
                     if (nact > a.pS) nact = a.pS;
                     const size_t idx = ((size_t)m * a.pheads + head) * a.pS;
-                    float mx = -INFINITY;
-                    for (int sp = 0; sp < nact; ++sp) mx = fmaxf(mx, a.pm[idx + sp]);
-                    float L = 0.f, O[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                    for (int sp = 0; sp < nact; ++sp) {
-                        const float wgt = expf(a.pm[idx + sp] - mx);
-                        L += wgt * a.pl[idx + sp];
-                        const float4 o0 = *reinterpret_cast<const float4*>(a.po + (idx + sp) * a.pd + e0);
-                        const float4 o1 = *reinterpret_cast<const float4*>(a.po + (idx + sp) * a.pd + e0 + 4);
-                        O[0] += wgt * o0.x; O[1] += wgt * o0.y; O[2] += wgt * o0.z; O[3] += wgt * o0.w;
-                        O[4] += wgt * o1.x; O[5] += wgt * o1.y; O[6] += wgt * o1.z; O[7] += wgt * o1.w;
+                    // online merge in branch-free batches of 4 splits (clamped addresses, zero weight past nact)
+                    float mx = -INFINITY, L = 0.f, O[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    for (int sp0 = 0; sp0 < nact; sp0 += 4) {
+                        float pmv[4], plv[4];
+                        float4 o0[4], o1[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int sp = sp0 + q < nact ? sp0 + q : nact - 1;
+                            pmv[q] = a.pm[idx + sp]; plv[q] = a.pl[idx + sp];
+                            o0[q] = *reinterpret_cast<const float4*>(a.po + (idx + sp) * a.pd + e0);
+                            o1[q] = *reinterpret_cast<const float4*>(a.po + (idx + sp) * a.pd + e0 + 4);
+                        }
+                        float mn = mx;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) mn = fmaxf(mn, pmv[q]);
+                        const float corr = __expf(mx - mn);
+                        L *= corr;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) O[j] *= corr;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float wgt = sp0 + q < nact ? __expf(pmv[q] - mn) : 0.f;
+                            L += wgt * plv[q];
+                            O[0] += wgt * o0[q].x; O[1] += wgt * o0[q].y; O[2] += wgt * o0[q].z; O[3] += wgt * o0[q].w;
+                            O[4] += wgt * o1[q].x; O[5] += wgt * o1[q].y; O[6] += wgt * o1[q].z; O[7] += wgt * o1[q].w;
+                        }
+                        mx = mn;
                     }
 #pragma unroll
                     for (int j = 0; j < 8; ++j) xs[m * K + k8 + j] = O[j] / L;
@@ -477,13 +495,29 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
     const int kvh = blockIdx.x, bi = blockIdx.z;
     const int S = a.n_splits;
     const int inew = blockIdx.y / S, split = blockIdx.y % S;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); // provably wave-uniform: pointer selects stay scalar
     const int grp = a.nq / a.nkv;
     const int slot = a.slot_offset + bi;
-    const int base = a.pos_dev ? a.pos_dev[slot] : a.pos_scalar; // position of new token 0
     const int row = bi * a.n_new + inew;
+    const int pshift = a.page_shift, page_tokens = 1 << pshift;
+
+    __shared__ float q_s[G][D];
+    __shared__ float knew[ATT_MAX_NEW][D];
+    __shared__ float vnew[ATT_MAX_NEW][D];
+    __shared__ float cm[16][G], cl[16][G];
+    __shared__ float co[16][G][D];
+
+    // ---- round 1: position of new token 0 and the (at most 4) page ids this split can touch ----
+    const int* pt = a.page_table + (size_t)slot * a.pages_per_slot;
+    const int pbase = (split * a.chunk) >> pshift;
+    int pg[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const int pi = pbase + q < a.pages_per_slot ? pbase + q : a.pages_per_slot - 1; pg[q] = pt[pi]; }
+    int base = a.pos_scalar;
+    if (a.pos_dev) base = a.pos_dev[slot];
     const int pos = base + inew;
-    const int page_tokens = 1 << a.page_shift;
+    __builtin_amdgcn_sched_barrier(0);
 
     // token range of this split
     int lo = split * a.chunk;
@@ -494,82 +528,98 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
     const int cend = hi < n_cache ? hi : n_cache;           // cache tokens [lo, cend)
     const int nlo = lo > base ? lo : base;                  // new tokens [nlo, hi) come from qkv (new_from_raw)
 
-    __shared__ float q_s[G][D];
-    __shared__ float knew[ATT_MAX_NEW][D];
-    __shared__ float vnew[ATT_MAX_NEW][D];
-    __shared__ float cm[16][G], cl[16][G];
-    __shared__ float co[16][G][D];
-
-    const int* pt = a.page_table + (size_t)slot * a.pages_per_slot;
     auto cache_off = [&](int t) -> size_t {
-        const int page = pt[t >> a.page_shift];
+        const int q = (t >> pshift) - pbase;
+        const int page = q <= 0 ? pg[0] : (q == 1 ? pg[1] : (q == 2 ? pg[2] : pg[3]));
         return ((((size_t)page * a.n_layers + a.layer) * a.nkv + kvh) * page_tokens + (t & (page_tokens - 1))) * D;
     };
 
+    // ---- round 2: the first K/V batch and every prologue operand, all in flight together ----
     const int tg = wave * 4 + (lane >> 4), sub = lane & 15;
     float kr[U][EPL], vr[U][EPL];
     auto load_batch = [&](int t0) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int t = t0 + 16 * u;
-            if (t < cend) {
-                const size_t off = cache_off(t) + sub * EPL;
-                if (EPL >= 4) {
+            int t = t0 + 16 * u;           // clamp instead of branching: a conditional load costs a serial round trip
+            t = t < cend ? t : cend - 1;
+            t = t > 0 ? t : 0;
+            const size_t off = cache_off(t) + sub * EPL;
+            if (EPL >= 4) {
 #pragma unroll
-                    for (int e = 0; e < EPL; e += 4) {
-                        const float4 k4 = *reinterpret_cast<const float4*>(a.kcache + off + e);
-                        const float4 v4 = *reinterpret_cast<const float4*>(a.vcache + off + e);
-                        kr[u][e] = k4.x; kr[u][e + 1] = k4.y; kr[u][e + 2] = k4.z; kr[u][e + 3] = k4.w;
-                        vr[u][e] = v4.x; vr[u][e + 1] = v4.y; vr[u][e + 2] = v4.z; vr[u][e + 3] = v4.w;
-                    }
-                } else {
+                for (int e = 0; e < EPL; e += 4) {
+                    const float4 k4 = *reinterpret_cast<const float4*>(a.kcache + off + e);
+                    const float4 v4 = *reinterpret_cast<const float4*>(a.vcache + off + e);
+                    kr[u][e] = k4.x; kr[u][e + 1] = k4.y; kr[u][e + 2] = k4.z; kr[u][e + 3] = k4.w;
+                    vr[u][e] = v4.x; vr[u][e + 1] = v4.y; vr[u][e + 2] = v4.z; vr[u][e + 3] = v4.w;
+                }
+            } else {
 #pragma unroll
-                    for (int e = 0; e < EPL; ++e) { kr[u][e] = a.kcache[off + e]; vr[u][e] = a.vcache[off + e]; }
+                for (int e = 0; e < EPL; ++e) { kr[u][e] = a.kcache[off + e]; vr[u][e] = a.vcache[off + e]; }
+            }
+        }
+    };
+    // ---- 1. q heads of this group and this split's new keys: RMSNorm + RoPE; own K/V appended to the cache.
+    // Operand loads of each wave's first vector are issued BEFORE the K/V batch (vmcnt is in-order), so the
+    // prologue math runs while the batch is still in flight. ----
+    const int jlo = nlo - base;                    // first new token of this split
+    const int nnew = a.new_from_raw && hi > nlo ? hi - nlo : 0;
+    const int nvec = grp + nnew;
+    const int hl = lane < HALF ? lane : 0;         // clamped lane: loads stay unconditional
+    struct VecOps { float x0, x1, v0, v1, n0, n1, cs, sn; };
+    auto load_vec = [&](int v) -> VecOps {
+        const bool is_q = v < grp;
+        const int j = is_q ? inew : jlo + (v - grp);
+        const float* rowp = a.qkv + (size_t)(bi * a.n_new + j) * a.ld_qkv;
+        const float* src = rowp + (is_q ? (kvh * grp + v) * D : (a.nq + kvh) * D);
+        const float* vs = rowp + (a.nq + a.nkv + kvh) * D;
+        const int p = base + j;
+        VecOps r;
+        r.x0 = src[hl]; r.x1 = src[hl + HALF];
+        r.v0 = vs[hl]; r.v1 = vs[hl + HALF];
+        const float* nw = is_q ? a.q_norm : a.k_norm;
+        r.n0 = 1.f; r.n1 = 1.f; r.cs = 1.f; r.sn = 0.f;
+        if (a.new_from_raw) {
+            if (nw != nullptr) { r.n0 = nw[hl]; r.n1 = nw[hl + HALF]; }
+            r.cs = a.rope_cos[(size_t)p * HALF + hl]; r.sn = a.rope_sin[(size_t)p * HALF + hl];
+        }
+        return r;
+    };
+    auto finish_vec = [&](int v, VecOps r) {
+        const bool is_q = v < grp;
+        const int j = is_q ? inew : jlo + (v - grp);
+        const int p = base + j;
+        float x0 = lane < HALF ? r.x0 : 0.f, x1 = lane < HALF ? r.x1 : 0.f;
+        if (!a.new_from_raw) { // q was roped by k_rope_store
+            if (lane < HALF) { q_s[v][lane] = x0; q_s[v][lane + HALF] = x1; }
+            return;
+        }
+        const float* nw = is_q ? a.q_norm : a.k_norm;
+        if (nw != nullptr) {
+            const float ss = wave_sum(x0 * x0 + x1 * x1);
+            const float rr = 1.0f / sqrtf(ss / (float)D + a.eps);
+            x0 = r.n0 * (x0 * rr); x1 = r.n1 * (x1 * rr);
+        }
+        if (lane < HALF) {
+            const float y0 = x0 * r.cs + (-x1) * r.sn;
+            const float y1 = x1 * r.cs + x0 * r.sn;
+            if (is_q) { q_s[v][lane] = y0; q_s[v][lane + HALF] = y1; }
+            else {
+                knew[j][lane] = y0; knew[j][lane + HALF] = y1;
+                vnew[j][lane] = r.v0; vnew[j][lane + HALF] = r.v1;
+                if (j == inew) { // this workgroup owns position `pos`
+                    const size_t off = cache_off(p);
+                    a.kcache[off + lane] = y0; a.kcache[off + lane + HALF] = y1;
+                    a.vcache[off + lane] = r.v0; a.vcache[off + lane + HALF] = r.v1;
                 }
             }
         }
     };
-    load_batch(lo + tg); // in flight while the prologue below runs
-
-    // ---- 1. q heads of this group and this split's new keys: RMSNorm + RoPE; own K/V appended to the cache ----
-    const int jlo = nlo - base;                    // first new token of this split
-    const int nnew = a.new_from_raw && hi > nlo ? hi - nlo : 0;
-    const int nvec = grp + nnew;
-    for (int v = wave; v < nvec; v += 4) {
-        const bool is_q = v < grp;
-        const int j = is_q ? inew : jlo + (v - grp);
-        const float* src = a.qkv + (size_t)(bi * a.n_new + j) * a.ld_qkv + (is_q ? (kvh * grp + v) * D : (a.nq + kvh) * D);
-        const int p = base + j;
-        float x0 = 0.f, x1 = 0.f;
-        if (lane < HALF) { x0 = src[lane]; x1 = src[lane + HALF]; }
-        if (!a.new_from_raw) { // q was roped by k_rope_store
-            if (lane < HALF) { q_s[v][lane] = x0; q_s[v][lane + HALF] = x1; }
-            continue;
-        }
-        const float* nw = is_q ? a.q_norm : a.k_norm;
-        if (nw != nullptr) {
-            float ss = wave_sum(x0 * x0 + x1 * x1);
-            float r = 1.0f / sqrtf(ss / (float)D + a.eps);
-            if (lane < HALF) { x0 = nw[lane] * (x0 * r); x1 = nw[lane + HALF] * (x1 * r); }
-        }
-        if (lane < HALF) {
-            const float cs = a.rope_cos[(size_t)p * HALF + lane], sn = a.rope_sin[(size_t)p * HALF + lane];
-            const float y0 = x0 * cs + (-x1) * sn;
-            const float y1 = x1 * cs + x0 * sn;
-            if (is_q) { q_s[v][lane] = y0; q_s[v][lane + HALF] = y1; }
-            else {
-                knew[j][lane] = y0; knew[j][lane + HALF] = y1;
-                const float* vs = a.qkv + (size_t)(bi * a.n_new + j) * a.ld_qkv + (a.nq + a.nkv + kvh) * D;
-                const float v0 = vs[lane], v1 = vs[lane + HALF];
-                vnew[j][lane] = v0; vnew[j][lane + HALF] = v1;
-                if (j == inew) { // this workgroup owns position `pos`
-                    const size_t off = cache_off(p);
-                    a.kcache[off + lane] = y0; a.kcache[off + lane + HALF] = y1;
-                    a.vcache[off + lane] = v0; a.vcache[off + lane + HALF] = v1;
-                }
-            }
-        }
-    }
+    const VecOps first = load_vec(wave < nvec ? wave : 0);
+    __builtin_amdgcn_sched_barrier(0);
+    load_batch(lo + tg);
+    __builtin_amdgcn_sched_barrier(0);
+    if (wave < nvec) finish_vec(wave, first);
+    for (int v = wave + 4; v < nvec; v += 4) finish_vec(v, load_vec(v)); // prefill only (more than 4 vectors)
     __syncthreads();
 
     // ---- 2. online softmax ----
@@ -590,8 +640,8 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
                 s = row_sum16(s);
                 s *= a.scale;
                 const float mn = fmaxf(mrun[h], s);
-                const float corr = expf(mrun[h] - mn); // exp(-inf) = 0 on the first token
-                const float pw = expf(s - mn);
+                const float corr = __expf(mrun[h] - mn); // exp(-inf) = 0 on the first token
+                const float pw = __expf(s - mn);
                 lrun[h] = lrun[h] * corr + pw;
 #pragma unroll
                 for (int e = 0; e < EPL; ++e) o[h][e] = o[h][e] * corr + pw * vv[e];
@@ -601,9 +651,43 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
     };
     for (int t0 = lo + tg; t0 < cend; t0 += 16 * U) {
         if (t0 != lo + tg) load_batch(t0);
+        // all U scores first (independent dot products), then one running-max update per head
+        float sc[U][G];
 #pragma unroll
-        for (int u = 0; u < U; ++u)
-            if (t0 + 16 * u < cend) consume(kr[u], vr[u]);
+        for (int u = 0; u < U; ++u) {
+            const bool valid = t0 + 16 * u < cend;
+#pragma unroll
+            for (int h = 0; h < G; ++h) {
+                float sdot = 0.f;
+                if (h < grp) {
+#pragma unroll
+                    for (int e = 0; e < EPL; ++e) sdot = fmaf(qr[h][e], kr[u][e], sdot);
+                    sdot = row_sum16(sdot) * a.scale;
+                }
+                sc[u][h] = valid ? sdot : -INFINITY;
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < G; ++h) {
+            if (h < grp) {
+                float mn = mrun[h];
+#pragma unroll
+                for (int u = 0; u < U; ++u) mn = fmaxf(mn, sc[u][h]);   // token u=0 is always valid -> finite
+                const float corr = __expf(mrun[h] - mn);
+                float l = lrun[h] * corr;
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) o[h][e] *= corr;
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const float pw = __expf(sc[u][h] - mn);           // exp(-inf) = 0 for padding tokens
+                    l += pw;
+#pragma unroll
+                    for (int e = 0; e < EPL; ++e) o[h][e] = fmaf(pw, t0 + 16 * u < cend ? vr[u][e] : 0.f, o[h][e]);
+                }
+                lrun[h] = l;
+                mrun[h] = mn;
+            }
+        }
     }
     for (int t = nlo + tg; t < hi && a.new_from_raw; t += 16) { // this split's new tokens (LDS)
         const int j = t - base;
@@ -650,6 +734,7 @@ void launch_attn(const AttnArgs& a, hipStream_t s) {
     if (a.n_new > ATT_MAX_NEW && a.new_from_raw) throw Error("attn: too many new tokens per launch");
     if (a.n_splits < 1 || (a.n_splits > 1 && (a.po == nullptr || a.window > 0))) throw Error("attn: split mode needs partial buffers and no window");
     if ((size_t)a.n_new * a.n_splits > 65535) throw Error("attn: grid too large");
+    if (a.n_splits > 1 && (a.chunk >> a.page_shift) + 1 > 4) throw Error("attn: a split may touch at most 4 KV pages");
     dim3 grid(a.nkv, a.n_new * a.n_splits, a.nb);
 #define Q3_ATT(D, U) do { if (grp == 1) hipLaunchKernelGGL((k_attn<D, U, 1>), grid, dim3(256), 0, s, a); \
         else if (grp == 2) hipLaunchKernelGGL((k_attn<D, U, 2>), grid, dim3(256), 0, s, a); \
@@ -757,15 +842,22 @@ __global__ __launch_bounds__(64) void k_sample(SampleArgs a) {
     float x[SAMP_PER];
     const float* lg = a.logits + (size_t)b * a.ld;
     float lmax = -INFINITY;
+    // unconditional loads from clamped addresses, selects afterwards: a load under a runtime condition
+    // gets its own branch + vmcnt(0) from hipcc, i.e. one serial memory round trip per element
+    const bool use_temp = temperature > 0.0f && temperature != 1.0f;
 #pragma unroll
     for (int j = 0; j < SAMP_PER; ++j) {
         const int i = j * 64 + lane;
-        float v = -INFINITY;
-        if (j < PER && i < V) {
-            v = lg[i];
-            if (suppress && i >= a.sup_begin && i < a.sup_end && !(i == a.eos_id && keep_eos)) v = -INFINITY; // :803-807
-            if (temperature > 0.0f && temperature != 1.0f) v = v / temperature;                              // :882-884
-        }
+        x[j] = lg[i < V ? i : V - 1];
+    }
+#pragma unroll
+    for (int j = 0; j < SAMP_PER; ++j) {
+        const int i = j * 64 + lane;
+        float v = x[j];
+        const bool sup = suppress && i >= a.sup_begin && i < a.sup_end && !(i == a.eos_id && keep_eos);  // :803-807
+        const float vt = v / temperature;                                                                // :882-884
+        v = use_temp ? vt : v;
+        v = (sup || i >= V) ? -INFINITY : v;
         x[j] = v;
         lmax = fmaxf(lmax, v);
     }
@@ -778,8 +870,9 @@ __global__ __launch_bounds__(64) void k_sample(SampleArgs a) {
         if (top_k == 1) { thr = mx; done = true; }
         else if (top_k <= 64) {
             // The k-th largest of the 64 lane maxima is a lower bound L of the k-th largest overall, so
-            // only the few elements >= L can matter; rank those exactly.
+            // only the few elements >= L (~100 of 3072) can matter; rank those exactly with ballots.
             int gt = 0, ge = 0;
+#pragma unroll 8
             for (int o2 = 0; o2 < 64; ++o2) { const float v = lane_bcast(lmax, o2); gt += v > lmax ? 1 : 0; ge += v >= lmax ? 1 : 0; }
             const float L = wave_max((gt < top_k && top_k <= ge) ? lmax : -INFINITY);
             int ns = 0;
@@ -794,15 +887,26 @@ __global__ __launch_bounds__(64) void k_sample(SampleArgs a) {
             }
             __syncthreads();
             if (L != -INFINITY && ns >= top_k && ns <= 256) {
-                float cand = -INFINITY;
-                for (int i = lane; i < ns; i += 64) {
-                    const float vi = sorted_p[i];
-                    int g2 = 0, e2 = 0;
-                    for (int o2 = 0; o2 < ns; ++o2) { const float vo = sorted_p[o2]; g2 += vo > vi ? 1 : 0; e2 += vo >= vi ? 1 : 0; }
-                    if (g2 < top_k && top_k <= e2) cand = vi;
+                // survivor i lives in register i/64 of lane i%64 (-inf padding never outranks anything)
+                float sv4[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) sv4[q] = q * 64 + lane < ns ? sorted_p[q * 64 + lane] : -INFINITY;
+                float found = -INFINITY;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (q * 64 < ns) {
+                        const int lim = ns - q * 64 < 64 ? ns - q * 64 : 64;
+#pragma unroll 4
+                        for (int i = 0; i < lim; ++i) {
+                            const float v = lane_bcast(sv4[q], i);
+                            const int g2 = __popcll(__ballot(sv4[0] > v)) + __popcll(__ballot(sv4[1] > v)) + __popcll(__ballot(sv4[2] > v)) + __popcll(__ballot(sv4[3] > v));
+                            const int e2 = __popcll(__ballot(sv4[0] >= v)) + __popcll(__ballot(sv4[1] >= v)) + __popcll(__ballot(sv4[2] >= v)) + __popcll(__ballot(sv4[3] >= v));
+                            if (g2 < top_k && top_k <= e2) found = v;
+                        }
+                    }
                 }
-                thr = wave_max(cand);
-                done = true;
+                thr = found;
+                done = found != -INFINITY;
             }
             __syncthreads();
         }
@@ -869,17 +973,15 @@ __global__ __launch_bounds__(64) void k_sample(SampleArgs a) {
         const bool have = lane < n_kept;
         float p = have ? cand_p[lane] / esum : 0.f;
         const int myidx = have ? cand_idx[lane] : 0;
-        if (top_p < 1.0f) { // :929-950 — rank by (p desc, index asc); keep through the first cumulative sum > top_p
-            int rank = 0;
+        if (top_p < 1.0f) { // :929-950 — order by (p desc, index asc); keep through the first cumulative sum > top_p
+            int rank = 0;      // candidates ordered strictly before this one
+            float cum = 0.f;   // sum of every candidate ordered at or before this one
+#pragma unroll 4
             for (int o2 = 0; o2 < n_kept; ++o2) {
                 const float po = lane_bcast(p, o2);
-                rank += (have && (po > p || (po == p && o2 < lane))) ? 1 : 0;
-            }
-            float cum = 0.f; // sum of every candidate ranked at or before this one
-            for (int o2 = 0; o2 < n_kept; ++o2) {
-                const float po = lane_bcast(p, o2);
-                const int ro = lane_bcast_i(rank, o2);
-                if (ro <= rank) cum += po;
+                const bool before = po > p || (po == p && o2 < lane);
+                rank += before ? 1 : 0;
+                cum += (before || o2 == lane) ? po : 0.f;
             }
             int rcut = (have && cum > top_p) ? rank : 0x7FFFFFFF;
 #pragma unroll

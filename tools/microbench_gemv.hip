@@ -73,6 +73,54 @@ __global__ __launch_bounds__(TPB) void k_gemv_t(const bf16_t* __restrict__ W, co
 
 struct Layer { bf16_t *qkv, *o, *gu, *down; };
 
+// MODE 2 ("k-split"): one 512-wide K chunk per wave; the KS=NCH waves of a row group combine through LDS.
+// Workgroup = NCH k-waves x RG row groups, each wave RW rows.  Wide and shallow: ~16-32 waves per CU.
+template <int NCH, int RW, int RG, bool NT>
+__global__ __launch_bounds__(64 * NCH * RG) void k_gemv_ks(const bf16_t* __restrict__ W, const float* __restrict__ x, float* __restrict__ out, int N) {
+    constexpr int K = NCH * 512;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ks = wave % NCH, rg = wave / NCH;
+    const int n0 = (blockIdx.x * RG + rg) * RW;
+    __shared__ float part[RG][NCH][RW];
+    u32x4 w[RW];
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+        const int n = n0 + r < N ? n0 + r : N - 1;
+        const u32x4* p = reinterpret_cast<const u32x4*>(W + (size_t)n * K + ks * 512 + lane * 8);
+        w[r] = NT ? __builtin_nontemporal_load(p) : *p;
+    }
+    const float4 a = *reinterpret_cast<const float4*>(x + ks * 512 + lane * 8);
+    const float4 b = *reinterpret_cast<const float4*>(x + ks * 512 + lane * 8 + 4);
+    const float xv[8] = { a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w };
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+        const unsigned wu[4] = { w[r].x, w[r].y, w[r].z, w[r].w };
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            s = fmaf(xv[2 * j], __uint_as_float(wu[j] << 16), s);
+            s = fmaf(xv[2 * j + 1], __uint_as_float(wu[j] & 0xFFFF0000u), s);
+        }
+        s = wave_sum(s);
+        if (lane == 0) part[rg][ks][r] = s;
+    }
+    __syncthreads();
+    if (ks == 0 && lane < RW && n0 + lane < N) {
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) s += part[rg][c][lane];
+        out[n0 + lane] = s * 1e-3f;
+    }
+}
+template <bool NT, int RWQ, int RGQ, int RGO, int RWG, int RGG, int RGD>
+static void record_layer_ks(const Layer& L, float* x, float* t1, float* t2, hipStream_t s) {
+    hipLaunchKernelGGL((k_gemv_ks<2, RWQ, RGQ, NT>), dim3(4096 / (RWQ * RGQ)), dim3(64 * 2 * RGQ), 0, s, L.qkv, x, t1, 4096);
+    hipLaunchKernelGGL((k_gemv_ks<4, 1, RGO, NT>), dim3(1024 / RGO), dim3(64 * 4 * RGO), 0, s, L.o, t1, t2, 1024);
+    hipLaunchKernelGGL((k_gemv_ks<2, RWG, RGG, NT>), dim3(6144 / (RWG * RGG)), dim3(64 * 2 * RGG), 0, s, L.gu, t2, t1, 6144);
+    hipLaunchKernelGGL((k_gemv_ks<6, 1, RGD, NT>), dim3(1024 / RGD), dim3(64 * 6 * RGD), 0, s, L.down, t1, x, 1024);
+}
+
+
 template <int MODE, bool NT, int TPB>
 static void record_layer(const Layer& L, float* x, float* t1, float* t2, hipStream_t s) {
     constexpr int WPB = TPB / 64;
@@ -132,9 +180,11 @@ int main() {
         run("full gemv, 256thr, nontemporal", [&](const Layer& l) { record_layer<0, true, 256>(l, x, t1, t2, s); });
         run("loads only, 256thr, default", [&](const Layer& l) { record_layer<1, false, 256>(l, x, t1, t2, s); });
         run("loads only, 256thr, nontemporal", [&](const Layer& l) { record_layer<1, true, 256>(l, x, t1, t2, s); });
-        run("full gemv, 512thr, default", [&](const Layer& l) { record_layer<0, false, 512>(l, x, t1, t2, s); });
-        run("full gemv, 1024thr, default", [&](const Layer& l) { record_layer<0, false, 1024>(l, x, t1, t2, s); });
-        run("full gemv, 128thr, default", [&](const Layer& l) { record_layer<0, false, 128>(l, x, t1, t2, s); });
+        run("ksplit RW1 (qkv rg2,o rg1,gu rg2,d rg1)", [&](const Layer& l) { record_layer_ks<true, 1, 2, 1, 1, 2, 1>(l, x, t1, t2, s); });
+        run("ksplit RW2 (qkv rg2,o rg1,gu rg2,d rg1)", [&](const Layer& l) { record_layer_ks<true, 2, 2, 1, 2, 2, 1>(l, x, t1, t2, s); });
+        run("ksplit RW2 bigger WGs (rg4,2,4,1)", [&](const Layer& l) { record_layer_ks<true, 2, 4, 2, 2, 4, 1>(l, x, t1, t2, s); });
+        run("ksplit RW4 (rg2,o rg2,gu rg2,d rg1)", [&](const Layer& l) { record_layer_ks<true, 4, 2, 2, 4, 2, 1>(l, x, t1, t2, s); });
+        run("ksplit RW1 default loads", [&](const Layer& l) { record_layer_ks<false, 1, 2, 1, 1, 2, 1>(l, x, t1, t2, s); });
     }
     return 0;
 }
