@@ -739,7 +739,9 @@ void launch_attn(const AttnArgs& a, hipStream_t s) {
 #define Q3_ATT(D, U) do { if (grp == 1) hipLaunchKernelGGL((k_attn<D, U, 1>), grid, dim3(256), 0, s, a); \
         else if (grp == 2) hipLaunchKernelGGL((k_attn<D, U, 2>), grid, dim3(256), 0, s, a); \
         else hipLaunchKernelGGL((k_attn<D, U, 4>), grid, dim3(256), 0, s, a); } while (0)
-    if (a.d == 128) Q3_ATT(128, 8);
+    const bool tiny_ctx = a.n_splits == 1 && a.window == 0 && (a.pages_per_slot << a.page_shift) <= 32; // code predictor
+    if (a.d == 128 && tiny_ctx) Q3_ATT(128, 2);
+    else if (a.d == 128) Q3_ATT(128, 8);
     else if (a.d == 64) Q3_ATT(64, 8);
     else if (a.d == 16) Q3_ATT(16, 4);
     else throw Error("attn: head_dim must be 16, 64 or 128");
@@ -778,7 +780,6 @@ void launch_attn_combine(const AttnArgs& a, hipStream_t s) {
 // (tts_onnx.cpp:824-842), which keeps the generation loop free of host round trips.
 // ================================================================================================
 #define SAMP_MAXV 4096
-#define SAMP_PER 64
 
 static __device__ __forceinline__ uint64_t mix64(uint64_t z) {
     z += 0x9E3779B97F4A7C15ull;
@@ -813,14 +814,26 @@ static __device__ __forceinline__ float wave_scan_f(float v, int lane) {
     return v;
 }
 
+// k-th largest of one value per lane (ties allowed), -inf when fewer than k lanes hold a finite value:
+// 64 scalar broadcasts, no LDS.
+static __device__ __forceinline__ float kth_largest_of_lanes(float v, int k) {
+    int gt = 0, ge = 0;
+#pragma unroll 8
+    for (int o2 = 0; o2 < 64; ++o2) { const float w = lane_bcast(v, o2); gt += w > v ? 1 : 0; ge += w >= v ? 1 : 0; }
+    return wave_max((gt < k && k <= ge) ? v : -INFINITY);
+}
+
 __global__ __launch_bounds__(64) void k_sample(SampleArgs a) {
     const int b = blockIdx.x, lane = threadIdx.x;
     const int V = a.V;
-    __shared__ int hist[256];
-    __shared__ int cand_idx[SAMP_MAXV];
-    __shared__ float cand_p[SAMP_MAXV];
-    __shared__ float sorted_p[SAMP_MAXV];
+    // Compact loops over LDS-staged logits on purpose: a fully unrolled register-resident version is ~80 KB
+    // of straight-line code, and a lone wave then stalls on instruction fetch every few instructions.
+    __shared__ float xs[SAMP_MAXV];              // suppressed, temperature-scaled logits; later reused as sorted_p
+    __shared__ float svb[256 + 64];              // survivor staging (+64 dump slots for branch-free stores)
+    __shared__ int cand_idx[SAMP_MAXV + 64];
+    __shared__ float cand_p[SAMP_MAXV + 64];
     __shared__ int sh_i[4];
+    float* sorted_p = xs;
 
     float temperature = a.temperature, top_p = a.top_p, u = a.u;
     int top_k = a.top_k, suppress = a.suppress, keep_eos = 1;
@@ -836,32 +849,25 @@ __global__ __launch_bounds__(64) void k_sample(SampleArgs a) {
         keep_eos = !st->ignore_eos;
     }
     const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-
-    // ---- load (coalesced): lane owns indices j*64 + lane ----
     const int PER = (V + 63) / 64;
-    float x[SAMP_PER];
+
+    // ---- load (coalesced, unconditional, clamped): lane owns indices j*64 + lane ----
     const float* lg = a.logits + (size_t)b * a.ld;
-    float lmax = -INFINITY;
-    // unconditional loads from clamped addresses, selects afterwards: a load under a runtime condition
-    // gets its own branch + vmcnt(0) from hipcc, i.e. one serial memory round trip per element
     const bool use_temp = temperature > 0.0f && temperature != 1.0f;
-#pragma unroll
-    for (int j = 0; j < SAMP_PER; ++j) {
+    float lmax = -INFINITY;
+#pragma unroll 8
+    for (int j = 0; j < PER; ++j) {
         const int i = j * 64 + lane;
-        x[j] = lg[i < V ? i : V - 1];
-    }
-#pragma unroll
-    for (int j = 0; j < SAMP_PER; ++j) {
-        const int i = j * 64 + lane;
-        float v = x[j];
+        float v = lg[i < V ? i : V - 1];
         const bool sup = suppress && i >= a.sup_begin && i < a.sup_end && !(i == a.eos_id && keep_eos);  // :803-807
         const float vt = v / temperature;                                                                // :882-884
         v = use_temp ? vt : v;
         v = (sup || i >= V) ? -INFINITY : v;
-        x[j] = v;
+        xs[i] = v;
         lmax = fmaxf(lmax, v);
     }
     const float mx = wave_max(lmax);
+    __syncthreads();
 
     // ---- top-k threshold = k-th largest value, ties kept (:917-927) ----
     float thr = -INFINITY;
@@ -869,98 +875,75 @@ __global__ __launch_bounds__(64) void k_sample(SampleArgs a) {
         bool done = false;
         if (top_k == 1) { thr = mx; done = true; }
         else if (top_k <= 64) {
-            // The k-th largest of the 64 lane maxima is a lower bound L of the k-th largest overall, so
-            // only the few elements >= L (~100 of 3072) can matter; rank those exactly with ballots.
-            int gt = 0, ge = 0;
-#pragma unroll 8
-            for (int o2 = 0; o2 < 64; ++o2) { const float v = lane_bcast(lmax, o2); gt += v > lmax ? 1 : 0; ge += v >= lmax ? 1 : 0; }
-            const float L = wave_max((gt < top_k && top_k <= ge) ? lmax : -INFINITY);
+            // Iterated prefilter: the k-th largest of the 64 lane maxima is a lower bound L of the k-th
+            // largest overall, so only elements >= L can matter (~100 of 3072); re-deal those over the
+            // lanes and repeat (~k + a few survive); the third round has one candidate per lane and is exact.
+            const float L1 = kth_largest_of_lanes(lmax, top_k);
             int ns = 0;
-#pragma unroll
-            for (int j = 0; j < SAMP_PER; ++j) {
-                if (j < PER) {
-                    const bool sv = x[j] >= L && x[j] != -INFINITY;
-                    const unsigned long long m = __ballot(sv);
-                    if (sv) { const int ppos = ns + __popcll(m & lt_mask); if (ppos < 256) sorted_p[ppos] = x[j]; }
-                    ns += __popcll(m);
-                }
+#pragma unroll 4
+            for (int j = 0; j < PER; ++j) {
+                const float v = xs[j * 64 + lane];
+                const bool sv = v >= L1 && v != -INFINITY;
+                const unsigned long long m = __ballot(sv);
+                const int ppos = ns + __popcll(m & lt_mask);
+                svb[(sv && ppos < 256) ? ppos : 256 + lane] = v;
+                ns += __popcll(m);
             }
             __syncthreads();
-            if (L != -INFINITY && ns >= top_k && ns <= 256) {
-                // survivor i lives in register i/64 of lane i%64 (-inf padding never outranks anything)
-                float sv4[4];
+            if (L1 != -INFINITY && ns <= 256) {
+                float s4[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) sv4[q] = q * 64 + lane < ns ? sorted_p[q * 64 + lane] : -INFINITY;
-                float found = -INFINITY;
+                for (int q = 0; q < 4; ++q) { const float v = svb[q * 64 + lane]; s4[q] = q * 64 + lane < ns ? v : -INFINITY; }
+                const float L2 = kth_largest_of_lanes(fmaxf(fmaxf(s4[0], s4[1]), fmaxf(s4[2], s4[3])), top_k);
+                __syncthreads();
+                int ns2 = 0;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    if (q * 64 < ns) {
-                        const int lim = ns - q * 64 < 64 ? ns - q * 64 : 64;
-#pragma unroll 4
-                        for (int i = 0; i < lim; ++i) {
-                            const float v = lane_bcast(sv4[q], i);
-                            const int g2 = __popcll(__ballot(sv4[0] > v)) + __popcll(__ballot(sv4[1] > v)) + __popcll(__ballot(sv4[2] > v)) + __popcll(__ballot(sv4[3] > v));
-                            const int e2 = __popcll(__ballot(sv4[0] >= v)) + __popcll(__ballot(sv4[1] >= v)) + __popcll(__ballot(sv4[2] >= v)) + __popcll(__ballot(sv4[3] >= v));
-                            if (g2 < top_k && top_k <= e2) found = v;
-                        }
-                    }
+                    const bool sv = s4[q] >= L2 && s4[q] != -INFINITY;
+                    const unsigned long long m = __ballot(sv);
+                    const int ppos = ns2 + __popcll(m & lt_mask);
+                    svb[(sv && ppos < 64) ? ppos : 256 + lane] = s4[q];
+                    ns2 += __popcll(m);
                 }
-                thr = found;
-                done = found != -INFINITY;
+                __syncthreads();
+                if (L2 != -INFINITY && ns2 <= 64) {
+                    const float v = svb[lane];
+                    thr = kth_largest_of_lanes(lane < ns2 ? v : -INFINITY, top_k);
+                    done = thr != -INFINITY;
+                }
             }
             __syncthreads();
         }
-        if (!done) { // 4-pass MSB radix select on order-preserving keys (LDS histogram)
-            uint32_t prefix = 0, mask = 0;
-            int remaining = top_k;
-            for (int pass = 0; pass < 4; ++pass) {
-                const int shift = 24 - 8 * pass;
-                hist[lane] = 0; hist[lane + 64] = 0; hist[lane + 128] = 0; hist[lane + 192] = 0;
-                __syncthreads();
-#pragma unroll
-                for (int j = 0; j < SAMP_PER; ++j) {
-                    if (j < PER && j * 64 + lane < V) {
-                        const uint32_t key = fkey(x[j]);
-                        if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255], 1);
-                    }
+        if (!done) { // rare fallback (top_k > 64, or pathological ties): bitwise search of the k-th largest key
+            uint32_t prefix = 0;
+            for (int bit = 31; bit >= 0; --bit) {
+                const uint32_t cand = prefix | (1u << bit);
+                int cnt = 0;
+                for (int j = 0; j < PER; ++j) {
+                    const int i = j * 64 + lane;
+                    cnt += __popcll(__ballot(i < V && fkey(xs[i]) >= cand));
                 }
-                __syncthreads();
-                const int h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
-                const int tot = h0 + h1 + h2 + h3;
-                const int incl = wave_scan_i(tot, lane);
-                const int all = __shfl(incl, 63, 64);
-                const int above = all - incl;
-                const int ge3 = above + h3, ge2 = ge3 + h2, ge1 = ge2 + h1, ge0 = ge1 + h0;
-                if (ge3 >= remaining && above < remaining) { sh_i[0] = 4 * lane + 3; sh_i[1] = above; }
-                else if (ge2 >= remaining && ge3 < remaining) { sh_i[0] = 4 * lane + 2; sh_i[1] = ge3; }
-                else if (ge1 >= remaining && ge2 < remaining) { sh_i[0] = 4 * lane + 1; sh_i[1] = ge2; }
-                else if (ge0 >= remaining && ge1 < remaining) { sh_i[0] = 4 * lane; sh_i[1] = ge1; }
-                __syncthreads();
-                prefix |= (uint32_t)sh_i[0] << shift;
-                mask |= 255u << shift;
-                remaining -= sh_i[1];
-                __syncthreads();
+                if (cnt >= top_k) prefix = cand;
             }
             const uint32_t ku = (prefix & 0x80000000u) ? (prefix & 0x7FFFFFFFu) : ~prefix;
             thr = __uint_as_float(ku);
         }
     }
 
-    // ---- index-ordered compaction of survivors; softmax numerators exp(x - max) (:907-915) ----
+    // ---- index-ordered, branch-free compaction of survivors; softmax numerators exp(x - max) (:907-915) ----
     int n_kept = 0;
     float esum = 0.f;
-#pragma unroll
-    for (int j = 0; j < SAMP_PER; ++j) {
-        if (j < PER) {
-            const bool keep = x[j] >= thr && x[j] != -INFINITY;
-            const unsigned long long m = __ballot(keep);
-            if (keep) {
-                const int wpos = n_kept + __popcll(m & lt_mask);
-                const float e = expf(x[j] - mx);
-                cand_idx[wpos] = j * 64 + lane;
-                cand_p[wpos] = e;
-                esum += e;
-            }
+#pragma unroll 4
+    for (int j = 0; j < PER; ++j) {
+        const float v = xs[j * 64 + lane];
+        const bool keep = v >= thr && v != -INFINITY;
+        const unsigned long long m = __ballot(keep);
+        if (m) { // wave-uniform: most 64-element slices hold no survivor at all
+            const int wpos = keep ? n_kept + __popcll(m & lt_mask) : SAMP_MAXV + lane;
+            const float e = keep ? expf(v - mx) : 0.f;
+            cand_idx[wpos] = j * 64 + lane;
+            cand_p[wpos] = e;
+            esum += e;
             n_kept += __popcll(m);
         }
     }
