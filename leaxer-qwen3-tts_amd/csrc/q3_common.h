@@ -114,7 +114,9 @@ struct SlotState { // device-resident per-slot generation state
     uint32_t stream_id;
     uint32_t pad0;
     uint64_t seed;
+    uint32_t pad1[2]; // 64 bytes: read by the sampler as four 16-byte loads
 };
+static_assert(sizeof(SlotState) == 64, "SlotState must be 64 bytes");
 
 struct SampleArgs {
     const float* logits = nullptr; // [nb][ld]

@@ -835,39 +835,69 @@ __global__ __launch_bounds__(64) void k_sample(SampleArgs a) {
     __shared__ int sh_i[4];
     float* sorted_p = xs;
 
+    // ---- round trip 1: slot state (one 64-byte struct) and the logits row (float4 per lane), all in flight ----
     float temperature = a.temperature, top_p = a.top_p, u = a.u;
     int top_k = a.top_k, suppress = a.suppress, keep_eos = 1;
     int frame = 0;
     SlotState* st = a.st ? a.st + b : nullptr;
+    SlotState sl;
     if (st) {
-        if (!st->active || st->finished) return;
-        if (a.group == 0 && st->n_frames >= st->max_frames) { if (lane == 0) st->finished = 1; return; }
-        temperature = st->temperature; top_p = st->top_p; top_k = st->top_k;
-        frame = st->n_frames;
-        u = rng_uniform_dev(st->seed, st->stream_id, (uint32_t)frame, (uint32_t)a.group);
+        const uint4* sp = reinterpret_cast<const uint4*>(st);
+        uint4 raw[4] = { sp[0], sp[1], sp[2], sp[3] };
+        __builtin_memcpy(&sl, raw, sizeof sl);
+    }
+    const float* lg = a.logits + (size_t)b * a.ld;
+    const bool vec4 = (V & 3) == 0 && (a.ld & 3) == 0;
+    const int PER4 = (V / 4 + 63) / 64;            // float4 slots per lane
+    float4 lv[SAMP_MAXV / 256];
+    if (vec4) {
+#pragma unroll
+        for (int j = 0; j < SAMP_MAXV / 256; ++j) {
+            const int i4 = j * 64 + lane;           // clamped, unconditional
+            lv[j] = reinterpret_cast<const float4*>(lg)[i4 * 4 < V ? i4 : V / 4 - 1];
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (st) {
+        if (!sl.active || sl.finished) return;
+        if (a.group == 0 && sl.n_frames >= sl.max_frames) { if (lane == 0) st->finished = 1; return; }
+        temperature = sl.temperature; top_p = sl.top_p; top_k = sl.top_k;
+        frame = sl.n_frames;
+        u = rng_uniform_dev(sl.seed, sl.stream_id, (uint32_t)frame, (uint32_t)a.group);
         suppress = a.group == 0;
-        keep_eos = !st->ignore_eos;
+        keep_eos = !sl.ignore_eos;
     }
     const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
     const int PER = (V + 63) / 64;
 
-    // ---- load (coalesced, unconditional, clamped): lane owns indices j*64 + lane ----
-    const float* lg = a.logits + (size_t)b * a.ld;
+    // suppress (:803-807) + temperature (:882-884), staged into LDS in plain index order
     const bool use_temp = temperature > 0.0f && temperature != 1.0f;
-    float lmax = -INFINITY;
-#pragma unroll 8
-    for (int j = 0; j < PER; ++j) {
-        const int i = j * 64 + lane;
-        float v = lg[i < V ? i : V - 1];
-        const bool sup = suppress && i >= a.sup_begin && i < a.sup_end && !(i == a.eos_id && keep_eos);  // :803-807
-        const float vt = v / temperature;                                                                // :882-884
+    auto prep = [&](float v, int i) -> float {
+        const bool sup = suppress && i >= a.sup_begin && i < a.sup_end && !(i == a.eos_id && keep_eos);
+        const float vt = v / temperature;
         v = use_temp ? vt : v;
-        v = (sup || i >= V) ? -INFINITY : v;
-        xs[i] = v;
-        lmax = fmaxf(lmax, v);
+        return (sup || i >= V) ? -INFINITY : v;
+    };
+    float lmax = -INFINITY;
+    if (vec4) {
+#pragma unroll
+        for (int j = 0; j < SAMP_MAXV / 256; ++j) {
+            if (j < PER4) {
+                const int i = (j * 64 + lane) * 4;
+                float4 o;
+                o.x = prep(lv[j].x, i); o.y = prep(lv[j].y, i + 1); o.z = prep(lv[j].z, i + 2); o.w = prep(lv[j].w, i + 3);
+                if (i < SAMP_MAXV) *reinterpret_cast<float4*>(&xs[i]) = o;
+            }
+        }
+    } else {
+        for (int j = 0; j < PER; ++j) { const int i = j * 64 + lane; xs[i] = prep(lg[i < V ? i : V - 1], i); }
     }
-    const float mx = wave_max(lmax);
     __syncthreads();
+    for (int i = V + lane; i < PER * 64; i += 64) xs[i] = -INFINITY; // pad the last 64-slice
+    __syncthreads();
+#pragma unroll 8
+    for (int j = 0; j < PER; ++j) lmax = fmaxf(lmax, xs[j * 64 + lane]);
+    const float mx = wave_max(lmax);
 
     // ---- top-k threshold = k-th largest value, ties kept (:917-927) ----
     float thr = -INFINITY;
@@ -876,43 +906,41 @@ __global__ __launch_bounds__(64) void k_sample(SampleArgs a) {
         if (top_k == 1) { thr = mx; done = true; }
         else if (top_k <= 64) {
             // Iterated prefilter: the k-th largest of the 64 lane maxima is a lower bound L of the k-th
-            // largest overall, so only elements >= L can matter (~100 of 3072); re-deal those over the
-            // lanes and repeat (~k + a few survive); the third round has one candidate per lane and is exact.
+            // largest overall, so only elements >= L can matter (~100 of 3072); re-deal the survivors over
+            // the lanes and repeat until at most one candidate per lane is left, which is ranked exactly.
             const float L1 = kth_largest_of_lanes(lmax, top_k);
-            int ns = 0;
+            int n = 0;
 #pragma unroll 4
             for (int j = 0; j < PER; ++j) {
                 const float v = xs[j * 64 + lane];
                 const bool sv = v >= L1 && v != -INFINITY;
                 const unsigned long long m = __ballot(sv);
-                const int ppos = ns + __popcll(m & lt_mask);
+                const int ppos = n + __popcll(m & lt_mask);
                 svb[(sv && ppos < 256) ? ppos : 256 + lane] = v;
-                ns += __popcll(m);
+                n += __popcll(m);
             }
             __syncthreads();
-            if (L1 != -INFINITY && ns <= 256) {
+            bool ok = L1 != -INFINITY && n <= 256;
+            for (int round = 0; ok && round < 8; ++round) {
                 float s4[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) { const float v = svb[q * 64 + lane]; s4[q] = q * 64 + lane < ns ? v : -INFINITY; }
-                const float L2 = kth_largest_of_lanes(fmaxf(fmaxf(s4[0], s4[1]), fmaxf(s4[2], s4[3])), top_k);
+                for (int q = 0; q < 4; ++q) { const float v = svb[q * 64 + lane]; s4[q] = q * 64 + lane < n ? v : -INFINITY; }
                 __syncthreads();
-                int ns2 = 0;
+                if (n <= 64) { thr = kth_largest_of_lanes(s4[0], top_k); done = thr != -INFINITY; break; }
+                const float L2 = kth_largest_of_lanes(fmaxf(fmaxf(s4[0], s4[1]), fmaxf(s4[2], s4[3])), top_k);
+                int n2 = 0;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const bool sv = s4[q] >= L2 && s4[q] != -INFINITY;
                     const unsigned long long m = __ballot(sv);
-                    const int ppos = ns2 + __popcll(m & lt_mask);
-                    svb[(sv && ppos < 64) ? ppos : 256 + lane] = s4[q];
-                    ns2 += __popcll(m);
+                    const int ppos = n2 + __popcll(m & lt_mask);
+                    svb[sv ? ppos : 256 + lane] = s4[q];
+                    n2 += __popcll(m);
                 }
                 __syncthreads();
-                if (L2 != -INFINITY && ns2 <= 64) {
-                    const float v = svb[lane];
-                    thr = kth_largest_of_lanes(lane < ns2 ? v : -INFINITY, top_k);
-                    done = thr != -INFINITY;
-                }
+                ok = L2 != -INFINITY && n2 < n; // no progress (mass ties): take the exact fallback
+                n = n2;
             }
-            __syncthreads();
         }
         if (!done) { // rare fallback (top_k > 64, or pathological ties): bitwise search of the k-th largest key
             uint32_t prefix = 0;
@@ -1053,22 +1081,22 @@ __global__ __launch_bounds__(64) void k_sample(SampleArgs a) {
     const bf16_t* er = a.embed + (size_t)tok * a.H;
     const bool last_group = a.group == a.n_groups - 1;
     const float* text = nullptr;
-    if (last_group) text = frame < st->trailing_len ? a.trailing + ((size_t)b * a.max_trailing + frame) * a.H : a.tts_pad; // :833-842
+    if (last_group) text = frame < sl.trailing_len ? a.trailing + ((size_t)b * a.max_trailing + frame) * a.H : a.tts_pad; // :833-842
     // every load of the row first, then the stores (the pointers may alias as far as the compiler
     // knows, which would otherwise serialise 16 load->store round trips)
     constexpr int EP_MAX = 8; // H <= 2048
     for (int h0 = 0; h0 < a.H; h0 += 256 * EP_MAX) {
         float e[EP_MAX][4], sm[EP_MAX][4], tx[EP_MAX][4];
+        const float* sum_r = a.group != 0 ? a.sum + (size_t)b * a.H : nullptr;   // wave-uniform
 #pragma unroll
         for (int it = 0; it < EP_MAX; ++it) {
-            const int h = h0 + (it * 64 + lane) * 4;
-            if (h < a.H) {
-                const uint2 raw = *reinterpret_cast<const uint2*>(er + h);
-                e[it][0] = __uint_as_float(raw.x << 16); e[it][1] = __uint_as_float(raw.x & 0xFFFF0000u);
-                e[it][2] = __uint_as_float(raw.y << 16); e[it][3] = __uint_as_float(raw.y & 0xFFFF0000u);
-                if (a.group != 0) { const float4 v = *reinterpret_cast<const float4*>(a.sum + (size_t)b * a.H + h); sm[it][0] = v.x; sm[it][1] = v.y; sm[it][2] = v.z; sm[it][3] = v.w; }
-                if (last_group) { const float4 v = *reinterpret_cast<const float4*>(text + h); tx[it][0] = v.x; tx[it][1] = v.y; tx[it][2] = v.z; tx[it][3] = v.w; }
-            }
+            int h = h0 + (it * 64 + lane) * 4;
+            h = h < a.H ? h : a.H - 4;               // clamped address, unconditional loads (stores are guarded)
+            const uint2 raw = *reinterpret_cast<const uint2*>(er + h);
+            e[it][0] = __uint_as_float(raw.x << 16); e[it][1] = __uint_as_float(raw.x & 0xFFFF0000u);
+            e[it][2] = __uint_as_float(raw.y << 16); e[it][3] = __uint_as_float(raw.y & 0xFFFF0000u);
+            if (sum_r) { const float4 v = *reinterpret_cast<const float4*>(sum_r + h); sm[it][0] = v.x; sm[it][1] = v.y; sm[it][2] = v.z; sm[it][3] = v.w; }
+            if (last_group) { const float4 v = *reinterpret_cast<const float4*>(text + h); tx[it][0] = v.x; tx[it][1] = v.y; tx[it][2] = v.z; tx[it][3] = v.w; }
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1089,7 +1117,7 @@ __global__ __launch_bounds__(64) void k_sample(SampleArgs a) {
     }
     if (last_group && lane == 0) {
         st->n_frames = frame + 1;
-        a.talker_pos[b] = st->prompt_len + frame; // position of the token the talker decodes next
+        a.talker_pos[b] = sl.prompt_len + frame; // position of the token the talker decodes next
     }
 }
 
