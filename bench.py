@@ -116,9 +116,9 @@ def main():
     def step(i):
         pcm, codes, nfr = eng.synthesize_batch(toks, sp, lang=0, seed=100 + i, ignore_eos=True, want_codes=True)
         if dist is not None:  # the only exchange on the path: gather of the generated codes (RCCL over xGMI)
-            t = torch.from_numpy(np.stack([c.astype(np.int32) for c in codes])).cuda()
-            out = [torch.empty_like(t) for _ in range(world)]
-            dist.all_gather(out, t)
+            import q3dist
+            q3dist.gather_codes(dist, codes, [rank * B + u for u in range(B)], world * B, F, cfg.n_groups,
+                                device=torch.device("cuda", local_rank))
         return int(nfr.sum()), sum(len(p) for p in pcm)
 
     for i in range(args.warmup):

@@ -68,6 +68,13 @@ int q3tts_fill_synthetic(q3tts_engine* e, uint64_t seed);
 /* call after the last set_tensor / fill: builds RoPE tables, packed conv weights, tts_pad row */
 int q3tts_finalize(q3tts_engine* e);
 
+/* Weight files ("Q3TW0001": config + named tensors, fp32 or bf16 payloads; written by
+ * q3tts_save_weights_file or tools/pack_weights.py).  This is what TTSEngine(model_dir) loads in
+ * place of the reference's seven .onnx files (tts_onnx.cpp:91-107). */
+int q3tts_read_weights_config(const char* path, q3tts_config* out);
+int q3tts_load_weights_file(q3tts_engine* e, const char* path);   /* set_tensor for every entry + finalize */
+int q3tts_save_weights_file(q3tts_engine* e, const char* path);
+
 /* ---- session-shaped entry points, host I/O, one per reference run_* ---- */
 /* run_text_project, tts_onnx.cpp:545-559: ids[n] -> out[n][hidden] */
 int q3tts_text_project_host(q3tts_engine* e, const int64_t* ids, int n, float* out);

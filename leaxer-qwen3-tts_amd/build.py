@@ -55,7 +55,24 @@ def build(force=False, verbose=False):
         os.replace(LIB + ".tmp", LIB)
         if verbose:
             print("linked", LIB)
+    _build_cli(force)
     return LIB
+
+
+CLI = os.path.join(HERE, "leaxer-tts")
+
+
+def _build_cli(force=False):
+    """leaxer-tts: the reference's CLI surface over TTSEngine (plain g++-style host code, links the .so)."""
+    srcs = [os.path.join(CSRC, "tts_engine.cpp"), os.path.join(CSRC, "main.cpp")]
+    deps = srcs + [os.path.join(CSRC, "tts_engine.h"), os.path.join(HERE, "..", "include", "q3tts.h"), LIB]
+    if not force and os.path.exists(CLI) and all(os.path.getmtime(CLI) >= os.path.getmtime(d) for d in deps):
+        return CLI
+    cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-o", CLI] + srcs + ["-L" + HERE, "-lq3tts_hip", "-Wl,-rpath,$ORIGIN"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("building leaxer-tts failed:\n" + r.stderr[-4000:])
+    return CLI
 
 
 if __name__ == "__main__":

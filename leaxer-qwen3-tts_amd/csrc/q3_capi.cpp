@@ -241,3 +241,103 @@ int q3tts_decode_step_bytes(q3tts_engine* h, double* wb, double* kvb) {
 }
 
 } // extern "C"
+
+// ---- weight files -----------------------------------------------------------------------------
+namespace {
+const char kMagic[8] = { 'Q', '3', 'T', 'W', '0', '0', '0', '1' };
+struct File {
+    FILE* f;
+    explicit File(const char* p, const char* mode) : f(fopen(p, mode)) {}
+    ~File() { if (f) fclose(f); }
+};
+void rd(FILE* f, void* p, size_t n) { if (fread(p, 1, n, f) != n) throw q3::Error("weights file truncated"); }
+void wr(FILE* f, const void* p, size_t n) { if (fwrite(p, 1, n, f) != n) throw q3::Error("weights file write failed"); }
+void read_header(FILE* f, q3tts_config* cfg, uint32_t* n) {
+    char magic[8];
+    rd(f, magic, 8);
+    if (memcmp(magic, kMagic, 8) != 0) throw q3::Error("not a Q3TW0001 weights file");
+    uint32_t cfg_bytes = 0;
+    rd(f, &cfg_bytes, 4);
+    if (cfg_bytes != sizeof(q3tts_config)) throw q3::Error("weights file: config struct size mismatch");
+    rd(f, cfg, sizeof *cfg);
+    rd(f, n, 4);
+}
+} // namespace
+
+extern "C" {
+
+int q3tts_read_weights_config(const char* path, q3tts_config* out) {
+    try {
+        File fl(path, "rb");
+        if (!fl.f) throw q3::Error(std::string("cannot open ") + path);
+        uint32_t n = 0;
+        read_header(fl.f, out, &n);
+        return 0;
+    } catch (const q3::Error& ex) { g_create_err = ex.msg; return -1; }
+}
+
+int q3tts_load_weights_file(q3tts_engine* h, const char* path) {
+    Q3_API_BEGIN(h)
+    File fl(path, "rb");
+    if (!fl.f) throw q3::Error(std::string("cannot open ") + path);
+    q3tts_config cfg;
+    uint32_t n = 0;
+    read_header(fl.f, &cfg, &n);
+    if (memcmp(&cfg, &h->e->c, sizeof cfg) != 0) throw q3::Error("weights file was written for a different model config");
+    std::vector<float> f32;
+    std::vector<uint16_t> b16;
+    for (uint32_t t = 0; t < n; ++t) {
+        uint16_t nl = 0;
+        rd(fl.f, &nl, 2);
+        std::string name(nl, '\0');
+        rd(fl.f, &name[0], nl);
+        uint8_t dtype = 0;
+        rd(fl.f, &dtype, 1);
+        uint64_t numel = 0;
+        rd(fl.f, &numel, 8);
+        f32.resize(numel);
+        if (dtype == 0) rd(fl.f, f32.data(), numel * 4);
+        else if (dtype == 1) {
+            b16.resize(numel);
+            rd(fl.f, b16.data(), numel * 2);
+            for (uint64_t i = 0; i < numel; ++i) f32[i] = q3::bf16_to_f32(b16[i]);
+        } else throw q3::Error("weights file: unknown dtype for " + name);
+        h->e->set_tensor(name, f32.data(), (int64_t)numel);
+    }
+    h->e->finalize();
+    return 0;
+    Q3_API_END(h)
+}
+
+int q3tts_save_weights_file(q3tts_engine* h, const char* path) {
+    Q3_API_BEGIN(h)
+    File fl(path, "wb");
+    if (!fl.f) throw q3::Error(std::string("cannot create ") + path);
+    wr(fl.f, kMagic, 8);
+    const uint32_t cfg_bytes = sizeof(q3tts_config), n = (uint32_t)h->e->tensors.size();
+    wr(fl.f, &cfg_bytes, 4);
+    wr(fl.f, &h->e->c, sizeof(q3tts_config));
+    wr(fl.f, &n, 4);
+    std::vector<float> f32;
+    std::vector<uint16_t> b16;
+    for (const q3::Tensor& t : h->e->tensors) {
+        const uint16_t nl = (uint16_t)t.name.size();
+        wr(fl.f, &nl, 2);
+        wr(fl.f, t.name.data(), nl);
+        const uint8_t dtype = t.bf16 ? 1 : 0;
+        wr(fl.f, &dtype, 1);
+        const uint64_t numel = (uint64_t)t.numel;
+        wr(fl.f, &numel, 8);
+        f32.resize(numel);
+        h->e->get_tensor(t.name, f32.data(), t.numel);
+        if (t.bf16) {
+            b16.resize(numel);
+            for (uint64_t i = 0; i < numel; ++i) b16[i] = q3::f32_to_bf16(f32[i]);
+            wr(fl.f, b16.data(), numel * 2);
+        } else wr(fl.f, f32.data(), numel * 4);
+    }
+    return 0;
+    Q3_API_END(h)
+}
+
+} // extern "C"

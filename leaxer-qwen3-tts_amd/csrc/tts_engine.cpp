@@ -1,0 +1,103 @@
+// tts_engine.cpp — leaxer_qwen::TTSEngine over the C-ABI (include/q3tts.h).
+#include "tts_engine.h"
+
+#include <algorithm>
+#include <cctype>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+
+#include "../../include/q3tts.h"
+
+namespace leaxer_qwen {
+
+Speaker parse_speaker(const std::string& name) { // reference src/tts_onnx.cpp:54-68: case-insensitive names
+    std::string s;
+    for (char ch : name) s.push_back((char)std::tolower((unsigned char)ch));
+    static const struct { const char* n; Speaker v; } table[] = {
+        { "serena", Speaker::Serena }, { "vivian", Speaker::Vivian }, { "uncle_fu", Speaker::Uncle_Fu },
+        { "dylan", Speaker::Dylan }, { "eric", Speaker::Eric }, { "ryan", Speaker::Ryan }, { "aiden", Speaker::Aiden },
+        { "ono_anna", Speaker::Ono_Anna }, { "sohee", Speaker::Sohee } };
+    for (const auto& e : table) if (s == e.n) return e.v;
+    return Speaker::None;
+}
+
+static int lang_index(Language l) { return l == Language::Auto ? 0 : (int)(language_to_codec_id(l) - config::LANG_ENGLISH) + 1; }
+
+TTSEngine::TTSEngine(const std::string& model_dir) {
+    const char* env_b = std::getenv("Q3TTS_MAX_BATCH");
+    max_batch_ = env_b ? std::max(1, std::atoi(env_b)) : 1;
+    const int device = std::getenv("Q3TTS_DEVICE") ? std::atoi(std::getenv("Q3TTS_DEVICE")) : 0;
+    const int max_ctx = config::MAX_NEW_TOKENS + 64;
+    q3tts_config cfg;
+    if (model_dir.rfind("synthetic:", 0) == 0) {
+        q3tts_default_config("0.6b", &cfg);
+        h_ = q3tts_create(&cfg, device, max_batch_, max_ctx, 0);
+        if (!h_) { error_msg_ = q3tts_last_error(nullptr); return; }
+        if (q3tts_fill_synthetic(h_, std::strtoull(model_dir.c_str() + 10, nullptr, 10)) != 0 || q3tts_finalize(h_) != 0) { error_msg_ = q3tts_last_error(h_); return; }
+    } else {
+        const std::string path = model_dir + "/model.q3w";
+        if (q3tts_read_weights_config(path.c_str(), &cfg) != 0) { error_msg_ = std::string("Failed to load ") + path + ": " + q3tts_last_error(nullptr); return; }
+        h_ = q3tts_create(&cfg, device, max_batch_, max_ctx, 0);
+        if (!h_) { error_msg_ = q3tts_last_error(nullptr); return; }
+        if (q3tts_load_weights_file(h_, path.c_str()) != 0) { error_msg_ = q3tts_last_error(h_); return; }
+    }
+    ready_ = true; // the BPE tokenizer (reference tts_onnx.cpp:110-121) is a later row
+}
+
+TTSEngine::~TTSEngine() { if (h_) q3tts_destroy(h_); }
+
+std::vector<float> TTSEngine::synthesize(const std::string&, Language, const SamplingParams&) {
+    if (!ready_) return {};
+    // reference tts_onnx.cpp:249-256: without a loaded tokenizer synthesize() logs and returns empty
+    std::cerr << "[TTSEngine] Tokenizer not ready" << std::endl;
+    return {};
+}
+
+std::vector<float> TTSEngine::synthesize_clone(const std::string&, const std::string&, Language, const SamplingParams&) {
+    if (!ready_) return {};
+    std::cerr << "[TTSEngine] Speaker encoder not available" << std::endl; // reference tts_onnx.cpp:269-272
+    return {};
+}
+
+std::vector<float> TTSEngine::synthesize_speaker(const std::string& text, Speaker, Language lang, const SamplingParams& params) {
+    std::cerr << "[TTSEngine] Preset speakers require CustomVoice model (not yet supported)" << std::endl; // :327
+    return synthesize(text, lang, params);
+}
+
+std::vector<float> TTSEngine::extract_speaker_embedding(const std::string&) { return {}; } // :332
+
+std::vector<std::vector<float>> TTSEngine::synthesize_tokens_batch(const std::vector<std::vector<int64_t>>& token_ids,
+                                                                   Language lang, const SamplingParams& params) {
+    std::vector<std::vector<float>> out(token_ids.size());
+    if (!ready_ || token_ids.empty()) return out;
+    q3tts_config cfg;
+    q3tts_sampling sp{ params.temperature, params.top_p, params.top_k, params.repetition_penalty, params.max_new_tokens };
+    std::vector<int64_t> flat;
+    std::vector<int32_t> offs(1, 0);
+    for (const auto& t : token_ids) { flat.insert(flat.end(), t.begin(), t.end()); offs.push_back((int32_t)flat.size()); }
+    // capacity: samples of max_new_tokens frames
+    q3tts_default_config("0.6b", &cfg);
+    const int64_t cap = (int64_t)params.max_new_tokens * 1920 + 1920;
+    std::vector<float*> ptrs(token_ids.size());
+    for (size_t i = 0; i < token_ids.size(); ++i) { out[i].resize((size_t)cap); ptrs[i] = out[i].data(); }
+    std::vector<int64_t> lens(token_ids.size(), 0);
+    std::vector<int32_t> frames(token_ids.size(), 0);
+    const int rc = q3tts_synthesize_batch_host(h_, (int)token_ids.size(), flat.data(), offs.data(), lang_index(lang), &sp, seed_, 0,
+                                               ptrs.data(), cap, lens.data(), frames.data(), nullptr);
+    if (rc != 0) { // reference tts_onnx.cpp:432-435: log, return empty
+        std::cerr << "[TTSEngine] Synthesis error: " << q3tts_last_error(h_) << std::endl;
+        for (auto& v : out) v.clear();
+        return out;
+    }
+    for (size_t i = 0; i < out.size(); ++i) out[i].resize((size_t)std::min<int64_t>(lens[i], cap));
+    return out;
+}
+
+std::vector<float> TTSEngine::synthesize_tokens(const std::vector<int64_t>& token_ids, Language lang, const SamplingParams& params) {
+    if (!ready_) return {};
+    auto r = synthesize_tokens_batch({ token_ids }, lang, params);
+    return r.empty() ? std::vector<float>() : std::move(r[0]);
+}
+
+} // namespace leaxer_qwen

@@ -75,7 +75,7 @@ EXPORTS = [
     "q3tts_sample_host", "q3tts_rng_uniform", "q3tts_build_prompt_host", "q3tts_slot_begin", "q3tts_decode_steps",
     "q3tts_slot_status", "q3tts_slot_codes_host", "q3tts_slot_codec_decode_host", "q3tts_slot_release",
     "q3tts_synthesize_batch_host", "q3tts_last_decode_ms", "q3tts_last_codec_ms", "q3tts_decode_step_bytes",
-    "q3tts_counters",
+    "q3tts_counters", "q3tts_read_weights_config", "q3tts_load_weights_file", "q3tts_save_weights_file",
 ]
 
 _lib = None
@@ -127,6 +127,9 @@ def lib():
     L.q3tts_last_codec_ms.argtypes = [vp, C.POINTER(f32)]
     L.q3tts_counters.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(C.c_double), C.POINTER(i64), i32]
     L.q3tts_decode_step_bytes.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.q3tts_read_weights_config.argtypes = [C.c_char_p, C.POINTER(Config)]
+    L.q3tts_load_weights_file.argtypes = [vp, C.c_char_p]
+    L.q3tts_save_weights_file.argtypes = [vp, C.c_char_p]
     _lib = L
     return L
 
@@ -201,6 +204,12 @@ class Engine:
 
     def finalize(self):
         self._ck(self.L.q3tts_finalize(self.h))
+
+    def save_weights(self, path):
+        self._ck(self.L.q3tts_save_weights_file(self.h, os.fsencode(path)))
+
+    def load_weights(self, path):
+        self._ck(self.L.q3tts_load_weights_file(self.h, os.fsencode(path)))
 
     # ---- session-shaped ----
     def text_project(self, ids):

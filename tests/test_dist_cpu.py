@@ -1,0 +1,71 @@
+"""N>1 path on CPU: world_size-2 gloo.  Each rank 'synthesises' its shard with the CPU oracle (tiny
+config) and the ranks exchange codes exactly as bench.py does over RCCL."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    for p in ("leaxer-qwen3-tts_amd", "oracle", "tests"):
+        sys.path.insert(0, os.path.join(ROOT, p))
+    import torch.distributed as dist
+    import q3_oracle as qo
+    import q3dist
+    from util import frame_tokens
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg = qo.config_tiny()
+    orc = qo.Oracle(cfg, max_ctx=64, weights=qo.random_weights(cfg, 0))
+    texts = [[1, 2, 3], [4], [5, 6, 7, 8, 9], [10, 11], [12, 13, 14, 15, 16, 17, 18]]
+    mine = q3dist.shard_utterances([len(t) for t in texts], world, rank)
+    sp = qo.Sampling(temperature=1.0, top_p=1.0, top_k=1, max_new_tokens=6)
+    codes = [orc.generate(orc.build_prompt(frame_tokens(texts[i]), 0), sp, seed=5, stream=i, ignore_eos=True) for i in mine]
+    allc = q3dist.gather_codes(dist, codes, mine, len(texts), 6, cfg.n_groups)
+    ref = [orc.generate(orc.build_prompt(frame_tokens(t), 0), sp, seed=5, stream=i, ignore_eos=True) for i, t in enumerate(texts)]
+    ok = all(a is not None and np.array_equal(a, b) for a, b in zip(allc, ref))
+    q.put((rank, mine, ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_is_a_partition_and_balanced():
+    sys.path.insert(0, os.path.join(ROOT, "leaxer-qwen3-tts_amd"))
+    import q3dist
+    lengths = [3, 40, 7, 7, 19, 2, 64, 11, 5]
+    for world in (1, 2, 4, 8):
+        shards = [q3dist.shard_utterances(lengths, world, r) for r in range(world)]
+        flat = sorted(i for s in shards for i in s)
+        assert flat == list(range(len(lengths)))
+        loads = [sum(lengths[i] for i in s) for s in shards]
+        assert max(loads) - min(loads) <= max(lengths)
+
+
+def test_two_rank_gloo_gather():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    seen = sorted(i for _, mine, _ in res for i in mine)
+    assert seen == [0, 1, 2, 3, 4]
+    assert all(ok for _, _, ok in res)

@@ -1,0 +1,64 @@
+"""The reference-shaped C++ surface: weight file round trip, TTSEngine via the leaxer-tts CLI
+(flags of reference src/main_onnx.cpp:99-124), 16-bit WAV writer semantics (:47-54)."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from util import frame_tokens, tiny_pair, to_osampling
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "leaxer-qwen3-tts_amd", "leaxer-tts")
+
+
+def read_wav16(path):
+    b = open(path, "rb").read()
+    assert b[:4] == b"RIFF" and b[8:16] == b"WAVEfmt " and b[36:40] == b"data"
+    fmt, ch, rate, _, align, bits = struct.unpack("<HHIIHH", b[20:36])
+    assert (fmt, ch, rate, align, bits) == (1, 1, 24000, 2, 16)
+    n = struct.unpack("<I", b[40:44])[0]
+    assert struct.unpack("<I", b[4:8])[0] == 36 + n and len(b) == 44 + n
+    return np.frombuffer(b[44:], np.int16)
+
+
+def test_weight_file_roundtrip_and_cli(tmp_path):
+    import q3tts
+    eng, orc, w = tiny_pair(seed=4, max_batch=1, max_ctx=96)
+    mdir = tmp_path / "model"
+    mdir.mkdir()
+    eng.save_weights(str(mdir / "model.q3w"))
+    eng2 = q3tts.Engine(eng.cfg, device=0, max_batch=1, max_ctx=96)
+    eng2.load_weights(str(mdir / "model.q3w"))
+    for name in ("talker.layers.1.q_proj", "cd.dec.blocks.2.res.1.conv1.w", "cp.embed.7", "text.fc2.b"):
+        assert np.array_equal(eng2.get_tensor(name, w[name].shape), w[name]), name
+    eng2.close()
+
+    out = tmp_path / "o" / "x.wav"
+    out.parent.mkdir()
+    r = subprocess.run([CLI, "-m", str(mdir), "--tokens", "11,22,33,44", "-o", str(out), "--lang", "ja", "--temp", "0.8",
+                        "--top-k", "50", "--top-p", "0.95", "--max-tokens", "12", "--seed", "7", "--bogus-flag"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "Generated" in r.stdout and "Saved to" in r.stdout
+    got = read_wav16(str(out))
+    sp = q3tts.Sampling(temperature=0.8, top_p=0.95, top_k=50, max_new_tokens=12)
+    ids = frame_tokens([11, 22, 33, 44])
+    codes = orc.generate(orc.build_prompt(ids, 3), to_osampling(sp), seed=7, stream=0, cp_cached=True, ignore_eos=False)
+    ref = orc.vocoder(codes)
+    ref16 = (np.clip(ref, -1, 1) * 32767.0).astype(np.int16)   # truncation toward zero, like the reference writer
+    assert got.shape == ref16.shape
+    assert np.abs(got.astype(np.int32) - ref16.astype(np.int32)).max() <= 2   # 1e-4 RMS tolerance is ~3 LSB of int16
+    eng.close()
+    orc.close()
+
+
+def test_cli_errors_like_the_reference(tmp_path):
+    r = subprocess.run([CLI, "-p", "hello"], capture_output=True, text=True)
+    assert r.returncode == 1 and "required" in r.stderr
+    r = subprocess.run([CLI, "-m", str(tmp_path / "nope"), "-p", "hello"], capture_output=True, text=True)
+    assert r.returncode == 1 and "model directory not found" in r.stderr
+    r = subprocess.run([CLI, "-m", "synthetic:0", "-p", "hello", "--max-tokens", "4"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 1 and "Tokenizer not ready" in r.stderr and "synthesis failed" in r.stderr
