@@ -35,6 +35,15 @@ def test_weight_file_roundtrip_and_cli(tmp_path):
     for name in ("talker.layers.1.q_proj", "cd.dec.blocks.2.res.1.conv1.w", "cp.embed.7", "text.fc2.b"):
         assert np.array_equal(eng2.get_tensor(name, w[name].shape), w[name]), name
     eng2.close()
+    # the Python writer produces a file the C loader accepts and that holds the same values
+    import sys
+    sys.path.insert(0, ROOT)
+    from tools.pack_weights import write_q3w
+    write_q3w(str(mdir / "py.q3w"), eng.cfg, w)
+    eng3 = q3tts.Engine(eng.cfg, device=0, max_batch=1, max_ctx=96)
+    eng3.load_weights(str(mdir / "py.q3w"))
+    assert np.array_equal(eng3.get_tensor("cp.layers.0.down_proj", w["cp.layers.0.down_proj"].shape), w["cp.layers.0.down_proj"])
+    eng3.close()
 
     out = tmp_path / "o" / "x.wav"
     out.parent.mkdir()

@@ -1,0 +1,38 @@
+"""Write a Q3TW0001 weight file (the format TTSEngine(model_dir) loads as <model_dir>/model.q3w).
+
+    from tools.pack_weights import write_q3w
+    write_q3w("model/model.q3w", cfg, {"talker.layers.0.q_proj": np.ndarray, ...})
+
+Tensor names / shapes: q3_oracle.tensor_specs(cfg) (same registry as csrc/q3_engine.cpp).  Matrices of
+the talker / predictor / text stacks may be stored bf16 (dtype code 1), everything else fp32 (0).
+Converting a real checkpoint = mapping its parameter names onto this registry.
+"""
+import ctypes
+import struct
+
+import numpy as np
+
+MAGIC = b"Q3TW0001"
+
+
+def _bf16_bits(a):
+    u = np.ascontiguousarray(a, np.float32).view(np.uint32).astype(np.uint64)
+    return ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16)
+
+
+def write_q3w(path, cfg, tensors, bf16_prefixes=("talker.", "cp.", "text.")):
+    """cfg: a ctypes Config (q3tts.Config or q3_oracle.Config); tensors: dict name -> array."""
+    with open(path, "wb") as f:
+        f.write(MAGIC)
+        raw = bytes(ctypes.string_at(ctypes.addressof(cfg), ctypes.sizeof(cfg)))
+        f.write(struct.pack("<I", len(raw)))
+        f.write(raw)
+        f.write(struct.pack("<I", len(tensors)))
+        for name, arr in tensors.items():
+            nb = name.encode()
+            a = np.ascontiguousarray(arr, np.float32)
+            as_bf16 = a.ndim >= 2 and name.startswith(bf16_prefixes)
+            f.write(struct.pack("<H", len(nb)))
+            f.write(nb)
+            f.write(struct.pack("<BQ", 1 if as_bf16 else 0, a.size))
+            f.write(_bf16_bits(a).tobytes() if as_bf16 else a.tobytes())
