@@ -53,7 +53,7 @@ def cpu_baseline(eng, cfg, ids, sp_kwargs, frames):
     baseline here; nothing measured as `value` touches it."""
     import q3_oracle as qo
     ocfg = qo.Config.from_dict(cfg.to_dict())
-    orc = qo.Oracle(ocfg, max_ctx=64)
+    orc = qo.Oracle(ocfg, max_ctx=frames + 32)
     for name, shape in eng.tensor_infos():
         orc.set_tensor(name, eng.get_tensor(name, shape))
     threads = orc.threads

@@ -59,7 +59,8 @@ def test_weight_file_roundtrip_and_cli(tmp_path):
     ref = orc.vocoder(codes)
     ref16 = (np.clip(ref, -1, 1) * 32767.0).astype(np.int16)   # truncation toward zero, like the reference writer
     assert got.shape == ref16.shape
-    assert np.abs(got.astype(np.int32) - ref16.astype(np.int32)).max() <= 2   # 1e-4 RMS tolerance is ~3 LSB of int16
+    d = got.astype(np.float64) - ref16.astype(np.float64)
+    assert np.sqrt(np.mean(d ** 2)) < 3.3 and np.abs(d).max() <= 64   # north_star: 1e-4 RMS = 3.3 LSB of int16
     eng.close()
     orc.close()
 
