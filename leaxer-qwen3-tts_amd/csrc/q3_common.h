@@ -97,9 +97,29 @@ struct AttnArgs {
     // un-normalised partials instead of `out`; combined by the o_proj GEMV prologue or launch_attn_combine
     int n_splits = 1, chunk = 1 << 30;
     float* po = nullptr; float* pm = nullptr; float* pl = nullptr;
+    // optional (hi, lo) bf16 plane outputs of launch_attn_combine for the MFMA GEMM path
+    bf16_t* oh = nullptr; bf16_t* ol = nullptr; int ldp = 0;
 };
 void launch_attn(const AttnArgs& a, hipStream_t s);
 void launch_attn_combine(const AttnArgs& a, hipStream_t s); // partials -> a.out
+
+// Skinny-M bf16-MFMA GEMM (q3_gemm_kernels.hip): activations as (hi, lo) bf16 planes, fp32 accumulate
+struct GemmArgs {
+    const bf16_t* W = nullptr;   // [N][K]
+    const bf16_t* W2 = nullptr;  // EPI_SWIGLU: up_proj rows
+    const bf16_t* xh = nullptr;  // [M][ldx] hi plane
+    const bf16_t* xl = nullptr;  // [M][ldx] lo plane
+    int ldx = 0;
+    const float* res = nullptr; int ldres = 0;
+    const float* bias = nullptr;
+    float* out = nullptr; int ldo = 0;        // fp32 output (may be null when only planes are wanted)
+    bf16_t* oh = nullptr; bf16_t* ol = nullptr; int ldp = 0; // optional plane outputs (input of the next GEMM)
+    int M = 0, N = 0, K = 0, epi = EPI_STORE;
+};
+bool gemm_mfma_ok(int M, int K);
+void launch_gemm_mfma(const GemmArgs& a, hipStream_t s);
+void launch_rmsnorm_split(const float* x, int ldx, const float* gamma, float eps, int rows, int K,
+                          bf16_t* oh, bf16_t* ol, int ldp, float* xn_out, int ld_xn, hipStream_t s);
 
 struct SlotState { // device-resident per-slot generation state
     int32_t n_frames;     // frames recorded so far

@@ -765,7 +765,16 @@ __global__ __launch_bounds__(256) void k_attn_combine(AttnArgs a) {
             L += w * a.pl[pi + sp];
             O += w * a.po[(pi + sp) * a.d + e];
         }
-        a.out[(size_t)row * a.ld_out + idx] = O / L;
+        const float o = O / L;
+        if (a.out) a.out[(size_t)row * a.ld_out + idx] = o;
+        if (a.oh) {
+            const uint32_t u = __float_as_uint(o);
+            const bf16_t hi = (bf16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+            const float rem = o - __uint_as_float((uint32_t)hi << 16);
+            const uint32_t v = __float_as_uint(rem);
+            a.oh[(size_t)row * a.ldp + idx] = hi;
+            a.ol[(size_t)row * a.ldp + idx] = (bf16_t)((v + 0x7FFFu + ((v >> 16) & 1u)) >> 16);
+        }
     }
 }
 void launch_attn_combine(const AttnArgs& a, hipStream_t s) {

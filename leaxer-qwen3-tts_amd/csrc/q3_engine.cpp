@@ -166,6 +166,9 @@ Engine::Engine(const q3tts_config& cfg, int device_, int max_batch, int max_ctx_
     tts_pad_d = fm(H);
     text_tmp = fm((size_t)16 * c.text_hidden);
     text_tmp2 = fm((size_t)16 * c.text_hidden);
+    ldp = (std::max(std::max(H, AO), std::max(c.ffn, c.cp_ffn)) + 7) / 8 * 8;
+    pl0h = (bf16_t*)dmalloc((size_t)rows_max * ldp * 2); pl0l = (bf16_t*)dmalloc((size_t)rows_max * ldp * 2);
+    pl1h = (bf16_t*)dmalloc((size_t)rows_max * ldp * 2); pl1l = (bf16_t*)dmalloc((size_t)rows_max * ldp * 2);
     ids_d = (int64_t*)dmalloc(64 * sizeof(int64_t));
     tok_d = (int64_t*)dmalloc(sizeof(int64_t));
     codes_d = (int32_t*)dmalloc((size_t)B * max_frames_cap * c.n_groups * sizeof(int32_t));
@@ -317,12 +320,21 @@ void Engine::finalize() {
 // ------------------------------------------------------------------------------------------------
 void Engine::run_layers(const DecStack& W, float* x, int ldx, int nb, int n_new, int slot_offset, const int* pos_dev, int pos_scalar) {
     const int M = nb * n_new, QKV = (W.nq + 2 * W.nkv) * W.d, AO = W.nq * W.d;
+    // M > 8 rows: bf16-MFMA skinny GEMM over (hi, lo) activation planes; else the GEMV family
+    const bool mfma = M > 8 && gemm_mfma_ok(M, W.H) && gemm_mfma_ok(M, AO) && gemm_mfma_ok(M, W.ffn);
     for (int l = 0; l < W.L; ++l) {
         const DecLayerW& w = W.layers[l];
-        GemvArgs g;
-        g.W = w.qkv; g.x = x; g.ldx = ldx; g.gamma = w.in_norm; g.eps = W.eps; g.out = qkv; g.ldo = QKV;
-        g.M = M; g.N = QKV; g.K = W.H; g.epi = EPI_STORE; g.nt = W.nt;
-        launch_gemv(g, stream);
+        if (mfma) {
+            launch_rmsnorm_split(x, ldx, w.in_norm, W.eps, M, W.H, pl0h, pl0l, ldp, nullptr, 0, stream);
+            GemmArgs g;
+            g.W = w.qkv; g.xh = pl0h; g.xl = pl0l; g.ldx = ldp; g.out = qkv; g.ldo = QKV; g.M = M; g.N = QKV; g.K = W.H; g.epi = EPI_STORE;
+            launch_gemm_mfma(g, stream);
+        } else {
+            GemvArgs g;
+            g.W = w.qkv; g.x = x; g.ldx = ldx; g.gamma = w.in_norm; g.eps = W.eps; g.out = qkv; g.ldo = QKV;
+            g.M = M; g.N = QKV; g.K = W.H; g.epi = EPI_STORE; g.nt = W.nt;
+            launch_gemv(g, stream);
+        }
         AttnArgs a;
         a.qkv = qkv; a.ld_qkv = QKV; a.out = attn; a.ld_out = AO; a.kcache = W.kc; a.vcache = W.vc;
         a.page_table = W.page_table; a.pages_per_slot = W.pages_per_slot; a.page_shift = W.page_shift;
@@ -332,6 +344,24 @@ void Engine::run_layers(const DecStack& W, float* x, int ldx, int nb, int n_new,
         a.scale = 1.0f / sqrtf((float)W.d); a.window = 0; a.new_from_raw = 1;
         a.n_splits = W.n_splits; a.chunk = W.chunk; a.po = W.po; a.pm = W.pm; a.pl = W.pl;
         launch_attn(a, stream);
+        if (mfma) {
+            a.out = nullptr; a.oh = pl1h; a.ol = pl1l; a.ldp = ldp;
+            launch_attn_combine(a, stream);                      // partials -> (hi, lo) planes
+            GemmArgs o;
+            o.W = w.o; o.xh = pl1h; o.xl = pl1l; o.ldx = ldp; o.res = x; o.ldres = ldx; o.out = x; o.ldo = ldx;
+            o.M = M; o.N = W.H; o.K = AO; o.epi = EPI_RESIDUAL;
+            launch_gemm_mfma(o, stream);
+            launch_rmsnorm_split(x, ldx, w.post_norm, W.eps, M, W.H, pl0h, pl0l, ldp, nullptr, 0, stream);
+            GemmArgs f;
+            f.W = w.gate; f.W2 = w.up; f.xh = pl0h; f.xl = pl0l; f.ldx = ldp; f.out = nullptr; f.oh = pl1h; f.ol = pl1l; f.ldp = ldp;
+            f.M = M; f.N = W.ffn; f.K = W.H; f.epi = EPI_SWIGLU;
+            launch_gemm_mfma(f, stream);
+            GemmArgs d;
+            d.W = w.down; d.xh = pl1h; d.xl = pl1l; d.ldx = ldp; d.res = x; d.ldres = ldx; d.out = x; d.ldo = ldx;
+            d.M = M; d.N = W.H; d.K = W.ffn; d.epi = EPI_RESIDUAL;
+            launch_gemm_mfma(d, stream);
+            continue;
+        }
         GemvArgs o;
         o.W = w.o; o.x = attn; o.ldx = AO; o.res = x; o.ldres = ldx; o.out = x; o.ldo = ldx;
         o.M = M; o.N = W.H; o.K = AO; o.epi = EPI_RESIDUAL; o.nt = W.nt;
@@ -351,6 +381,22 @@ void Engine::run_layers(const DecStack& W, float* x, int ldx, int nb, int n_new,
         d.M = M; d.N = W.H; d.K = W.ffn; d.epi = EPI_RESIDUAL; d.nt = W.nt;
         launch_gemv(d, stream);
     }
+}
+
+// final RMSNorm + output head (codec_head / cp.head.j); optionally keeps the normalised rows
+void Engine::head_proj(const bf16_t* Wm, const float* x, int ldx, const float* gamma, float eps, float* xn_out, int ld_xn,
+                       float* out, int ldo, int M, int N, int K, bool nt) {
+    if (M > 8 && gemm_mfma_ok(M, K)) {
+        launch_rmsnorm_split(x, ldx, gamma, eps, M, K, pl0h, pl0l, ldp, xn_out, ld_xn, stream);
+        GemmArgs g;
+        g.W = Wm; g.xh = pl0h; g.xl = pl0l; g.ldx = ldp; g.out = out; g.ldo = ldo; g.M = M; g.N = N; g.K = K; g.epi = EPI_STORE;
+        launch_gemm_mfma(g, stream);
+        return;
+    }
+    GemvArgs g;
+    g.W = Wm; g.x = x; g.ldx = ldx; g.gamma = gamma; g.eps = eps; g.xn_out = xn_out; g.ld_xn = ld_xn;
+    g.out = out; g.ldo = ldo; g.M = M; g.N = N; g.K = K; g.epi = EPI_STORE; g.nt = nt;
+    launch_gemv(g, stream);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -404,10 +450,8 @@ void Engine::talker_prefill(int slot, const float* embeds, int S, float* logits,
     const int H = c.hidden, V = c.vocab;
     Q3_HIP_CHECK(hipMemcpyAsync(xp, embeds, (size_t)S * H * sizeof(float), hipMemcpyHostToDevice, stream));
     run_layers(talker, xp, H, 1, S, slot, nullptr, 0);
-    GemvArgs g; // final norm + codec head on every row; normalised rows kept for last_hidden
-    g.W = codec_head; g.x = xp; g.ldx = H; g.gamma = talker_norm; g.eps = c.rms_eps; g.xn_out = hn; g.ld_xn = H;
-    g.out = logits_p; g.ldo = V; g.M = S; g.N = V; g.K = H; g.epi = EPI_STORE; g.nt = true;
-    launch_gemv(g, stream);
+    // final norm + codec head on every row; normalised rows kept for last_hidden
+    head_proj(codec_head, xp, H, talker_norm, c.rms_eps, hn, H, logits_p, V, S, V, H, true);
     // arm the fused path: logits of the last row -> logits_t[slot], last_hidden -> x_cp[slot][0]
     launch_copy_rows(logits_p + (size_t)(S - 1) * V, V, logits_t + (size_t)slot * V, V, 1, V, stream);
     launch_copy_rows(hn + (size_t)(S - 1) * H, H, x_cp + (size_t)slot * 2 * H, H, 1, H, stream);
@@ -525,20 +569,14 @@ void Engine::record_step(int nb) {
         float* xin = j == 0 ? x_cp : x_cp1;
         if (j == 0) run_layers(cp, x_cp, H, nb, 2, 0, nullptr, 0);        // rows [last_hidden, embed(code0)]
         else run_layers(cp, x_cp1, H, nb, 1, 0, nullptr, j + 1);
-        GemvArgs g;
-        g.W = cp_head[j]; g.x = j == 0 ? xin + H : xin; g.ldx = j == 0 ? 2 * H : H; g.gamma = cp_norm; g.eps = c.cp_rms_eps;
-        g.out = logits_cp; g.ldo = SV; g.M = nb; g.N = SV; g.K = H; g.epi = EPI_STORE;
-        launch_gemv(g, stream);
+        head_proj(cp_head[j], j == 0 ? xin + H : xin, j == 0 ? 2 * H : H, cp_norm, c.cp_rms_eps, nullptr, 0, logits_cp, SV, nb, SV, H, false);
         SampleArgs s = s0;
         s.logits = logits_cp; s.ld = SV; s.V = SV; s.group = j + 1; s.embed = cp_embed_w[j];
         s.x_next = j + 1 < G - 1 ? x_cp1 : nullptr; s.ld_xnext = H;
         launch_sample(s, stream);
     }
     run_layers(talker, x_talk, H, nb, 1, 0, talker_pos_d, 0);  // run_decode (:845)
-    GemvArgs g;
-    g.W = codec_head; g.x = x_talk; g.ldx = H; g.gamma = talker_norm; g.eps = c.rms_eps; g.xn_out = x_cp; g.ld_xn = 2 * H;
-    g.out = logits_t; g.ldo = V; g.M = nb; g.N = V; g.K = H; g.epi = EPI_STORE; g.nt = true;
-    launch_gemv(g, stream);
+    head_proj(codec_head, x_talk, H, talker_norm, c.rms_eps, x_cp, 2 * H, logits_t, V, nb, V, H, true);
 }
 
 int Engine::nb_in_use() const {

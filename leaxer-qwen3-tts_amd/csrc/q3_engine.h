@@ -109,6 +109,8 @@ public:
     float *x_cp = nullptr, *x_cp1 = nullptr, *sum = nullptr, *xp = nullptr, *hn = nullptr, *logits_p = nullptr;
     float *trailing_d = nullptr, *tts_pad_d = nullptr, *text_tmp = nullptr, *text_tmp2 = nullptr;
     int64_t* ids_d = nullptr;
+    bf16_t *pl0h = nullptr, *pl0l = nullptr, *pl1h = nullptr, *pl1l = nullptr; // (hi, lo) activation planes for the MFMA GEMM path
+    int ldp = 0;
     int32_t* codes_d = nullptr;
     int32_t* codes_scratch_d = nullptr;
     int32_t* talker_pos_d = nullptr;
@@ -123,6 +125,8 @@ public:
     void* dmalloc(size_t bytes);
     void run_layers(const DecStack& W, float* x, int ldx, int nb, int n_new, int slot_offset, const int* pos_dev, int pos_scalar);
     void record_step(int nb);
+    void head_proj(const bf16_t* Wm, const float* x, int ldx, const float* gamma, float eps, float* xn_out, int ld_xn,
+                   float* out, int ldo, int M, int N, int K, bool nt);
     int nb_in_use() const;
     void sync();
 };

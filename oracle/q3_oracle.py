@@ -96,6 +96,15 @@ def config_tiny():
         codec_eos=2150, suppress_begin=64, suppress_end=2176))
 
 
+def config_medium():
+    """Dims that are multiples of 128, so batches > 8 rows take the bf16-MFMA skinny-GEMM path
+    (K in {128, 256}) while staying small enough for the CPU oracle."""
+    d = config_tiny().to_dict()
+    d.update(hidden=128, n_layers=2, n_heads=2, n_kv_heads=1, head_dim=64, ffn=256,
+             cp_layers=2, cp_heads=2, cp_kv_heads=1, cp_head_dim=64, cp_ffn=256, text_hidden=64)
+    return Config.from_dict(d)
+
+
 def tensor_specs(cfg):
     """(name, shape, kind) for every tensor of the model.  kind: 'w' matrix, 'norm' (ones-centred),
     'b' bias, 'scale' LayerScale/gamma, 'snake' alpha/beta."""

@@ -1,0 +1,71 @@
+"""Batched decode (M > 8 rows -> bf16-MFMA skinny GEMM with hi/lo-split activations) against the oracle:
+configs[2]-style batches at test size, and a 16-utterance batch at 0.6B dims."""
+import numpy as np
+import pytest
+
+import q3_oracle as qo
+from util import frame_tokens, tiny_pair, to_ocfg, to_osampling
+
+pytestmark = pytest.mark.gpu
+
+
+def test_batch12_generation_medium_config():
+    import q3tts
+    eng, orc, _ = tiny_pair(seed=6, max_batch=12, max_ctx=160, ocfg=qo.config_medium())
+    sp = q3tts.Sampling(temperature=0.8, top_p=0.95, top_k=50, max_new_tokens=40)
+    rng = np.random.default_rng(0)
+    toks = [frame_tokens(rng.integers(0, 151643, int(n))) for n in rng.integers(1, 24, 12)]
+    pcm, codes, nfr = eng.synthesize_batch(toks, sp, lang=0, seed=21, ignore_eos=False)
+    n_eos = 0
+    for u, t in enumerate(toks):
+        ref = orc.generate(orc.build_prompt(t, 0), to_osampling(sp), seed=21, stream=u, cp_cached=True, ignore_eos=False)
+        assert nfr[u] == len(ref) and np.array_equal(codes[u], ref), (u, nfr[u], len(ref))
+        n_eos += len(ref) < sp.max_new_tokens
+        if len(ref):
+            ref_pcm = orc.vocoder(ref)
+            assert float(np.sqrt(np.mean((pcm[u] - ref_pcm) ** 2))) < 1e-4
+    eng.close()
+    orc.close()
+
+
+def test_batch12_logits_tolerance_medium_config():
+    """Teacher-forced single steps: the MFMA path's logits stay within fp32-summation noise of the oracle."""
+    import q3tts
+    eng, orc, _ = tiny_pair(seed=7, max_batch=12, max_ctx=96, ocfg=qo.config_medium())
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((12, eng.cfg.hidden)).astype(np.float32)
+    lg, lh = eng.prefill(x)            # S = 12 rows > 8 -> MFMA GEMM inside one slot's prefill
+    lo, ho = orc.prefill(x)
+    assert np.abs(lg - lo).max() < 2e-4 and np.abs(lh - ho).max() < 2e-4
+    seq = rng.standard_normal((14, eng.cfg.hidden)).astype(np.float32)
+    assert np.abs(eng.code_predictor(seq, 12) - orc.code_predictor(seq, 12)).max() < 2e-4
+    eng.close()
+    orc.close()
+
+
+def test_batch16_full_size_greedy():
+    """0.6B dims, 16 utterances in one batch, greedy, 4 frames: codec ids bit-exact vs the oracle."""
+    import q3tts
+    cfg = q3tts.default_config("0.6b")
+    eng = q3tts.Engine(cfg, device=0, max_batch=16, max_ctx=128)
+    eng.fill_synthetic(seed=0)
+    orc = qo.Oracle(to_ocfg(cfg), max_ctx=48)
+    for name, shape in eng.tensor_infos():
+        if not name.startswith("cd."):
+            orc.set_tensor(name, eng.get_tensor(name, shape))
+    sp = q3tts.Sampling(temperature=1.0, top_p=1.0, top_k=1, max_new_tokens=4)
+    rng = np.random.default_rng(5)
+    toks = [frame_tokens(rng.integers(0, 151643, 16)) for _ in range(16)]
+    for b, t in enumerate(toks):
+        p, tr = eng.build_prompt(t, 0)
+        eng.slot_begin(b, p, tr, sp, seed=2, stream_id=b, ignore_eos=True)
+    assert eng.decode_steps(4) == 0
+    bad = []
+    for b, t in enumerate(toks):
+        got = eng.slot_codes(b)
+        ref = orc.generate(orc.build_prompt(t, 0), to_osampling(sp), seed=2, stream=b, cp_cached=True, ignore_eos=True)
+        if not np.array_equal(got, ref):
+            bad.append(b)
+    assert not bad, bad
+    eng.close()
+    orc.close()

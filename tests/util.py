@@ -47,10 +47,10 @@ def calibrate_codec(w, ocfg, target_rms=0.2):
     return w
 
 
-def tiny_pair(seed=0, max_batch=4, max_ctx=128, extra=None, flags=0):
-    """(engine, oracle, weights) on config_tiny with identical bf16-representable weights."""
+def tiny_pair(seed=0, max_batch=4, max_ctx=128, extra=None, flags=0, ocfg=None):
+    """(engine, oracle, weights) on config_tiny (or `ocfg`) with identical bf16-representable weights."""
     import q3tts
-    ocfg = qo.config_tiny()
+    ocfg = ocfg or qo.config_tiny()
     w = calibrate_codec(qo.random_weights(ocfg, seed), ocfg)
     if extra:
         w.update(extra)
