@@ -832,19 +832,27 @@ static __device__ __forceinline__ float kth_largest_of_lanes(float v, int k) {
     return wave_max((gt < k && k <= ge) ? v : -INFINITY);
 }
 
-__global__ __launch_bounds__(64) void k_sample(SampleArgs a) {
-    const int b = blockIdx.x, lane = threadIdx.x;
+// Four waves per utterance: wave w owns the 64-element slices j = w, w+4, ... of the logits row (registers),
+// the few cross-wave hand-offs go through LDS; the serial tail (threshold rounds, top-p, draw) runs on wave 0
+// only, the embedding epilogue on all 256 threads.
+#define SAMP_PERW (SAMP_MAXV / 256)
+__global__ __launch_bounds__(256) void k_sample(SampleArgs a) {
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int V = a.V;
-    // Compact loops over LDS-staged logits on purpose: a fully unrolled register-resident version is ~80 KB
-    // of straight-line code, and a lone wave then stalls on instruction fetch every few instructions.
-    __shared__ float xs[SAMP_MAXV];              // suppressed, temperature-scaled logits; later reused as sorted_p
-    __shared__ float svb[256 + 64];              // survivor staging (+64 dump slots for branch-free stores)
+    __shared__ float gmax[4][64];                // per-wave lane maxima
+    __shared__ float svw[4][256 + 64];           // per-wave survivor staging (+64 dump slots)
+    __shared__ int svn[4];
+    __shared__ float svb[256 + 64];              // wave 0: survivor rounds
+    __shared__ int cnt_s[SAMP_MAXV / 64];        // survivors per 64-slice (index-ordered compaction)
     __shared__ int cand_idx[SAMP_MAXV + 64];
     __shared__ float cand_p[SAMP_MAXV + 64];
+    __shared__ float sorted_p[SAMP_MAXV];        // general path only
+    __shared__ float esum_s[4];
+    __shared__ float sh_f[4];
     __shared__ int sh_i[4];
-    float* sorted_p = xs;
 
-    // ---- round trip 1: slot state (one 64-byte struct) and the logits row (float4 per lane), all in flight ----
+    // ---- round trip 1: slot state (one 64-byte struct) and this wave's logits slices, all in flight ----
     float temperature = a.temperature, top_p = a.top_p, u = a.u;
     int top_k = a.top_k, suppress = a.suppress, keep_eos = 1;
     int frame = 0;
@@ -856,20 +864,17 @@ __global__ __launch_bounds__(64) void k_sample(SampleArgs a) {
         __builtin_memcpy(&sl, raw, sizeof sl);
     }
     const float* lg = a.logits + (size_t)b * a.ld;
-    const bool vec4 = (V & 3) == 0 && (a.ld & 3) == 0;
-    const int PER4 = (V / 4 + 63) / 64;            // float4 slots per lane
-    float4 lv[SAMP_MAXV / 256];
-    if (vec4) {
+    const int PER = (V + 63) / 64;               // 64-element slices in the row
+    float x[SAMP_PERW];
 #pragma unroll
-        for (int j = 0; j < SAMP_MAXV / 256; ++j) {
-            const int i4 = j * 64 + lane;           // clamped, unconditional
-            lv[j] = reinterpret_cast<const float4*>(lg)[i4 * 4 < V ? i4 : V / 4 - 1];
-        }
+    for (int jj = 0; jj < SAMP_PERW; ++jj) {
+        const int i = (jj * 4 + wave) * 64 + lane;
+        x[jj] = lg[i < V ? i : V - 1];           // clamped, unconditional
     }
     __builtin_amdgcn_sched_barrier(0);
     if (st) {
         if (!sl.active || sl.finished) return;
-        if (a.group == 0 && sl.n_frames >= sl.max_frames) { if (lane == 0) st->finished = 1; return; }
+        if (a.group == 0 && sl.n_frames >= sl.max_frames) { if (tid == 0) st->finished = 1; return; }
         temperature = sl.temperature; top_p = sl.top_p; top_k = sl.top_k;
         frame = sl.n_frames;
         u = rng_uniform_dev(sl.seed, sl.stream_id, (uint32_t)frame, (uint32_t)a.group);
@@ -877,36 +882,26 @@ __global__ __launch_bounds__(64) void k_sample(SampleArgs a) {
         keep_eos = !sl.ignore_eos;
     }
     const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-    const int PER = (V + 63) / 64;
 
-    // suppress (:803-807) + temperature (:882-884), staged into LDS in plain index order
+    // suppress (:803-807) + temperature (:882-884)
     const bool use_temp = temperature > 0.0f && temperature != 1.0f;
-    auto prep = [&](float v, int i) -> float {
+    float lmax = -INFINITY;
+#pragma unroll
+    for (int jj = 0; jj < SAMP_PERW; ++jj) {
+        const int i = (jj * 4 + wave) * 64 + lane;
+        float v = x[jj];
         const bool sup = suppress && i >= a.sup_begin && i < a.sup_end && !(i == a.eos_id && keep_eos);
         const float vt = v / temperature;
         v = use_temp ? vt : v;
-        return (sup || i >= V) ? -INFINITY : v;
-    };
-    float lmax = -INFINITY;
-    if (vec4) {
-#pragma unroll
-        for (int j = 0; j < SAMP_MAXV / 256; ++j) {
-            if (j < PER4) {
-                const int i = (j * 64 + lane) * 4;
-                float4 o;
-                o.x = prep(lv[j].x, i); o.y = prep(lv[j].y, i + 1); o.z = prep(lv[j].z, i + 2); o.w = prep(lv[j].w, i + 3);
-                if (i < SAMP_MAXV) *reinterpret_cast<float4*>(&xs[i]) = o;
-            }
-        }
-    } else {
-        for (int j = 0; j < PER; ++j) { const int i = j * 64 + lane; xs[i] = prep(lg[i < V ? i : V - 1], i); }
+        v = (sup || i >= V) ? -INFINITY : v;
+        x[jj] = v;
+        lmax = fmaxf(lmax, v);
     }
+    gmax[wave][lane] = lmax;
     __syncthreads();
-    for (int i = V + lane; i < PER * 64; i += 64) xs[i] = -INFINITY; // pad the last 64-slice
-    __syncthreads();
-#pragma unroll 8
-    for (int j = 0; j < PER; ++j) lmax = fmaxf(lmax, xs[j * 64 + lane]);
-    const float mx = wave_max(lmax);
+    // 64 group maxima (group = lane, over all four waves) -> global max and the prefilter bound
+    const float gm = fmaxf(fmaxf(gmax[0][lane], gmax[1][lane]), fmaxf(gmax[2][lane], gmax[3][lane]));
+    const float mx = wave_max(gm);
 
     // ---- top-k threshold = k-th largest value, ties kept (:917-927) ----
     float thr = -INFINITY;
@@ -914,193 +909,221 @@ __global__ __launch_bounds__(64) void k_sample(SampleArgs a) {
         bool done = false;
         if (top_k == 1) { thr = mx; done = true; }
         else if (top_k <= 64) {
-            // Iterated prefilter: the k-th largest of the 64 lane maxima is a lower bound L of the k-th
-            // largest overall, so only elements >= L can matter (~100 of 3072); re-deal the survivors over
-            // the lanes and repeat until at most one candidate per lane is left, which is ranked exactly.
-            const float L1 = kth_largest_of_lanes(lmax, top_k);
-            int n = 0;
-#pragma unroll 4
-            for (int j = 0; j < PER; ++j) {
-                const float v = xs[j * 64 + lane];
-                const bool sv = v >= L1 && v != -INFINITY;
+            // Iterated prefilter: the k-th largest of the 64 group maxima is a lower bound L of the k-th
+            // largest overall, so only elements >= L can matter (~100 of 3072); wave 0 re-deals the survivors
+            // over its lanes and repeats until at most one candidate per lane is left, ranked exactly.
+            const float L1 = kth_largest_of_lanes(gm, top_k);   // every wave computes the same L1
+            int nw = 0;
+#pragma unroll
+            for (int jj = 0; jj < SAMP_PERW; ++jj) {
+                const bool sv = x[jj] >= L1 && x[jj] != -INFINITY;
                 const unsigned long long m = __ballot(sv);
-                const int ppos = n + __popcll(m & lt_mask);
-                svb[(sv && ppos < 256) ? ppos : 256 + lane] = v;
-                n += __popcll(m);
+                const int ppos = nw + __popcll(m & lt_mask);
+                svw[wave][(sv && ppos < 256) ? ppos : 256 + lane] = x[jj];
+                nw += __popcll(m);
+            }
+            if (lane == 0) svn[wave] = nw;
+            __syncthreads();
+            if (wave == 0) {
+                const int n0 = svn[0], n1 = svn[1], n2 = svn[2], n3 = svn[3];
+                int n = n0 + n1 + n2 + n3;
+                bool ok = L1 != -INFINITY && n <= 256;
+                if (ok) { // gather the four wave-local lists into svb[0..n)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int i = q * 64 + lane;
+                        float v = -INFINITY;
+                        if (i < n0) v = svw[0][i];
+                        else if (i < n0 + n1) v = svw[1][i - n0];
+                        else if (i < n0 + n1 + n2) v = svw[2][i - n0 - n1];
+                        else if (i < n) v = svw[3][i - n0 - n1 - n2];
+                        svb[i] = v;
+                    }
+                }
+                for (int round = 0; ok && round < 8; ++round) {
+                    float s4[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { const float v = svb[q * 64 + lane]; s4[q] = q * 64 + lane < n ? v : -INFINITY; }
+                    if (n <= 64) { thr = kth_largest_of_lanes(s4[0], top_k); done = thr != -INFINITY; break; }
+                    const float L2 = kth_largest_of_lanes(fmaxf(fmaxf(s4[0], s4[1]), fmaxf(s4[2], s4[3])), top_k);
+                    int n2c = 0;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const bool sv = s4[q] >= L2 && s4[q] != -INFINITY;
+                        const unsigned long long m = __ballot(sv);
+                        const int ppos = n2c + __popcll(m & lt_mask);
+                        svb[sv ? ppos : 256 + lane] = s4[q];
+                        n2c += __popcll(m);
+                    }
+                    ok = L2 != -INFINITY && n2c < n; // no progress (mass ties): exact fallback below
+                    n = n2c;
+                }
+                if (lane == 0) { sh_f[0] = thr; sh_i[0] = done ? 1 : 0; }
             }
             __syncthreads();
-            bool ok = L1 != -INFINITY && n <= 256;
-            for (int round = 0; ok && round < 8; ++round) {
-                float s4[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) { const float v = svb[q * 64 + lane]; s4[q] = q * 64 + lane < n ? v : -INFINITY; }
-                __syncthreads();
-                if (n <= 64) { thr = kth_largest_of_lanes(s4[0], top_k); done = thr != -INFINITY; break; }
-                const float L2 = kth_largest_of_lanes(fmaxf(fmaxf(s4[0], s4[1]), fmaxf(s4[2], s4[3])), top_k);
-                int n2 = 0;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const bool sv = s4[q] >= L2 && s4[q] != -INFINITY;
-                    const unsigned long long m = __ballot(sv);
-                    const int ppos = n2 + __popcll(m & lt_mask);
-                    svb[sv ? ppos : 256 + lane] = s4[q];
-                    n2 += __popcll(m);
-                }
-                __syncthreads();
-                ok = L2 != -INFINITY && n2 < n; // no progress (mass ties): take the exact fallback
-                n = n2;
-            }
+            thr = sh_f[0];
+            done = sh_i[0] != 0;
         }
         if (!done) { // rare fallback (top_k > 64, or pathological ties): bitwise search of the k-th largest key
             uint32_t prefix = 0;
             for (int bit = 31; bit >= 0; --bit) {
                 const uint32_t cand = prefix | (1u << bit);
-                int cnt = 0;
-                for (int j = 0; j < PER; ++j) {
-                    const int i = j * 64 + lane;
-                    cnt += __popcll(__ballot(i < V && fkey(xs[i]) >= cand));
-                }
-                if (cnt >= top_k) prefix = cand;
+                int c = 0;
+#pragma unroll
+                for (int jj = 0; jj < SAMP_PERW; ++jj) c += ((jj * 4 + wave) * 64 + lane < V && fkey(x[jj]) >= cand) ? 1 : 0;
+                c = wave_sum_i(c);
+                __syncthreads();
+                if (lane == 0) svn[wave] = c;
+                __syncthreads();
+                if (svn[0] + svn[1] + svn[2] + svn[3] >= top_k) prefix = cand;
             }
             const uint32_t ku = (prefix & 0x80000000u) ? (prefix & 0x7FFFFFFFu) : ~prefix;
             thr = __uint_as_float(ku);
         }
     }
 
-    // ---- index-ordered, branch-free compaction of survivors; softmax numerators exp(x - max) (:907-915) ----
-    int n_kept = 0;
+    // ---- index-ordered compaction of the kept entries; softmax numerators exp(x - max) (:907-915) ----
+    unsigned long long km[SAMP_PERW];
+#pragma unroll
+    for (int jj = 0; jj < SAMP_PERW; ++jj) {
+        const bool keep = x[jj] >= thr && x[jj] != -INFINITY;
+        km[jj] = __ballot(keep);
+        const int j = jj * 4 + wave;
+        if (lane == 0 && j < PER) cnt_s[j] = __popcll(km[jj]);
+    }
+    __syncthreads();
+    // exclusive prefix of the per-slice counts (slice order = index order); lane j holds slice j
+    const int cmine = lane < PER ? cnt_s[lane] : 0;
+    const int cincl = wave_scan_i(cmine, lane);
+    const int n_kept = lane_bcast_i(cincl, 63);
     float esum = 0.f;
-#pragma unroll 4
-    for (int j = 0; j < PER; ++j) {
-        const float v = xs[j * 64 + lane];
-        const bool keep = v >= thr && v != -INFINITY;
-        const unsigned long long m = __ballot(keep);
-        if (m) { // wave-uniform: most 64-element slices hold no survivor at all
-            const int wpos = keep ? n_kept + __popcll(m & lt_mask) : SAMP_MAXV + lane;
-            const float e = keep ? expf(v - mx) : 0.f;
+#pragma unroll
+    for (int jj = 0; jj < SAMP_PERW; ++jj) {
+        const int j = jj * 4 + wave;
+        if (km[jj]) { // wave-uniform: most slices hold no survivor
+            const int base = lane_bcast_i(cincl, j) - lane_bcast_i(cmine, j);
+            const bool keep = (km[jj] >> lane) & 1ull;
+            const int wpos = keep ? base + __popcll(km[jj] & lt_mask) : SAMP_MAXV + lane;
+            const float e = keep ? expf(x[jj] - mx) : 0.f;
             cand_idx[wpos] = j * 64 + lane;
             cand_p[wpos] = e;
             esum += e;
-            n_kept += __popcll(m);
         }
     }
     esum = wave_sum(esum);
+    if (lane == 0) esum_s[wave] = esum;
     __syncthreads();
+    esum = ((esum_s[0] + esum_s[1]) + esum_s[2]) + esum_s[3];
 
     int tok = 0;
-    if (n_kept <= 64) {
-        // ---- wave path: one candidate per lane, everything in registers ----
-        const bool have = lane < n_kept;
-        float p = have ? cand_p[lane] / esum : 0.f;
-        const int myidx = have ? cand_idx[lane] : 0;
-        if (top_p < 1.0f) { // :929-950 — order by (p desc, index asc); keep through the first cumulative sum > top_p
-            int rank = 0;      // candidates ordered strictly before this one
-            float cum = 0.f;   // sum of every candidate ordered at or before this one
+    if (wave == 0) {
+        if (n_kept <= 64) {
+            // ---- wave path: one candidate per lane, everything in registers ----
+            const bool have = lane < n_kept;
+            float p = have ? cand_p[lane] / esum : 0.f;
+            const int myidx = have ? cand_idx[lane] : 0;
+            if (top_p < 1.0f) { // :929-950 — order by (p desc, index asc); keep through the first cumulative sum > top_p
+                int rank = 0;      // candidates ordered strictly before this one
+                float cum = 0.f;   // sum of every candidate ordered at or before this one
 #pragma unroll 4
-            for (int o2 = 0; o2 < n_kept; ++o2) {
-                const float po = lane_bcast(p, o2);
-                const bool before = po > p || (po == p && o2 < lane);
-                rank += before ? 1 : 0;
-                cum += (before || o2 == lane) ? po : 0.f;
-            }
-            int rcut = (have && cum > top_p) ? rank : 0x7FFFFFFF;
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) { const int t = __shfl_xor(rcut, off, 64); rcut = t < rcut ? t : rcut; }
-            if (!(have && rank <= rcut)) p = 0.f;
-            const float s2 = wave_sum(p);
-            if (s2 > 0.f) p = p / s2; // :893-898
-        }
-        // draw: inverse CDF in index order
-        const float total = wave_sum(p);
-        const float target = u * total;
-        const float cum = wave_scan_f(p, lane);
-        const unsigned long long hit = __ballot(p > 0.f && cum > target);
-        const unsigned long long pos_mask = __ballot(p > 0.f);
-        int pick;
-        if (hit) pick = __ffsll((long long)hit) - 1;
-        else pick = pos_mask ? 63 - __clzll((long long)pos_mask) : 0;
-        tok = lane_bcast_i(myidx, pick);
-    } else {
-        // ---- general path (top_k == 0 or > 64, or many ties): LDS-resident candidates ----
-        for (int c = lane; c < n_kept; c += 64) cand_p[c] = cand_p[c] / esum;
-        __syncthreads();
-        if (top_p < 1.0f) {
-            for (int c = lane; c < n_kept; c += 64) {
-                const float pc = cand_p[c];
-                int rank = 0;
                 for (int o2 = 0; o2 < n_kept; ++o2) {
-                    const float po = cand_p[o2];
-                    rank += (po > pc || (po == pc && o2 < c)) ? 1 : 0;
+                    const float po = lane_bcast(p, o2);
+                    const bool before = po > p || (po == p && o2 < lane);
+                    rank += before ? 1 : 0;
+                    cum += (before || o2 == lane) ? po : 0.f;
                 }
-                sorted_p[rank] = pc;
+                int rcut = (have && cum > top_p) ? rank : 0x7FFFFFFF;
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) { const int t = __shfl_xor(rcut, off, 64); rcut = t < rcut ? t : rcut; }
+                if (!(have && rank <= rcut)) p = 0.f;
+                const float s2 = wave_sum(p);
+                if (s2 > 0.f) p = p / s2; // :893-898
             }
-            __syncthreads();
-            if (lane == 0) {
-                float cum = 0.f;
-                int cutoff = n_kept;
-                for (int i = 0; i < n_kept; ++i) { cum += sorted_p[i]; if (cum > top_p) { cutoff = i + 1; break; } }
-                sh_i[2] = cutoff;
-            }
-            __syncthreads();
-            const int cutoff = sh_i[2];
-            const float pcut = sorted_p[cutoff - 1]; // probability of the last kept rank
-            // rank(c) < cutoff  <=>  p > pcut, or p == pcut and few enough equal-p candidates precede c
-            int n_gt = 0;
-            for (int c = lane; c < n_kept; c += 64) n_gt += cand_p[c] > pcut ? 1 : 0;
-            n_gt = wave_sum_i(n_gt);
-            const int n_eq_keep = cutoff - n_gt; // equal-p candidates kept, lowest indices first
-            __syncthreads();
-            if (lane == 0) {
-                int seen = 0;
-                for (int c = 0; c < n_kept; ++c) {
-                    const float pc = cand_p[c];
-                    if (pc > pcut) continue;
-                    if (pc == pcut && seen < n_eq_keep) { ++seen; continue; }
-                    cand_p[c] = 0.f;
-                }
-            }
-            __syncthreads();
-            float s2 = 0.f;
-            for (int c = lane; c < n_kept; c += 64) s2 += cand_p[c];
-            s2 = wave_sum(s2);
-            if (s2 > 0.f) for (int c = lane; c < n_kept; c += 64) cand_p[c] = cand_p[c] / s2;
-            __syncthreads();
-        }
-        if (lane == 0) {
-            float total = 0.f;
-            for (int c = 0; c < n_kept; ++c) total += cand_p[c];
+            // draw: inverse CDF in index order
+            const float total = wave_sum(p);
             const float target = u * total;
-            float cum = 0.f;
-            int pick = -1, last = -1;
-            for (int c = 0; c < n_kept; ++c) {
-                if (cand_p[c] > 0.f) { last = c; cum += cand_p[c]; if (cum > target) { pick = c; break; } }
+            const float cum = wave_scan_f(p, lane);
+            const unsigned long long hit = __ballot(p > 0.f && cum > target);
+            const unsigned long long pos_mask = __ballot(p > 0.f);
+            int pick;
+            if (hit) pick = __ffsll((long long)hit) - 1;
+            else pick = pos_mask ? 63 - __clzll((long long)pos_mask) : 0;
+            tok = lane_bcast_i(myidx, pick);
+        } else {
+            // ---- general path (top_k == 0 or > 64, or many ties): LDS-resident candidates, wave 0 only ----
+            for (int c = lane; c < n_kept; c += 64) cand_p[c] = cand_p[c] / esum;
+            if (top_p < 1.0f) {
+                for (int c = lane; c < n_kept; c += 64) {
+                    const float pc = cand_p[c];
+                    int rank = 0;
+                    for (int o2 = 0; o2 < n_kept; ++o2) {
+                        const float po = cand_p[o2];
+                        rank += (po > pc || (po == pc && o2 < c)) ? 1 : 0;
+                    }
+                    sorted_p[rank] = pc;
+                }
+                int cutoff = n_kept;
+                if (lane == 0) {
+                    float cum = 0.f;
+                    for (int i = 0; i < n_kept; ++i) { cum += sorted_p[i]; if (cum > top_p) { cutoff = i + 1; break; } }
+                }
+                cutoff = lane_bcast_i(cutoff, 0);
+                const float pcut = sorted_p[cutoff - 1]; // probability of the last kept rank
+                int n_gt = 0;
+                for (int c = lane; c < n_kept; c += 64) n_gt += cand_p[c] > pcut ? 1 : 0;
+                n_gt = wave_sum_i(n_gt);
+                const int n_eq_keep = cutoff - n_gt; // equal-p candidates kept, lowest indices first
+                if (lane == 0) {
+                    int seen = 0;
+                    for (int c = 0; c < n_kept; ++c) {
+                        const float pc = cand_p[c];
+                        if (pc > pcut) continue;
+                        if (pc == pcut && seen < n_eq_keep) { ++seen; continue; }
+                        cand_p[c] = 0.f;
+                    }
+                }
+                float s2 = 0.f;
+                for (int c = lane; c < n_kept; c += 64) s2 += cand_p[c];
+                s2 = wave_sum(s2);
+                if (s2 > 0.f) for (int c = lane; c < n_kept; c += 64) cand_p[c] = cand_p[c] / s2;
             }
-            if (pick < 0) pick = last;
-            sh_i[3] = pick >= 0 ? cand_idx[pick] : 0;
+            int picked = 0;
+            if (lane == 0) {
+                float total = 0.f;
+                for (int c = 0; c < n_kept; ++c) total += cand_p[c];
+                const float target = u * total;
+                float cum = 0.f;
+                int pick = -1, last = -1;
+                for (int c = 0; c < n_kept; ++c) {
+                    if (cand_p[c] > 0.f) { last = c; cum += cand_p[c]; if (cum > target) { pick = c; break; } }
+                }
+                if (pick < 0) pick = last;
+                picked = pick >= 0 ? cand_idx[pick] : 0;
+            }
+            tok = lane_bcast_i(picked, 0);
         }
-        __syncthreads();
-        tok = sh_i[3];
+        if (lane == 0) sh_i[3] = tok;
     }
+    __syncthreads();
+    tok = sh_i[3];
 
-    if (!st) { if (lane == 0) a.token_out[b] = tok; return; }
+    if (!st) { if (tid == 0) a.token_out[b] = tok; return; }
 
-    // ---- fused epilogue of the generation loop (tts_onnx.cpp:812-842, 864-868) ----
-    if (a.group == 0 && tok == a.eos_id) { if (lane == 0) st->finished = 1; return; } // :812 — no frame recorded
-    if (lane == 0) a.codes[((size_t)b * a.max_frames_cap + frame) * a.n_groups + a.group] = tok;
+    // ---- fused epilogue of the generation loop (tts_onnx.cpp:812-842, 864-868), all 256 threads ----
+    if (a.group == 0 && tok == a.eos_id) { if (tid == 0) st->finished = 1; return; } // :812 — no frame recorded
+    if (tid == 0) a.codes[((size_t)b * a.max_frames_cap + frame) * a.n_groups + a.group] = tok;
     const bf16_t* er = a.embed + (size_t)tok * a.H;
     const bool last_group = a.group == a.n_groups - 1;
     const float* text = nullptr;
     if (last_group) text = frame < sl.trailing_len ? a.trailing + ((size_t)b * a.max_trailing + frame) * a.H : a.tts_pad; // :833-842
-    // every load of the row first, then the stores (the pointers may alias as far as the compiler
-    // knows, which would otherwise serialise 16 load->store round trips)
-    constexpr int EP_MAX = 8; // H <= 2048
-    for (int h0 = 0; h0 < a.H; h0 += 256 * EP_MAX) {
+    const float* sum_r = a.group != 0 ? a.sum + (size_t)b * a.H : nullptr;
+    constexpr int EP_MAX = 2; // H <= 2048: 256 threads x 4 floats x 2
+    for (int h0 = 0; h0 < a.H; h0 += 1024 * EP_MAX) {
         float e[EP_MAX][4], sm[EP_MAX][4], tx[EP_MAX][4];
-        const float* sum_r = a.group != 0 ? a.sum + (size_t)b * a.H : nullptr;   // wave-uniform
 #pragma unroll
-        for (int it = 0; it < EP_MAX; ++it) {
-            int h = h0 + (it * 64 + lane) * 4;
-            h = h < a.H ? h : a.H - 4;               // clamped address, unconditional loads (stores are guarded)
+        for (int it = 0; it < EP_MAX; ++it) { // every load first (clamped, unconditional), stores below
+            int h = h0 + (it * 256 + tid) * 4;
+            h = h < a.H ? h : a.H - 4;
             const uint2 raw = *reinterpret_cast<const uint2*>(er + h);
             e[it][0] = __uint_as_float(raw.x << 16); e[it][1] = __uint_as_float(raw.x & 0xFFFF0000u);
             e[it][2] = __uint_as_float(raw.y << 16); e[it][3] = __uint_as_float(raw.y & 0xFFFF0000u);
@@ -1110,7 +1133,7 @@ __global__ __launch_bounds__(64) void k_sample(SampleArgs a) {
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int it = 0; it < EP_MAX; ++it) {
-            const int h = h0 + (it * 64 + lane) * 4;
+            const int h = h0 + (it * 256 + tid) * 4;
             if (h < a.H) {
                 float o[4];
 #pragma unroll
@@ -1124,7 +1147,7 @@ __global__ __launch_bounds__(64) void k_sample(SampleArgs a) {
             }
         }
     }
-    if (last_group && lane == 0) {
+    if (last_group && tid == 0) {
         st->n_frames = frame + 1;
         a.talker_pos[b] = sl.prompt_len + frame; // position of the token the talker decodes next
     }
@@ -1132,7 +1155,7 @@ __global__ __launch_bounds__(64) void k_sample(SampleArgs a) {
 
 void launch_sample(const SampleArgs& a, hipStream_t s) {
     if (a.V > SAMP_MAXV) throw Error("sample: vocabulary larger than 4096");
-    hipLaunchKernelGGL(k_sample, dim3(a.nb), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(k_sample, dim3(a.nb), dim3(256), 0, s, a);
 }
 
 // ================================================================================================
@@ -1157,7 +1180,7 @@ void launch_copy_rows(const float* src, int lds, float* dst, int ldd, int rows, 
 
 __global__ void k_count_active(const SlotState* st, int nb, int32_t* out) {
     int n = 0;
-    for (int b = 0; b < nb; ++b) n += (st[b].active && !st[b].finished) ? 1 : 0;
+    for (int b = 0; b < nb; ++b) n += (st[b].active && !st[b].finished && st[b].n_frames < st[b].max_frames) ? 1 : 0;
     *out = n;
 }
 void launch_count_active(const SlotState* st, int nb, int32_t* out, hipStream_t s) {
