@@ -39,7 +39,7 @@ inline float bf16_to_f32(bf16_t b) {
 // kernel argument blocks + launchers (q3_decode_kernels.hip)
 // ------------------------------------------------------------------------------------------------
 
-enum GemvEpi { EPI_STORE = 0, EPI_RESIDUAL = 1, EPI_SWIGLU = 2, EPI_BIAS = 3, EPI_BIAS_SILU = 4 };
+enum GemvEpi { EPI_STORE = 0, EPI_RESIDUAL = 1, EPI_SWIGLU = 2, EPI_BIAS = 3, EPI_BIAS_SILU = 4, EPI_SLAB = 5 };
 
 // out[m][n] = epi( sum_k xin[m][k] * W[n][k] ),  W row-major bf16 [N][K] (nn.Linear.weight layout)
 struct GemvArgs {
@@ -118,6 +118,9 @@ struct GemmArgs {
 };
 bool gemm_mfma_ok(int M, int K);
 void launch_gemm_mfma(const GemmArgs& a, hipStream_t s);
+void launch_gemm2(const GemmArgs& a, int ksplit, int nw, hipStream_t s); // EPI_SLAB: out = slabs [ksplit][M][ldo]
+void launch_finish(float* x, int ldx, const float* slab, int nslab, size_t slab_stride, int ld_slab, const float* gamma, float eps,
+                   int rows, int K, bf16_t* oh, bf16_t* ol, int ldp, float* xn_out, int ld_xn, hipStream_t s);
 void launch_rmsnorm_split(const float* x, int ldx, const float* gamma, float eps, int rows, int K,
                           bf16_t* oh, bf16_t* ol, int ldp, float* xn_out, int ld_xn, hipStream_t s);
 

@@ -169,6 +169,7 @@ Engine::Engine(const q3tts_config& cfg, int device_, int max_batch, int max_ctx_
     ldp = (std::max(std::max(H, AO), std::max(c.ffn, c.cp_ffn)) + 7) / 8 * 8;
     pl0h = (bf16_t*)dmalloc((size_t)rows_max * ldp * 2); pl0l = (bf16_t*)dmalloc((size_t)rows_max * ldp * 2);
     pl1h = (bf16_t*)dmalloc((size_t)rows_max * ldp * 2); pl1l = (bf16_t*)dmalloc((size_t)rows_max * ldp * 2);
+    slab_d = fm((size_t)16 * rows_max * H);
     ids_d = (int64_t*)dmalloc(64 * sizeof(int64_t));
     tok_d = (int64_t*)dmalloc(sizeof(int64_t));
     codes_d = (int32_t*)dmalloc((size_t)B * max_frames_cap * c.n_groups * sizeof(int32_t));
@@ -318,17 +319,27 @@ void Engine::finalize() {
 // ------------------------------------------------------------------------------------------------
 // decoder stack: five launches per layer
 // ------------------------------------------------------------------------------------------------
-void Engine::run_layers(const DecStack& W, float* x, int ldx, int nb, int n_new, int slot_offset, const int* pos_dev, int pos_scalar) {
+static int pick_ksplit(int K) { // K slices per GEMM: 256 (two LDS chunks) per workgroup, 128 for small K
+    int ks = K <= 512 ? K / 128 : K / 256;
+    if (ks < 1) ks = 1;
+    if (ks > 16) ks = 16;
+    while (K % (128 * ks) != 0) --ks;
+    return ks;
+}
+
+bool Engine::run_layers(const DecStack& W, float* x, int ldx, int nb, int n_new, int slot_offset, const int* pos_dev, int pos_scalar,
+                        const float* final_gamma, float final_eps, float* final_xn, int final_ld_xn) {
     const int M = nb * n_new, QKV = (W.nq + 2 * W.nkv) * W.d, AO = W.nq * W.d;
     // M > 8 rows: bf16-MFMA skinny GEMM over (hi, lo) activation planes; else the GEMV family
-    const bool mfma = M > 8 && gemm_mfma_ok(M, W.H) && gemm_mfma_ok(M, AO) && gemm_mfma_ok(M, W.ffn);
+    const bool mfma = M > 8 && M <= 128 && W.H % 128 == 0 && AO % 128 == 0 && W.ffn % 128 == 0 && W.H <= 4096;
+    if (mfma) // planes0 = RMSNorm(in_norm[0])(x)
+        launch_finish(x, ldx, nullptr, 0, 0, 0, W.layers[0].in_norm, W.eps, M, W.H, pl0h, pl0l, ldp, nullptr, 0, stream);
     for (int l = 0; l < W.L; ++l) {
         const DecLayerW& w = W.layers[l];
         if (mfma) {
-            launch_rmsnorm_split(x, ldx, w.in_norm, W.eps, M, W.H, pl0h, pl0l, ldp, nullptr, 0, stream);
             GemmArgs g;
             g.W = w.qkv; g.xh = pl0h; g.xl = pl0l; g.ldx = ldp; g.out = qkv; g.ldo = QKV; g.M = M; g.N = QKV; g.K = W.H; g.epi = EPI_STORE;
-            launch_gemm_mfma(g, stream);
+            launch_gemm2(g, 1, 4, stream);
         } else {
             GemvArgs g;
             g.W = w.qkv; g.x = x; g.ldx = ldx; g.gamma = w.in_norm; g.eps = W.eps; g.out = qkv; g.ldo = QKV;
@@ -347,19 +358,24 @@ void Engine::run_layers(const DecStack& W, float* x, int ldx, int nb, int n_new,
         if (mfma) {
             a.out = nullptr; a.oh = pl1h; a.ol = pl1l; a.ldp = ldp;
             launch_attn_combine(a, stream);                      // partials -> (hi, lo) planes
+            const int ks_o = pick_ksplit(AO), ks_d = pick_ksplit(W.ffn);
             GemmArgs o;
-            o.W = w.o; o.xh = pl1h; o.xl = pl1l; o.ldx = ldp; o.res = x; o.ldres = ldx; o.out = x; o.ldo = ldx;
-            o.M = M; o.N = W.H; o.K = AO; o.epi = EPI_RESIDUAL;
-            launch_gemm_mfma(o, stream);
-            launch_rmsnorm_split(x, ldx, w.post_norm, W.eps, M, W.H, pl0h, pl0l, ldp, nullptr, 0, stream);
+            o.W = w.o; o.xh = pl1h; o.xl = pl1l; o.ldx = ldp; o.out = slab_d; o.ldo = W.H; o.M = M; o.N = W.H; o.K = AO; o.epi = EPI_SLAB;
+            launch_gemm2(o, ks_o, 4, stream);
+            // x += sum(slabs); planes0 = RMSNorm(post_norm)(x)
+            launch_finish(x, ldx, slab_d, ks_o, (size_t)M * W.H, W.H, w.post_norm, W.eps, M, W.H, pl0h, pl0l, ldp, nullptr, 0, stream);
             GemmArgs f;
             f.W = w.gate; f.W2 = w.up; f.xh = pl0h; f.xl = pl0l; f.ldx = ldp; f.out = nullptr; f.oh = pl1h; f.ol = pl1l; f.ldp = ldp;
             f.M = M; f.N = W.ffn; f.K = W.H; f.epi = EPI_SWIGLU;
-            launch_gemm_mfma(f, stream);
+            launch_gemm2(f, 1, 2, stream);
             GemmArgs d;
-            d.W = w.down; d.xh = pl1h; d.xl = pl1l; d.ldx = ldp; d.res = x; d.ldres = ldx; d.out = x; d.ldo = ldx;
-            d.M = M; d.N = W.H; d.K = W.ffn; d.epi = EPI_RESIDUAL;
-            launch_gemm_mfma(d, stream);
+            d.W = w.down; d.xh = pl1h; d.xl = pl1l; d.ldx = ldp; d.out = slab_d; d.ldo = W.H; d.M = M; d.N = W.H; d.K = W.ffn; d.epi = EPI_SLAB;
+            launch_gemm2(d, ks_d, 4, stream);
+            // x += sum(slabs); planes0 = RMSNorm(next layer's input norm | the stack's final norm)(x)
+            const bool last = l + 1 == W.L;
+            const float* ng = last ? final_gamma : W.layers[l + 1].in_norm;
+            launch_finish(x, ldx, slab_d, ks_d, (size_t)M * W.H, W.H, ng, last ? final_eps : W.eps, M, W.H, pl0h, pl0l, ldp,
+                          last ? final_xn : nullptr, last ? final_ld_xn : 0, stream);
             continue;
         }
         GemvArgs o;
@@ -381,16 +397,21 @@ void Engine::run_layers(const DecStack& W, float* x, int ldx, int nb, int n_new,
         d.M = M; d.N = W.H; d.K = W.ffn; d.epi = EPI_RESIDUAL; d.nt = W.nt;
         launch_gemv(d, stream);
     }
+    return mfma && final_gamma != nullptr;
 }
 
 // final RMSNorm + output head (codec_head / cp.head.j); optionally keeps the normalised rows
 void Engine::head_proj(const bf16_t* Wm, const float* x, int ldx, const float* gamma, float eps, float* xn_out, int ld_xn,
-                       float* out, int ldo, int M, int N, int K, bool nt) {
-    if (M > 8 && gemm_mfma_ok(M, K)) {
-        launch_rmsnorm_split(x, ldx, gamma, eps, M, K, pl0h, pl0l, ldp, xn_out, ld_xn, stream);
+                       float* out, int ldo, int M, int N, int K, bool nt, bool planes_ready, int plane_row0, int plane_row_stride) {
+    if (planes_ready || (M > 8 && M <= 128 && K % 128 == 0 && K <= 4096)) {
+        if (!planes_ready) {
+            launch_finish(const_cast<float*>(x), ldx, nullptr, 0, 0, 0, gamma, eps, M, K, pl0h, pl0l, ldp, xn_out, ld_xn, stream);
+            plane_row0 = 0; plane_row_stride = 1;
+        }
         GemmArgs g;
-        g.W = Wm; g.xh = pl0h; g.xl = pl0l; g.ldx = ldp; g.out = out; g.ldo = ldo; g.M = M; g.N = N; g.K = K; g.epi = EPI_STORE;
-        launch_gemm_mfma(g, stream);
+        g.W = Wm; g.xh = pl0h + (size_t)plane_row0 * ldp; g.xl = pl0l + (size_t)plane_row0 * ldp; g.ldx = ldp * plane_row_stride;
+        g.out = out; g.ldo = ldo; g.M = M; g.N = N; g.K = K; g.epi = EPI_STORE;
+        launch_gemm2(g, 1, 4, stream);
         return;
     }
     GemvArgs g;
@@ -449,9 +470,9 @@ void Engine::talker_prefill(int slot, const float* embeds, int S, float* logits,
     if (S < 1 || S > 16) throw Error("prefill length must be 1..16 rows");
     const int H = c.hidden, V = c.vocab;
     Q3_HIP_CHECK(hipMemcpyAsync(xp, embeds, (size_t)S * H * sizeof(float), hipMemcpyHostToDevice, stream));
-    run_layers(talker, xp, H, 1, S, slot, nullptr, 0);
+    const bool pr = run_layers(talker, xp, H, 1, S, slot, nullptr, 0, talker_norm, c.rms_eps, hn, H);
     // final norm + codec head on every row; normalised rows kept for last_hidden
-    head_proj(codec_head, xp, H, talker_norm, c.rms_eps, hn, H, logits_p, V, S, V, H, true);
+    head_proj(codec_head, xp, H, talker_norm, c.rms_eps, hn, H, logits_p, V, S, V, H, true, pr);
     // arm the fused path: logits of the last row -> logits_t[slot], last_hidden -> x_cp[slot][0]
     launch_copy_rows(logits_p + (size_t)(S - 1) * V, V, logits_t + (size_t)slot * V, V, 1, V, stream);
     launch_copy_rows(hn + (size_t)(S - 1) * H, H, x_cp + (size_t)slot * 2 * H, H, 1, H, stream);
@@ -567,16 +588,19 @@ void Engine::record_step(int nb) {
     launch_sample(s0, stream);                                  // code0 (tts_onnx.cpp:803-812)
     for (int j = 0; j < G - 1; ++j) {                           // predict_subcodes (:851-872), KV-cached
         float* xin = j == 0 ? x_cp : x_cp1;
-        if (j == 0) run_layers(cp, x_cp, H, nb, 2, 0, nullptr, 0);        // rows [last_hidden, embed(code0)]
-        else run_layers(cp, x_cp1, H, nb, 1, 0, nullptr, j + 1);
-        head_proj(cp_head[j], j == 0 ? xin + H : xin, j == 0 ? 2 * H : H, cp_norm, c.cp_rms_eps, nullptr, 0, logits_cp, SV, nb, SV, H, false);
+        bool pr;
+        if (j == 0) pr = run_layers(cp, x_cp, H, nb, 2, 0, nullptr, 0, cp_norm, c.cp_rms_eps);        // rows [last_hidden, embed(code0)]
+        else pr = run_layers(cp, x_cp1, H, nb, 1, 0, nullptr, j + 1, cp_norm, c.cp_rms_eps);
+        // head j on the last row of every utterance (pass 0 holds two rows per utterance: planes row b*2+1)
+        head_proj(cp_head[j], j == 0 ? xin + H : xin, j == 0 ? 2 * H : H, cp_norm, c.cp_rms_eps, nullptr, 0, logits_cp, SV, nb, SV, H, false,
+                  pr, j == 0 ? 1 : 0, j == 0 ? 2 : 1);
         SampleArgs s = s0;
         s.logits = logits_cp; s.ld = SV; s.V = SV; s.group = j + 1; s.embed = cp_embed_w[j];
         s.x_next = j + 1 < G - 1 ? x_cp1 : nullptr; s.ld_xnext = H;
         launch_sample(s, stream);
     }
-    run_layers(talker, x_talk, H, nb, 1, 0, talker_pos_d, 0);  // run_decode (:845)
-    head_proj(codec_head, x_talk, H, talker_norm, c.rms_eps, x_cp, 2 * H, logits_t, V, nb, V, H, true);
+    const bool pr = run_layers(talker, x_talk, H, nb, 1, 0, talker_pos_d, 0, talker_norm, c.rms_eps, x_cp, 2 * H);  // run_decode (:845)
+    head_proj(codec_head, x_talk, H, talker_norm, c.rms_eps, x_cp, 2 * H, logits_t, V, nb, V, H, true, pr);
 }
 
 int Engine::nb_in_use() const {

@@ -111,6 +111,7 @@ public:
     int64_t* ids_d = nullptr;
     bf16_t *pl0h = nullptr, *pl0l = nullptr, *pl1h = nullptr, *pl1l = nullptr; // (hi, lo) activation planes for the MFMA GEMM path
     int ldp = 0;
+    float* slab_d = nullptr; // split-K partial sums [ks][rows][H]
     int32_t* codes_d = nullptr;
     int32_t* codes_scratch_d = nullptr;
     int32_t* talker_pos_d = nullptr;
@@ -123,10 +124,13 @@ public:
     std::unordered_map<int, hipGraphExec_t> graphs; // keyed by nb
 
     void* dmalloc(size_t bytes);
-    void run_layers(const DecStack& W, float* x, int ldx, int nb, int n_new, int slot_offset, const int* pos_dev, int pos_scalar);
+    // final_gamma != null (MFMA path only): the last layer's finish kernel also applies the stack's final RMSNorm,
+    // leaving (hi, lo) planes of the normalised rows in pl0 (+ fp32 rows in final_xn); returns true in that case
+    bool run_layers(const DecStack& W, float* x, int ldx, int nb, int n_new, int slot_offset, const int* pos_dev, int pos_scalar,
+                    const float* final_gamma = nullptr, float final_eps = 0.f, float* final_xn = nullptr, int final_ld_xn = 0);
     void record_step(int nb);
     void head_proj(const bf16_t* Wm, const float* x, int ldx, const float* gamma, float eps, float* xn_out, int ld_xn,
-                   float* out, int ldo, int M, int N, int K, bool nt);
+                   float* out, int ldo, int M, int N, int K, bool nt, bool planes_ready = false, int plane_row0 = 0, int plane_row_stride = 1);
     int nb_in_use() const;
     void sync();
 };

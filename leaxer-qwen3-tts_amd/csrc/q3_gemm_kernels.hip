@@ -175,4 +175,170 @@ void launch_rmsnorm_split(const float* x, int ldx, const float* gamma, float eps
     if (rows > 0) hipLaunchKernelGGL(k_rmsnorm_split, dim3(rows), dim3(256), 0, s, x, ldx, gamma, eps, K, oh, ol, ldp, xn_out, ld_xn);
 }
 
+
+// ================================================================================================
+// k_gemm2 — second-generation batched-decode GEMM.  Workgroup = (n-group of NW*16 columns, K slice):
+// its NW waves each own one 16-column tile and SHARE the activation slice, staged once per 128-wide
+// K chunk into LDS (row stride padded by 16 B so the ds_read_b128 fragment reads are conflict-free).
+// K slices of different workgroups meet through fp32 partial slabs [ks][M][N] that k_finish reduces in
+// fixed order (deterministic) — this is what lets the N=1024 projections (o_proj, down) use
+// 128-192 workgroups instead of 64, and cuts the L2 traffic of the activation planes 4x.
+// ================================================================================================
+#define G2_KC 128
+#define G2_LD (G2_KC + 8)
+
+template <int MTILES, int EPI, int NW>
+__global__ __launch_bounds__(NW * 64) void k_gemm2(GemmArgs a) {
+    constexpr int NT = NW * 64;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, q = lane >> 4;
+    const int n0 = (blockIdx.x * NW + wave) * 16;
+    const int K = a.K, M = a.M;
+    const int kslice = K / gridDim.y, kbeg = blockIdx.y * kslice;
+    __shared__ __attribute__((aligned(16))) bf16_t xs[2][MTILES * 16][G2_LD];
+
+    int nrow = n0 + r16;
+    nrow = nrow < a.N ? nrow : a.N - 1;
+    const bf16_t* wp = a.W + (size_t)nrow * K + q * 8;
+    const bf16_t* wp2 = EPI == EPI_SWIGLU ? a.W2 + (size_t)nrow * K + q * 8 : nullptr;
+    f32x4 acc[MTILES], acc2[MTILES];
+#pragma unroll
+    for (int mt = 0; mt < MTILES; ++mt) { acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[mt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+    // staging assignment: 16 threads per row (8 bf16 = 16 B each), NT/16 rows per pass
+    constexpr int ROWS = MTILES * 16, RPP = NT / 16, PASSES = (ROWS + RPP - 1) / RPP;
+    const int srow = tid >> 4, scol = (tid & 15) * 8;
+
+    for (int k0 = kbeg; k0 < kbeg + kslice; k0 += G2_KC) {
+        // weights of this chunk first (HBM), then the activation slice (L2) -> LDS
+        bf16x8 b[G2_KC / 32], b2[G2_KC / 32];
+#pragma unroll
+        for (int st = 0; st < G2_KC / 32; ++st) {
+            b[st] = *reinterpret_cast<const bf16x8*>(wp + k0 + st * 32);
+            if (EPI == EPI_SWIGLU) b2[st] = *reinterpret_cast<const bf16x8*>(wp2 + k0 + st * 32);
+        }
+        uint4 sh[PASSES], sl[PASSES];
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p) {
+            int row = srow + p * RPP;
+            row = row < M ? row : M - 1;
+            sh[p] = *reinterpret_cast<const uint4*>(a.xh + (size_t)row * a.ldx + k0 + scol);
+            sl[p] = *reinterpret_cast<const uint4*>(a.xl + (size_t)row * a.ldx + k0 + scol);
+        }
+        __syncthreads(); // previous chunk's fragment reads are done
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p) {
+            const int row = srow + p * RPP;
+            if (row < ROWS) {
+                *reinterpret_cast<uint4*>(&xs[0][row][scol]) = sh[p];
+                *reinterpret_cast<uint4*>(&xs[1][row][scol]) = sl[p];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int st = 0; st < G2_KC / 32; ++st) {
+#pragma unroll
+            for (int mt = 0; mt < MTILES; ++mt) {
+                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&xs[0][mt * 16 + r16][st * 32 + q * 8]);
+                const bf16x8 al = *reinterpret_cast<const bf16x8*>(&xs[1][mt * 16 + r16][st * 32 + q * 8]);
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, b[st], acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, b[st], acc[mt], 0, 0, 0);
+                if (EPI == EPI_SWIGLU) {
+                    acc2[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, b2[st], acc2[mt], 0, 0, 0);
+                    acc2[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, b2[st], acc2[mt], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    const int n = n0 + r16;
+    if (n >= a.N) return;
+#pragma unroll
+    for (int mt = 0; mt < MTILES; ++mt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = mt * 16 + q * 4 + r; // D layout: col = lane&15, row = (lane>>4)*4 + reg
+            if (m >= M) continue;
+            float o = acc[mt][r];
+            if (EPI == EPI_SWIGLU) o = silu_g(o) * acc2[mt][r];
+            if (EPI == EPI_SLAB) { a.out[((size_t)blockIdx.y * M + m) * a.ldo + n] = o; continue; }
+            if (a.out) a.out[(size_t)m * a.ldo + n] = o;
+            if (a.oh) split_store(o, a.oh + (size_t)m * a.ldp + n, a.ol + (size_t)m * a.ldp + n);
+        }
+    }
+}
+
+template <int MTILES, int NW>
+static void gemm2_epi(const GemmArgs& a, int ksplit, hipStream_t s) {
+    const dim3 grid((a.N + NW * 16 - 1) / (NW * 16), ksplit), block(NW * 64);
+    switch (a.epi) {
+    case EPI_STORE: hipLaunchKernelGGL((k_gemm2<MTILES, EPI_STORE, NW>), grid, block, 0, s, a); break;
+    case EPI_SWIGLU: hipLaunchKernelGGL((k_gemm2<MTILES, EPI_SWIGLU, NW>), grid, block, 0, s, a); break;
+    case EPI_SLAB: hipLaunchKernelGGL((k_gemm2<MTILES, EPI_SLAB, NW>), grid, block, 0, s, a); break;
+    default: throw Error("gemm2: unsupported epilogue");
+    }
+}
+template <int MTILES>
+static void gemm2_nw(const GemmArgs& a, int ksplit, int nw, hipStream_t s) {
+    if (nw == 2) gemm2_epi<MTILES, 2>(a, ksplit, s); else gemm2_epi<MTILES, 4>(a, ksplit, s);
+}
+// ksplit: number of K slices (1 = complete sums, direct epilogue; >1 requires EPI_SLAB); nw: waves (= 16-column tiles) per workgroup
+void launch_gemm2(const GemmArgs& a, int ksplit, int nw, hipStream_t s) {
+    if (a.M < 1 || a.M > 128 || a.K % (G2_KC * ksplit) != 0 || a.ldx % 8 != 0) throw Error("gemm2: unsupported shape");
+    if (ksplit > 1 && a.epi != EPI_SLAB) throw Error("gemm2: split-K needs the slab epilogue");
+    if (a.M <= 16) gemm2_nw<1>(a, ksplit, nw, s);
+    else if (a.M <= 32) gemm2_nw<2>(a, ksplit, nw, s);
+    else if (a.M <= 64) gemm2_nw<4>(a, ksplit, nw, s);
+    else gemm2_nw<8>(a, ksplit, nw, s);
+}
+
+// x[m][:] += sum_ks slab[ks][m][:] (fixed order), then RMSNorm(gamma) -> (hi, lo) planes (+ optional fp32 rows).
+// One workgroup per row.  nslab == 0: plain RMSNorm + split.  gamma == null: residual update only.
+__global__ __launch_bounds__(256) void k_finish(float* x, int ldx, const float* slab, int nslab, size_t slab_stride, int ld_slab,
+                                                 const float* gamma, float eps, int K, bf16_t* oh, bf16_t* ol, int ldp,
+                                                 float* xn_out, int ld_xn) {
+    __shared__ float red[4];
+    const int m = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* xr = x + (size_t)m * ldx;
+    float4 v[4]; // K <= 4096
+    float ss = 0.f;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int k = (it * 256 + threadIdx.x) * 4;
+        if (k < K) {
+            float4 t = *reinterpret_cast<const float4*>(xr + k);
+            for (int sidx = 0; sidx < nslab; ++sidx) {
+                const float4 p = *reinterpret_cast<const float4*>(slab + sidx * slab_stride + (size_t)m * ld_slab + k);
+                t.x += p.x; t.y += p.y; t.z += p.z; t.w += p.w;
+            }
+            if (nslab > 0) *reinterpret_cast<float4*>(xr + k) = t;
+            v[it] = t;
+            ss = fmaf(t.x, t.x, ss); ss = fmaf(t.y, t.y, ss); ss = fmaf(t.z, t.z, ss); ss = fmaf(t.w, t.w, ss);
+        }
+    }
+    if (gamma == nullptr) return;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) ss += __shfl_xor(ss, off, 64);
+    if (lane == 0) red[wave] = ss;
+    __syncthreads();
+    const float r = 1.0f / sqrtf((((red[0] + red[1]) + red[2]) + red[3]) / (float)K + eps);
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int k = (it * 256 + threadIdx.x) * 4;
+        if (k < K) {
+            const float4 g = *reinterpret_cast<const float4*>(gamma + k);
+            const float y[4] = { g.x * (v[it].x * r), g.y * (v[it].y * r), g.z * (v[it].z * r), g.w * (v[it].w * r) };
+#pragma unroll
+            for (int j = 0; j < 4; ++j) split_store(y[j], oh + (size_t)m * ldp + k + j, ol + (size_t)m * ldp + k + j);
+            if (xn_out) *reinterpret_cast<float4*>(xn_out + (size_t)m * ld_xn + k) = make_float4(y[0], y[1], y[2], y[3]);
+        }
+    }
+}
+void launch_finish(float* x, int ldx, const float* slab, int nslab, size_t slab_stride, int ld_slab, const float* gamma, float eps,
+                   int rows, int K, bf16_t* oh, bf16_t* ol, int ldp, float* xn_out, int ld_xn, hipStream_t s) {
+    if (K % 4 || K > 4096) throw Error("finish: K must be a multiple of 4 and <= 4096");
+    if (rows > 0) hipLaunchKernelGGL(k_finish, dim3(rows), dim3(256), 0, s, x, ldx, slab, nslab, slab_stride, ld_slab, gamma, eps, K, oh, ol, ldp, xn_out, ld_xn);
+}
+
 } // namespace q3
