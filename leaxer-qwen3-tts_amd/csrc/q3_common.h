@@ -74,6 +74,7 @@ bool gemv_fast_path(const GemvArgs& a); // single-pass kernel available (M <= 2,
 struct AttnArgs {
     const float* qkv = nullptr; // [nb*n_new][ld_qkv]: q heads | k heads | v heads (raw projections)
     int ld_qkv = 0;
+    int qkv_nslab = 1; size_t qkv_slab_stride = 0; // > 1: qkv is the sum of that many split-K partial slabs
     float* out = nullptr;       // [nb*n_new][nq*d]
     int ld_out = 0;
     float* kcache = nullptr;    // [page][layer][kvh][page_tokens][d]

@@ -576,6 +576,11 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
         VecOps r;
         r.x0 = src[hl]; r.x1 = src[hl + HALF];
         r.v0 = vs[hl]; r.v1 = vs[hl + HALF];
+        for (int sb = 1; sb < a.qkv_nslab; ++sb) { // split-K partial slabs of the QKV projection, fixed order
+            const size_t so = sb * a.qkv_slab_stride;
+            r.x0 += src[so + hl]; r.x1 += src[so + hl + HALF];
+            r.v0 += vs[so + hl]; r.v1 += vs[so + hl + HALF];
+        }
         const float* nw = is_q ? a.q_norm : a.k_norm;
         r.n0 = 1.f; r.n1 = 1.f; r.cs = 1.f; r.sn = 0.f;
         if (a.new_from_raw) {

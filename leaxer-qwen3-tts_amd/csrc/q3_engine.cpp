@@ -170,6 +170,7 @@ Engine::Engine(const q3tts_config& cfg, int device_, int max_batch, int max_ctx_
     pl0h = (bf16_t*)dmalloc((size_t)rows_max * ldp * 2); pl0l = (bf16_t*)dmalloc((size_t)rows_max * ldp * 2);
     pl1h = (bf16_t*)dmalloc((size_t)rows_max * ldp * 2); pl1l = (bf16_t*)dmalloc((size_t)rows_max * ldp * 2);
     slab_d = fm((size_t)16 * rows_max * H);
+    qkv_slab_d = fm((size_t)4 * rows_max * std::max(QKV, QKVp));
     ids_d = (int64_t*)dmalloc(64 * sizeof(int64_t));
     tok_d = (int64_t*)dmalloc(sizeof(int64_t));
     codes_d = (int32_t*)dmalloc((size_t)B * max_frames_cap * c.n_groups * sizeof(int32_t));
@@ -332,14 +333,15 @@ bool Engine::run_layers(const DecStack& W, float* x, int ldx, int nb, int n_new,
     const int M = nb * n_new, QKV = (W.nq + 2 * W.nkv) * W.d, AO = W.nq * W.d;
     // M > 8 rows: bf16-MFMA skinny GEMM over (hi, lo) activation planes; else the GEMV family
     const bool mfma = M > 8 && M <= 128 && W.H % 128 == 0 && AO % 128 == 0 && W.ffn % 128 == 0 && W.H <= 4096;
+    const int ks_q = std::min(4, pick_ksplit(W.H));
     if (mfma) // planes0 = RMSNorm(in_norm[0])(x)
         launch_finish(x, ldx, nullptr, 0, 0, 0, W.layers[0].in_norm, W.eps, M, W.H, pl0h, pl0l, ldp, nullptr, 0, stream);
     for (int l = 0; l < W.L; ++l) {
         const DecLayerW& w = W.layers[l];
         if (mfma) {
-            GemmArgs g;
-            g.W = w.qkv; g.xh = pl0h; g.xl = pl0l; g.ldx = ldp; g.out = qkv; g.ldo = QKV; g.M = M; g.N = QKV; g.K = W.H; g.epi = EPI_STORE;
-            launch_gemm2(g, 1, 4, stream);
+            GemmArgs g; // split-K slabs; the attention prologue sums them
+            g.W = w.qkv; g.xh = pl0h; g.xl = pl0l; g.ldx = ldp; g.out = qkv_slab_d; g.ldo = QKV; g.M = M; g.N = QKV; g.K = W.H; g.epi = EPI_SLAB;
+            launch_gemm2(g, ks_q, 4, stream);
         } else {
             GemvArgs g;
             g.W = w.qkv; g.x = x; g.ldx = ldx; g.gamma = w.in_norm; g.eps = W.eps; g.out = qkv; g.ldo = QKV;
@@ -348,6 +350,7 @@ bool Engine::run_layers(const DecStack& W, float* x, int ldx, int nb, int n_new,
         }
         AttnArgs a;
         a.qkv = qkv; a.ld_qkv = QKV; a.out = attn; a.ld_out = AO; a.kcache = W.kc; a.vcache = W.vc;
+        if (mfma) { a.qkv = qkv_slab_d; a.qkv_nslab = ks_q; a.qkv_slab_stride = (size_t)M * QKV; }
         a.page_table = W.page_table; a.pages_per_slot = W.pages_per_slot; a.page_shift = W.page_shift;
         a.layer = l; a.n_layers = W.L; a.q_norm = w.q_norm; a.k_norm = w.k_norm; a.eps = W.eps;
         a.rope_cos = W.rope_cos; a.rope_sin = W.rope_sin; a.pos_dev = pos_dev; a.pos_scalar = pos_scalar;

@@ -112,6 +112,7 @@ public:
     bf16_t *pl0h = nullptr, *pl0l = nullptr, *pl1h = nullptr, *pl1l = nullptr; // (hi, lo) activation planes for the MFMA GEMM path
     int ldp = 0;
     float* slab_d = nullptr; // split-K partial sums [ks][rows][H]
+    float* qkv_slab_d = nullptr; // split-K partial sums of the QKV projection [<=4][rows][QKV]
     int32_t* codes_d = nullptr;
     int32_t* codes_scratch_d = nullptr;
     int32_t* talker_pos_d = nullptr;

@@ -210,29 +210,31 @@ __global__ __launch_bounds__(NW * 64) void k_gemm2(GemmArgs a) {
     constexpr int ROWS = MTILES * 16, RPP = NT / 16, PASSES = (ROWS + RPP - 1) / RPP;
     const int srow = tid >> 4, scol = (tid & 15) * 8;
 
-    for (int k0 = kbeg; k0 < kbeg + kslice; k0 += G2_KC) {
-        // weights of this chunk first (HBM), then the activation slice (L2) -> LDS
-        bf16x8 b[G2_KC / 32], b2[G2_KC / 32];
+    // Two register sets: while chunk c is multiplied out of LDS, chunk c+1's weight fragments (HBM) and
+    // activation slice (L2) are already in flight.
+    struct Stage { bf16x8 b[G2_KC / 32], b2[G2_KC / 32]; uint4 sh[PASSES], sl[PASSES]; };
+    auto issue = [&](Stage& S, int k0) {
 #pragma unroll
         for (int st = 0; st < G2_KC / 32; ++st) {
-            b[st] = *reinterpret_cast<const bf16x8*>(wp + k0 + st * 32);
-            if (EPI == EPI_SWIGLU) b2[st] = *reinterpret_cast<const bf16x8*>(wp2 + k0 + st * 32);
+            S.b[st] = *reinterpret_cast<const bf16x8*>(wp + k0 + st * 32);
+            if (EPI == EPI_SWIGLU) S.b2[st] = *reinterpret_cast<const bf16x8*>(wp2 + k0 + st * 32);
         }
-        uint4 sh[PASSES], sl[PASSES];
 #pragma unroll
         for (int p = 0; p < PASSES; ++p) {
             int row = srow + p * RPP;
             row = row < M ? row : M - 1;
-            sh[p] = *reinterpret_cast<const uint4*>(a.xh + (size_t)row * a.ldx + k0 + scol);
-            sl[p] = *reinterpret_cast<const uint4*>(a.xl + (size_t)row * a.ldx + k0 + scol);
+            S.sh[p] = *reinterpret_cast<const uint4*>(a.xh + (size_t)row * a.ldx + k0 + scol);
+            S.sl[p] = *reinterpret_cast<const uint4*>(a.xl + (size_t)row * a.ldx + k0 + scol);
         }
+    };
+    auto consume = [&](Stage& S) {
         __syncthreads(); // previous chunk's fragment reads are done
 #pragma unroll
         for (int p = 0; p < PASSES; ++p) {
             const int row = srow + p * RPP;
             if (row < ROWS) {
-                *reinterpret_cast<uint4*>(&xs[0][row][scol]) = sh[p];
-                *reinterpret_cast<uint4*>(&xs[1][row][scol]) = sl[p];
+                *reinterpret_cast<uint4*>(&xs[0][row][scol]) = S.sh[p];
+                *reinterpret_cast<uint4*>(&xs[1][row][scol]) = S.sl[p];
             }
         }
         __syncthreads();
@@ -242,13 +244,26 @@ __global__ __launch_bounds__(NW * 64) void k_gemm2(GemmArgs a) {
             for (int mt = 0; mt < MTILES; ++mt) {
                 const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&xs[0][mt * 16 + r16][st * 32 + q * 8]);
                 const bf16x8 al = *reinterpret_cast<const bf16x8*>(&xs[1][mt * 16 + r16][st * 32 + q * 8]);
-                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, b[st], acc[mt], 0, 0, 0);
-                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, b[st], acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, S.b[st], acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, S.b[st], acc[mt], 0, 0, 0);
                 if (EPI == EPI_SWIGLU) {
-                    acc2[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, b2[st], acc2[mt], 0, 0, 0);
-                    acc2[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, b2[st], acc2[mt], 0, 0, 0);
+                    acc2[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, S.b2[st], acc2[mt], 0, 0, 0);
+                    acc2[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, S.b2[st], acc2[mt], 0, 0, 0);
                 }
             }
+        }
+    };
+    Stage s0, s1;
+    const int kend = kbeg + kslice;
+    issue(s0, kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += 2 * G2_KC) {
+        if (k0 + G2_KC < kend) issue(s1, k0 + G2_KC);
+        __builtin_amdgcn_sched_barrier(0);
+        consume(s0);
+        if (k0 + G2_KC < kend) {
+            if (k0 + 2 * G2_KC < kend) issue(s0, k0 + 2 * G2_KC);
+            __builtin_amdgcn_sched_barrier(0);
+            consume(s1);
         }
     }
 
