@@ -324,7 +324,7 @@ static int pick_ksplit(int K) { // K slices per GEMM: 256 (two LDS chunks) per w
     int ks = K <= 512 ? K / 128 : K / 256;
     if (ks < 1) ks = 1;
     if (ks > 16) ks = 16;
-    while (K % (128 * ks) != 0) --ks;
+    while (ks > 1 && K % (128 * ks) != 0) --ks;
     return ks;
 }
 
@@ -333,7 +333,7 @@ bool Engine::run_layers(const DecStack& W, float* x, int ldx, int nb, int n_new,
     const int M = nb * n_new, QKV = (W.nq + 2 * W.nkv) * W.d, AO = W.nq * W.d;
     // M > 8 rows: bf16-MFMA skinny GEMM over (hi, lo) activation planes; else the GEMV family
     const bool mfma = M > 8 && M <= 128 && W.H % 128 == 0 && AO % 128 == 0 && W.ffn % 128 == 0 && W.H <= 4096;
-    const int ks_q = std::min(4, pick_ksplit(W.H));
+    const int ks_q = mfma ? std::min(4, pick_ksplit(W.H)) : 1;
     if (mfma) // planes0 = RMSNorm(in_norm[0])(x)
         launch_finish(x, ldx, nullptr, 0, 0, 0, W.layers[0].in_norm, W.eps, M, W.H, pl0h, pl0l, ldp, nullptr, 0, stream);
     for (int l = 0; l < W.L; ++l) {
