@@ -207,9 +207,8 @@ int q3tts_synthesize_batch_host(q3tts_engine* h, int n_utt, const int64_t* ids, 
             e.slot_status(b, &nf, nullptr);
             if (n_frames) n_frames[u] = nf;
             if (codes_out) e.slot_codes(b, codes_out + (size_t)u * p->max_new_tokens * G, p->max_new_tokens);
-            const int64_t n = e.slot_codec_decode(b, pcm_out ? pcm_out[u] : nullptr, pcm_cap);
-            if (pcm_len) pcm_len[u] = n;
         }
+        e.codec_decode_slots(nb, pcm_out ? pcm_out + u0 : nullptr, pcm_cap, pcm_len ? pcm_len + u0 : nullptr);
         for (int b = 0; b < nb; ++b) e.slot_release(b);
     }
     return 0;

@@ -4,7 +4,9 @@
 // tests/golden/hf_code2wav.npz.  Whole-utterance decode like the reference (tts_onnx.cpp:430):
 // with 288 GB of HBM the largest activation (F=2048: 3.9 M samples x 96 ch fp32 = 1.5 GB) needs no
 // chunking.
+#include <algorithm>
 #include <cmath>
+#include <cstring>
 #include <vector>
 
 #include "q3_engine.h"
@@ -26,8 +28,11 @@ struct CodecW {
     std::vector<Block> blocks;
     SnakeP snake_out;
     std::vector<float*> packed; // owned
-    // run-time workspace
-    char* arena = nullptr; size_t arena_bytes = 0;
+    // run-time workspace: one bump arena per codec stream (lane 0 = the engine's own stream)
+    static constexpr int NLANE = 4;
+    char* arena[NLANE] = {nullptr, nullptr, nullptr, nullptr}; size_t arena_bytes[NLANE] = {0, 0, 0, 0};
+    hipStream_t lane_stream[NLANE] = {nullptr, nullptr, nullptr, nullptr};
+    float* pinned[NLANE] = {nullptr, nullptr, nullptr, nullptr}; size_t pinned_floats[NLANE] = {0, 0, 0, 0};
     float *rope_cos = nullptr, *rope_sin = nullptr; int rope_P = 0;
     int* page_table = nullptr;
 };
@@ -35,7 +40,11 @@ struct CodecW {
 void Engine::codec_free() {
     if (!codec) return;
     for (float* p : codec->packed) (void)hipFree(p);
-    if (codec->arena) (void)hipFree(codec->arena);
+    for (int i = 0; i < CodecW::NLANE; ++i) {
+        if (codec->arena[i]) (void)hipFree(codec->arena[i]);
+        if (codec->pinned[i]) (void)hipHostFree(codec->pinned[i]);
+        if (i > 0 && codec->lane_stream[i]) (void)hipStreamDestroy(codec->lane_stream[i]);
+    }
     if (codec->rope_cos) (void)hipFree(codec->rope_cos);
     if (codec->rope_sin) (void)hipFree(codec->rope_sin);
     if (codec->page_table) (void)hipFree(codec->page_table);
@@ -93,6 +102,8 @@ void Engine::codec_finalize() {
     }
     W.snake_out = snake("cd.dec.snake_out");
     W.conv_out = pack("cd.dec.conv_out", D >> c.cd_n_blocks, 1, 7, false);
+    W.lane_stream[0] = stream;
+    for (int i = 1; i < CodecW::NLANE; ++i) Q3_HIP_CHECK(hipStreamCreateWithFlags(&W.lane_stream[i], hipStreamNonBlocking));
     int zero = 0;
     Q3_HIP_CHECK(hipMalloc((void**)&W.page_table, sizeof(int)));
     Q3_HIP_CHECK(hipMemcpy(W.page_table, &zero, sizeof(int), hipMemcpyHostToDevice));
@@ -105,14 +116,17 @@ static int tconv_out_len(const q3tts_config& c, int T, int k, int s, int* left_o
     return (T - 1) * s + k - left - pad;
 }
 
-int64_t Engine::codec_run(const int32_t* codes_dev, int F, float** pcm_dev) {
+int64_t Engine::codec_run(const int32_t* codes_dev, int F, float** pcm_dev, int lane) {
     if (!codec) throw Error("codec decoder not finalized");
     CodecW& W = *codec;
+    if (lane < 0 || lane >= CodecW::NLANE) throw Error("codec: bad lane");
+    hipStream_t stream = W.lane_stream[lane]; // shadows the engine stream for every launch below
     const int CH = c.cd_hidden, NH = c.cd_heads, HD = c.cd_head_dim, FF = c.cd_ffn, D = c.cd_decoder_dim;
     if (NH * HD != CH) throw Error("codec: heads*head_dim must equal hidden");
     int P = 1, pshift = 0;
     while (P < F) { P <<= 1; ++pshift; }
     if (W.rope_P < P) { // RoPE tables, oracle formula (fp32 libm)
+        for (int i = 0; i < CodecW::NLANE; ++i) Q3_HIP_CHECK(hipStreamSynchronize(W.lane_stream[i])); // tables may be in use
         if (W.rope_cos) (void)hipFree(W.rope_cos);
         if (W.rope_sin) (void)hipFree(W.rope_sin);
         const int half = HD / 2;
@@ -137,7 +151,7 @@ int64_t Engine::codec_run(const int32_t* codes_dev, int F, float** pcm_dev) {
         size_t off = 0;
         auto take = [&](size_t nfloat) -> float* {
             const size_t bytes = (nfloat * sizeof(float) + 255) & ~(size_t)255;
-            float* p = plan ? nullptr : (float*)(W.arena + off);
+            float* p = plan ? nullptr : (float*)(W.arena[lane] + off);
             off += bytes;
             return p;
         };
@@ -226,16 +240,79 @@ int64_t Engine::codec_run(const int32_t* codes_dev, int F, float** pcm_dev) {
         { ConvArgs a; a.in = sx; a.T_in = Tc; a.C_in = C; a.out = pcm; a.T_out = Tc; a.C_out = 1; a.W = W.conv_out.w; a.bias = W.conv_out.b;
           a.taps = 7; a.clamp = 1; conv(a); }
         n_pcm = Tc;
-        if (plan && off > W.arena_bytes) {
-            sync();
-            if (W.arena) (void)hipFree(W.arena);
-            W.arena = nullptr;
-            Q3_HIP_CHECK(hipMalloc((void**)&W.arena, off));
-            W.arena_bytes = off;
+        if (plan && off > W.arena_bytes[lane]) {
+            Q3_HIP_CHECK(hipStreamSynchronize(stream));
+            if (W.arena[lane]) (void)hipFree(W.arena[lane]);
+            W.arena[lane] = nullptr;
+            Q3_HIP_CHECK(hipMalloc((void**)&W.arena[lane], off));
+            W.arena_bytes[lane] = off;
         }
     }
     *pcm_dev = pcm;
     return n_pcm;
+}
+
+
+// Vocoder for slots [0, nb): utterances are independent, so their (small-grid) conv kernels are spread
+// over NLANE HIP streams with private arenas; PCM leaves through per-lane pinned staging buffers.
+void Engine::codec_decode_slots(int nb, float* const* pcm_out, int64_t cap, int64_t* lens) {
+    if (!codec) throw Error("codec decoder not finalized");
+    CodecW& W = *codec;
+    const int G = c.n_groups;
+    sync();
+    std::vector<SlotState> st(nb);
+    Q3_HIP_CHECK(hipMemcpy(st.data(), st_d, (size_t)nb * sizeof(SlotState), hipMemcpyDeviceToHost));
+    int maxF = 1;
+    for (int b = 0; b < nb; ++b) maxF = std::max(maxF, (int)st[b].n_frames);
+    int Pneed = 1;
+    while (Pneed < maxF) Pneed <<= 1;
+    if (W.rope_P < Pneed) { float* dummy = nullptr; std::vector<int32_t> z((size_t)G, 0); // grow the shared RoPE tables up front
+        Q3_HIP_CHECK(hipMemcpy(codes_scratch_d, z.data(), z.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        int32_t* tmp = nullptr; Q3_HIP_CHECK(hipMalloc((void**)&tmp, (size_t)maxF * G * sizeof(int32_t)));
+        Q3_HIP_CHECK(hipMemset(tmp, 0, (size_t)maxF * G * sizeof(int32_t)));
+        codec_run(tmp, maxF, &dummy, 0); sync(); (void)hipFree(tmp); }
+    hipEvent_t e0, e1;
+    Q3_HIP_CHECK(hipEventCreate(&e0)); Q3_HIP_CHECK(hipEventCreate(&e1));
+    Q3_HIP_CHECK(hipEventRecord(e0, stream));
+    for (int i = 1; i < CodecW::NLANE; ++i) Q3_HIP_CHECK(hipStreamWaitEvent(W.lane_stream[i], e0, 0));
+    std::vector<int> pending(CodecW::NLANE, -1);
+    std::vector<int64_t> pending_n(CodecW::NLANE, 0);
+    auto drain = [&](int lane) {
+        if (pending[lane] < 0) return;
+        Q3_HIP_CHECK(hipStreamSynchronize(W.lane_stream[lane]));
+        const int u = pending[lane];
+        const int64_t m = std::min(pending_n[lane], cap);
+        if (pcm_out && pcm_out[u] && m > 0) memcpy(pcm_out[u], W.pinned[lane], (size_t)m * sizeof(float));
+        pending[lane] = -1;
+    };
+    int64_t frames = 0;
+    for (int b = 0; b < nb; ++b) {
+        const int lane = b % CodecW::NLANE;
+        drain(lane);
+        const int nf = st[b].n_frames;
+        if (lens) lens[b] = 0;
+        if (nf <= 0) continue; // reference returns an empty vector when no frame was generated (tts_onnx.cpp:418)
+        float* pcm_d = nullptr;
+        const int64_t n = codec_run(codes_d + (size_t)b * max_frames_cap * G, nf, &pcm_d, lane);
+        frames += nf;
+        if (lens) lens[b] = n;
+        const int64_t m = std::min(n, cap);
+        if ((size_t)m > W.pinned_floats[lane]) {
+            if (W.pinned[lane]) (void)hipHostFree(W.pinned[lane]);
+            Q3_HIP_CHECK(hipHostMalloc((void**)&W.pinned[lane], (size_t)m * sizeof(float)));
+            W.pinned_floats[lane] = (size_t)m;
+        }
+        if (m > 0) Q3_HIP_CHECK(hipMemcpyAsync(W.pinned[lane], pcm_d, (size_t)m * sizeof(float), hipMemcpyDeviceToHost, W.lane_stream[lane]));
+        pending[lane] = b; pending_n[lane] = n;
+    }
+    for (int i = 0; i < CodecW::NLANE; ++i) drain(i);
+    for (int i = 1; i < CodecW::NLANE; ++i) { Q3_HIP_CHECK(hipEventRecord(e1, W.lane_stream[i])); Q3_HIP_CHECK(hipStreamWaitEvent(stream, e1, 0)); }
+    Q3_HIP_CHECK(hipEventRecord(e1, stream));
+    sync();
+    float ms = 0.f;
+    Q3_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    total_codec_ms += ms; total_codec_frames += frames; last_codec_ms = ms;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
 }
 
 } // namespace q3

@@ -94,7 +94,8 @@ public:
     // ---- codec decoder (q3_codec.cpp) ----
     CodecW* codec = nullptr;
     void codec_finalize();
-    int64_t codec_run(const int32_t* codes_dev, int F, float** pcm_dev); // returns sample count
+    int64_t codec_run(const int32_t* codes_dev, int F, float** pcm_dev, int lane = 0); // returns sample count
+    void codec_decode_slots(int nb, float* const* pcm_out, int64_t cap, int64_t* lens);
     void codec_free();
 
     // ---- internals ----
