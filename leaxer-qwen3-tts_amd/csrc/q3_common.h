@@ -39,7 +39,7 @@ inline float bf16_to_f32(bf16_t b) {
 // kernel argument blocks + launchers (q3_decode_kernels.hip)
 // ------------------------------------------------------------------------------------------------
 
-enum GemvEpi { EPI_STORE = 0, EPI_RESIDUAL = 1, EPI_SWIGLU = 2, EPI_BIAS = 3, EPI_BIAS_SILU = 4, EPI_SLAB = 5 };
+enum GemvEpi { EPI_STORE = 0, EPI_RESIDUAL = 1, EPI_SWIGLU = 2, EPI_BIAS = 3, EPI_BIAS_SILU = 4, EPI_SLAB = 5, EPI_SLAB2 = 6 };
 
 // out[m][n] = epi( sum_k xin[m][k] * W[n][k] ),  W row-major bf16 [N][K] (nn.Linear.weight layout)
 struct GemvArgs {
@@ -114,6 +114,7 @@ struct GemmArgs {
     const float* res = nullptr; int ldres = 0;
     const float* bias = nullptr;
     float* out = nullptr; int ldo = 0;        // fp32 output (may be null when only planes are wanted)
+    float* out2 = nullptr;                    // EPI_SLAB2: slabs of the W2 product
     bf16_t* oh = nullptr; bf16_t* ol = nullptr; int ldp = 0; // optional plane outputs (input of the next GEMM)
     int M = 0, N = 0, K = 0, epi = EPI_STORE;
 };
@@ -122,6 +123,8 @@ void launch_gemm_mfma(const GemmArgs& a, hipStream_t s);
 void launch_gemm2(const GemmArgs& a, int ksplit, int nw, hipStream_t s); // EPI_SLAB: out = slabs [ksplit][M][ldo]
 void launch_finish(float* x, int ldx, const float* slab, int nslab, size_t slab_stride, int ld_slab, const float* gamma, float eps,
                    int rows, int K, bf16_t* oh, bf16_t* ol, int ldp, float* xn_out, int ld_xn, hipStream_t s);
+void launch_finish_swiglu(const float* gs, const float* us, int nslab, size_t slab_stride, int rows, int N,
+                          bf16_t* oh, bf16_t* ol, int ldp, hipStream_t s);
 void launch_rmsnorm_split(const float* x, int ldx, const float* gamma, float eps, int rows, int K,
                           bf16_t* oh, bf16_t* ol, int ldp, float* xn_out, int ld_xn, hipStream_t s);
 

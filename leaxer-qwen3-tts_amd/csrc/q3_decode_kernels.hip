@@ -762,13 +762,26 @@ __global__ __launch_bounds__(256) void k_attn_combine(AttnArgs a) {
     for (int idx = threadIdx.x; idx < a.nq * a.d; idx += 256) {
         const int head = idx / a.d, e = idx % a.d;
         const size_t pi = ((size_t)row * a.nq + head) * a.n_splits;
-        float mx = -INFINITY;
-        for (int sp = 0; sp < nact; ++sp) mx = fmaxf(mx, a.pm[pi + sp]);
-        float L = 0.f, O = 0.f;
-        for (int sp = 0; sp < nact; ++sp) {
-            const float w = expf(a.pm[pi + sp] - mx);
-            L += w * a.pl[pi + sp];
-            O += w * a.po[(pi + sp) * a.d + e];
+        // online merge in branch-free batches of 4 splits (clamped addresses, zero weight past nact)
+        float mx = -INFINITY, L = 0.f, O = 0.f;
+        for (int sp0 = 0; sp0 < nact; sp0 += 4) {
+            float pmv[4], plv[4], pov[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int sp = sp0 + q < nact ? sp0 + q : nact - 1;
+                pmv[q] = a.pm[pi + sp]; plv[q] = a.pl[pi + sp]; pov[q] = a.po[(pi + sp) * a.d + e];
+            }
+            float mn = mx;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) mn = fmaxf(mn, pmv[q]);
+            const float corr = __expf(mx - mn);
+            L *= corr; O *= corr;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float w = sp0 + q < nact ? __expf(pmv[q] - mn) : 0.f;
+                L += w * plv[q]; O += w * pov[q];
+            }
+            mx = mn;
         }
         const float o = O / L;
         if (a.out) a.out[(size_t)row * a.ld_out + idx] = o;

@@ -171,6 +171,7 @@ Engine::Engine(const q3tts_config& cfg, int device_, int max_batch, int max_ctx_
     pl1h = (bf16_t*)dmalloc((size_t)rows_max * ldp * 2); pl1l = (bf16_t*)dmalloc((size_t)rows_max * ldp * 2);
     slab_d = fm((size_t)16 * rows_max * H);
     qkv_slab_d = fm((size_t)4 * rows_max * std::max(QKV, QKVp));
+    gu_slab_d = fm((size_t)2 * 4 * rows_max * std::max(c.ffn, c.cp_ffn));
     ids_d = (int64_t*)dmalloc(64 * sizeof(int64_t));
     tok_d = (int64_t*)dmalloc(sizeof(int64_t));
     codes_d = (int32_t*)dmalloc((size_t)B * max_frames_cap * c.n_groups * sizeof(int32_t));
@@ -367,10 +368,11 @@ bool Engine::run_layers(const DecStack& W, float* x, int ldx, int nb, int n_new,
             launch_gemm2(o, ks_o, 4, stream);
             // x += sum(slabs); planes0 = RMSNorm(post_norm)(x)
             launch_finish(x, ldx, slab_d, ks_o, (size_t)M * W.H, W.H, w.post_norm, W.eps, M, W.H, pl0h, pl0l, ldp, nullptr, 0, stream);
-            GemmArgs f;
-            f.W = w.gate; f.W2 = w.up; f.xh = pl0h; f.xl = pl0l; f.ldx = ldp; f.out = nullptr; f.oh = pl1h; f.ol = pl1l; f.ldp = ldp;
-            f.M = M; f.N = W.ffn; f.K = W.H; f.epi = EPI_SWIGLU;
-            launch_gemm2(f, 1, 2, stream);
+            GemmArgs f; // gate and up as split-K slab pairs, SwiGLU applied by the finish kernel
+            f.W = w.gate; f.W2 = w.up; f.xh = pl0h; f.xl = pl0l; f.ldx = ldp; f.out = gu_slab_d; f.out2 = gu_slab_d + (size_t)4 * rows_max * W.ffn; f.ldo = W.ffn;
+            f.M = M; f.N = W.ffn; f.K = W.H; f.epi = EPI_SLAB2;
+            launch_gemm2(f, ks_q, 4, stream);
+            launch_finish_swiglu(gu_slab_d, gu_slab_d + (size_t)4 * rows_max * W.ffn, ks_q, (size_t)M * W.ffn, M, W.ffn, pl1h, pl1l, ldp, stream);
             GemmArgs d;
             d.W = w.down; d.xh = pl1h; d.xl = pl1l; d.ldx = ldp; d.out = slab_d; d.ldo = W.H; d.M = M; d.N = W.H; d.K = W.ffn; d.epi = EPI_SLAB;
             launch_gemm2(d, ks_d, 4, stream);

@@ -113,6 +113,7 @@ public:
     bf16_t *pl0h = nullptr, *pl0l = nullptr, *pl1h = nullptr, *pl1l = nullptr; // (hi, lo) activation planes for the MFMA GEMM path
     int ldp = 0;
     float* slab_d = nullptr; // split-K partial sums [ks][rows][H]
+    float* gu_slab_d = nullptr;  // gate | up split-K partial sums, 2 x [<=4][rows][ffn]
     float* qkv_slab_d = nullptr; // split-K partial sums of the QKV projection [<=4][rows][QKV]
     int32_t* codes_d = nullptr;
     int32_t* codes_scratch_d = nullptr;

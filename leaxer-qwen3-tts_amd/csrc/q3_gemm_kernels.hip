@@ -189,6 +189,7 @@ void launch_rmsnorm_split(const float* x, int ldx, const float* gamma, float eps
 
 template <int MTILES, int EPI, int NW>
 __global__ __launch_bounds__(NW * 64) void k_gemm2(GemmArgs a) {
+    constexpr bool DUAL = EPI == EPI_SWIGLU || EPI == EPI_SLAB2;
     constexpr int NT = NW * 64;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -201,7 +202,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm2(GemmArgs a) {
     int nrow = n0 + r16;
     nrow = nrow < a.N ? nrow : a.N - 1;
     const bf16_t* wp = a.W + (size_t)nrow * K + q * 8;
-    const bf16_t* wp2 = EPI == EPI_SWIGLU ? a.W2 + (size_t)nrow * K + q * 8 : nullptr;
+    const bf16_t* wp2 = DUAL ? a.W2 + (size_t)nrow * K + q * 8 : nullptr;
     f32x4 acc[MTILES], acc2[MTILES];
 #pragma unroll
     for (int mt = 0; mt < MTILES; ++mt) { acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[mt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -217,7 +218,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm2(GemmArgs a) {
 #pragma unroll
         for (int st = 0; st < G2_KC / 32; ++st) {
             S.b[st] = *reinterpret_cast<const bf16x8*>(wp + k0 + st * 32);
-            if (EPI == EPI_SWIGLU) S.b2[st] = *reinterpret_cast<const bf16x8*>(wp2 + k0 + st * 32);
+            if (DUAL) S.b2[st] = *reinterpret_cast<const bf16x8*>(wp2 + k0 + st * 32);
         }
 #pragma unroll
         for (int p = 0; p < PASSES; ++p) {
@@ -246,7 +247,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm2(GemmArgs a) {
                 const bf16x8 al = *reinterpret_cast<const bf16x8*>(&xs[1][mt * 16 + r16][st * 32 + q * 8]);
                 acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, S.b[st], acc[mt], 0, 0, 0);
                 acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, S.b[st], acc[mt], 0, 0, 0);
-                if (EPI == EPI_SWIGLU) {
+                if (DUAL) {
                     acc2[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, S.b2[st], acc2[mt], 0, 0, 0);
                     acc2[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, S.b2[st], acc2[mt], 0, 0, 0);
                 }
@@ -278,6 +279,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm2(GemmArgs a) {
             float o = acc[mt][r];
             if (EPI == EPI_SWIGLU) o = silu_g(o) * acc2[mt][r];
             if (EPI == EPI_SLAB) { a.out[((size_t)blockIdx.y * M + m) * a.ldo + n] = o; continue; }
+            if (EPI == EPI_SLAB2) { a.out[((size_t)blockIdx.y * M + m) * a.ldo + n] = o; a.out2[((size_t)blockIdx.y * M + m) * a.ldo + n] = acc2[mt][r]; continue; }
             if (a.out) a.out[(size_t)m * a.ldo + n] = o;
             if (a.oh) split_store(o, a.oh + (size_t)m * a.ldp + n, a.ol + (size_t)m * a.ldp + n);
         }
@@ -291,6 +293,7 @@ static void gemm2_epi(const GemmArgs& a, int ksplit, hipStream_t s) {
     case EPI_STORE: hipLaunchKernelGGL((k_gemm2<MTILES, EPI_STORE, NW>), grid, block, 0, s, a); break;
     case EPI_SWIGLU: hipLaunchKernelGGL((k_gemm2<MTILES, EPI_SWIGLU, NW>), grid, block, 0, s, a); break;
     case EPI_SLAB: hipLaunchKernelGGL((k_gemm2<MTILES, EPI_SLAB, NW>), grid, block, 0, s, a); break;
+    case EPI_SLAB2: hipLaunchKernelGGL((k_gemm2<MTILES, EPI_SLAB2, NW>), grid, block, 0, s, a); break;
     default: throw Error("gemm2: unsupported epilogue");
     }
 }
@@ -301,7 +304,7 @@ static void gemm2_nw(const GemmArgs& a, int ksplit, int nw, hipStream_t s) {
 // ksplit: number of K slices (1 = complete sums, direct epilogue; >1 requires EPI_SLAB); nw: waves (= 16-column tiles) per workgroup
 void launch_gemm2(const GemmArgs& a, int ksplit, int nw, hipStream_t s) {
     if (a.M < 1 || a.M > 128 || a.K % (G2_KC * ksplit) != 0 || a.ldx % 8 != 0) throw Error("gemm2: unsupported shape");
-    if (ksplit > 1 && a.epi != EPI_SLAB) throw Error("gemm2: split-K needs the slab epilogue");
+    if (ksplit > 1 && a.epi != EPI_SLAB && a.epi != EPI_SLAB2) throw Error("gemm2: split-K needs a slab epilogue");
     if (a.M <= 16) gemm2_nw<1>(a, ksplit, nw, s);
     else if (a.M <= 32) gemm2_nw<2>(a, ksplit, nw, s);
     else if (a.M <= 64) gemm2_nw<4>(a, ksplit, nw, s);
@@ -354,6 +357,29 @@ void launch_finish(float* x, int ldx, const float* slab, int nslab, size_t slab_
                    int rows, int K, bf16_t* oh, bf16_t* ol, int ldp, float* xn_out, int ld_xn, hipStream_t s) {
     if (K % 4 || K > 4096) throw Error("finish: K must be a multiple of 4 and <= 4096");
     if (rows > 0) hipLaunchKernelGGL(k_finish, dim3(rows), dim3(256), 0, s, x, ldx, slab, nslab, slab_stride, ld_slab, gamma, eps, K, oh, ol, ldp, xn_out, ld_xn);
+}
+
+// act = silu(sum gate slabs) * (sum up slabs) -> (hi, lo) planes; one workgroup per row
+__global__ __launch_bounds__(256) void k_finish_swiglu(const float* gs, const float* us, int nslab, size_t slab_stride, int N,
+                                                        bf16_t* oh, bf16_t* ol, int ldp) {
+    const int m = blockIdx.x;
+    for (int n = threadIdx.x * 4; n < N; n += 1024) {
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f), u = g;
+        for (int sidx = 0; sidx < nslab; ++sidx) {
+            const float4 pg = *reinterpret_cast<const float4*>(gs + sidx * slab_stride + (size_t)m * N + n);
+            const float4 pu = *reinterpret_cast<const float4*>(us + sidx * slab_stride + (size_t)m * N + n);
+            g.x += pg.x; g.y += pg.y; g.z += pg.z; g.w += pg.w;
+            u.x += pu.x; u.y += pu.y; u.z += pu.z; u.w += pu.w;
+        }
+        const float o[4] = { silu_g(g.x) * u.x, silu_g(g.y) * u.y, silu_g(g.z) * u.z, silu_g(g.w) * u.w };
+#pragma unroll
+        for (int j = 0; j < 4; ++j) split_store(o[j], oh + (size_t)m * ldp + n + j, ol + (size_t)m * ldp + n + j);
+    }
+}
+void launch_finish_swiglu(const float* gs, const float* us, int nslab, size_t slab_stride, int rows, int N,
+                          bf16_t* oh, bf16_t* ol, int ldp, hipStream_t s) {
+    if (N % 4) throw Error("finish_swiglu: N must be a multiple of 4");
+    if (rows > 0) hipLaunchKernelGGL(k_finish_swiglu, dim3(rows), dim3(256), 0, s, gs, us, nslab, slab_stride, N, oh, ol, ldp);
 }
 
 } // namespace q3
