@@ -170,8 +170,9 @@ def main():
             "pcm_samples": samples,
             "decode_ms_per_frame_step": round(step_ms, 4),
             "codec_decode_ms_per_frame": round(ctr["codec_ms"] / max(ctr["codec_frames"], 1), 5),
-            "roofline": {"bound": "hbm", "kernel": "decode step (hipGraph: q3::k_gemv x" + str(5 * (cfg.n_layers + 15 * cfg.cp_layers) + 16)
-                                                   + " + k_attn + k_sample)",
+            "roofline": {"bound": "hbm", "kernel": "decode step = one hipGraph replay per frame ("
+                                   + ("651 nodes: q3::k_gemv1 x531, k_attn x103, k_sample x16, k_gemv x1" if B <= 4 else
+                                      "q3::k_gemm2 + k_finish + k_attn + k_attn_combine + k_sample") + ")",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "algorithmic_bytes_per_launch": int(abytes), "launch_ms": round(step_ms, 4)},

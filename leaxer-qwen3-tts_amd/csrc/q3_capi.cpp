@@ -1,4 +1,5 @@
 // q3_capi.cpp — extern "C" surface declared in include/q3tts.h.  No exception crosses the ABI.
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -50,6 +51,7 @@ q3tts_engine* q3tts_create(const q3tts_config* cfg, int device, int max_batch, i
         int n = 0;
         if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) throw q3::Error("no HIP device: libq3tts_hip needs an MI355X (gfx950); there is no CPU fallback");
         if (device < 0 || device >= n) throw q3::Error("device index out of range");
+        if (const char* ng = getenv("Q3TTS_NO_GRAPH")) if (ng[0] == '1') flags |= Q3TTS_FLAG_NO_GRAPH; // profiling aid
         q3tts_engine* h = new q3tts_engine;
         h->e = new Engine(*cfg, device, max_batch, max_ctx, flags);
         return h;

@@ -43,7 +43,7 @@ void Engine::codec_free() {
     for (int i = 0; i < CodecW::NLANE; ++i) {
         if (codec->arena[i]) (void)hipFree(codec->arena[i]);
         if (codec->pinned[i]) (void)hipHostFree(codec->pinned[i]);
-        if (i > 0 && codec->lane_stream[i]) (void)hipStreamDestroy(codec->lane_stream[i]);
+        if (i > 0 && codec->lane_stream[i] && !null_stream) (void)hipStreamDestroy(codec->lane_stream[i]);
     }
     if (codec->rope_cos) (void)hipFree(codec->rope_cos);
     if (codec->rope_sin) (void)hipFree(codec->rope_sin);
@@ -103,7 +103,10 @@ void Engine::codec_finalize() {
     W.snake_out = snake("cd.dec.snake_out");
     W.conv_out = pack("cd.dec.conv_out", D >> c.cd_n_blocks, 1, 7, false);
     W.lane_stream[0] = stream;
-    for (int i = 1; i < CodecW::NLANE; ++i) Q3_HIP_CHECK(hipStreamCreateWithFlags(&W.lane_stream[i], hipStreamNonBlocking));
+    for (int i = 1; i < CodecW::NLANE; ++i) {
+        if (null_stream) W.lane_stream[i] = nullptr;
+        else Q3_HIP_CHECK(hipStreamCreateWithFlags(&W.lane_stream[i], hipStreamNonBlocking));
+    }
     int zero = 0;
     Q3_HIP_CHECK(hipMalloc((void**)&W.page_table, sizeof(int)));
     Q3_HIP_CHECK(hipMemcpy(W.page_table, &zero, sizeof(int), hipMemcpyHostToDevice));

@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 namespace q3 {
@@ -52,7 +53,11 @@ Engine::Engine(const q3tts_config& cfg, int device_, int max_batch, int max_ctx_
     if (c.vocab > 4096 || c.sub_vocab > 4096) throw Error("codec vocabularies larger than 4096 are not supported");
     if (c.n_groups < 2 || c.n_groups > 32) throw Error("n_groups out of range");
     Q3_HIP_CHECK(hipSetDevice(device));
-    Q3_HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    // Q3TTS_NULL_STREAM=1 (profiling aid): rocprofv3 --pmc crashes on user-created streams on this ROCm; run on the
+    // default stream instead (forces eager launches: the default stream cannot be captured)
+    null_stream = getenv("Q3TTS_NULL_STREAM") && getenv("Q3TTS_NULL_STREAM")[0] == '1';
+    if (null_stream) { stream = nullptr; flags |= Q3TTS_FLAG_NO_GRAPH; }
+    else Q3_HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     Q3_HIP_CHECK(hipEventCreate(&ev0));
     Q3_HIP_CHECK(hipEventCreate(&ev1));
 
@@ -234,7 +239,7 @@ Engine::~Engine() {
     if (active_h) (void)hipHostFree(active_h);
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
-    if (stream) (void)hipStreamDestroy(stream);
+    if (stream && !null_stream) (void)hipStreamDestroy(stream);
 }
 
 // ------------------------------------------------------------------------------------------------

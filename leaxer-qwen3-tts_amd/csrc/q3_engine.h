@@ -50,6 +50,7 @@ public:
     int device, B, max_ctx;
     uint32_t flags;
     hipStream_t stream = nullptr;
+    bool null_stream = false;
     std::string err;
 
     // ---- weights ----

@@ -1,0 +1,36 @@
+// which library call kills rocprofv3 --pmc?  prints progress to stderr
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "../include/q3tts.h"
+int main(int argc, char** argv) {
+    const int steps = argc > 1 ? atoi(argv[1]) : 4;
+    q3tts_config c; q3tts_default_config("0.6b", &c);
+    fprintf(stderr, "[1] create\n");
+    q3tts_engine* e = q3tts_create(&c, 0, 1, steps + 64, 0);
+    if (!e) { fprintf(stderr, "create failed: %s\n", q3tts_last_error(nullptr)); return 1; }
+    fprintf(stderr, "[2] fill\n");
+    q3tts_fill_synthetic(e, 0);
+    fprintf(stderr, "[3] finalize\n");
+    q3tts_finalize(e);
+    fprintf(stderr, "[4] text_project\n");
+    int64_t ids[3] = {1, 2, 3}; std::vector<float> out(3 * 1024);
+    q3tts_text_project_host(e, ids, 3, out.data());
+    fprintf(stderr, "[5] prefill\n");
+    std::vector<float> x(8 * 1024, 0.01f), lg(8 * 3072), lh(1024);
+    q3tts_talker_prefill_host(e, 0, x.data(), 8, lg.data(), lh.data());
+    fprintf(stderr, "[6] decode\n");
+    q3tts_talker_decode_host(e, 0, x.data(), lg.data(), lh.data());
+    fprintf(stderr, "[7] slot_begin\n");
+    q3tts_sampling sp{0.8f, 0.95f, 50, 1.0f, steps};
+    std::vector<float> tr(4 * 1024, 0.01f);
+    q3tts_slot_begin(e, 0, x.data(), 8, tr.data(), 4, &sp, 1, 0, 1);
+    fprintf(stderr, "[8] decode_steps\n");
+    int act = q3tts_decode_steps(e, steps);
+    fprintf(stderr, "[9] active=%d codec\n", act);
+    std::vector<float> pcm((size_t)(steps + 8) * 1920); int64_t n = 0;
+    q3tts_slot_codec_decode_host(e, 0, pcm.data(), (int64_t)pcm.size(), &n);
+    fprintf(stderr, "[10] done n=%lld\n", (long long)n);
+    q3tts_destroy(e);
+    return 0;
+}
