@@ -126,6 +126,20 @@ int q3tts_synthesize_batch_host(q3tts_engine* e, int n_utt, const int64_t* ids, 
                                 float* const* pcm_out, int64_t pcm_cap, int64_t* pcm_len, int32_t* n_frames,
                                 int64_t* codes_out);
 
+/* ---- text front end: the reference's byte-level BPE tokenizer ---- */
+/* Replaces leaxer_qwen::io::load_vocab / load_merges / is_tokenizer_ready / tokenize (reference
+ * src/io/tokenizer.h:13-22, src/io/tokenizer.cpp:538-561) with the same ids for the same files and text.
+ * The reference keeps one process-global tokenizer; here it is a handle (host-only, no GPU work).
+ * load_* return 0 on success, -1 on failure (the reference's `false`).  q3tts_tokenize writes up to
+ * `cap` ids and returns the number of ids the text produces (call with cap=0 to size the buffer). */
+typedef struct q3tts_tokenizer q3tts_tokenizer;
+q3tts_tokenizer* q3tts_tokenizer_create(void);
+void q3tts_tokenizer_destroy(q3tts_tokenizer* t);
+int q3tts_tokenizer_load_vocab(q3tts_tokenizer* t, const char* vocab_json_path);
+int q3tts_tokenizer_load_merges(q3tts_tokenizer* t, const char* merges_txt_path);
+int q3tts_tokenizer_ready(const q3tts_tokenizer* t);
+int64_t q3tts_tokenize(const q3tts_tokenizer* t, const char* text, int64_t len, int32_t* ids, int64_t cap);
+
 /* ---- measurement hooks (bench.py) ---- */
 /* device time in ms of the last q3tts_decode_steps call, from HIP events on the engine's stream */
 int q3tts_last_decode_ms(q3tts_engine* e, float* ms, int* steps);

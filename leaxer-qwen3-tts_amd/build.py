@@ -10,8 +10,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libq3tts_hip.so")
-SOURCES = ["q3_decode_kernels.hip", "q3_gemm_kernels.hip", "q3_codec_kernels.hip", "q3_engine.cpp", "q3_codec.cpp", "q3_capi.cpp"]
-HEADERS = ["q3_common.h", "q3_engine.h", os.path.join("..", "..", "include", "q3tts.h")]
+SOURCES = ["q3_decode_kernels.hip", "q3_gemm_kernels.hip", "q3_codec_kernels.hip", "q3_engine.cpp", "q3_codec.cpp", "q3_bpe.cpp", "q3_capi.cpp"]
+HEADERS = ["q3_common.h", "q3_engine.h", "q3_bpe.h", os.path.join("..", "..", "include", "q3tts.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall", "-Wno-unused-function",
          "-Wno-unused-variable", "-Wno-unused-but-set-variable"]
 
@@ -68,7 +68,7 @@ def _build_cli(force=False):
     deps = srcs + [os.path.join(CSRC, "tts_engine.h"), os.path.join(HERE, "..", "include", "q3tts.h"), LIB]
     if not force and os.path.exists(CLI) and all(os.path.getmtime(CLI) >= os.path.getmtime(d) for d in deps):
         return CLI
-    cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-o", CLI] + srcs + ["-L" + HERE, "-lq3tts_hip", "-Wl,-rpath,$ORIGIN"]
+    cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-o", CLI] + srcs + ["-L" + HERE, "-lq3tts_hip", "-lstdc++fs", "-Wl,-rpath,$ORIGIN"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("building leaxer-tts failed:\n" + r.stderr[-4000:])

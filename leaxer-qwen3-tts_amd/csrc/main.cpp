@@ -1,7 +1,7 @@
 // leaxer-tts — command line of the MI355X engine.  Flag set of the reference CLI
 // (reference src/main_onnx.cpp:60-77, 99-124): -m -p -o --lang --ref --temp --top-k --top-p --max-tokens -h,
 // unknown flags ignored, 16-bit mono WAV at 24 kHz (clip to [-1,1], truncate x*32767).  Additions:
-// --tokens "id,id,..." (pre-tokenised text between TTS_BOS and TTS_EOS; the BPE tokenizer is a later row),
+// --tokens "id,id,..." (pre-tokenised text between TTS_BOS and TTS_EOS, bypassing vocab.json/merges.txt),
 // --seed N.
 #include <cstdio>
 #include <cstdlib>
@@ -36,7 +36,7 @@ static int save_wav16(const char* path, const std::vector<float>& audio, uint32_
 static void usage(const char* prog) {
     printf("Usage: %s [options]\n\nQwen3-TTS synthesis on MI355X (HIP)\n\nOptions:\n", prog);
     printf("  -m, --model DIR       model directory holding model.q3w, or synthetic:<seed> (required)\n");
-    printf("  -p, --prompt TEXT     text to synthesize (needs the BPE tokenizer: not built yet, use --tokens)\n");
+    printf("  -p, --prompt TEXT     text to synthesize (needs vocab.json + merges.txt, see README)\n");
     printf("      --tokens IDS      comma-separated text token ids (framed as IM_START ASSISTANT TTS_BOS ids TTS_EOS IM_END)\n");
     printf("  -o, --output PATH     output WAV file (default: output.wav)\n");
     printf("  --lang LANG           auto, en, zh, ja, ko (default: auto)\n");

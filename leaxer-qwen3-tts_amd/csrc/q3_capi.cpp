@@ -3,6 +3,7 @@
 #include <cstring>
 #include <vector>
 
+#include "q3_bpe.h"
 #include "q3_engine.h"
 
 using q3::Engine;
@@ -339,6 +340,34 @@ int q3tts_save_weights_file(q3tts_engine* h, const char* path) {
     }
     return 0;
     Q3_API_END(h)
+}
+
+// ---- text front end (host only) ----
+struct q3tts_tokenizer {
+    q3::BpeTokenizer t;
+};
+
+q3tts_tokenizer* q3tts_tokenizer_create(void) {
+    try { return new q3tts_tokenizer(); } catch (...) { return nullptr; }
+}
+void q3tts_tokenizer_destroy(q3tts_tokenizer* t) { delete t; }
+int q3tts_tokenizer_load_vocab(q3tts_tokenizer* t, const char* path) {
+    if (!t || !path) return -1;
+    try { return t->t.load_vocab(path) ? 0 : -1; } catch (...) { return -1; }
+}
+int q3tts_tokenizer_load_merges(q3tts_tokenizer* t, const char* path) {
+    if (!t || !path) return -1;
+    try { return t->t.load_merges(path) ? 0 : -1; } catch (...) { return -1; }
+}
+int q3tts_tokenizer_ready(const q3tts_tokenizer* t) { return t && t->t.ready() ? 1 : 0; }
+int64_t q3tts_tokenize(const q3tts_tokenizer* t, const char* text, int64_t len, int32_t* ids, int64_t cap) {
+    if (!t || len < 0 || (len > 0 && !text)) return -1;
+    try {
+        std::vector<int32_t> v;
+        t->t.encode(text, (size_t)len, v);
+        for (int64_t i = 0; i < (int64_t)v.size() && i < cap && ids; ++i) ids[i] = v[(size_t)i];
+        return (int64_t)v.size();
+    } catch (...) { return -1; }
 }
 
 } // extern "C"

@@ -5,6 +5,7 @@
 #include <cctype>
 #include <cstdlib>
 #include <cstring>
+#include <filesystem>
 #include <iostream>
 
 #include "../../include/q3tts.h"
@@ -42,16 +43,73 @@ TTSEngine::TTSEngine(const std::string& model_dir) {
         if (!h_) { error_msg_ = q3tts_last_error(nullptr); return; }
         if (q3tts_load_weights_file(h_, path.c_str()) != 0) { error_msg_ = q3tts_last_error(h_); return; }
     }
-    ready_ = true; // the BPE tokenizer (reference tts_onnx.cpp:110-121) is a later row
+    // tokenizer files: where the reference looks (tts_onnx.cpp:110-121: <parent of model_dir>/models/
+    // Qwen3-TTS-12Hz-0.6B-Base/{vocab.json,merges.txt}), then model_dir itself.  Present but unreadable is
+    // an error, absent is a warning and text synthesis stays unavailable — as in the reference.
+    namespace fs = std::filesystem;
+    tok_ = q3tts_tokenizer_create();
+    const fs::path ref_base = fs::path(model_dir).parent_path() / "models" / "Qwen3-TTS-12Hz-0.6B-Base";
+    fs::path base = ref_base;
+    std::error_code ec;
+    if (!(fs::exists(base / "vocab.json", ec) && fs::exists(base / "merges.txt", ec)) && model_dir.rfind("synthetic:", 0) != 0)
+        base = fs::path(model_dir);
+    if (fs::exists(base / "vocab.json", ec) && fs::exists(base / "merges.txt", ec)) {
+        if (!tok_ || q3tts_tokenizer_load_vocab(tok_, (base / "vocab.json").string().c_str()) != 0 ||
+            q3tts_tokenizer_load_merges(tok_, (base / "merges.txt").string().c_str()) != 0) {
+            error_msg_ = "Failed to load tokenizer";
+            return;
+        }
+    } else {
+        std::cerr << "[TTSEngine] Warning: Tokenizer not found at " << ref_base << std::endl;
+    }
+    ready_ = true;
 }
 
-TTSEngine::~TTSEngine() { if (h_) q3tts_destroy(h_); }
+TTSEngine::~TTSEngine() {
+    if (tok_) q3tts_tokenizer_destroy(tok_);
+    if (h_) q3tts_destroy(h_);
+}
 
-std::vector<float> TTSEngine::synthesize(const std::string&, Language, const SamplingParams&) {
+bool TTSEngine::wrap_text(const std::string& text, std::vector<int64_t>& ids) const {
+    // reference tts_onnx.cpp:243-259: [IM_START, ASSISTANT, TTS_BOS, ...text..., TTS_EOS, IM_END]
+    if (!q3tts_tokenizer_ready(tok_)) {
+        std::cerr << "[TTSEngine] Tokenizer not ready" << std::endl;
+        return false;
+    }
+    const int64_t n = q3tts_tokenize(tok_, text.data(), (int64_t)text.size(), nullptr, 0);
+    if (n < 0) return false;
+    std::vector<int32_t> t((size_t)n);
+    q3tts_tokenize(tok_, text.data(), (int64_t)text.size(), t.data(), n);
+    ids = { config::IM_START, config::ASSISTANT, config::TTS_BOS };
+    ids.insert(ids.end(), t.begin(), t.end());
+    ids.push_back(config::TTS_EOS);
+    ids.push_back(config::IM_END);
+    return true;
+}
+
+std::vector<int32_t> TTSEngine::tokenize(const std::string& text) const {
+    std::vector<int32_t> t;
+    const int64_t n = q3tts_tokenize(tok_, text.data(), (int64_t)text.size(), nullptr, 0);
+    if (n <= 0) return t;
+    t.resize((size_t)n);
+    q3tts_tokenize(tok_, text.data(), (int64_t)text.size(), t.data(), n);
+    return t;
+}
+
+std::vector<float> TTSEngine::synthesize(const std::string& text, Language lang, const SamplingParams& params) {
     if (!ready_) return {};
-    // reference tts_onnx.cpp:249-256: without a loaded tokenizer synthesize() logs and returns empty
-    std::cerr << "[TTSEngine] Tokenizer not ready" << std::endl;
-    return {};
+    std::vector<int64_t> ids;
+    if (!wrap_text(text, ids)) return {};
+    return synthesize_tokens(ids, lang, params);
+}
+
+std::vector<std::vector<float>> TTSEngine::synthesize_batch(const std::vector<std::string>& texts, Language lang,
+                                                            const SamplingParams& params) {
+    std::vector<std::vector<int64_t>> ids(texts.size());
+    if (!ready_) return std::vector<std::vector<float>>(texts.size());
+    for (size_t i = 0; i < texts.size(); ++i)
+        if (!wrap_text(texts[i], ids[i])) return std::vector<std::vector<float>>(texts.size());
+    return synthesize_tokens_batch(ids, lang, params);
 }
 
 std::vector<float> TTSEngine::synthesize_clone(const std::string&, const std::string&, Language, const SamplingParams&) {

@@ -11,6 +11,7 @@
 #include <vector>
 
 struct q3tts_engine;
+struct q3tts_tokenizer;
 
 namespace leaxer_qwen {
 
@@ -44,6 +45,8 @@ class TTSEngine {
 public:
     // model_dir: a directory holding `model.q3w` (see q3tts_save_weights_file / tools/pack_weights.py),
     // or the literal "synthetic:<seed>" for seeded random 0.6B weights (benchmarks, smoke tests).
+    // vocab.json + merges.txt are looked up where the reference looks (<parent of model_dir>/models/
+    // Qwen3-TTS-12Hz-0.6B-Base/, tts_onnx.cpp:110-112), then in model_dir.
     explicit TTSEngine(const std::string& model_dir);
     ~TTSEngine();
     TTSEngine(const TTSEngine&) = delete;
@@ -63,14 +66,20 @@ public:
     std::vector<std::vector<float>> synthesize_tokens_batch(const std::vector<std::vector<int64_t>>& token_ids,
                                                             Language lang = Language::Auto,
                                                             const SamplingParams& params = SamplingParams());
+    std::vector<std::vector<float>> synthesize_batch(const std::vector<std::string>& texts, Language lang = Language::Auto,
+                                                     const SamplingParams& params = SamplingParams());
     void set_seed(uint64_t seed) { seed_ = seed; }
+    // ids of `text` from the loaded tokenizer (reference io::tokenize, src/io/tokenizer.h:22)
+    std::vector<int32_t> tokenize(const std::string& text) const;
 
     bool has_speaker_encoder() const { return false; } // speaker_encoder.onnx has no HIP counterpart yet
     bool is_ready() const { return ready_; }
     const std::string& get_error() const { return error_msg_; }
 
 private:
+    bool wrap_text(const std::string& text, std::vector<int64_t>& ids) const;
     q3tts_engine* h_ = nullptr;
+    q3tts_tokenizer* tok_ = nullptr;
     bool ready_ = false;
     std::string error_msg_;
     uint64_t seed_ = 0;

@@ -76,6 +76,8 @@ EXPORTS = [
     "q3tts_slot_status", "q3tts_slot_codes_host", "q3tts_slot_codec_decode_host", "q3tts_slot_release",
     "q3tts_synthesize_batch_host", "q3tts_last_decode_ms", "q3tts_last_codec_ms", "q3tts_decode_step_bytes",
     "q3tts_counters", "q3tts_read_weights_config", "q3tts_load_weights_file", "q3tts_save_weights_file",
+    "q3tts_tokenizer_create", "q3tts_tokenizer_destroy", "q3tts_tokenizer_load_vocab", "q3tts_tokenizer_load_merges",
+    "q3tts_tokenizer_ready", "q3tts_tokenize",
 ]
 
 _lib = None
@@ -130,6 +132,15 @@ def lib():
     L.q3tts_read_weights_config.argtypes = [C.c_char_p, C.POINTER(Config)]
     L.q3tts_load_weights_file.argtypes = [vp, C.c_char_p]
     L.q3tts_save_weights_file.argtypes = [vp, C.c_char_p]
+    L.q3tts_tokenizer_create.restype = vp
+    L.q3tts_tokenizer_create.argtypes = []
+    L.q3tts_tokenizer_destroy.restype = None
+    L.q3tts_tokenizer_destroy.argtypes = [vp]
+    L.q3tts_tokenizer_load_vocab.argtypes = [vp, C.c_char_p]
+    L.q3tts_tokenizer_load_merges.argtypes = [vp, C.c_char_p]
+    L.q3tts_tokenizer_ready.argtypes = [vp]
+    L.q3tts_tokenize.restype = i64
+    L.q3tts_tokenize.argtypes = [vp, C.c_char_p, i64, C.POINTER(C.c_int32), i64]
     _lib = L
     return L
 
@@ -362,6 +373,51 @@ class Engine:
         w, kv = C.c_double(0), C.c_double(0)
         self._ck(self.L.q3tts_decode_step_bytes(self.h, C.byref(w), C.byref(kv)))
         return w.value, kv.value
+
+
+class Tokenizer:
+    """Byte-level BPE tokenizer of the text prompt (q3tts_tokenizer_*; reference src/io/tokenizer.h:13-22).
+    Host-only: usable without a GPU."""
+
+    def __init__(self, vocab_json=None, merges_txt=None):
+        self._h = lib().q3tts_tokenizer_create()
+        if not self._h:
+            raise MemoryError("q3tts_tokenizer_create failed")
+        if vocab_json is not None and not self.load_vocab(vocab_json):
+            raise ValueError(f"cannot load vocab {vocab_json}")
+        if merges_txt is not None and not self.load_merges(merges_txt):
+            raise ValueError(f"cannot load merges {merges_txt}")
+
+    def load_vocab(self, path):
+        return lib().q3tts_tokenizer_load_vocab(self._h, os.fsencode(path)) == 0
+
+    def load_merges(self, path):
+        return lib().q3tts_tokenizer_load_merges(self._h, os.fsencode(path)) == 0
+
+    @property
+    def ready(self):
+        return bool(lib().q3tts_tokenizer_ready(self._h))
+
+    def encode(self, text):
+        b = text if isinstance(text, (bytes, bytearray)) else text.encode("utf-8")
+        b = bytes(b)
+        n = lib().q3tts_tokenize(self._h, b, len(b), None, 0)
+        if n < 0:
+            raise RuntimeError("q3tts_tokenize failed")
+        out = np.zeros(max(n, 1), np.int32)
+        lib().q3tts_tokenize(self._h, b, len(b), out.ctypes.data_as(C.POINTER(C.c_int32)), n)
+        return out[:n]
+
+    def close(self):
+        if self._h:
+            lib().q3tts_tokenizer_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def rng_uniform(seed, stream, frame, group):

@@ -65,6 +65,40 @@ def test_weight_file_roundtrip_and_cli(tmp_path):
     orc.close()
 
 
+def test_cli_text_prompt_uses_the_tokenizer(tmp_path):
+    """-p TEXT == --tokens <ids of the tokenizer> (the ids themselves are pinned against the
+    reference's tokenizer in tests/test_tokenizer.py); files in the reference's location (tts_onnx.cpp:110-112)."""
+    import json
+    import q3tts
+    eng, orc, _ = tiny_pair(seed=5, max_batch=1, max_ctx=96)
+    mdir = tmp_path / "models" / "onnx"
+    mdir.mkdir(parents=True)
+    eng.save_weights(str(mdir / "model.q3w"))
+    eng.close()
+    orc.close()
+    tdir = tmp_path / "models" / "models" / "Qwen3-TTS-12Hz-0.6B-Base"   # <parent of model_dir>/models/<name>
+    tdir.mkdir(parents=True)
+    vocab = {ch: 10 + k for k, ch in enumerate("abcdefghijklmnopqrstuvwxyz")}
+    vocab.update({"\u0120": 40, "he": 41, "ll": 42, "hell": 43, "hello": 44, "\u0120w": 45, "or": 46, "\u0120wor": 47, ",": 48})
+    json.dump(vocab, open(tdir / "vocab.json", "w"))
+    open(tdir / "merges.txt", "w").write("#version: 0.2\nh e\nl l\nhe ll\nhell o\n\u0120 w\no r\n\u0120w or\n")
+    tok = q3tts.Tokenizer(str(tdir / "vocab.json"), str(tdir / "merges.txt"))
+    ids = [int(t) for t in tok.encode("hello, world")]
+    tok.close()
+    assert ids == [44, 48, 47, 21, 13]
+    common = ["-m", str(mdir), "--max-tokens", "8", "--seed", "3"]
+    a, b = tmp_path / "a.wav", tmp_path / "b.wav"
+    r = subprocess.run([CLI, "-p", "hello, world", "-o", str(a)] + common, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    r = subprocess.run([CLI, "--tokens", ",".join(map(str, ids)), "-o", str(b)] + common, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert open(a, "rb").read() == open(b, "rb").read() and len(read_wav16(str(a))) > 0
+    # present but unreadable tokenizer files are a constructor error (tts_onnx.cpp:114-117)
+    open(tdir / "vocab.json", "w").write("[1,2]")
+    r = subprocess.run([CLI, "-p", "hello", "-o", str(a)] + common, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 1 and "Failed to load tokenizer" in r.stderr
+
+
 def test_cli_errors_like_the_reference(tmp_path):
     r = subprocess.run([CLI, "-p", "hello"], capture_output=True, text=True)
     assert r.returncode == 1 and "required" in r.stderr
