@@ -37,6 +37,10 @@ typedef struct q3tts_config {
     int32_t cd_up_rates[8];
     int32_t cd_tconv_trim; /* 0: trim k-s on both sides, 1: right side only */
     int32_t codec_eos, suppress_begin, suppress_end; /* tts_onnx.h:51, tts_onnx.cpp:803-807 */
+    /* speaker encoder of the clone path (speaker_encoder.onnx, tts_onnx.cpp:367-403): ECAPA-TDNN, channel plan
+     * (C, C, C, C, 3C), kernels (5,3,3,3,1), dilations (1,2,3,4,1).  spk_enc_dim == 0: no speaker encoder
+     * (has_speaker_encoder() false, as when the reference finds no speaker_encoder.onnx). */
+    int32_t spk_enc_dim, spk_mel, spk_channels, spk_scale, spk_se, spk_att;
 } q3tts_config;
 
 /* SamplingParams, reference src/tts_onnx.h:99-105 (repetition_penalty is never read there) */
@@ -125,6 +129,29 @@ int q3tts_synthesize_batch_host(q3tts_engine* e, int n_utt, const int64_t* ids, 
                                 const q3tts_sampling* p, uint64_t seed, int ignore_eos,
                                 float* const* pcm_out, int64_t pcm_cap, int64_t* pcm_len, int32_t* n_frames,
                                 int64_t* codes_out);
+
+/* ---- voice-clone front end ---- */
+/* synthesize_tokens with one speaker embedding per utterance spliced before CODEC_BOS (synthesize_clone,
+ * tts_onnx.cpp:264-318; splice :481-498).  speakers[u] = [hidden] floats or NULL; speakers == NULL is
+ * q3tts_synthesize_batch_host. */
+int q3tts_synthesize_clone_batch_host(q3tts_engine* e, int n_utt, const int64_t* ids, const int32_t* offsets, int lang,
+                                      const float* const* speakers, const q3tts_sampling* p, uint64_t seed, int ignore_eos,
+                                      float* const* pcm_out, int64_t pcm_cap, int64_t* pcm_len, int32_t* n_frames,
+                                      int64_t* codes_out);
+/* io::read_wav (src/io/wav_reader.h:13, wav_reader.cpp:28-143): mono float samples; -1 when the reference
+ * returns an empty vector.  Call with out == NULL to learn *n_samples. */
+int q3tts_read_wav_host(const char* path, float* out, int64_t cap, int64_t* n_samples, int32_t* sample_rate);
+/* io::resample (wav_reader.cpp:145-164): linear interpolation; returns the output length */
+int64_t q3tts_resample_host(const float* in, int64_t n, int32_t src_rate, int32_t dst_rate, float* out, int64_t cap);
+/* MelExtractor::extract with the settings of tts_onnx.cpp:347-354 (24 kHz, n_fft = win = 1024, hop 256, 128 HTK
+ * mels, 0-12 kHz, log power): mel[128][*frames].  Call with mel == NULL to learn *frames. */
+int q3tts_mel_host(const float* audio, int64_t n, float* mel, int64_t cap, int32_t* frames);
+/* has_speaker_encoder (tts_onnx.h:172) */
+int q3tts_has_speaker_encoder(q3tts_engine* e);
+/* run_speaker_encoder (tts_onnx.cpp:367-403): mel[128][frames] (MelExtractor layout) -> embed[spk_enc_dim], on the GPU */
+int q3tts_speaker_encoder_host(q3tts_engine* e, const float* mel, int frames, float* embed);
+/* extract_speaker_embedding (tts_onnx.cpp:331-365): wav -> 24 kHz -> mel -> speaker encoder */
+int q3tts_extract_speaker_embedding_host(q3tts_engine* e, const char* wav_path, float* embed);
 
 /* ---- text front end: the reference's byte-level BPE tokenizer ---- */
 /* Replaces leaxer_qwen::io::load_vocab / load_merges / is_tokenizer_ready / tokenize (reference

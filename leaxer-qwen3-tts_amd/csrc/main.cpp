@@ -97,12 +97,21 @@ int main(int argc, char** argv) {
     std::vector<float> audio;
     if (!ref.empty()) {
         if (!engine.has_speaker_encoder()) { fprintf(stderr, "Error: speaker encoder not available for voice clone\n"); return 1; }
-        audio = engine.synthesize_clone(prompt, ref, lang_of(lang), sp);
-    } else if (!tokens.empty()) {
-        std::vector<int64_t> ids = { config::IM_START, config::ASSISTANT, config::TTS_BOS };
+    }
+    std::vector<int64_t> ids;
+    if (!tokens.empty()) {
+        ids = { config::IM_START, config::ASSISTANT, config::TTS_BOS };
         for (char* tok = strtok(&tokens[0], ", "); tok; tok = strtok(nullptr, ", ")) ids.push_back(strtoll(tok, nullptr, 10));
         ids.push_back(config::TTS_EOS);
         ids.push_back(config::IM_END);
+    }
+    if (!ref.empty() && !ids.empty()) {
+        const std::vector<float> spk = engine.extract_speaker_embedding(ref);
+        if (spk.empty()) { fprintf(stderr, "[TTSEngine] Failed to extract speaker embedding\n"); }
+        else audio = engine.synthesize_tokens_clone(ids, spk, lang_of(lang), sp);
+    } else if (!ref.empty()) {
+        audio = engine.synthesize_clone(prompt, ref, lang_of(lang), sp);
+    } else if (!ids.empty()) {
         audio = engine.synthesize_tokens(ids, lang_of(lang), sp);
     } else audio = engine.synthesize(prompt, lang_of(lang), sp);
     if (audio.empty()) { fprintf(stderr, "Error: synthesis failed\n"); return 1; }

@@ -1,8 +1,10 @@
 // q3_capi.cpp — extern "C" surface declared in include/q3tts.h.  No exception crosses the ABI.
+#include <cstddef>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
 
+#include "q3_audio.h"
 #include "q3_bpe.h"
 #include "q3_engine.h"
 
@@ -43,6 +45,8 @@ int q3tts_default_config(const char* name, q3tts_config* o) {
     o->cd_up_rates[0] = 8; o->cd_up_rates[1] = 5; o->cd_up_rates[2] = 4; o->cd_up_rates[3] = 3;
     o->cd_tconv_trim = 0;
     o->codec_eos = 2150; o->suppress_begin = 2048; o->suppress_end = 3072;
+    // speaker encoder of the Base checkpoints [HINT: Qwen3-TTS speaker_encoder_config]: ECAPA-TDNN 512/1536 channels -> hidden
+    o->spk_enc_dim = 1024; o->spk_mel = 128; o->spk_channels = 512; o->spk_scale = 8; o->spk_se = 128; o->spk_att = 128;
     return 0;
 }
 
@@ -184,6 +188,13 @@ int q3tts_synthesize_batch_host(q3tts_engine* h, int n_utt, const int64_t* ids, 
                                 const q3tts_sampling* p, uint64_t seed, int ignore_eos,
                                 float* const* pcm_out, int64_t pcm_cap, int64_t* pcm_len, int32_t* n_frames,
                                 int64_t* codes_out) {
+    return q3tts_synthesize_clone_batch_host(h, n_utt, ids, offsets, lang, nullptr, p, seed, ignore_eos, pcm_out, pcm_cap, pcm_len, n_frames, codes_out);
+}
+
+int q3tts_synthesize_clone_batch_host(q3tts_engine* h, int n_utt, const int64_t* ids, const int32_t* offsets, int lang,
+                                      const float* const* speakers, const q3tts_sampling* p, uint64_t seed, int ignore_eos,
+                                      float* const* pcm_out, int64_t pcm_cap, int64_t* pcm_len, int32_t* n_frames,
+                                      int64_t* codes_out) {
     Q3_API_BEGIN(h)
     Engine& e = *h->e;
     const int H = e.c.hidden, G = e.c.n_groups;
@@ -194,7 +205,8 @@ int q3tts_synthesize_batch_host(q3tts_engine* h, int n_utt, const int64_t* ids, 
         for (int b = 0; b < nb; ++b) {
             const int u = u0 + b;
             int S = 0, nt = 0;
-            e.build_prompt(ids + offsets[u], offsets[u + 1] - offsets[u], lang, nullptr, prompt.data(), &S, trailing.data(), e.max_trailing, &nt);
+            e.build_prompt(ids + offsets[u], offsets[u + 1] - offsets[u], lang, speakers ? speakers[u] : nullptr, prompt.data(), &S, trailing.data(),
+                           e.max_trailing, &nt);
             e.slot_begin(b, prompt.data(), S, trailing.data(), nt, *p, seed, (uint32_t)u, ignore_eos);
         }
         int left = p->max_new_tokens;
@@ -214,6 +226,60 @@ int q3tts_synthesize_batch_host(q3tts_engine* h, int n_utt, const int64_t* ids, 
         e.codec_decode_slots(nb, pcm_out ? pcm_out + u0 : nullptr, pcm_cap, pcm_len ? pcm_len + u0 : nullptr);
         for (int b = 0; b < nb; ++b) e.slot_release(b);
     }
+    return 0;
+    Q3_API_END(h)
+}
+
+// ---- voice-clone front end (host audio code + the speaker encoder on the GPU) ----
+int q3tts_read_wav_host(const char* path, float* out, int64_t cap, int64_t* n_samples, int32_t* sample_rate) {
+    if (!path || !n_samples || !sample_rate) return -1;
+    try {
+        int sr = 0;
+        const std::vector<float> a = q3::read_wav(path, &sr);
+        if (a.empty()) return -1;
+        *n_samples = (int64_t)a.size();
+        *sample_rate = sr;
+        for (int64_t i = 0; i < (int64_t)a.size() && i < cap && out; ++i) out[i] = a[(size_t)i];
+        return 0;
+    } catch (...) { return -1; }
+}
+int64_t q3tts_resample_host(const float* in, int64_t n, int32_t src_rate, int32_t dst_rate, float* out, int64_t cap) {
+    if (n < 0 || (n > 0 && !in) || src_rate <= 0 || dst_rate <= 0) return -1;
+    try {
+        const std::vector<float> r = q3::resample_linear(std::vector<float>(in, in + n), src_rate, dst_rate);
+        for (int64_t i = 0; i < (int64_t)r.size() && i < cap && out; ++i) out[i] = r[(size_t)i];
+        return (int64_t)r.size();
+    } catch (...) { return -1; }
+}
+int q3tts_mel_host(const float* audio, int64_t n, float* mel, int64_t cap, int32_t* frames) {
+    if (n < 0 || (n > 0 && !audio) || !frames) return -1;
+    try {
+        int f = 0;
+        const std::vector<float> m = q3::log_mel(std::vector<float>(audio, audio + n), q3::MelSpec(), &f);
+        *frames = f;
+        if (m.empty()) return -1;
+        if (mel) {
+            if ((int64_t)m.size() > cap) return -1;
+            memcpy(mel, m.data(), m.size() * sizeof(float));
+        }
+        return 0;
+    } catch (...) { return -1; }
+}
+int q3tts_has_speaker_encoder(q3tts_engine* h) { return h && h->e && h->e->has_speaker() ? 1 : 0; }
+int q3tts_speaker_encoder_host(q3tts_engine* h, const float* mel, int frames, float* embed) {
+    Q3_API_BEGIN(h) h->e->speaker_encode(mel, frames, embed); return 0; Q3_API_END(h)
+}
+int q3tts_extract_speaker_embedding_host(q3tts_engine* h, const char* wav_path, float* embed) {
+    Q3_API_BEGIN(h)
+    if (!h->e->has_speaker()) throw q3::Error("model has no speaker encoder");
+    int sr = 0;
+    std::vector<float> a = q3::read_wav(wav_path, &sr);
+    if (a.empty()) throw q3::Error(std::string("Failed to read audio: ") + wav_path);
+    if (sr != 24000) a = q3::resample_linear(a, sr, 24000);
+    int frames = 0;
+    const std::vector<float> m = q3::log_mel(a, q3::MelSpec(), &frames);
+    if (m.empty()) throw q3::Error("Failed to extract mel spectrogram");
+    h->e->speaker_encode(m.data(), frames, embed);
     return 0;
     Q3_API_END(h)
 }
@@ -260,8 +326,10 @@ void read_header(FILE* f, q3tts_config* cfg, uint32_t* n) {
     if (memcmp(magic, kMagic, 8) != 0) throw q3::Error("not a Q3TW0001 weights file");
     uint32_t cfg_bytes = 0;
     rd(f, &cfg_bytes, 4);
-    if (cfg_bytes != sizeof(q3tts_config)) throw q3::Error("weights file: config struct size mismatch");
-    rd(f, cfg, sizeof *cfg);
+    // files written before the speaker-encoder fields existed carry a shorter config: the missing tail reads as zero
+    if (cfg_bytes > sizeof(q3tts_config) || cfg_bytes < offsetof(q3tts_config, spk_enc_dim)) throw q3::Error("weights file: config struct size mismatch");
+    memset(cfg, 0, sizeof *cfg);
+    rd(f, cfg, cfg_bytes);
     rd(f, n, 4);
 }
 } // namespace

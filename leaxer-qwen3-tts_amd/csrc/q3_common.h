@@ -205,4 +205,23 @@ void launch_rope_store(float* qkv, int ld, int T, int nq, int nkv, int d, const 
 void launch_dwconv_ln(const float* x, int T, int C, const float* dw_w, const float* dw_b, const float* ln_w,
                       const float* ln_b, float* out, hipStream_t s);
 
+
+// ---- speaker encoder (q3_speaker_kernels.hip) ----
+struct SpkConvArgs {
+    const float* x = nullptr; int ldx = 0;   // [T][ldx] time-major (or [Cin][ldx] when x_channel_major)
+    const float* x2 = nullptr; int ldx2 = 0; // optional second input added to x before the convolution
+    int x_channel_major = 0;
+    int T = 0, Cin = 0, Cout = 0, k = 1, dil = 1;
+    int act = 0;                              // 0 none, 1 ReLU, 2 tanh(ReLU)
+    const float* W = nullptr;                 // [k][Cin][Cout]
+    const float* bias = nullptr;
+    float* y = nullptr; int ldy = 0;
+};
+void launch_spk_conv(const SpkConvArgs& a, hipStream_t s);
+void launch_spk_repack(const float* w, float* out, int cout, int cin, int k, hipStream_t s);
+void launch_spk_colstats(const float* x, int ld, int T, int C, float* mean, float* sd, hipStream_t s);
+void launch_spk_se_gate(const float* y, const float* g, float* h, float* cat, int ld_cat, int T, int C, hipStream_t s);
+void launch_spk_asp_input(const float* x, const float* mean, const float* sd, float* out, int T, int C, hipStream_t s);
+void launch_spk_asp_pool(const float* scores, const float* x, int T, int C, float* out, hipStream_t s);
+
 } // namespace q3

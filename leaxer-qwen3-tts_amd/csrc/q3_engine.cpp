@@ -147,6 +147,28 @@ Engine::Engine(const q3tts_config& cfg, int device_, int max_batch, int max_ctx_
     add("cd.dec.snake_out.beta", {OD}, TK_SNAKE, false);
     add("cd.dec.conv_out.w", {1, OD, 7}, TK_W, false, nullptr, 0.002f);
     add("cd.dec.conv_out.b", {1}, TK_BIAS, false);
+    if (c.spk_enc_dim > 0) { // ECAPA-TDNN speaker encoder (clone path), torch Conv1d layout [out][in][k], fp32
+        if (c.spk_scale < 2 || c.spk_scale > 16 || c.spk_channels % c.spk_scale || c.spk_mel < 1 || c.spk_se < 1 || c.spk_att < 1)
+            throw Error("speaker encoder dims out of range");
+        const int SC = c.spk_channels, sub = SC / c.spk_scale;
+        auto conv = [&](const std::string& n, int cout, int cin, int k) {
+            add(n + ".w", {cout, cin, k}, TK_W, false, nullptr, 1.0f / sqrtf((float)(cin * k)));
+            add(n + ".b", {cout}, TK_BIAS, false);
+        };
+        conv("spk.tdnn0", SC, c.spk_mel, 5);
+        for (int i = 0; i < 3; ++i) {
+            const std::string p = "spk.blocks." + std::to_string(i) + ".";
+            conv(p + "tdnn1", SC, SC, 1);
+            for (int j = 0; j < c.spk_scale - 1; ++j) conv(p + "res2net." + std::to_string(j), sub, sub, 3);
+            conv(p + "tdnn2", SC, SC, 1);
+            conv(p + "se1", c.spk_se, SC, 1);
+            conv(p + "se2", SC, c.spk_se, 1);
+        }
+        conv("spk.mfa", 3 * SC, 3 * SC, 1);
+        conv("spk.asp.tdnn", c.spk_att, 9 * SC, 1);
+        conv("spk.asp.conv", 3 * SC, c.spk_att, 1);
+        conv("spk.fc", c.spk_enc_dim, 6 * SC, 1);
+    }
 
     // ---- workspaces ----
     rows_max = std::max(2 * B, 16);
@@ -235,6 +257,7 @@ Engine::~Engine() {
     if (stream) (void)hipStreamSynchronize(stream);
     for (auto& kv : graphs) (void)hipGraphExecDestroy(kv.second);
     codec_free();
+    speaker_free();
     for (void* p : allocs) (void)hipFree(p);
     if (active_h) (void)hipHostFree(active_h);
     if (ev0) (void)hipEventDestroy(ev0);
@@ -311,6 +334,7 @@ void Engine::finalize() {
     cp_head.clear(); cp_embed_w.clear();
     for (int j = 0; j < c.n_groups - 1; ++j) { cp_head.push_back(bp("cp.head." + std::to_string(j))); cp_embed_w.push_back(bp("cp.embed." + std::to_string(j))); }
     codec_finalize();
+    speaker_finalize();
     finalized = true;
     // tts_pad_embed_ = text_project(TTS_PAD) (tts_onnx.cpp:459-463), model-wide constant kept on device
     if (TTS_PAD < c.text_vocab) {

@@ -40,6 +40,7 @@ struct DecStack {
 };
 
 struct CodecW; // q3_codec.cpp
+struct SpeakerW; // q3_speaker.cpp
 
 class Engine {
 public:
@@ -98,6 +99,14 @@ public:
     int64_t codec_run(const int32_t* codes_dev, int F, float** pcm_dev, int lane = 0); // returns sample count
     void codec_decode_slots(int nb, float* const* pcm_out, int64_t cap, int64_t* lens);
     void codec_free();
+
+    // ---- speaker encoder of the clone path (q3_speaker.cpp) ----
+    SpeakerW* spk = nullptr;
+    bool has_speaker() const { return c.spk_enc_dim > 0; }
+    void speaker_finalize();
+    void speaker_free();
+    // mel [spk_mel][frames] (the reference MelExtractor layout) on the host -> embedding [spk_enc_dim] on the host
+    void speaker_encode(const float* mel, int frames, float* out);
 
     // ---- internals ----
     DecStack talker, cp;

@@ -43,6 +43,7 @@ TTSEngine::TTSEngine(const std::string& model_dir) {
         if (!h_) { error_msg_ = q3tts_last_error(nullptr); return; }
         if (q3tts_load_weights_file(h_, path.c_str()) != 0) { error_msg_ = q3tts_last_error(h_); return; }
     }
+    spk_dim_ = cfg.spk_enc_dim;
     // tokenizer files: where the reference looks (tts_onnx.cpp:110-121: <parent of model_dir>/models/
     // Qwen3-TTS-12Hz-0.6B-Base/{vocab.json,merges.txt}), then model_dir itself.  Present but unreadable is
     // an error, absent is a warning and text synthesis stays unavailable — as in the reference.
@@ -112,10 +113,42 @@ std::vector<std::vector<float>> TTSEngine::synthesize_batch(const std::vector<st
     return synthesize_tokens_batch(ids, lang, params);
 }
 
-std::vector<float> TTSEngine::synthesize_clone(const std::string&, const std::string&, Language, const SamplingParams&) {
+bool TTSEngine::has_speaker_encoder() const { return h_ && q3tts_has_speaker_encoder(h_); }
+
+std::vector<float> TTSEngine::synthesize_clone(const std::string& text, const std::string& ref_audio_path, Language lang,
+                                               const SamplingParams& params) { // reference tts_onnx.cpp:264-318
     if (!ready_) return {};
-    std::cerr << "[TTSEngine] Speaker encoder not available" << std::endl; // reference tts_onnx.cpp:269-272
-    return {};
+    if (!has_speaker_encoder()) {
+        std::cerr << "[TTSEngine] Speaker encoder not available" << std::endl;
+        return {};
+    }
+    const std::vector<float> spk = extract_speaker_embedding(ref_audio_path);
+    if (spk.empty()) {
+        std::cerr << "[TTSEngine] Failed to extract speaker embedding" << std::endl;
+        return {};
+    }
+    std::vector<int64_t> ids;
+    if (!wrap_text(text, ids)) return {};
+    return synthesize_tokens_clone(ids, spk, lang, params);
+}
+
+std::vector<float> TTSEngine::synthesize_tokens_clone(const std::vector<int64_t>& token_ids, const std::vector<float>& speaker_embed,
+                                                      Language lang, const SamplingParams& params) {
+    if (!ready_) return {};
+    q3tts_sampling sp{ params.temperature, params.top_p, params.top_k, params.repetition_penalty, params.max_new_tokens };
+    const int32_t offs[2] = { 0, (int32_t)token_ids.size() };
+    const int64_t cap = (int64_t)params.max_new_tokens * 1920 + 1920;
+    std::vector<float> pcm((size_t)cap);
+    float* ptr = pcm.data();
+    const float* spk = speaker_embed.empty() ? nullptr : speaker_embed.data();
+    int64_t len = 0;
+    int32_t frames = 0;
+    if (q3tts_synthesize_clone_batch_host(h_, 1, token_ids.data(), offs, lang_index(lang), &spk, &sp, seed_, 0, &ptr, cap, &len, &frames, nullptr) != 0) {
+        std::cerr << "[TTSEngine] Synthesis error: " << q3tts_last_error(h_) << std::endl;
+        return {};
+    }
+    pcm.resize((size_t)std::min<int64_t>(len, cap));
+    return pcm;
 }
 
 std::vector<float> TTSEngine::synthesize_speaker(const std::string& text, Speaker, Language lang, const SamplingParams& params) {
@@ -123,7 +156,15 @@ std::vector<float> TTSEngine::synthesize_speaker(const std::string& text, Speake
     return synthesize(text, lang, params);
 }
 
-std::vector<float> TTSEngine::extract_speaker_embedding(const std::string&) { return {}; } // :332
+std::vector<float> TTSEngine::extract_speaker_embedding(const std::string& audio_path) { // reference tts_onnx.cpp:331-365
+    if (!has_speaker_encoder()) return {};
+    std::vector<float> embed((size_t)spk_dim_);
+    if (q3tts_extract_speaker_embedding_host(h_, audio_path.c_str(), embed.data()) != 0) {
+        std::cerr << "[TTSEngine] " << q3tts_last_error(h_) << std::endl; // "Failed to read audio: <path>" / "Failed to extract mel spectrogram"
+        return {};
+    }
+    return embed;
+}
 
 std::vector<std::vector<float>> TTSEngine::synthesize_tokens_batch(const std::vector<std::vector<int64_t>>& token_ids,
                                                                    Language lang, const SamplingParams& params) {

@@ -72,7 +72,10 @@ public:
     // ids of `text` from the loaded tokenizer (reference io::tokenize, src/io/tokenizer.h:22)
     std::vector<int32_t> tokenize(const std::string& text) const;
 
-    bool has_speaker_encoder() const { return false; } // speaker_encoder.onnx has no HIP counterpart yet
+    // clone with a ready speaker embedding (what synthesize_clone does after extract_speaker_embedding)
+    std::vector<float> synthesize_tokens_clone(const std::vector<int64_t>& token_ids, const std::vector<float>& speaker_embed,
+                                               Language lang = Language::Auto, const SamplingParams& params = SamplingParams());
+    bool has_speaker_encoder() const; // true when the weight file carries the spk.* tensors (reference: speaker_encoder.onnx present)
     bool is_ready() const { return ready_; }
     const std::string& get_error() const { return error_msg_; }
 
@@ -84,6 +87,7 @@ private:
     std::string error_msg_;
     uint64_t seed_ = 0;
     int max_batch_ = 1;
+    int spk_dim_ = 0;
 };
 
 inline int64_t language_to_codec_id(Language lang) { // reference src/tts_onnx.h:230-238

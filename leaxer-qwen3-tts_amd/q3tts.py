@@ -27,6 +27,8 @@ _CFG_FIELDS = [
     ("cd_decoder_dim", C.c_int32), ("cd_n_blocks", C.c_int32), ("cd_up_rates", C.c_int32 * 8),
     ("cd_tconv_trim", C.c_int32),
     ("codec_eos", C.c_int32), ("suppress_begin", C.c_int32), ("suppress_end", C.c_int32),
+    ("spk_enc_dim", C.c_int32), ("spk_mel", C.c_int32), ("spk_channels", C.c_int32), ("spk_scale", C.c_int32),
+    ("spk_se", C.c_int32), ("spk_att", C.c_int32),
 ]
 
 
@@ -44,7 +46,7 @@ class Config(C.Structure):
     def from_dict(cls, d):
         c = cls()
         for n, t in _CFG_FIELDS:
-            v = d[n]
+            v = d[n] if n in d or not n.startswith("spk_") else 0
             if hasattr(t, "_length_"):
                 arr = t()
                 for i, x in enumerate(v):
@@ -78,6 +80,8 @@ EXPORTS = [
     "q3tts_counters", "q3tts_read_weights_config", "q3tts_load_weights_file", "q3tts_save_weights_file",
     "q3tts_tokenizer_create", "q3tts_tokenizer_destroy", "q3tts_tokenizer_load_vocab", "q3tts_tokenizer_load_merges",
     "q3tts_tokenizer_ready", "q3tts_tokenize",
+    "q3tts_synthesize_clone_batch_host", "q3tts_read_wav_host", "q3tts_resample_host", "q3tts_mel_host",
+    "q3tts_has_speaker_encoder", "q3tts_speaker_encoder_host", "q3tts_extract_speaker_embedding_host",
 ]
 
 _lib = None
@@ -132,6 +136,14 @@ def lib():
     L.q3tts_read_weights_config.argtypes = [C.c_char_p, C.POINTER(Config)]
     L.q3tts_load_weights_file.argtypes = [vp, C.c_char_p]
     L.q3tts_save_weights_file.argtypes = [vp, C.c_char_p]
+    L.q3tts_synthesize_clone_batch_host.argtypes = [vp, i32, vp, vp, i32, vp, C.POINTER(Sampling), C.c_uint64, i32, vp, i64, vp, vp, vp]
+    L.q3tts_read_wav_host.argtypes = [C.c_char_p, vp, i64, C.POINTER(i64), C.POINTER(C.c_int32)]
+    L.q3tts_resample_host.restype = i64
+    L.q3tts_resample_host.argtypes = [vp, i64, i32, i32, vp, i64]
+    L.q3tts_mel_host.argtypes = [vp, i64, vp, i64, C.POINTER(C.c_int32)]
+    L.q3tts_has_speaker_encoder.argtypes = [vp]
+    L.q3tts_speaker_encoder_host.argtypes = [vp, vp, i32, vp]
+    L.q3tts_extract_speaker_embedding_host.argtypes = [vp, C.c_char_p, vp]
     L.q3tts_tokenizer_create.restype = vp
     L.q3tts_tokenizer_create.argtypes = []
     L.q3tts_tokenizer_destroy.restype = None
@@ -333,8 +345,26 @@ class Engine:
         codes = self.slot_codes(slot)
         return codes
 
-    def synthesize_batch(self, token_lists, sp, lang=0, seed=0, ignore_eos=False, want_codes=True):
-        """synthesize_tokens (reference src/tts_onnx.cpp:405-436) for a batch of utterances."""
+    # ---- voice-clone front end ----
+    @property
+    def has_speaker_encoder(self):
+        return bool(self.L.q3tts_has_speaker_encoder(self.h))
+
+    def speaker_encoder(self, mel):
+        """run_speaker_encoder (tts_onnx.cpp:367-403): mel [128][frames] -> [spk_enc_dim]"""
+        mel = np.ascontiguousarray(mel, np.float32)
+        out = np.zeros(self.cfg.spk_enc_dim, np.float32)
+        self._ck(self.L.q3tts_speaker_encoder_host(self.h, _p(mel), mel.shape[1], _p(out)))
+        return out
+
+    def extract_speaker_embedding(self, wav_path):
+        out = np.zeros(self.cfg.spk_enc_dim, np.float32)
+        self._ck(self.L.q3tts_extract_speaker_embedding_host(self.h, os.fsencode(wav_path), _p(out)))
+        return out
+
+    def synthesize_batch(self, token_lists, sp, lang=0, seed=0, ignore_eos=False, want_codes=True, speakers=None):
+        """synthesize_tokens (reference src/tts_onnx.cpp:405-436) for a batch of utterances; `speakers` (one
+        [hidden] embedding or None per utterance) makes it synthesize_clone (:264-318)."""
         n = len(token_lists)
         flat = np.ascontiguousarray(np.concatenate([np.asarray(t, np.int64) for t in token_lists]))
         offs = np.zeros(n + 1, np.int32)
@@ -345,9 +375,13 @@ class Engine:
         pcm_len = np.zeros(n, np.int64)
         nfr = np.zeros(n, np.int32)
         codes = np.zeros((n, sp.max_new_tokens, self.cfg.n_groups), np.int64) if want_codes else None
-        self._ck(self.L.q3tts_synthesize_batch_host(self.h, n, _p(flat), _p(offs), lang, C.byref(sp), seed, int(ignore_eos),
-                                                    C.cast(ptrs, C.c_void_p), cap, _p(pcm_len), _p(nfr),
-                                                    _p(codes) if want_codes else None))
+        spk_keep, spk_ptrs = [], None
+        if speakers is not None:
+            spk_keep = [None if s_ is None else np.ascontiguousarray(s_, np.float32) for s_ in speakers]
+            spk_ptrs = C.cast((C.c_void_p * n)(*[None if a is None else a.ctypes.data for a in spk_keep]), C.c_void_p)
+        self._ck(self.L.q3tts_synthesize_clone_batch_host(self.h, n, _p(flat), _p(offs), lang, spk_ptrs, C.byref(sp), seed, int(ignore_eos),
+                                                          C.cast(ptrs, C.c_void_p), cap, _p(pcm_len), _p(nfr),
+                                                          _p(codes) if want_codes else None))
         outs = [pcm[i][: pcm_len[i]] for i in range(n)]
         cl = [codes[i, : nfr[i]] for i in range(n)] if want_codes else None
         return outs, cl, nfr
@@ -373,6 +407,39 @@ class Engine:
         w, kv = C.c_double(0), C.c_double(0)
         self._ck(self.L.q3tts_decode_step_bytes(self.h, C.byref(w), C.byref(kv)))
         return w.value, kv.value
+
+
+def read_wav(path):
+    """io::read_wav (reference src/io/wav_reader.cpp:28-143): (mono float32 samples, sample_rate) or None.  Host-only."""
+    n, sr = C.c_int64(0), C.c_int32(0)
+    if lib().q3tts_read_wav_host(os.fsencode(path), None, 0, C.byref(n), C.byref(sr)) != 0:
+        return None
+    out = np.zeros(n.value, np.float32)
+    lib().q3tts_read_wav_host(os.fsencode(path), _p(out), n.value, C.byref(n), C.byref(sr))
+    return out, sr.value
+
+
+def resample(audio, src_rate, dst_rate):
+    """io::resample (wav_reader.cpp:145-164).  Host-only."""
+    a = np.ascontiguousarray(audio, np.float32)
+    n = lib().q3tts_resample_host(_p(a), a.size, src_rate, dst_rate, None, 0)
+    if n < 0:
+        raise ValueError("q3tts_resample_host failed")
+    out = np.zeros(max(n, 1), np.float32)
+    lib().q3tts_resample_host(_p(a), a.size, src_rate, dst_rate, _p(out), n)
+    return out[:n]
+
+
+def log_mel(audio):
+    """MelExtractor::extract with the clone path's settings (tts_onnx.cpp:347-354): [128][frames].  Host-only."""
+    a = np.ascontiguousarray(audio, np.float32)
+    fr = C.c_int32(0)
+    if lib().q3tts_mel_host(_p(a), a.size, None, 0, C.byref(fr)) != 0:
+        return np.zeros((128, 0), np.float32)
+    out = np.zeros((128, fr.value), np.float32)
+    if lib().q3tts_mel_host(_p(a), a.size, _p(out), out.size, C.byref(fr)) != 0:
+        raise RuntimeError("q3tts_mel_host failed")
+    return out
 
 
 class Tokenizer:

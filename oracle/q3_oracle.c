@@ -124,6 +124,8 @@ struct q3o_model {
     conv_w conv_in, conv_out;
     block_w blk[8];
     snake_w snake_out;
+    /* speaker encoder (ECAPA-TDNN), torch Conv1d layout [out][in][k] */
+    conv_w s_tdnn0, s_tdnn1[3], s_res[3][16], s_tdnn2[3], s_se1[3], s_se2[3], s_mfa, s_asp_tdnn, s_asp_conv, s_fc;
     /* host-logic state (tts_onnx.h:182-186) */
     float *last_hidden, *trailing, *tts_pad;
     int trailing_len;
@@ -209,6 +211,21 @@ q3o_model* q3o_create(const q3o_config* cfg, int max_ctx) {
     int OD = D >> c->cd_n_blocks;
     alloc_snake(&m->snake_out, OD);
     alloc_conv(&m->conv_out, OD, 1, 7, 0);
+    if (c->spk_enc_dim > 0) {
+        int SC = c->spk_channels, sub = SC / c->spk_scale;
+        alloc_conv(&m->s_tdnn0, c->spk_mel, SC, 5, 0);
+        for (int i = 0; i < 3; ++i) {
+            alloc_conv(&m->s_tdnn1[i], SC, SC, 1, 0);
+            for (int j = 0; j < c->spk_scale - 1; ++j) alloc_conv(&m->s_res[i][j], sub, sub, 3, 0);
+            alloc_conv(&m->s_tdnn2[i], SC, SC, 1, 0);
+            alloc_conv(&m->s_se1[i], SC, c->spk_se, 1, 0);
+            alloc_conv(&m->s_se2[i], c->spk_se, SC, 1, 0);
+        }
+        alloc_conv(&m->s_mfa, 3 * SC, 3 * SC, 1, 0);
+        alloc_conv(&m->s_asp_tdnn, 9 * SC, c->spk_att, 1, 0);
+        alloc_conv(&m->s_asp_conv, c->spk_att, 3 * SC, 1, 0);
+        alloc_conv(&m->s_fc, 6 * SC, c->spk_enc_dim, 1, 0);
+    }
     m->last_hidden = zalloc(H); m->tts_pad = zalloc(H); m->trailing = NULL; m->trailing_len = 0;
     return m;
 }
@@ -238,6 +255,13 @@ void q3o_destroy(q3o_model* m) {
         }
     }
     free(m->snake_out.alpha); free(m->snake_out.beta);
+    if (c->spk_enc_dim > 0) {
+        free_conv(&m->s_tdnn0); free_conv(&m->s_mfa); free_conv(&m->s_asp_tdnn); free_conv(&m->s_asp_conv); free_conv(&m->s_fc);
+        for (int i = 0; i < 3; ++i) {
+            free_conv(&m->s_tdnn1[i]); free_conv(&m->s_tdnn2[i]); free_conv(&m->s_se1[i]); free_conv(&m->s_se2[i]);
+            for (int j = 0; j < c->spk_scale - 1; ++j) free_conv(&m->s_res[i][j]);
+        }
+    }
     free(m->last_hidden); free(m->tts_pad); free(m->trailing);
     free(m);
 }
@@ -321,6 +345,20 @@ static int resolve(q3o_model* m, const char* name, slot* s) {
         if (!strcmp(f, "pw2.w")) { s->p = us->pw2_w; s->n = (int64_t)4 * CH * CH; return 0; }
         if (!strcmp(f, "pw2.b")) { s->p = us->pw2_b; s->n = CH; return 0; }
         if (!strcmp(f, "gamma")) { s->p = us->gamma; s->n = CH; return 0; }
+        return -1;
+    }
+    if (c->spk_enc_dim > 0 && !strncmp(name, "spk.", 4)) {
+        if (sscanf(name, "spk.tdnn0.%63s", f) == 1) return conv_slot(&m->s_tdnn0, f, 0, 0, s);
+        if (sscanf(name, "spk.blocks.%d.res2net.%d.%63s", &i, &j, f) == 3 && i >= 0 && i < 3 && j >= 0 && j < c->spk_scale - 1)
+            return conv_slot(&m->s_res[i][j], f, 0, 0, s);
+        if (sscanf(name, "spk.blocks.%d.tdnn1.%63s", &i, f) == 2 && i >= 0 && i < 3) return conv_slot(&m->s_tdnn1[i], f, 0, 0, s);
+        if (sscanf(name, "spk.blocks.%d.tdnn2.%63s", &i, f) == 2 && i >= 0 && i < 3) return conv_slot(&m->s_tdnn2[i], f, 0, 0, s);
+        if (sscanf(name, "spk.blocks.%d.se1.%63s", &i, f) == 2 && i >= 0 && i < 3) return conv_slot(&m->s_se1[i], f, 0, 0, s);
+        if (sscanf(name, "spk.blocks.%d.se2.%63s", &i, f) == 2 && i >= 0 && i < 3) return conv_slot(&m->s_se2[i], f, 0, 0, s);
+        if (sscanf(name, "spk.mfa.%63s", f) == 1) return conv_slot(&m->s_mfa, f, 0, 0, s);
+        if (sscanf(name, "spk.asp.tdnn.%63s", f) == 1) return conv_slot(&m->s_asp_tdnn, f, 0, 0, s);
+        if (sscanf(name, "spk.asp.conv.%63s", f) == 1) return conv_slot(&m->s_asp_conv, f, 0, 0, s);
+        if (sscanf(name, "spk.fc.%63s", f) == 1) return conv_slot(&m->s_fc, f, 0, 0, s);
         return -1;
     }
     if (sscanf(name, "cd.dec.conv_in.%63s", f) == 1) return conv_slot(&m->conv_in, f, 0, 0, s);
@@ -949,6 +987,108 @@ static int64_t vocoder_run(q3o_model* m, const int64_t* codes, int F, int stage,
 
 int64_t q3o_vocoder(q3o_model* m, const int64_t* codes, int F, float* pcm, int64_t cap) { return vocoder_run(m, codes, F, -1, pcm, cap); }
 int64_t q3o_vocoder_tap(q3o_model* m, const int64_t* codes, int F, int stage, float* out, int64_t cap) { return vocoder_run(m, codes, F, stage, out, cap); }
+
+/* ------------------------------------------------------------------------------------------ */
+/* speaker encoder — run_speaker_encoder (src/tts_onnx.cpp:367-403).  The reference runs an opaque   */
+/* speaker_encoder.onnx; the network restated here is the published ECAPA-TDNN of the Qwen audio    */
+/* stack [HINT: transformers models/qwen2_5_omni/modeling_qwen2_5_omni.py:2412-2716], pinned on     */
+/* tests/golden/hf_speaker.npz.  Activations are channel-major [C][T]; every Conv1d uses "same"     */
+/* reflect padding (so frames must exceed the largest pad, 4).                                      */
+/* ------------------------------------------------------------------------------------------ */
+static inline int reflect_idx(int i, int T) { return i < 0 ? -i : (i >= T ? 2 * (T - 1) - i : i); }
+
+/* y[co][t] = act(b[co] + sum_{ci,j} W[co][ci][j] * (x[ci] (+ x2[ci]))[reflect(t + (j - k/2) * dil)]); act: 0 none, 1 relu */
+static void conv1d_reflect(const float* x, const float* x2, int T, const conv_w* c, int dil, int act, float* y) {
+    const int k = c->k, half = k / 2;
+#pragma omp parallel for schedule(static) if (c->cout * T > 4096)
+    for (int co = 0; co < c->cout; ++co) {
+        for (int t = 0; t < T; ++t) {
+            float acc = c->b[co];
+            for (int ci = 0; ci < c->cin; ++ci) {
+                const float* w = c->w + ((size_t)co * c->cin + ci) * k;
+                const float* xr = x + (size_t)ci * T;
+                const float* xr2 = x2 ? x2 + (size_t)ci * T : NULL;
+                for (int j = 0; j < k; ++j) {
+                    const int src = reflect_idx(t + (j - half) * dil, T);
+                    const float v = xr2 ? xr[src] + xr2[src] : xr[src];
+                    acc = fmaf(w[j], v, acc);
+                }
+            }
+            y[(size_t)co * T + t] = act == 1 ? (acc > 0.f ? acc : 0.f) : acc;
+        }
+    }
+}
+
+int q3o_speaker_encoder(q3o_model* m, const float* mel, int T, float* out) {
+    const q3o_config* c = &m->c;
+    if (c->spk_enc_dim <= 0) FAIL("model has no speaker encoder");
+    if (T < 5) FAIL("speaker encoder needs at least 5 mel frames (reflect padding), got %d", T);
+    const int SC = c->spk_channels, sub = SC / c->spk_scale, C3 = 3 * SC;
+    float* h = zalloc((size_t)SC * T);       /* block input / residual */
+    float* a = zalloc((size_t)SC * T);
+    float* r2 = zalloc((size_t)SC * T);
+    float* cc = zalloc((size_t)SC * T);
+    float* cat = zalloc((size_t)C3 * T);
+    conv1d_reflect(mel, NULL, T, &m->s_tdnn0, 1, 1, h);
+    for (int i = 0; i < 3; ++i) {
+        conv1d_reflect(h, NULL, T, &m->s_tdnn1[i], 1, 1, a);
+        /* Res2Net: chunk 0 passes through, chunk 1 = f(chunk 1), chunk j = f(chunk j + out j-1) */
+        memcpy(r2, a, (size_t)sub * T * sizeof(float));
+        for (int j = 1; j < c->spk_scale; ++j)
+            conv1d_reflect(a + (size_t)j * sub * T, j >= 2 ? r2 + (size_t)(j - 1) * sub * T : NULL, T, &m->s_res[i][j - 1], i + 2, 1,
+                           r2 + (size_t)j * sub * T);
+        conv1d_reflect(r2, NULL, T, &m->s_tdnn2[i], 1, 1, cc);
+        /* squeeze-excitation: per-channel gate from the time mean */
+        float* mean = zalloc(SC); float* s1 = zalloc(c->spk_se); float* g = zalloc(SC);
+        for (int ch = 0; ch < SC; ++ch) { float s = 0.f; for (int t = 0; t < T; ++t) s += cc[(size_t)ch * T + t]; mean[ch] = s / (float)T; }
+        conv1d_reflect(mean, NULL, 1, &m->s_se1[i], 1, 1, s1);
+        conv1d_reflect(s1, NULL, 1, &m->s_se2[i], 1, 0, g);
+        for (int ch = 0; ch < SC; ++ch) {
+            const float gate = 1.0f / (1.0f + expf(-g[ch]));
+            for (int t = 0; t < T; ++t) {
+                const float v = cc[(size_t)ch * T + t] * gate + h[(size_t)ch * T + t];
+                h[(size_t)ch * T + t] = v;
+                cat[((size_t)i * SC + ch) * T + t] = v;
+            }
+        }
+        free(mean); free(s1); free(g);
+    }
+    float* mf = zalloc((size_t)C3 * T);
+    conv1d_reflect(cat, NULL, T, &m->s_mfa, 1, 1, mf);
+    /* attentive statistics pooling */
+    float* att_in = zalloc((size_t)3 * C3 * T);
+    memcpy(att_in, mf, (size_t)C3 * T * sizeof(float));
+    for (int ch = 0; ch < C3; ++ch) {
+        const float* x = mf + (size_t)ch * T;
+        float mu = 0.f;
+        for (int t = 0; t < T; ++t) mu += x[t] / (float)T;   /* sum of (1/T)*x, as the masked mean is written */
+        float var = 0.f;
+        for (int t = 0; t < T; ++t) { const float d = x[t] - mu; var += d * d / (float)T; }
+        const float sd = sqrtf(var > 1e-12f ? var : 1e-12f);
+        for (int t = 0; t < T; ++t) { att_in[((size_t)C3 + ch) * T + t] = mu; att_in[((size_t)2 * C3 + ch) * T + t] = sd; }
+    }
+    float* at = zalloc((size_t)c->spk_att * T);
+    conv1d_reflect(att_in, NULL, T, &m->s_asp_tdnn, 1, 1, at);
+    for (size_t i = 0; i < (size_t)c->spk_att * T; ++i) at[i] = tanhf(at[i]);
+    float* w = zalloc((size_t)C3 * T);
+    conv1d_reflect(at, NULL, T, &m->s_asp_conv, 1, 0, w);
+    float* pooled = zalloc((size_t)2 * C3);
+    for (int ch = 0; ch < C3; ++ch) {
+        float* wr = w + (size_t)ch * T;
+        const float* x = mf + (size_t)ch * T;
+        q3o_softmax(wr, T);
+        float mu = 0.f;
+        for (int t = 0; t < T; ++t) mu += wr[t] * x[t];
+        float var = 0.f;
+        for (int t = 0; t < T; ++t) { const float d = x[t] - mu; var += wr[t] * d * d; }
+        pooled[ch] = mu;
+        pooled[C3 + ch] = sqrtf(var > 1e-12f ? var : 1e-12f);
+    }
+    conv1d_reflect(pooled, NULL, 1, &m->s_fc, 1, 0, out);
+    free(h); free(a); free(r2); free(cc); free(cat); free(mf); free(att_in); free(at); free(w); free(pooled);
+    return 0;
+}
+
 
 /* synthesize_tokens (tts_onnx.cpp:405-436) */
 int64_t q3o_synthesize_tokens(q3o_model* m, const int64_t* ids, int n_ids, int lang, const q3o_sampling* sp,

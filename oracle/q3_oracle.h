@@ -51,6 +51,10 @@ typedef struct q3o_config {
     int32_t cd_tconv_trim;    /* 0: trim k-s on BOTH sides (transformers code as written), 1: right only */
     /* generation-loop constants (src/tts_onnx.h:50-51, tts_onnx.cpp:803-807) */
     int32_t codec_eos, suppress_begin, suppress_end;
+    /* speaker encoder of the voice-clone path (speaker_encoder.onnx, src/tts_onnx.cpp:367-403): ECAPA-TDNN
+     * [HINT: transformers qwen2_5_omni ECAPA_TimeDelayNet].  spk_enc_dim == 0: no speaker encoder.
+     * Channel plan (C, C, C, C, 3C), kernels (5,3,3,3,1), dilations (1,2,3,4,1). */
+    int32_t spk_enc_dim, spk_mel, spk_channels, spk_scale, spk_se, spk_att;
 } q3o_config;
 
 /* src/tts_onnx.h:99-105 */
@@ -86,6 +90,10 @@ int64_t q3o_vocoder_len(const q3o_config* cfg, int F);
 /* codec-decoder intermediate taps for kernel-level parity: stage 0 = after pre-transformer+norm
  * [F][H]; 1 = after upsample stages [4F][H]; 2 = after decoder.conv_in [4F][D]; 3.. = after block i */
 int64_t q3o_vocoder_tap(q3o_model* m, const int64_t* codes, int F, int stage, float* out, int64_t cap);
+
+/* run_speaker_encoder (tts_onnx.cpp:367-403): mel [n_mels][frames] as MelExtractor::extract returns it
+ * (the session input is its transpose [1, frames, n_mels]); out [spk_enc_dim].  frames >= 5. */
+int q3o_speaker_encoder(q3o_model* m, const float* mel, int frames, float* out);
 
 /* ---- sampler (tts_onnx.cpp:878-950) with a counter-based RNG instead of mt19937 ---- */
 float q3o_rng_uniform(uint64_t seed, uint32_t stream, uint32_t frame, uint32_t group);

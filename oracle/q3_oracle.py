@@ -27,6 +27,8 @@ _CFG_FIELDS = [
     ("cd_decoder_dim", C.c_int32), ("cd_n_blocks", C.c_int32), ("cd_up_rates", C.c_int32 * 8),
     ("cd_tconv_trim", C.c_int32),
     ("codec_eos", C.c_int32), ("suppress_begin", C.c_int32), ("suppress_end", C.c_int32),
+    ("spk_enc_dim", C.c_int32), ("spk_mel", C.c_int32), ("spk_channels", C.c_int32), ("spk_scale", C.c_int32),
+    ("spk_se", C.c_int32), ("spk_att", C.c_int32),
 ]
 
 
@@ -44,7 +46,7 @@ class Config(C.Structure):
     def from_dict(cls, d):
         c = cls()
         for n, t in _CFG_FIELDS:
-            v = d[n]
+            v = d[n] if n in d or not n.startswith("spk_") else 0   # configs saved before the speaker rows existed
             if hasattr(t, "_length_"):
                 arr = t()
                 for i, x in enumerate(v):
@@ -76,7 +78,8 @@ def config_06b():
         cd_rope_theta=10000.0, cd_rms_eps=1e-5,
         cd_n_up=2, cd_up_ratios=[2, 2, 0, 0], cd_decoder_dim=1536, cd_n_blocks=4,
         cd_up_rates=[8, 5, 4, 3, 0, 0, 0, 0], cd_tconv_trim=0,
-        codec_eos=2150, suppress_begin=2048, suppress_end=3072))
+        codec_eos=2150, suppress_begin=2048, suppress_end=3072,
+        spk_enc_dim=1024, spk_mel=128, spk_channels=512, spk_scale=8, spk_se=128, spk_att=128))
 
 
 def config_tiny():
@@ -93,7 +96,8 @@ def config_tiny():
         cd_rope_theta=10000.0, cd_rms_eps=1e-5,
         cd_n_up=2, cd_up_ratios=[2, 2, 0, 0], cd_decoder_dim=64, cd_n_blocks=4,
         cd_up_rates=[8, 5, 4, 3, 0, 0, 0, 0], cd_tconv_trim=0,
-        codec_eos=2150, suppress_begin=64, suppress_end=2176))
+        codec_eos=2150, suppress_begin=64, suppress_end=2176,
+        spk_enc_dim=64, spk_mel=128, spk_channels=32, spk_scale=8, spk_se=8, spk_att=8))
 
 
 def config_medium():
@@ -101,7 +105,7 @@ def config_medium():
     (K in {128, 256}) while staying small enough for the CPU oracle."""
     d = config_tiny().to_dict()
     d.update(hidden=128, n_layers=2, n_heads=2, n_kv_heads=1, head_dim=64, ffn=256,
-             cp_layers=2, cp_heads=2, cp_kv_heads=1, cp_head_dim=64, cp_ffn=256, text_hidden=64)
+             cp_layers=2, cp_heads=2, cp_kv_heads=1, cp_head_dim=64, cp_ffn=256, text_hidden=64, spk_enc_dim=128)
     return Config.from_dict(d)
 
 
@@ -189,6 +193,24 @@ def tensor_specs(cfg):
     out.append(("cd.dec.snake_out.beta", (OD,), "snake"))
     out.append(("cd.dec.conv_out.w", (1, OD, 7), "w"))
     out.append(("cd.dec.conv_out.b", (1,), "b"))
+    if c.spk_enc_dim > 0:   # ECAPA-TDNN speaker encoder, torch Conv1d layout [out][in][k]
+        SC, sub = c.spk_channels, c.spk_channels // c.spk_scale
+
+        def conv(name, cout, cin, k):
+            out.append((name + ".w", (cout, cin, k), "w"))
+            out.append((name + ".b", (cout,), "b"))
+        conv("spk.tdnn0", SC, c.spk_mel, 5)
+        for i in range(3):
+            conv(f"spk.blocks.{i}.tdnn1", SC, SC, 1)
+            for j in range(c.spk_scale - 1):
+                conv(f"spk.blocks.{i}.res2net.{j}", sub, sub, 3)
+            conv(f"spk.blocks.{i}.tdnn2", SC, SC, 1)
+            conv(f"spk.blocks.{i}.se1", c.spk_se, SC, 1)
+            conv(f"spk.blocks.{i}.se2", SC, c.spk_se, 1)
+        conv("spk.mfa", 3 * SC, 3 * SC, 1)
+        conv("spk.asp.tdnn", c.spk_att, 9 * SC, 1)
+        conv("spk.asp.conv", 3 * SC, c.spk_att, 1)
+        conv("spk.fc", c.spk_enc_dim, 6 * SC, 1)
     return out
 
 
@@ -269,6 +291,7 @@ def lib():
         L.q3o_vocoder_len.argtypes = [C.POINTER(Config), C.c_int]
         L.q3o_vocoder_tap.restype = C.c_int64
         L.q3o_vocoder_tap.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64]
+        L.q3o_speaker_encoder.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.q3o_rng_uniform.restype = C.c_float
         L.q3o_rng_uniform.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]
         L.q3o_sample.restype = C.c_int64
@@ -325,6 +348,14 @@ class Oracle:
     def load(self, weights):
         for k, v in weights.items():
             self.set_tensor(k, v)
+
+    def speaker_encoder(self, mel):
+        """mel [n_mels][frames] (MelExtractor layout) -> [spk_enc_dim]"""
+        mel = np.ascontiguousarray(mel, dtype=np.float32)
+        assert mel.ndim == 2 and mel.shape[0] == self.cfg.spk_mel
+        out = np.zeros(self.cfg.spk_enc_dim, np.float32)
+        self._check(self.L.q3o_speaker_encoder(self.h, _p(mel), mel.shape[1], _p(out)))
+        return out
 
     def text_project(self, ids):
         ids = np.ascontiguousarray(ids, dtype=np.int64)

@@ -209,7 +209,49 @@ def code2wav():
     print("hf_code2wav.npz", {k: v.shape for k, v in res.items()}, "pcm rms", float(np.sqrt((res["pcm_7"] ** 2).mean())))
 
 
+def speaker():
+    """ECAPA-TDNN speaker encoder of the clone path (the reference runs it as an opaque speaker_encoder.onnx,
+    src/tts_onnx.cpp:367-403): transformers' ECAPA_TimeDelayNet at the tiny config's dims."""
+    from types import SimpleNamespace
+    from transformers.models.qwen2_5_omni.modeling_qwen2_5_omni import ECAPA_TimeDelayNet
+    c = CFG
+    SC = c.spk_channels
+    hc = SimpleNamespace(mel_dim=c.spk_mel, enc_dim=c.spk_enc_dim, enc_channels=[SC, SC, SC, SC, 3 * SC],
+                         enc_kernel_sizes=[5, 3, 3, 3, 1], enc_dilations=[1, 2, 3, 4, 1], enc_attention_channels=c.spk_att,
+                         enc_res2net_scale=c.spk_scale, enc_se_channels=c.spk_se)
+    net = ECAPA_TimeDelayNet(hc).eval()
+    mp = {}
+
+    def conv(name, mod):
+        mp[name + ".w"] = (mod.weight, "w")
+        mp[name + ".b"] = (mod.bias, "b")
+    conv("spk.tdnn0", net.blocks[0].conv)
+    for i in range(3):
+        b = net.blocks[i + 1]
+        conv(f"spk.blocks.{i}.tdnn1", b.tdnn1.conv)
+        for j in range(c.spk_scale - 1):
+            conv(f"spk.blocks.{i}.res2net.{j}", b.res2net_block.blocks[j].conv)
+        conv(f"spk.blocks.{i}.tdnn2", b.tdnn2.conv)
+        conv(f"spk.blocks.{i}.se1", b.se_block.conv1)
+        conv(f"spk.blocks.{i}.se2", b.se_block.conv2)
+    conv("spk.mfa", net.mfa.conv)
+    conv("spk.asp.tdnn", net.asp.tdnn.conv)
+    conv("spk.asp.conv", net.asp.conv)
+    conv("spk.fc", net.fc)
+    w = fill(mp, 31)
+    g = torch.Generator().manual_seed(32)
+    res = {}
+    for T in (5, 9, 40):
+        mel = torch.from_numpy(bf16_round((2.0 * torch.randn(c.spk_mel, T, generator=g) - 4.0).numpy()))   # log-mel-like range
+        out = net(mel.t().unsqueeze(0))          # the session input layout [1, frames, n_mels]
+        res[f"mel_{T}"] = mel.numpy()
+        res[f"embed_{T}"] = out[0].numpy()
+    np.savez_compressed(os.path.join(HERE, "hf_speaker.npz"), **{"w:" + k: v for k, v in w.items()}, **res)
+    print("hf_speaker.npz", {k: v.shape for k, v in res.items()})
+
+
 if __name__ == "__main__":
-    talker()
-    predictor()
-    code2wav()
+    only = sys.argv[1:]
+    for fn in (talker, predictor, code2wav, speaker):
+        if not only or fn.__name__ in only:
+            fn()

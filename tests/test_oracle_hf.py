@@ -58,3 +58,22 @@ def test_code2wav(oracle, F):
     rms = float(np.sqrt(np.mean((pcm - ref) ** 2)))
     assert rms < 2e-5, rms  # north_star PCM tolerance is 1e-4 RMS
     assert float(np.sqrt(np.mean(ref ** 2))) > 0.05  # fixture is not silent / not saturated
+
+
+@pytest.mark.parametrize("T", [5, 9, 40])
+def test_speaker_encoder(oracle, T):
+    """ECAPA-TDNN speaker encoder vs transformers' ECAPA_TimeDelayNet."""
+    w, d = load("hf_speaker.npz")
+    oracle.load(w)
+    out = oracle.speaker_encoder(d[f"mel_{T}"])
+    ref = d[f"embed_{T}"]
+    assert out.shape == ref.shape
+    assert np.abs(out - ref).max() < 1e-4 * max(1.0, float(np.abs(ref).max())), float(np.abs(out - ref).max())
+    assert float(np.abs(ref).max()) > 0.05
+
+
+def test_speaker_encoder_needs_five_frames(oracle):
+    w, d = load("hf_speaker.npz")
+    oracle.load(w)
+    with pytest.raises(RuntimeError):
+        oracle.speaker_encoder(d["mel_5"][:, :4])
