@@ -102,6 +102,21 @@ struct AttnArgs {
     bf16_t* oh = nullptr; bf16_t* ol = nullptr; int ldp = 0;
 };
 void launch_attn(const AttnArgs& a, hipStream_t s);
+// code-predictor attention + o_proj (+ residual) for one utterance: see k_cp_attn_oproj
+struct CpAttnOprojArgs {
+    const float* qkv = nullptr; int ld_qkv = 0; // [n_new][ld_qkv] raw q | k | v projections
+    float* kc = nullptr; float* vc = nullptr;    // this (slot, layer)'s cache rows: [nkv][page_tokens][d]
+    int page_tokens = 0;
+    int base = 0;                                // tokens already cached = position of new row 0
+    const float* q_norm = nullptr; const float* k_norm = nullptr; float eps = 0.f;
+    const float* rope_cos = nullptr; const float* rope_sin = nullptr;
+    float scale = 0.f;
+    int nq = 0, nkv = 0, d = 0;
+    const bf16_t* W = nullptr; int K = 0, N = 0; // o_proj [N][K]
+    float* x = nullptr; int ldx = 0;             // residual stream rows [n_new][ldx], updated in place
+};
+bool cp_attn_oproj_ok(const CpAttnOprojArgs& a, int n_new);
+void launch_cp_attn_oproj(const CpAttnOprojArgs& a, int n_new, hipStream_t s);
 void launch_attn_combine(const AttnArgs& a, hipStream_t s); // partials -> a.out
 
 // Skinny-M bf16-MFMA GEMM (q3_gemm_kernels.hip): activations as (hi, lo) bf16 planes, fp32 accumulate

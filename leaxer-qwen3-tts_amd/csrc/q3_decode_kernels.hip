@@ -800,6 +800,205 @@ void launch_attn_combine(const AttnArgs& a, hipStream_t s) {
 }
 
 // ================================================================================================
+// k_cp_attn_oproj — the code predictor's attention AND its output projection in one launch (b = 1).
+// The predictor context is at most 17 tokens, so attention is a few KB of L2-resident K/V per head; what a
+// separate attention launch costs is its dependent-launch slot (~4.6 us of the 2.67 ms step, 75 per frame).
+// Here every workgroup of the o_proj GEMV (4 output rows x K) recomputes the whole attention vector itself:
+// wave w = kv head w (both of its query heads), all addresses known at launch (contiguous per-slot cache,
+// host-known position), so weights, q/k/v rows, norm/RoPE operands and the cached K/V are ONE memory round.
+// The 4 token groups of a wave meet in LDS, the 8 heads meet in LDS, then 2 waves per output row split K.
+// Workgroup 0 appends the new K/V rows to the cache.  NEW = new rows (1, or 2 for the predictor's first pass),
+// U = cached tokens per 16-lane group in flight (cached tokens <= 4 U).
+// ================================================================================================
+template <int NEW, int U>
+__global__ __launch_bounds__(512) void k_cp_attn_oproj(CpAttnOprojArgs a) {
+    constexpr int D = 128, HALF = 64, EPL = 8, G = 2, NKV = 8, K = 2048;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kvh = wave;
+    const int base = a.base;
+
+    __shared__ float q_s[NKV][NEW][G][D];
+    __shared__ float knew[NKV][NEW][D];
+    __shared__ float vnew[NKV][NEW][D];
+    __shared__ float cm[NKV][NEW][G][4], cl[NKV][NEW][G][4];
+    __shared__ float co[NKV][NEW][G][4][D];
+    __shared__ float attn_s[NEW][K];
+    __shared__ float part[NEW][8];
+
+    // ---- the one memory round: o_proj weights, residual, q/k/v rows + their norm / RoPE operands, cached K/V ----
+    const int orow = blockIdx.x * 4 + (wave & 3), khalf = wave >> 2;
+    const int orow_c = orow < a.N ? orow : a.N - 1;
+    uint4 w4[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) w4[c] = ldw_rt(a.W + (size_t)orow_c * K + (khalf * 2 + c) * 512 + lane * 8, false);
+    float resid[NEW];
+#pragma unroll
+    for (int m = 0; m < NEW; ++m) resid[m] = a.x[(size_t)m * a.ldx + orow_c];
+    __builtin_amdgcn_sched_barrier(0);
+
+    struct VecOps { float x0, x1, v0, v1, n0, n1, cs, sn; };
+    constexpr int NVEC = NEW * G + NEW;          // q vectors (row-major over (row, head)), then the new keys
+    VecOps vec[NVEC];
+#pragma unroll
+    for (int v = 0; v < NVEC; ++v) {
+        const bool is_q = v < NEW * G;
+        const int j = is_q ? v / G : v - NEW * G;
+        const float* rowp = a.qkv + (size_t)j * a.ld_qkv;
+        const float* src = rowp + (is_q ? (kvh * G + v % G) * D : (NKV * G + kvh) * D);
+        const float* vs = rowp + (NKV * G + NKV + kvh) * D;
+        const float* nw = is_q ? a.q_norm : a.k_norm;
+        vec[v].x0 = src[lane]; vec[v].x1 = src[lane + HALF];
+        vec[v].v0 = vs[lane]; vec[v].v1 = vs[lane + HALF];
+        vec[v].n0 = nw[lane]; vec[v].n1 = nw[lane + HALF];
+        vec[v].cs = a.rope_cos[(size_t)(base + j) * HALF + lane]; vec[v].sn = a.rope_sin[(size_t)(base + j) * HALF + lane];
+    }
+    const int tg = lane >> 4, sub = lane & 15;
+    float kr[U][EPL], vr[U][EPL];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        int t = tg + 4 * u;                      // clamped, unconditional (a conditional load is a serial round trip)
+        t = t < base ? t : base - 1;
+        t = t > 0 ? t : 0;
+        const size_t off = ((size_t)kvh * a.page_tokens + t) * D + sub * EPL;
+        const float4 k0 = *reinterpret_cast<const float4*>(a.kc + off), k1 = *reinterpret_cast<const float4*>(a.kc + off + 4);
+        const float4 v0 = *reinterpret_cast<const float4*>(a.vc + off), v1 = *reinterpret_cast<const float4*>(a.vc + off + 4);
+        kr[u][0] = k0.x; kr[u][1] = k0.y; kr[u][2] = k0.z; kr[u][3] = k0.w; kr[u][4] = k1.x; kr[u][5] = k1.y; kr[u][6] = k1.z; kr[u][7] = k1.w;
+        vr[u][0] = v0.x; vr[u][1] = v0.y; vr[u][2] = v0.z; vr[u][3] = v0.w; vr[u][4] = v1.x; vr[u][5] = v1.y; vr[u][6] = v1.z; vr[u][7] = v1.w;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- 1. q / k RMSNorm + RoPE (reference graphs: per-head norm, rotate-half RoPE), new K/V to LDS and the cache ----
+#pragma unroll
+    for (int v = 0; v < NVEC; ++v) {
+        const bool is_q = v < NEW * G;
+        const int j = is_q ? v / G : v - NEW * G;
+        const float ss = wave_sum(vec[v].x0 * vec[v].x0 + vec[v].x1 * vec[v].x1);
+        const float rr = 1.0f / sqrtf(ss / (float)D + a.eps);
+        const float x0 = vec[v].n0 * (vec[v].x0 * rr), x1 = vec[v].n1 * (vec[v].x1 * rr);
+        const float y0 = x0 * vec[v].cs + (-x1) * vec[v].sn;
+        const float y1 = x1 * vec[v].cs + x0 * vec[v].sn;
+        if (is_q) { q_s[kvh][j][v % G][lane] = y0; q_s[kvh][j][v % G][lane + HALF] = y1; }
+        else {
+            knew[kvh][j][lane] = y0; knew[kvh][j][lane + HALF] = y1;
+            vnew[kvh][j][lane] = vec[v].v0; vnew[kvh][j][lane + HALF] = vec[v].v1;
+            if (blockIdx.x == 0) {
+                const size_t off = ((size_t)kvh * a.page_tokens + base + j) * D;
+                a.kc[off + lane] = y0; a.kc[off + lane + HALF] = y1;
+                a.vc[off + lane] = vec[v].v0; a.vc[off + lane + HALF] = vec[v].v1;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- 2. scores and weighted values: token group tg owns cached tokens tg, tg+4, ... and new token j if (j & 3) == tg ----
+#pragma unroll
+    for (int inew = 0; inew < NEW; ++inew) {
+#pragma unroll
+        for (int h = 0; h < G; ++h) {
+            float qr[EPL];
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) qr[e] = q_s[kvh][inew][h][sub * EPL + e];
+            float sc[U + NEW];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                float sdot = 0.f;
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) sdot = fmaf(qr[e], kr[u][e], sdot);
+                sdot = row_sum16(sdot) * a.scale;
+                sc[u] = tg + 4 * u < base ? sdot : -INFINITY;
+            }
+            float kn[NEW][EPL], vn[NEW][EPL];
+#pragma unroll
+            for (int j = 0; j < NEW; ++j) {
+                float sdot = 0.f;
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) { kn[j][e] = knew[kvh][j][sub * EPL + e]; vn[j][e] = vnew[kvh][j][sub * EPL + e]; sdot = fmaf(qr[e], kn[j][e], sdot); }
+                sdot = row_sum16(sdot) * a.scale;
+                sc[U + j] = (j <= inew && (j & 3) == tg) ? sdot : -INFINITY;   // causal among the new rows
+            }
+            float mx = -INFINITY;
+#pragma unroll
+            for (int i = 0; i < U + NEW; ++i) mx = fmaxf(mx, sc[i]);
+            float l = 0.f, o[EPL];
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) o[e] = 0.f;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const float pw = mx == -INFINITY ? 0.f : __expf(sc[u] - mx);
+                l += pw;
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) o[e] = fmaf(pw, tg + 4 * u < base ? vr[u][e] : 0.f, o[e]);   // never-written cache rows may hold NaN
+            }
+#pragma unroll
+            for (int j = 0; j < NEW; ++j) {
+                const float pw = mx == -INFINITY ? 0.f : __expf(sc[U + j] - mx);
+                l += pw;
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) o[e] = fmaf(pw, vn[j][e], o[e]);
+            }
+            if (sub == 0) { cm[kvh][inew][h][tg] = mx; cl[kvh][inew][h][tg] = l; }
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) co[kvh][inew][h][tg][sub * EPL + e] = o[e];
+        }
+    }
+    __syncthreads();
+    // ---- 3. merge the 4 token groups of every head -> attention rows in LDS ----
+    for (int idx = tid; idx < NEW * K; idx += 512) {
+        const int inew = idx / K, k = idx % K, head = k / D, e = k % D, kv = head / G, h = head % G;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) mx = fmaxf(mx, cm[kv][inew][h][g]);
+        float L = 0.f, O = 0.f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float wgt = cm[kv][inew][h][g] == -INFINITY ? 0.f : expf(cm[kv][inew][h][g] - mx);
+            L += wgt * cl[kv][inew][h][g];
+            O += wgt * co[kv][inew][h][g][e];
+        }
+        attn_s[inew][k] = O / L;
+    }
+    __syncthreads();
+    // ---- 4. o_proj: wave (row = wave & 3, K half = wave >> 2), residual add ----
+#pragma unroll
+    for (int m = 0; m < NEW; ++m) {
+        float s1 = 0.f;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const float* xr = &attn_s[m][(khalf * 2 + c) * 512 + lane * 8];
+            const float4 x0 = *reinterpret_cast<const float4*>(xr), x1 = *reinterpret_cast<const float4*>(xr + 4);
+            const float xv[8] = { x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w };
+            const uint32_t wu[4] = { w4[c].x, w4[c].y, w4[c].z, w4[c].w };
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { s1 = fmaf(xv[2 * j], bf_lo(wu[j]), s1); s1 = fmaf(xv[2 * j + 1], bf_hi(wu[j]), s1); }
+        }
+        s1 = wave_sum(s1);
+        if (lane == 0) part[m][wave] = s1;
+    }
+    __syncthreads();
+    if (wave < 4 && lane < NEW && orow < a.N) {
+        float r = resid[0];
+        if (NEW > 1 && lane == 1) r = resid[NEW - 1];
+        a.x[(size_t)lane * a.ldx + orow] = r + (part[lane][wave] + part[lane][wave + 4]);
+    }
+}
+
+void launch_cp_attn_oproj(const CpAttnOprojArgs& a, int n_new, hipStream_t s) {
+    if (!cp_attn_oproj_ok(a, n_new)) throw Error("cp_attn_oproj: unsupported shape");
+    const int U = a.base <= 4 ? 1 : (a.base <= 8 ? 2 : (a.base <= 12 ? 3 : 4));
+    const dim3 grid((a.N + 3) / 4), block(512);
+#define Q3_CAO(NEW, UU) hipLaunchKernelGGL((k_cp_attn_oproj<NEW, UU>), grid, block, 0, s, a)
+    if (n_new == 1) { if (U == 1) Q3_CAO(1, 1); else if (U == 2) Q3_CAO(1, 2); else if (U == 3) Q3_CAO(1, 3); else Q3_CAO(1, 4); }
+    else { if (U == 1) Q3_CAO(2, 1); else if (U == 2) Q3_CAO(2, 2); else if (U == 3) Q3_CAO(2, 3); else Q3_CAO(2, 4); }
+#undef Q3_CAO
+    Q3_HIP_CHECK(hipGetLastError());
+}
+bool cp_attn_oproj_ok(const CpAttnOprojArgs& a, int n_new) {
+    return (n_new == 1 || n_new == 2) && a.nq == 16 && a.nkv == 8 && a.d == 128 && a.K == 2048 && a.base >= 0 && a.base <= 16 &&
+           a.base + n_new <= a.page_tokens && a.q_norm && a.k_norm && a.ld_qkv >= 4096 && a.N >= 1;
+}
+
+// ================================================================================================
 // k_sample — temperature / top-k / top-p sampling (reference src/tts_onnx.cpp:878-950) on device.
 // ONE WAVE per batch row: the whole vocabulary (<= 4096) sits in the wave's registers, every
 // reduction / scan is a cross-lane DPP sequence, so there is no block barrier chain; the epilogue

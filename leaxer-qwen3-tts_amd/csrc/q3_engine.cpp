@@ -378,6 +378,27 @@ bool Engine::run_layers(const DecStack& W, float* x, int ldx, int nb, int n_new,
             g.M = M; g.N = QKV; g.K = W.H; g.epi = EPI_STORE; g.nt = W.nt;
             launch_gemv(g, stream);
         }
+        if (!mfma && nb == 1 && pos_dev == nullptr && W.n_splits == 1 && W.pages_per_slot == 1 && !(flags & Q3TTS_FLAG_NO_FUSED_CP)) {
+            // code predictor at b = 1: attention + o_proj + residual in one launch (identity page table: slot s owns page s)
+            CpAttnOprojArgs f;
+            const int ptok = 1 << W.page_shift;
+            const size_t coff = (((size_t)slot_offset * W.L + l) * W.nkv) * ptok * W.d;
+            f.qkv = qkv; f.ld_qkv = QKV; f.kc = W.kc + coff; f.vc = W.vc + coff; f.page_tokens = ptok; f.base = pos_scalar;
+            f.q_norm = w.q_norm; f.k_norm = w.k_norm; f.eps = W.eps; f.rope_cos = W.rope_cos; f.rope_sin = W.rope_sin;
+            f.scale = 1.0f / sqrtf((float)W.d); f.nq = W.nq; f.nkv = W.nkv; f.d = W.d; f.W = w.o; f.K = AO; f.N = W.H; f.x = x; f.ldx = ldx;
+            if (cp_attn_oproj_ok(f, n_new)) {
+                launch_cp_attn_oproj(f, n_new, stream);
+                GemvArgs fg;
+                fg.W = w.gate; fg.W2 = w.up; fg.x = x; fg.ldx = ldx; fg.gamma = w.post_norm; fg.eps = W.eps; fg.out = act; fg.ldo = W.ffn;
+                fg.M = M; fg.N = W.ffn; fg.K = W.H; fg.epi = EPI_SWIGLU; fg.nt = W.nt;
+                launch_gemv(fg, stream);
+                GemvArgs dg;
+                dg.W = w.down; dg.x = act; dg.ldx = W.ffn; dg.res = x; dg.ldres = ldx; dg.out = x; dg.ldo = ldx;
+                dg.M = M; dg.N = W.H; dg.K = W.ffn; dg.epi = EPI_RESIDUAL; dg.nt = W.nt;
+                launch_gemv(dg, stream);
+                continue;
+            }
+        }
         AttnArgs a;
         a.qkv = qkv; a.ld_qkv = QKV; a.out = attn; a.ld_out = AO; a.kcache = W.kc; a.vcache = W.vc;
         if (mfma) { a.qkv = qkv_slab_d; a.qkv_nslab = ks_q; a.qkv_slab_stride = (size_t)M * QKV; }

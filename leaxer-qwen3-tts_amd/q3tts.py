@@ -67,6 +67,7 @@ class Sampling(C.Structure):
 
 
 FLAG_NO_GRAPH = 1
+FLAG_NO_FUSED_CP = 2
 
 # every symbol include/q3tts.h declares
 EXPORTS = [

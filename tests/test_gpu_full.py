@@ -67,6 +67,29 @@ def test_greedy_generation_full_size(full):
     assert np.array_equal(codes, again)            # deterministic, slot-independent
 
 
+def test_fused_predictor_attention_matches_separate_launches(full):
+    """b = 1 runs the code predictor's attention + o_proj as one launch (k_cp_attn_oproj); the separate-launch
+    path (Q3TTS_FLAG_NO_FUSED_CP) and the oracle must give the same sampled frames."""
+    import q3tts
+    eng, orc = full
+    ids = frame_tokens(np.random.default_rng(2).integers(0, 151643, 9))
+    sp = q3tts.Sampling(temperature=0.8, top_p=0.95, top_k=50, max_new_tokens=24)
+    p, t = eng.build_prompt(ids, 1)
+    eng.slot_release(1)            # only slot 0 active -> the step is recorded for one utterance (fused path)
+    codes = eng.generate(p, t, sp, seed=11, stream_id=0, ignore_eos=True)
+    plain = q3tts.Engine(eng.cfg, device=0, max_batch=1, max_ctx=128, flags=q3tts.FLAG_NO_FUSED_CP)
+    plain.fill_synthetic(seed=0)
+    want = plain.generate(p, t, sp, seed=11, stream_id=0, ignore_eos=True)
+    plain.close()
+    assert codes.shape == (24, 16) and np.array_equal(codes, want)
+    sp4 = q3tts.Sampling(temperature=0.8, top_p=0.95, top_k=50, max_new_tokens=4)
+    ref = orc.generate(orc.build_prompt(ids, 1), to_osampling(sp4), seed=11, stream=0, cp_cached=True, ignore_eos=True)
+    assert np.array_equal(codes[:4], ref)
+    # the session-shaped predictor call (2 rows, no cache) takes the same fused launch
+    seq = np.stack([eng.codec_embed([5])[0], eng.cp_embed(7, 0)])
+    assert np.abs(eng.code_predictor(seq, 0) - orc.code_predictor(seq, 0)).max() < 2e-4
+
+
 def test_codec_full_size(full):
     eng, orc = full
     codes = np.random.default_rng(3).integers(0, 2048, (3, 16)).astype(np.int64)
