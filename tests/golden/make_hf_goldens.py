@@ -62,6 +62,15 @@ def layer_map(prefix, hf_layer, out, qk=True, ls=False):
         out[prefix + "mlp_scale"] = (hf_layer.mlp_layer_scale.scale, "scale")
 
 
+KEYS = {}
+
+
+def record_keys(component, module, mapping):
+    """state_dict key of every mapped parameter: the naming a checkpoint of this module uses (tools/import_safetensors.py)"""
+    by_id = {id(p): k for k, p in module.named_parameters()}
+    KEYS[component] = {name: by_id[id(p)] for name, (p, _) in mapping.items()}
+
+
 def fill(mapping, seed):
     g = torch.Generator().manual_seed(seed)
     w = {}
@@ -87,6 +96,7 @@ def talker():
         layer_map(f"talker.layers.{i}.", lyr, mp)
     mp["talker.norm"] = (m.model.norm.weight, "norm")
     mp["talker.codec_head"] = (m.lm_head.weight, "w")
+    record_keys("talker", m, mp)
     w = fill(mp, 11)
     g = torch.Generator().manual_seed(12)
     S, n_dec = 9, 4
@@ -125,6 +135,7 @@ def predictor():
     for j in range(c.n_groups - 1):
         mp[f"cp.head.{j}"] = (m.lm_head[j].weight, "w")
         mp[f"cp.embed.{j}"] = (m.model.codec_embedding[j].weight, "w")
+    record_keys("predictor", m, mp)
     w = fill(mp, 21)
     g = torch.Generator().manual_seed(22)
     seq = torch.randn(1, c.n_groups + 1, c.hidden, generator=g)
@@ -180,6 +191,7 @@ def code2wav():
     n = 1 + c.cd_n_blocks
     mp["cd.dec.snake_out.alpha"] = (dec[n].alpha, "snake"); mp["cd.dec.snake_out.beta"] = (dec[n].beta, "snake")
     mp["cd.dec.conv_out.w"] = (dec[n + 1].conv.weight, "w"); mp["cd.dec.conv_out.b"] = (dec[n + 1].conv.bias, "b")
+    record_keys("code2wav", m, mp)
     w = fill(mp, 31)
     g = torch.Generator().manual_seed(32)
 
@@ -238,6 +250,7 @@ def speaker():
     conv("spk.asp.tdnn", net.asp.tdnn.conv)
     conv("spk.asp.conv", net.asp.conv)
     conv("spk.fc", net.fc)
+    record_keys("speaker", net, mp)
     w = fill(mp, 31)
     g = torch.Generator().manual_seed(32)
     res = {}
@@ -255,3 +268,7 @@ if __name__ == "__main__":
     for fn in (talker, predictor, code2wav, speaker):
         if not only or fn.__name__ in only:
             fn()
+    if not only:
+        import json
+        json.dump(KEYS, open(os.path.join(HERE, "hf_state_dict_keys.json"), "w"), indent=0, sort_keys=True)
+        print("hf_state_dict_keys.json", {k: len(v) for k, v in KEYS.items()})

@@ -1,0 +1,89 @@
+"""SURVEY.md 8f-4 — tools/import_safetensors.py: the name rules reproduce, from state_dict-style key names, exactly
+the tensors the goldens were generated with.  tests/golden/hf_state_dict_keys.json lists the key every parameter of
+the `transformers` modules has (written by make_hf_goldens.py); the test writes those keys into safetensors files
+(BF16 for the matrices), imports them and compares with the goldens' weights bit for bit."""
+import json
+import os
+import sys
+
+import numpy as np
+
+import q3_oracle as qo
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def gold_weights(name):
+    z = np.load(os.path.join(GOLD, name))
+    return {k[2:]: z[k] for k in z.files if k.startswith("w:")}
+
+
+def test_rules_cover_every_transformers_key(tmp_path):
+    from tools.import_safetensors import import_checkpoint, map_names, read_safetensors, write_safetensors
+    keys = json.load(open(os.path.join(GOLD, "hf_state_dict_keys.json")))
+    cfg = qo.config_tiny()
+    prefixes = {"talker": "talker.", "predictor": "talker.code_predictor.", "code2wav": "speech.decoder.", "speaker": "spk_enc."}
+    files, want = [], {}
+    for comp, gold in (("talker", "hf_talker.npz"), ("predictor", "hf_predictor.npz"), ("code2wav", "hf_code2wav.npz"), ("speaker", "hf_speaker.npz")):
+        w = gold_weights(gold)
+        assert set(w) == set(keys[comp]), comp
+        tensors = {prefixes[comp] + keys[comp][n]: a for n, a in w.items()}
+        path = str(tmp_path / f"{comp}.safetensors")
+        write_safetensors(path, tensors, bf16={k for k, a in tensors.items() if a.ndim >= 2})   # goldens are bf16-representable
+        back = read_safetensors(path)
+        assert all(np.array_equal(back[k], tensors[k]) for k in tensors)
+        files.append(path)
+        want.update(w)
+    # every key maps, and to the right registry name
+    flat = {prefixes[c] + k: n for c in keys for n, k in keys[c].items()}
+    assert map_names(flat.keys(), prefixes) == flat
+    got, unused, missing = import_checkpoint(files, cfg, prefixes, allow_missing=True)
+    assert not unused
+    assert set(got) == set(want)
+    for n in want:
+        assert got[n].shape == want[n].shape and np.array_equal(got[n], want[n]), n
+    # what the transformers modules do not hold (the text side and the talker's codec embedding) is reported, not invented
+    assert set(missing) == {"talker.codec_embed", "text.embed", "text.fc1.w", "text.fc1.b", "text.fc2.w", "text.fc2.b"}
+    # [HINT] names for those are accepted when present
+    extra = {"talker.model.codec_embedding.weight": np.zeros((cfg.vocab, cfg.hidden), np.float32),
+             "talker.model.text_embedding.weight": np.zeros((cfg.text_vocab, cfg.text_hidden), np.float32),
+             "talker.text_projection.linear_fc1.weight": np.zeros((cfg.text_hidden, cfg.text_hidden), np.float32),
+             "talker.text_projection.linear_fc1.bias": np.zeros(cfg.text_hidden, np.float32),
+             "talker.text_projection.linear_fc2.weight": np.zeros((cfg.hidden, cfg.text_hidden), np.float32),
+             "talker.text_projection.linear_fc2.bias": np.zeros(cfg.hidden, np.float32)}
+    p2 = str(tmp_path / "extra.safetensors")
+    write_safetensors(p2, extra)
+    got2, _, missing2 = import_checkpoint(files + [p2], cfg, prefixes)
+    assert not missing2 and len(got2) == len(qo.tensor_specs(cfg))
+
+
+def test_imported_weights_drive_the_oracle(tmp_path):
+    """End to end on the CPU side: safetensors -> import -> Q3TW file bytes -> oracle reproduces the transformers golden."""
+    from tools.import_safetensors import import_checkpoint, write_safetensors
+    keys = json.load(open(os.path.join(GOLD, "hf_state_dict_keys.json")))
+    w = gold_weights("hf_code2wav.npz")
+    path = str(tmp_path / "c2w.safetensors")
+    write_safetensors(path, {"decoder." + keys["code2wav"][n]: a for n, a in w.items()})
+    cfg = qo.config_tiny()
+    got, _, _ = import_checkpoint([path], cfg, allow_missing=True)
+    z = np.load(os.path.join(GOLD, "hf_code2wav.npz"))
+    o = qo.Oracle(cfg, max_ctx=16)
+    o.load(got)
+    pcm = o.vocoder(z["codes_3"])
+    o.close()
+    assert float(np.sqrt(np.mean((pcm - z["pcm_3"]) ** 2))) < 2e-5
+
+
+def test_shape_mismatch_and_missing_are_errors(tmp_path):
+    import pytest
+    from tools.import_safetensors import import_checkpoint, write_safetensors
+    cfg = qo.config_tiny()
+    p = str(tmp_path / "bad.safetensors")
+    write_safetensors(p, {"talker.model.norm.weight": np.zeros(cfg.hidden + 1, np.float32)})
+    with pytest.raises(ValueError, match="shape"):
+        import_checkpoint([p], cfg, allow_missing=True)
+    write_safetensors(p, {"talker.model.norm.weight": np.zeros(cfg.hidden, np.float32)})
+    with pytest.raises(ValueError, match="not found"):
+        import_checkpoint([p], cfg)
