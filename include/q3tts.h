@@ -56,6 +56,7 @@ typedef struct q3tts_engine q3tts_engine;
 /* flags for q3tts_create */
 #define Q3TTS_FLAG_NO_GRAPH 1u   /* launch the decode step eagerly instead of replaying a hipGraph */
 #define Q3TTS_FLAG_NO_FUSED_CP 2u /* b = 1: keep code-predictor attention and o_proj as separate launches (A/B testing) */
+#define Q3TTS_FLAG_FP32_CODEC 4u  /* codec decoder on the exact-fp32 matrix-core path instead of the bf16 hi/lo split path */
 
 /* ---- lifecycle (replaces TTSEngine ctor / load_model, tts_onnx.cpp:84-232) ---- */
 int q3tts_default_config(const char* name /* "0.6b" */, q3tts_config* out);

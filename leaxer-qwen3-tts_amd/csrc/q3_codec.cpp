@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <unordered_map>
 #include <vector>
 
 #include "q3_engine.h"
@@ -28,6 +29,9 @@ struct CodecW {
     std::vector<Block> blocks;
     SnakeP snake_out;
     std::vector<float*> packed; // owned
+    // (hi, lo) bf16 planes of every conv / linear weight, keyed by the fp32 pointer the layer list holds (owned)
+    struct Planes { bf16_t* hi; bf16_t* lo; float scale_inv; };
+    std::unordered_map<const float*, Planes> planes;
     // run-time workspace: one bump arena per codec stream (lane 0 = the engine's own stream)
     static constexpr int NLANE = 4;
     char* arena[NLANE] = {nullptr, nullptr, nullptr, nullptr}; size_t arena_bytes[NLANE] = {0, 0, 0, 0};
@@ -40,6 +44,7 @@ struct CodecW {
 void Engine::codec_free() {
     if (!codec) return;
     for (float* p : codec->packed) (void)hipFree(p);
+    for (auto& kv : codec->planes) { (void)hipFree(kv.second.hi); (void)hipFree(kv.second.lo); }
     for (int i = 0; i < CodecW::NLANE; ++i) {
         if (codec->arena[i]) (void)hipFree(codec->arena[i]);
         if (codec->pinned[i]) (void)hipHostFree(codec->pinned[i]);
@@ -102,6 +107,40 @@ void Engine::codec_finalize() {
     }
     W.snake_out = snake("cd.dec.snake_out");
     W.conv_out = pack("cd.dec.conv_out", D >> c.cd_n_blocks, 1, 7, false);
+    if (!(flags & Q3TTS_FLAG_FP32_CODEC)) { // fp16 hi/lo planes for the split-precision matrix-core path
+        unsigned* amax_d = (unsigned*)dmalloc(sizeof(unsigned));
+        auto split = [&](const float* w, size_t n) {
+            if (!w || W.planes.count(w)) return;
+            // power-of-two pre-scale: largest |w| lands in [2^11, 2^12) so the low plane of ordinary weights stays normal
+            unsigned bits = 0;
+            Q3_HIP_CHECK(hipMemsetAsync(amax_d, 0, sizeof(unsigned), stream));
+            launch_absmax(w, n, amax_d, stream);
+            Q3_HIP_CHECK(hipMemcpyAsync(&bits, amax_d, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
+            sync();
+            float amax;
+            memcpy(&amax, &bits, sizeof amax);
+            int e = 0;
+            if (amax > 0.f && std::isfinite(amax)) (void)frexpf(amax, &e);   // amax = m * 2^e, m in [0.5, 1)
+            const int k = amax > 0.f ? 12 - e : 0;
+            bf16_t *hi = nullptr, *lo = nullptr;
+            Q3_HIP_CHECK(hipMalloc((void**)&hi, n * sizeof(bf16_t)));
+            Q3_HIP_CHECK(hipMalloc((void**)&lo, n * sizeof(bf16_t)));
+            launch_split_planes(w, hi, lo, n, ldexpf(1.0f, k), stream);
+            W.planes[w] = { hi, lo, ldexpf(1.0f, -k) };
+        };
+        const size_t FFn = (size_t)c.cd_ffn;
+        for (const CodecW::Layer& L : W.layers) {
+            split(L.qkv, (size_t)3 * CH * CH); split(L.o, (size_t)CH * CH);
+            split(L.gate, FFn * CH); split(L.up, FFn * CH); split(L.down, FFn * CH);
+        }
+        for (const CodecW::Up& u : W.up) {
+            split(u.tconv.w, (size_t)u.tconv.cin * u.tconv.cout * u.tconv.k);
+            split(u.pw1_w, (size_t)4 * CH * CH); split(u.pw2_w, (size_t)4 * CH * CH);
+        }
+        auto pc = [&](const PackedConv& p) { split(p.w, (size_t)p.cin * p.cout * p.k); };
+        pc(W.conv_in);
+        for (const CodecW::Block& B : W.blocks) { pc(B.tconv); for (int u = 0; u < 3; ++u) { pc(B.res[u].c1); pc(B.res[u].c2); } }
+    }
     W.lane_stream[0] = stream;
     for (int i = 1; i < CodecW::NLANE; ++i) {
         if (null_stream) W.lane_stream[i] = nullptr;
@@ -158,7 +197,12 @@ int64_t Engine::codec_run(const int32_t* codes_dev, int F, float** pcm_dev, int 
             off += bytes;
             return p;
         };
-        auto conv = [&](const ConvArgs& a) { if (!plan) launch_conv(a, stream); };
+        auto conv = [&](ConvArgs a) {
+            if (plan) return;
+            const auto it = W.planes.find(a.W);
+            if (it != W.planes.end()) { a.Wh = it->second.hi; a.Wl = it->second.lo; a.w_scale_inv = it->second.scale_inv; }
+            launch_conv(a, stream);
+        };
         auto gemm = [&](const float* in, int T, int Cin, const float* Wm, const float* bias, int Cout, float* out) {
             ConvArgs a; a.in = in; a.T_in = T; a.C_in = Cin; a.out = out; a.T_out = T; a.C_out = Cout; a.W = Wm; a.bias = bias;
             return a;

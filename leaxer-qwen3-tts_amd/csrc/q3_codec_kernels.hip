@@ -8,6 +8,9 @@
 // GEMMs accumulated in registers; a stride-s transposed conv is s phase GEMMs (blockIdx.z).
 // SnakeBeta is applied in the PRODUCER's epilogue (second output), never on the k-times-re-read
 // operand loads.
+#include <cstdlib>
+#include <utility>
+
 #include "q3_common.h"
 
 namespace q3 {
@@ -16,6 +19,20 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 static __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 static __device__ __forceinline__ float silu2_f(float x) { return x / (1.0f + expf(-x)); }
+// sin(x)^2 for SnakeBeta: three-term FMA reduction by pi/2 (exact products; good to |x| ~ 1e5, far past anything a*x reaches here),
+// then the fdlibm single-precision kernels on [-pi/4, pi/4]; the quadrant only picks sine or cosine since the square drops the sign.
+// ~25 instructions instead of libm sinf's ~65 (the snake is evaluated 5e9 times per 2048-frame utterance); within 2 ulp of it.
+static __device__ __forceinline__ float sin_sq(float x) {
+    const float kf = rintf(x * 0.63661977236758134308f);
+    float r = fmaf(-kf, 1.57079637050628662109375f, x);
+    r = fmaf(-kf, -4.37113900018624283e-8f, r);
+    r = fmaf(-kf, -1.71512451000590e-15f, r);
+    const float z = r * r;
+    const float sp = fmaf(r * z, fmaf(z, fmaf(z, fmaf(z, 2.7183114939898219064e-6f, -1.9839334836096632650e-4f), 8.3333293858894631756e-3f), -1.6666666641626524e-1f), r);
+    const float cp = fmaf(z * z, fmaf(z, fmaf(z, 2.4390448796277409065e-5f, -1.3886763774609869e-3f), 4.1666623323739063e-2f), fmaf(-0.5f, z, 1.0f));
+    const float v = ((int)kf & 1) ? cp : sp;
+    return v * v;
+}
 
 struct ConvKArgs {
     const float* in; int T_in, C_in;
@@ -26,7 +43,36 @@ struct ConvKArgs {
     const float* res; const float* res_scale; const float* mul;
     int act, clamp;
     float* out2; const float* s2_alpha; const float* s2_beta; // out2 = snake(out value)
+    const bf16_t* Wh; const bf16_t* Wl; // optional (hi, lo) fp16 planes of W * 2^k for k_conv_split (16-bit storage)
+    float acc_scale;                    // 2^-k (1 on the fp32 path)
 };
+
+// Epilogue of one 32x32 accumulator block: D[row][col], col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+static __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, const f32x16 acc, int mrow0, int co, int lane, int phase, int NT) {
+    if (co >= a.C_out) return;
+    const float bias = a.bias ? a.bias[co] : 0.f;
+    const float rs = a.res_scale ? a.res_scale[co] : 1.f;
+    float ea = 0.f, ib = 0.f;
+    if (a.out2) { ea = expf(a.s2_alpha[co]); ib = 1.0f / (expf(a.s2_beta[co]) + 0.000000001f); }
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int m = mrow0 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+        int t = m;
+        if (a.transposed) t = m * a.stride + phase - a.left;
+        if (t < 0 || t >= a.T_out) continue;
+        if (a.transposed && m >= a.T_in + NT - 1) continue;
+        float v = acc[reg] * a.acc_scale + bias;   // acc_scale undoes the power-of-two weight pre-scale of the split path (1 otherwise)
+        if (a.act == 1) v = gelu_f(v);
+        else if (a.act == 2) v = silu2_f(v);
+        const size_t o = (size_t)t * a.C_out + co;
+        if (a.mul) v = v * a.mul[o];
+        if (a.res_scale) v = rs * v;
+        if (a.res) v = a.res[o] + v;
+        if (a.clamp) v = v < -1.f ? -1.f : (v > 1.f ? 1.f : v);
+        if (a.out) a.out[o] = v;
+        if (a.out2) { const float sn = sinf(v * ea); a.out2[o] = v + ib * (sn * sn); }
+    }
+}
 
 #define CT_M 64
 #define CT_N 64
@@ -75,30 +121,292 @@ __global__ __launch_bounds__(256) void k_conv_mfma(ConvKArgs a) {
         }
     }
 
-    // epilogue: D[row][col], col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-    const int co = co0 + wc * 32 + (lane & 31);
-    if (co >= a.C_out) return;
-    const float bias = a.bias ? a.bias[co] : 0.f;
-    const float rs = a.res_scale ? a.res_scale[co] : 1.f;
-    float ea = 0.f, ib = 0.f;
-    if (a.out2) { ea = expf(a.s2_alpha[co]); ib = 1.0f / (expf(a.s2_beta[co]) + 0.000000001f); }
+    conv_epilogue(a, acc, m0 + wr * 32, co0 + wc * 32 + (lane & 31), lane, phase, NT);
+}
+
+// ================================================================================================
+// k_conv_split — the same implicit GEMM on the 16-bit matrix cores with fp32-grade accuracy.  Both operands are
+// split x = hi + lo into two fp16 planes (11 + 11 significant bits; the matrix core multiplies fp16 subnormals
+// exactly — tools/mfma_f16_denorm.hip — so small values keep an absolute resolution of 2^-24) and three
+// v_mfma_f32_32x32x16_f16 products per tile step (lo*hi + hi*lo + hi*hi, fp32 accumulate) stand in for one fp32
+// product: 1/3 of the 16-bit peak = 5x the fp32 matrix peak, dropped terms 2^-22 relative.  (bf16 planes carry only
+// 8 + 8 bits: measured PCM error 8e-5 RMS on the tiny golden, too close to the 1e-4 budget; fp16 planes: ~1e-6.)
+// Range: weights are pre-scaled per tensor by a power of two (k_split_planes; undone in the epilogue) so their
+// low plane stays normal; activations beyond +-65504 would saturate the high plane — it is clamped, the low plane
+// takes the remainder (exact to +-131008), values the codec's audio-scale features never approach.
+// Workgroup tile TM x TN = (WM*MB*32) x (WN*NB*32); K is walked as (C_in chunk of 32) x (tap).  The activation
+// rows of a chunk are staged ONCE with their tap halo (rows m0-halo .. m0+TM) and split to hi/lo on the way into
+// LDS; every tap reads the same rows at a shifted offset, so a 7-tap conv reads and splits its input once, not
+// seven times.  Weight planes are pre-split, double-buffered per tap.  LDS rows are 40 halves (80 B): the 16 rows
+// of a ds_read_b128 group land on disjoint banks.  Next tap's weights / next chunk's rows are in registers
+// (global loads in flight) during the current tap's MFMAs.
+// ================================================================================================
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+#define B3_LD 40
+
+static __device__ __forceinline__ float f16_hi_of(float x) {
+    const float c = x > 65504.f ? 65504.f : (x < -65504.f ? -65504.f : x);
+    return (float)(_Float16)c;
+}
+static __device__ __forceinline__ uint2 pack_f16x4(float a, float b, float c, float d) {
+    f16x4 v = { (_Float16)a, (_Float16)b, (_Float16)c, (_Float16)d };
+    return __builtin_bit_cast(uint2, v);
+}
+
+// Epilogue of one 32-row block of a wave's tile (32 x NB*32 outputs).  The accumulator layout (lane = column) would
+// make every global access a 4-byte-per-lane, two-rows-per-instruction affair — measured: half of the decoder's time.
+// The block is transposed through the wave's LDS slice instead, so each lane owns 4 consecutive channels of a row:
+// residual / multiplier rows come in as 16-byte loads issued up front (clamped addresses, never conditional), results
+// leave as 16-byte stores.
+template <int NB>
+static __device__ __forceinline__ void split_epilogue_block(const ConvKArgs& a, const f32x16 (&acc)[NB], float* stage, int mrow0, int co0w,
+                                                            int lane, int phase, int NT) {
+    constexpr int W = NB * 32, LDE = W + 8;      // padded row: the two 32-lane halves of a transposing write hit disjoint banks
+    const int c4 = lane & 31, rsel = lane >> 5;
+    const int co = co0w + c4 * 4;
+    const bool colok = c4 * 4 < W && co < a.C_out;
+    const int coc = colok ? co : 0, lc = c4 * 4 < W ? c4 * 4 : 0;
+    const float4 one4 = make_float4(1.f, 1.f, 1.f, 1.f), zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 bias4 = zero4, rs4 = one4, al4 = zero4, be4 = zero4;
+    if (a.bias) bias4 = *reinterpret_cast<const float4*>(a.bias + coc);
+    if (a.res_scale) rs4 = *reinterpret_cast<const float4*>(a.res_scale + coc);
+    if (a.out2) { al4 = *reinterpret_cast<const float4*>(a.s2_alpha + coc); be4 = *reinterpret_cast<const float4*>(a.s2_beta + coc); }
+    // accumulators -> LDS (transposing write), then rows come back 4 at a time; the residual / multiplier rows of the NEXT
+    // group of 4 are loaded while the current group is computed (rolled loop: the activation code is emitted once)
 #pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-        const int m = m0 + wr * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-        int t = m;
-        if (a.transposed) t = m * a.stride + phase - a.left;
-        if (t < 0 || t >= a.T_out) continue;
-        if (a.transposed && m >= a.T_in + NT - 1) continue;
-        float v = acc[reg] + bias;
-        if (a.act == 1) v = gelu_f(v);
-        else if (a.act == 2) v = silu2_f(v);
-        const size_t o = (size_t)t * a.C_out + co;
-        if (a.mul) v = v * a.mul[o];
-        if (a.res_scale) v = rs * v;
-        if (a.res) v = a.res[o] + v;
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) stage[((reg & 3) + 8 * (reg >> 2) + 4 * rsel) * LDE + j * 32 + c4] = acc[j][reg];
+    const float ea[4] = { expf(al4.x), expf(al4.y), expf(al4.z), expf(al4.w) };
+    const float ib[4] = { 1.0f / (expf(be4.x) + 0.000000001f), 1.0f / (expf(be4.y) + 0.000000001f), 1.0f / (expf(be4.z) + 0.000000001f),
+                          1.0f / (expf(be4.w) + 0.000000001f) };
+    const float bs[4] = { bias4.x, bias4.y, bias4.z, bias4.w }, rs[4] = { rs4.x, rs4.y, rs4.z, rs4.w };
+    auto row_off = [&](int p, bool* okp) -> size_t {
+        const int m = mrow0 + p * 2 + rsel;
+        int t = a.transposed ? m * a.stride + phase - a.left : m;
+        *okp = colok && t >= 0 && t < a.T_out && !(a.transposed && m >= a.T_in + NT - 1);
+        t = t < 0 ? 0 : (t < a.T_out ? t : a.T_out - 1);
+        return (size_t)t * a.C_out + coc;
+    };
+    float4 resv[4], mulv[4], resn[4], muln[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        bool okk;
+        const size_t o = row_off(k, &okk);
+        resv[k] = a.res ? *reinterpret_cast<const float4*>(a.res + o) : zero4;
+        mulv[k] = a.mul ? *reinterpret_cast<const float4*>(a.mul + o) : one4;
+    }
+#pragma unroll 1
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {                      // prefetch the next group (clamped to the last one on the final trip)
+            bool okk;
+            const size_t o = row_off((q < 3 ? q + 1 : q) * 4 + k, &okk);
+            resn[k] = a.res ? *reinterpret_cast<const float4*>(a.res + o) : zero4;
+            muln[k] = a.mul ? *reinterpret_cast<const float4*>(a.mul + o) : one4;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int p = q * 4 + k;
+            bool okp;
+            const size_t o = row_off(p, &okp);
+            const float4 raw = *reinterpret_cast<const float4*>(&stage[(p * 2 + rsel) * LDE + lc]);
+            float v[4] = { raw.x, raw.y, raw.z, raw.w }, s2[4] = { 0.f, 0.f, 0.f, 0.f };
+            const float rv[4] = { resv[k].x, resv[k].y, resv[k].z, resv[k].w }, mv[4] = { mulv[k].x, mulv[k].y, mulv[k].z, mulv[k].w };
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float x = v[e] * a.acc_scale + bs[e];
+                if (a.act == 1) x = gelu_f(x);
+                else if (a.act == 2) x = silu2_f(x);
+                if (a.mul) x = x * mv[e];
+                if (a.res_scale) x = rs[e] * x;
+                if (a.res) x = rv[e] + x;
+                if (a.clamp) x = x < -1.f ? -1.f : (x > 1.f ? 1.f : x);
+                v[e] = x;
+                if (a.out2) s2[e] = x + ib[e] * sin_sq(x * ea[e]);
+            }
+            if (okp) {
+                if (a.out) *reinterpret_cast<float4*>(a.out + o) = make_float4(v[0], v[1], v[2], v[3]);
+                if (a.out2) *reinterpret_cast<float4*>(a.out2 + o) = make_float4(s2[0], s2[1], s2[2], s2[3]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { resv[k] = resn[k]; mulv[k] = muln[k]; }
+    }
+}
+
+template <int MB, int NB, int WM, int WN, int PA>
+__global__ __launch_bounds__(256) void k_conv_split(ConvKArgs a) {
+    constexpr int TM = WM * MB * 32, TN = WN * NB * 32, AROWS = PA * 32;
+    constexpr int PB = TN * 8 / 256;                 // 16-B segments per thread of one weight tile (2 planes x TN rows x 4 segments)
+    constexpr int A_BYTES = 2 * AROWS * B3_LD * 2, B_BYTES = 2 * 2 * TN * B3_LD * 2;
+    constexpr int E_BYTES = 4 * 32 * (NB * 32 + 8) * 4;          // epilogue staging: 32 rows per wave
+    constexpr int SM_BYTES = A_BYTES + B_BYTES > E_BYTES ? A_BYTES + B_BYTES : E_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[SM_BYTES];
+    _Float16 (*As)[AROWS][B3_LD] = reinterpret_cast<_Float16 (*)[AROWS][B3_LD]>(smem);
+    _Float16 (*Bs)[2][TN][B3_LD] = reinterpret_cast<_Float16 (*)[2][TN][B3_LD]>(smem + A_BYTES);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int m0 = blockIdx.x * TM, co0 = blockIdx.y * TN, phase = blockIdx.z;
+    const int NT = a.transposed ? a.taps / a.stride : a.taps;
+    const int halo = a.transposed ? NT - 1 : (a.taps - 1) * a.dil;
+    const int n_chunks = a.C_in / 32, total = n_chunks * NT;
+
+    f32x16 acc[MB][NB];
+    const f32x16 zero16 = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) acc[i][j] = zero16;
+
+    const int arow = tid >> 3, acol = (tid & 7) * 4;
+    float4 areg[PA];
+    uint4 breg[PB];
+    auto loadA = [&](int ci0) {
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            const int src = m0 - halo + arow + 32 * i;
+            const int sc = src < 0 ? 0 : (src < a.T_in ? src : a.T_in - 1);      // clamped address; out-of-range rows are zeroed in storeA
+            areg[i] = *reinterpret_cast<const float4*>(a.in + (size_t)sc * a.C_in + ci0 + acol);
+        }
+    };
+    auto loadB = [&](int ci0, int ti) {
+        const int wtap = a.transposed ? phase + ti * a.stride : ti;
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+            const int idx = tid + 256 * i, plane = idx / (TN * 4), rem = idx % (TN * 4), brow = rem >> 2, bseg = rem & 3;
+            const int co = co0 + brow;
+            const int cc = co < a.C_out ? co : a.C_out - 1;               // rows past C_out repeat the last one; their columns are never stored
+            breg[i] = *reinterpret_cast<const uint4*>((plane ? a.Wl : a.Wh) + ((size_t)wtap * a.C_out + cc) * a.C_in + ci0 + bseg * 8);
+        }
+    };
+    auto storeA = [&]() {
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            const int src = m0 - halo + arow + 32 * i;
+            const bool inr = src >= 0 && src < a.T_in;
+            const float4 v = make_float4(inr ? areg[i].x : 0.f, inr ? areg[i].y : 0.f, inr ? areg[i].z : 0.f, inr ? areg[i].w : 0.f);
+            const float h0 = f16_hi_of(v.x), h1 = f16_hi_of(v.y), h2 = f16_hi_of(v.z), h3 = f16_hi_of(v.w);
+            *reinterpret_cast<uint2*>(&As[0][arow + 32 * i][acol]) = pack_f16x4(h0, h1, h2, h3);
+            *reinterpret_cast<uint2*>(&As[1][arow + 32 * i][acol]) = pack_f16x4(f16_hi_of(v.x - h0), f16_hi_of(v.y - h1), f16_hi_of(v.z - h2), f16_hi_of(v.w - h3));
+        }
+    };
+    auto storeB = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+            const int idx = tid + 256 * i, plane = idx / (TN * 4), rem = idx % (TN * 4), brow = rem >> 2, bseg = rem & 3;
+            *reinterpret_cast<uint4*>(&Bs[buf][plane][brow][bseg * 8]) = breg[i];
+        }
+    };
+
+    loadA(0);
+    loadB(0, 0);
+    int chunk = 0, ti = 0;
+    for (int it = 0; it < total; ++it) {
+        if (ti == 0) { __syncthreads(); storeA(); }          // every wave is done with the previous chunk's rows
+        storeB(it & 1);                                       // this buffer was last read two taps ago
+        __syncthreads();
+        int nchunk = chunk, nti = ti + 1;
+        if (nti == NT) { nti = 0; ++nchunk; }
+        if (it + 1 < total) {                                 // next tap's weights (and next chunk's rows) fly during the MFMAs below
+            loadB(nchunk * 32, nti);
+            if (nti == 0) loadA(nchunk * 32);
+        }
+        const int shift = a.transposed ? ti : (a.taps - 1 - ti) * a.dil;
+        const int roff = halo - shift + wm * MB * 32 + (lane & 31);
+        const int buf = it & 1;
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            const int kof = st * 16 + 8 * (lane >> 5);
+            f16x8 ah[MB], al[MB], bh[NB], bl[NB];
+#pragma unroll
+            for (int i = 0; i < MB; ++i) {
+                ah[i] = *reinterpret_cast<const f16x8*>(&As[0][roff + i * 32][kof]);
+                al[i] = *reinterpret_cast<const f16x8*>(&As[1][roff + i * 32][kof]);
+            }
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int brow = wn * NB * 32 + j * 32 + (lane & 31);
+                bh[j] = *reinterpret_cast<const f16x8*>(&Bs[buf][0][brow][kof]);
+                bl[j] = *reinterpret_cast<const f16x8*>(&Bs[buf][1][brow][kof]);
+            }
+#pragma unroll
+            for (int i = 0; i < MB; ++i)
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+        }
+        chunk = nchunk; ti = nti;
+    }
+    __syncthreads();                                          // the staging slices below overlay the operand tiles
+    float* stage = reinterpret_cast<float*>(smem) + wave * 32 * (NB * 32 + 8);
+    // statically indexed row blocks (a rolled loop would give the accumulators a scratch home that the main loop keeps in sync)
+    split_epilogue_block<NB>(a, acc[0], stage, m0 + wm * MB * 32, co0 + wn * NB * 32, lane, phase, NT);
+    if (MB > 1) split_epilogue_block<NB>(a, acc[MB - 1], stage, m0 + wm * MB * 32 + 32, co0 + wn * NB * 32, lane, phase, NT);
+}
+
+// fp32 weights * scale -> (hi, lo) fp16 planes; absmax for choosing the power-of-two scale
+__global__ void k_split_planes(const float* w, bf16_t* hi, bf16_t* lo, size_t n, float scale) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float x = w[i] * scale;
+        const _Float16 h = (_Float16)x;
+        const _Float16 l = (_Float16)(x - (float)h);
+        hi[i] = __builtin_bit_cast(bf16_t, h);
+        lo[i] = __builtin_bit_cast(bf16_t, l);
+    }
+}
+__global__ void k_absmax(const float* w, size_t n, unsigned* out) {
+    float m = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(w[i]));
+    atomicMax(out, __float_as_uint(m));   // non-negative floats order like their bit patterns
+}
+void launch_split_planes(const float* w, bf16_t* hi, bf16_t* lo, size_t n, float scale, hipStream_t s) {
+    hipLaunchKernelGGL(k_split_planes, dim3((unsigned)std::min<size_t>((n + 255) / 256, 8192)), dim3(256), 0, s, w, hi, lo, n, scale);
+    Q3_HIP_CHECK(hipGetLastError());
+}
+void launch_absmax(const float* w, size_t n, unsigned* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_absmax, dim3((unsigned)std::min<size_t>((n + 255) / 256, 1024)), dim3(256), 0, s, w, n, out);
+    Q3_HIP_CHECK(hipGetLastError());
+}
+
+template <int MB, int NB, int WM, int WN>
+static void launch_split_pa(const ConvKArgs& a, dim3 grid, int extra, hipStream_t s) {
+    constexpr int P0 = WM * MB;
+    if (extra == 0) hipLaunchKernelGGL((k_conv_split<MB, NB, WM, WN, P0>), grid, dim3(256), 0, s, a);
+    else if (extra == 1) hipLaunchKernelGGL((k_conv_split<MB, NB, WM, WN, P0 + 1>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_conv_split<MB, NB, WM, WN, P0 + 2>), grid, dim3(256), 0, s, a);
+}
+
+// C_out == 1 (the decoder's last conv): one output sample per thread, the input rows of a 128-sample tile (+ tap halo) staged in
+// LDS with an odd row stride; a matrix-core tile would be 1/64 full.  Causal taps, optional clamp.
+#define CO1_T 128
+__global__ __launch_bounds__(CO1_T) void k_conv_cout1(ConvKArgs a) {
+    extern __shared__ float xs[];                    // [(CO1_T + halo)][C_in + 1]
+    const int ld = a.C_in + 1, halo = (a.taps - 1) * a.dil, t0 = blockIdx.x * CO1_T, rows = CO1_T + halo;
+    for (int i = threadIdx.x; i < rows * (a.C_in / 4); i += CO1_T) {
+        const int r = i / (a.C_in / 4), c4 = (i % (a.C_in / 4)) * 4, src = t0 - halo + r;
+        const int sc = src < 0 ? 0 : (src < a.T_in ? src : a.T_in - 1);
+        const float4 v = *reinterpret_cast<const float4*>(a.in + (size_t)sc * a.C_in + c4);
+        const bool inr = src >= 0 && src < a.T_in;
+        xs[r * ld + c4] = inr ? v.x : 0.f; xs[r * ld + c4 + 1] = inr ? v.y : 0.f; xs[r * ld + c4 + 2] = inr ? v.z : 0.f; xs[r * ld + c4 + 3] = inr ? v.w : 0.f;
+    }
+    __syncthreads();
+    const int t = t0 + threadIdx.x;
+    float acc = 0.f;
+    for (int tap = 0; tap < a.taps; ++tap) {
+        const float* xr = xs + (threadIdx.x + tap * a.dil) * ld;   // row t - (taps-1-tap)*dil
+        const float* w = a.W + (size_t)tap * a.C_in;                // [tap][0][ci]: wave-uniform, scalar loads
+        for (int ci = 0; ci < a.C_in; ++ci) acc = fmaf(w[ci], xr[ci], acc);
+    }
+    if (t < a.T_out) {
+        float v = acc + (a.bias ? a.bias[0] : 0.f);
         if (a.clamp) v = v < -1.f ? -1.f : (v > 1.f ? 1.f : v);
-        if (a.out) a.out[o] = v;
-        if (a.out2) { const float sn = sinf(v * ea); a.out2[o] = v + ib * (sn * sn); }
+        a.out[t] = v;
     }
 }
 
@@ -109,10 +417,42 @@ void launch_conv(const ConvArgs& c, hipStream_t s) {
     a.W = c.W; a.bias = c.bias; a.taps = c.taps; a.dil = c.dil; a.transposed = c.transposed; a.stride = c.stride; a.left = c.left;
     a.res = c.res; a.res_scale = c.res_scale; a.mul = c.mul; a.act = c.act; a.clamp = c.clamp;
     a.out2 = c.out2; a.s2_alpha = c.snake_alpha; a.s2_beta = c.snake_beta;
+    a.Wh = c.Wh; a.Wl = c.Wl;
+    a.acc_scale = 1.0f;
     if (c.transposed && c.taps % c.stride != 0) throw Error("conv: transposed kernel must be a multiple of the stride");
     const int rows = c.transposed ? c.T_in + c.taps / c.stride - 1 : c.T_out;
     dim3 grid((rows + CT_M - 1) / CT_M, (c.C_out + CT_N - 1) / CT_N, c.transposed ? c.stride : 1);
     if (rows <= 0) return;
+    if (c.C_out == 1 && !c.transposed && c.C_in % 4 == 0 && c.out && !c.out2 && !c.res && !c.mul && !c.res_scale && c.act == 0) {
+        const size_t lds = (size_t)(CO1_T + (c.taps - 1) * c.dil) * (c.C_in + 1) * sizeof(float);
+        if (lds <= 60 * 1024) {
+            hipLaunchKernelGGL(k_conv_cout1, dim3((c.T_out + CO1_T - 1) / CO1_T), dim3(CO1_T), lds, s, a);
+            Q3_HIP_CHECK(hipGetLastError());
+            return;
+        }
+    }
+    const int NTt = c.transposed ? c.taps / c.stride : c.taps;
+    const int halo = c.transposed ? NTt - 1 : (c.taps - 1) * c.dil;
+    if (c.Wh && c.Wl && c.C_in % 32 == 0 && c.C_out >= 32 && c.C_out % 4 == 0 && halo <= 64) {   // fp16 hi/lo split path
+        a.acc_scale = c.w_scale_inv;
+        const int extra = (halo + 31) / 32, z = c.transposed ? c.stride : 1;
+        const bool n96 = c.C_out % 128 != 0 && c.C_out % 96 == 0;
+        const int ntile = n96 ? c.C_out / 96 : (c.C_out + 127) / 128;
+        const long n_big = (long)((rows + 255) / 256) * ntile * z, n_thin = (long)((rows + 127) / 128) * ntile * z;
+        // 256-row tiles when the grid still fills the chip a few times over and K is deep enough to be compute-bound; 128-row tiles
+        // (2-3 workgroups per CU) for bandwidth-bound or mid-sized launches; 64-row tiles for the short pre-transformer GEMMs
+        const bool deep = NTt * c.C_in > 512;
+        if (n_thin < 512) launch_split_pa<2, 1, 1, 4>(a, dim3((rows + 63) / 64, (c.C_out + 127) / 128, z), extra, s);
+        else if (!deep || n_big < 1024) {
+            if (n96) launch_split_pa<1, 3, 4, 1>(a, dim3((rows + 127) / 128, ntile, z), extra, s);
+            else launch_split_pa<1, 4, 4, 1>(a, dim3((rows + 127) / 128, ntile, z), extra, s);
+        } else {
+            if (n96) launch_split_pa<2, 3, 4, 1>(a, dim3((rows + 255) / 256, ntile, z), extra, s);
+            else launch_split_pa<2, 4, 4, 1>(a, dim3((rows + 255) / 256, ntile, z), extra, s);
+        }
+        Q3_HIP_CHECK(hipGetLastError());
+        return;
+    }
     hipLaunchKernelGGL(k_conv_mfma, grid, dim3(256), 0, s, a);
 }
 

@@ -199,6 +199,8 @@ struct ConvArgs { // out[t][co] = epi(bias[co] + sum_{tap,ci} W[tap][co][ci] * i
     const float* in = nullptr; int T_in = 0, C_in = 0;
     float* out = nullptr;      int T_out = 0, C_out = 0; // out may be null when only out2 is wanted
     const float* W = nullptr;  // [taps][C_out][C_in] fp32
+    const bf16_t* Wh = nullptr; const bf16_t* Wl = nullptr; // optional (hi, lo) fp16 planes of W * 2^k: selects the split-precision MFMA kernel
+    float w_scale_inv = 1.0f;                                  // 2^-k
     const float* bias = nullptr;
     int taps = 1, dil = 1;
     int transposed = 0, stride = 1, left = 0; // transposed: out index jo = m*stride + phase - left
@@ -212,6 +214,8 @@ struct ConvArgs { // out[t][co] = epi(bias[co] + sum_{tap,ci} W[tap][co][ci] * i
     const float* snake_beta = nullptr;
 };
 void launch_conv(const ConvArgs& a, hipStream_t s);
+void launch_split_planes(const float* w, bf16_t* hi, bf16_t* lo, size_t n, float scale, hipStream_t s);
+void launch_absmax(const float* w, size_t n, unsigned* out, hipStream_t s);
 void launch_repack_conv(const float* w, float* out, int cin, int cout, int k, int transposed, hipStream_t s);
 void launch_code_embed_mean(const float* table, const int32_t* codes, int F, int G, int codebook, int C, float* out, hipStream_t s);
 void launch_rmsnorm_rows(const float* x, const float* w, float eps, int rows, int C, float* out, hipStream_t s);

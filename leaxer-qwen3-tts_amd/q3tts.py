@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libq3tts_hip.so")
+LIB_PATH = os.environ.get("Q3TTS_LIB") or os.path.join(_HERE, "libq3tts_hip.so")   # Q3TTS_LIB: kernel experiments (tools/)
 
 _CFG_FIELDS = [
     ("hidden", C.c_int32), ("n_layers", C.c_int32), ("n_heads", C.c_int32), ("n_kv_heads", C.c_int32),
@@ -68,6 +68,7 @@ class Sampling(C.Structure):
 
 FLAG_NO_GRAPH = 1
 FLAG_NO_FUSED_CP = 2
+FLAG_FP32_CODEC = 4
 
 # every symbol include/q3tts.h declares
 EXPORTS = [

@@ -99,6 +99,27 @@ def test_codec_full_size(full):
     assert float(np.sqrt(np.mean((pcm - ref) ** 2))) < 1e-4
 
 
+def test_codec_split_precision_matrix_path_full_size(full):
+    """24 frames at 0.6B dims reach the 256-row tiles of k_conv_bf3 (bf16 hi/lo split, 3 products per fp32 product):
+    PCM against the fp32 oracle within the north_star tolerance, and against the exact-fp32 MFMA path."""
+    import q3tts
+    eng, orc = full
+    codes = np.random.default_rng(4).integers(0, 2048, (24, 16)).astype(np.int64)
+    pcm = eng.codec_decode(codes)
+    ref = orc.vocoder(codes)
+    assert pcm.shape == ref.shape == (eng.codec_decode_len(24),)
+    rms_ref = float(np.sqrt(np.mean(ref ** 2)))
+    err = float(np.sqrt(np.mean((pcm - ref) ** 2)))
+    assert rms_ref > 1e-3 and err < 1e-4 and err < 2e-3 * rms_ref, (err, rms_ref)
+    exact = q3tts.Engine(eng.cfg, device=0, max_batch=1, max_ctx=64, flags=q3tts.FLAG_FP32_CODEC)
+    exact.fill_synthetic(seed=0)
+    pcm32 = exact.codec_decode(codes)
+    exact.close()
+    err32 = float(np.sqrt(np.mean((pcm32 - ref) ** 2)))
+    assert err32 < 1e-4 and float(np.sqrt(np.mean((pcm - pcm32) ** 2))) < 1e-4
+    print("codec rms error vs oracle: split-bf16 %.3g, fp32-mfma %.3g, signal rms %.3g" % (err, err32, rms_ref))
+
+
 def test_talker_decode_across_split_boundary_full_size(full):
     """140 talker decode steps at 0.6B dims: the context crosses the first 128-token attention split."""
     eng, orc = full
