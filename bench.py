@@ -161,7 +161,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16 weights, fp32 activations/accumulate (fp32 codec decoder)", "data": "synthetic",
+            "dtype": "bf16 weights, fp32 activations/accumulate (codec decoder: fp16 hi/lo split operands, fp32 accumulate)", "data": "synthetic",
             "config": {"workload": f"Qwen3-TTS-0.6B, batch={B}/GPU, 16-token prompt, "
                                    + ("greedy top_k=1" if args.greedy else "sampled temp=0.8 top-k=50 top-p=0.95")
                                    + f", max-tokens={F} (EOS suppressed), synthetic seeded weights",
@@ -171,7 +171,7 @@ def main():
             "decode_ms_per_frame_step": round(step_ms, 4),
             "codec_decode_ms_per_frame": round(ctr["codec_ms"] / max(ctr["codec_frames"], 1), 5),
             "roofline": {"bound": "hbm", "kernel": "decode step = one hipGraph replay per frame ("
-                                   + ("651 nodes: q3::k_gemv1 x531, k_attn x103, k_sample x16, k_gemv x1" if B <= 4 else
+                                   + ("q3::k_gemv1 (QKV / o_proj / gate-up / down / heads), k_cp_attn_oproj x75, k_attn x28, k_sample x16" if B <= 4 else
                                       "q3::k_gemm2 + k_finish + k_attn + k_attn_combine + k_sample") + ")",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,

@@ -237,7 +237,7 @@ static __device__ __forceinline__ void split_epilogue_block(const ConvKArgs& a, 
 }
 
 template <int MB, int NB, int WM, int WN, int PA>
-__global__ __launch_bounds__(256) void k_conv_split(ConvKArgs a) {
+__global__ __launch_bounds__(256, (MB * NB <= 6 ? 2 : 1)) void k_conv_split(ConvKArgs a) {   // <= 96 accumulator registers: two workgroups per CU
     constexpr int TM = WM * MB * 32, TN = WN * NB * 32, AROWS = PA * 32;
     constexpr int PB = TN * 8 / 256;                 // 16-B segments per thread of one weight tile (2 planes x TN rows x 4 segments)
     constexpr int A_BYTES = 2 * AROWS * B3_LD * 2, B_BYTES = 2 * 2 * TN * B3_LD * 2;
@@ -436,7 +436,7 @@ void launch_conv(const ConvArgs& c, hipStream_t s) {
     if (c.Wh && c.Wl && c.C_in % 32 == 0 && c.C_out >= 32 && c.C_out % 4 == 0 && halo <= 64) {   // fp16 hi/lo split path
         a.acc_scale = c.w_scale_inv;
         const int extra = (halo + 31) / 32, z = c.transposed ? c.stride : 1;
-        const bool n96 = c.C_out % 128 != 0 && c.C_out % 96 == 0;
+        const bool n96 = c.C_out % 96 == 0;   // every decoder width (1536 .. 96) and the FFN; 96-wide tiles fit two workgroups per CU
         const int ntile = n96 ? c.C_out / 96 : (c.C_out + 127) / 128;
         const long n_big = (long)((rows + 255) / 256) * ntile * z, n_thin = (long)((rows + 127) / 128) * ntile * z;
         // 256-row tiles when the grid still fills the chip a few times over and K is deep enough to be compute-bound; 128-row tiles
@@ -450,6 +450,7 @@ void launch_conv(const ConvArgs& c, hipStream_t s) {
             if (n96) launch_split_pa<2, 3, 4, 1>(a, dim3((rows + 255) / 256, ntile, z), extra, s);
             else launch_split_pa<2, 4, 4, 1>(a, dim3((rows + 255) / 256, ntile, z), extra, s);
         }
+        (void)n_thin;
         Q3_HIP_CHECK(hipGetLastError());
         return;
     }

@@ -6,7 +6,7 @@ import json
 import sys
 from collections import defaultdict
 
-DECODE = ("k_gemv", "k_gemm", "k_attn", "k_sample", "k_finish", "k_rmsnorm_split")
+DECODE = ("k_gemv", "k_gemm", "k_attn", "k_cp_attn_oproj", "k_sample", "k_finish", "k_rmsnorm_split")
 
 
 def total(path, counter):
@@ -26,6 +26,6 @@ rd = sum(v for k, v in fetch.items() if k.startswith(DECODE)) * 1024 * 2
 wr = sum(v for k, v in write.items() if k.startswith(DECODE)) * 1024
 out = {"frames": frames, "batch": batch, "read_bytes_per_step": rd / frames, "write_bytes_per_step": wr / frames,
        "hbm_bytes_per_step": (rd + wr) / frames,
-       "note": "decode kernels only (k_gemv*/k_gemm*/k_attn*/k_sample/k_finish*), includes the one prefill; FETCH_SIZE doubled per the gfx950 correction",
+       "note": "decode kernels only (k_gemv*/k_gemm*/k_attn*/k_cp_attn_oproj/k_sample/k_finish*), includes the one prefill; FETCH_SIZE doubled per the gfx950 correction",
        "by_kernel_read_MB_per_step": {k: round(v * 2048 / frames / 1e6, 2) for k, v in sorted(fetch.items(), key=lambda kv: -kv[1])[:8]}}
 print(json.dumps(out))
