@@ -592,7 +592,9 @@ void Engine::sample(const float* logits, int n, const q3tts_sampling& p, float u
 void Engine::build_prompt(const int64_t* ids, int n_ids, int lang, const float* speaker, float* prompt, int* S,
                           float* trailing, int cap_rows, int* n_trailing) {
     const int H = c.hidden;
-    if (n_ids < 6) throw Error("token sequence too short: need [IM_START, ASSISTANT, TTS_BOS, text..., TTS_EOS, IM_END]");
+    // the reference indexes input_ids[0..3] unguarded (:493, :518): 4 ids is the least it can take.  Empty text = the 5-token frame:
+    // TTS_EOS lands in the "first text token" slot and the trailing block is just [tts_eos].
+    if (n_ids < 4) throw Error("token sequence too short: need at least 4 ids (the reference indexes input_ids[3])");
     std::vector<float> tts(3 * (size_t)H);
     const int64_t tts_ids[3] = { TTS_BOS, TTS_EOS, TTS_PAD };
     text_project(tts_ids, 3, tts.data());                       // :459-463

@@ -280,7 +280,7 @@ class Engine:
 
     def codec_decode(self, codes):
         c = np.ascontiguousarray(codes, dtype=np.int64)
-        n = self.codec_decode_len(c.shape[0])
+        n = max(self.codec_decode_len(c.shape[0]), 1)   # F = 0 is rejected by the library, not by numpy
         pcm = np.empty(n, np.float32)
         out_len = C.c_int64(0)
         self._ck(self.L.q3tts_codec_decode_host(self.h, _p(c), c.shape[0], _p(pcm), n, C.byref(out_len)))

@@ -706,7 +706,9 @@ int64_t q3o_sample(const float* logits, int n, const q3o_sampling* sp, float u) 
 
 int q3o_build_prompt(q3o_model* m, const int64_t* ids, int n_ids, int lang, const float* speaker, float* prompt, int* S) {
     int H = m->c.hidden;
-    if (n_ids < 6) FAIL("need at least [IM_START, ASSISTANT, TTS_BOS, text, TTS_EOS, IM_END]");
+    /* the reference indexes input_ids[0..3] unguarded (:493, :518): 4 ids is the least it can take; with the usual 5-token frame of
+     * an EMPTY text, TTS_EOS lands in the "first text token" slot and the trailing block is just [tts_eos] */
+    if (n_ids < 4) FAIL("need at least 4 token ids (role x3 + one more), as the reference indexes input_ids[3]");
     /* 1. tts special embeddings (:459-463) */
     int64_t tts_ids[3] = { TTS_BOS, TTS_EOS, TTS_PAD };
     float* tts = zalloc(3 * (size_t)H);
