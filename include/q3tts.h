@@ -98,6 +98,16 @@ int q3tts_code_predictor_host(q3tts_engine* e, const float* seq, int n, int gene
 /* run_vocoder, tts_onnx.cpp:759-776: codes[F][n_groups] (frame-major) -> pcm; *out_len = lengths[0] */
 int q3tts_codec_decode_host(q3tts_engine* e, const int64_t* codes, int F, float* pcm, int64_t cap, int64_t* out_len);
 int64_t q3tts_codec_decode_len(const q3tts_config* cfg, int F);
+/* Streaming / chunked decode (the reference decodes the whole utterance in one run_vocoder call, tts_onnx.cpp:430).
+ * The decoder is causal: frames [a, b) own the samples [L(a), L(b)) of the full decode (L = q3tts_codec_decode_len, L(0) = 0), and
+ * they are final as soon as frame b-1 exists.  Each call decodes the window [a - left_context, b) and returns exactly those
+ * samples; with left_context >= a the concatenation over chunks equals the whole-utterance decode (to RoPE rounding), smaller
+ * values bound work and memory at the price of a truncated history (the pre-transformer looks back 72 frames per layer). */
+int q3tts_codec_decode_chunked_host(q3tts_engine* e, const int64_t* codes, int F, int chunk_frames, int left_context, float* pcm, int64_t cap,
+                                    int64_t* out_len);
+/* the same for frames of a slot that is still generating: call after q3tts_decode_steps has produced frame_end frames */
+int q3tts_slot_codec_decode_range_host(q3tts_engine* e, int slot, int frame_begin, int frame_end, int left_context, float* pcm, int64_t cap,
+                                       int64_t* out_len);
 /* sample_token, tts_onnx.cpp:878-905, on device; u in [0,1) replaces the mt19937 draw.
  * suppress != 0 applies the special-token suppression of tts_onnx.cpp:803-807 first. */
 int q3tts_sample_host(q3tts_engine* e, const float* logits, int n, const q3tts_sampling* p, float u, int suppress, int64_t* token);

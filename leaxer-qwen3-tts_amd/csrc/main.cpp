@@ -43,7 +43,8 @@ static void usage(const char* prog) {
     printf("  --ref PATH            reference audio for voice clone (speaker encoder not built yet)\n");
     printf("  --temp FLOAT          temperature (default: 0.8; 0 samples at T=1 like the reference, use --top-k 1 for greedy)\n");
     printf("  --top-k N             top-k (default: 50)\n  --top-p FLOAT         top-p (default: 0.95)\n");
-    printf("  --max-tokens N        max codec frames (default: 2048)\n  --seed N              sampling seed (default: 0)\n  -h, --help\n");
+    printf("  --max-tokens N        max codec frames (default: 2048)\n  --seed N              sampling seed (default: 0)\n");
+    printf("  --stream-chunk N      with --tokens: decode audio every N frames while generating (same samples as the one-shot decode)\n  -h, --help\n");
 }
 
 static Language lang_of(const std::string& s) {
@@ -59,6 +60,7 @@ int main(int argc, char** argv) {
     bool have_prompt = false;
     SamplingParams sp;
     uint64_t seed = 0;
+    int stream_chunk = 0;
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
         const bool more = i + 1 < argc;
@@ -74,6 +76,7 @@ int main(int argc, char** argv) {
         else if (a == "--top-p" && more) sp.top_p = (float)atof(argv[++i]);
         else if (a == "--max-tokens" && more) sp.max_new_tokens = atoi(argv[++i]);
         else if (a == "--seed" && more) seed = strtoull(argv[++i], nullptr, 10);
+        else if (a == "--stream-chunk" && more) stream_chunk = atoi(argv[++i]);
     }
     if (model.empty() || (!have_prompt && tokens.empty())) {
         fprintf(stderr, "Error: --model and --prompt (or --tokens) are required\n");
@@ -111,6 +114,14 @@ int main(int argc, char** argv) {
         else audio = engine.synthesize_tokens_clone(ids, spk, lang_of(lang), sp);
     } else if (!ref.empty()) {
         audio = engine.synthesize_clone(prompt, ref, lang_of(lang), sp);
+    } else if (!ids.empty() && stream_chunk > 0) {   // chunks of audio as their frames are generated; the file holds their concatenation
+        size_t chunks = 0;
+        const int nf = engine.synthesize_tokens_streaming(ids, lang_of(lang), sp, stream_chunk, -1, [&](const float* p, size_t n) {
+            if (chunks++ == 0) printf("First %.2f seconds of audio ready\n", (float)n / config::SAMPLE_RATE);
+            audio.insert(audio.end(), p, p + n);
+        });
+        if (nf < 0) audio.clear();
+        else printf("Streamed %d frames in %zu chunks\n", nf, chunks);
     } else if (!ids.empty()) {
         audio = engine.synthesize_tokens(ids, lang_of(lang), sp);
     } else audio = engine.synthesize(prompt, lang_of(lang), sp);

@@ -126,6 +126,23 @@ int q3tts_codec_decode_host(q3tts_engine* h, const int64_t* codes, int F, float*
     Q3_API_END(h)
 }
 
+int q3tts_codec_decode_chunked_host(q3tts_engine* h, const int64_t* codes, int F, int chunk_frames, int left_context, float* pcm, int64_t cap,
+                                    int64_t* out_len) {
+    Q3_API_BEGIN(h)
+    const int64_t n = h->e->codec_decode_chunked_host(codes, F, chunk_frames, left_context, pcm, cap);
+    if (out_len) *out_len = n;
+    return 0;
+    Q3_API_END(h)
+}
+int q3tts_slot_codec_decode_range_host(q3tts_engine* h, int slot, int frame_begin, int frame_end, int left_context, float* pcm, int64_t cap,
+                                       int64_t* out_len) {
+    Q3_API_BEGIN(h)
+    const int64_t n = h->e->slot_codec_decode_range(slot, frame_begin, frame_end, left_context, pcm, cap);
+    if (out_len) *out_len = n;
+    return 0;
+    Q3_API_END(h)
+}
+
 int64_t q3tts_codec_decode_len(const q3tts_config* c, int F) {
     int64_t T = F;
     for (int s = 0; s < c->cd_n_up; ++s) T *= c->cd_up_ratios[s];

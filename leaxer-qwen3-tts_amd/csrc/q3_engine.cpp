@@ -753,6 +753,64 @@ int64_t Engine::slot_codec_decode(int slot, float* pcm, int64_t cap) {
     return n;
 }
 
+// ------------------------------------------------------------------------------------------------
+// streaming / chunked codec decode.  The decoder is causal, so the samples a chunk of frames [a, b) owns —
+// full-utterance indices [L(a), L(b)), L(n) = q3tts_codec_decode_len(n), L(0) = 0 — are final once frame b-1 exists, and a
+// decode of the window [a - left_context, b) reproduces them at offset L(a) - total_upsample * (a - left_context) (every
+// layer is shift-invariant).  With left_context covering the history the result equals the whole-utterance decode the
+// reference performs (tts_onnx.cpp:430) up to RoPE rounding; a shorter context trades exactness for bounded work
+// (transformers' chunked_decode uses 25 frames — and also drops L(1)-many samples per chunk, which this does not).
+// ------------------------------------------------------------------------------------------------
+static int64_t codec_len_of(const q3tts_config& c, int n) { return n <= 0 ? 0 : q3tts_codec_decode_len(&c, n); }
+
+int64_t Engine::codec_decode_range_dev(const int32_t* codes_dev, int a, int b, int left_context, float* pcm, int64_t cap) {
+    if (!finalized) throw Error("weights not finalized");
+    if (a < 0 || b <= a || b > max_frames_cap) throw Error("codec_decode_range: frame range out of range");
+    if (left_context < 0) throw Error("codec_decode_range: negative left context");
+    const int s = std::max(0, a - left_context);
+    int64_t up = 1;
+    for (int i = 0; i < c.cd_n_up; ++i) up *= c.cd_up_ratios[i];
+    for (int i = 0; i < c.cd_n_blocks; ++i) up *= c.cd_up_rates[i];
+    const int64_t first = codec_len_of(c, a) - up * s, n_own = codec_len_of(c, b) - codec_len_of(c, a);
+    float* pcm_d = nullptr;
+    Q3_HIP_CHECK(hipEventRecord(ev0, stream));
+    const int64_t n_win = codec_run(codes_dev + (size_t)s * c.n_groups, b - s, &pcm_d);
+    Q3_HIP_CHECK(hipEventRecord(ev1, stream));
+    if (first < 0 || first + n_own != n_win) throw Error("codec_decode_range: window arithmetic does not match the decoder length formula");
+    const int64_t m = std::min(n_own, cap);
+    if (m > 0 && pcm) Q3_HIP_CHECK(hipMemcpyAsync(pcm, pcm_d + first, (size_t)m * sizeof(float), hipMemcpyDeviceToHost, stream));
+    sync();
+    Q3_HIP_CHECK(hipEventElapsedTime(&last_codec_ms, ev0, ev1));
+    total_codec_ms += last_codec_ms; total_codec_frames += b - s;
+    return n_own;
+}
+
+int64_t Engine::slot_codec_decode_range(int slot, int a, int b, int left_context, float* pcm, int64_t cap) {
+    int nf = 0;
+    slot_status(slot, &nf, nullptr);
+    if (b > nf) throw Error("codec_decode_range: frames [" + std::to_string(a) + ", " + std::to_string(b) + ") are not generated yet (" + std::to_string(nf) + " so far)");
+    return codec_decode_range_dev(codes_d + (size_t)slot * max_frames_cap * c.n_groups, a, b, left_context, pcm, cap);
+}
+
+int64_t Engine::codec_decode_chunked_host(const int64_t* codes, int F, int chunk, int left_context, float* pcm, int64_t cap) {
+    if (F < 1 || F > max_frames_cap) throw Error("codec_decode: F out of range");
+    if (chunk < 1) throw Error("codec_decode_chunked: chunk must be positive");
+    const int G = c.n_groups;
+    std::vector<int32_t> tmp((size_t)F * G);
+    for (size_t i = 0; i < tmp.size(); ++i) {
+        if (codes[i] < 0 || codes[i] >= c.cd_codebook) throw Error("codec_decode: code out of range");
+        tmp[i] = (int32_t)codes[i];
+    }
+    Q3_HIP_CHECK(hipMemcpyAsync(codes_scratch_d, tmp.data(), tmp.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+    int64_t total = 0;
+    for (int a = 0; a < F; a += chunk) {
+        const int b = std::min(F, a + chunk);
+        const int64_t n = codec_decode_range_dev(codes_scratch_d, a, b, left_context, pcm ? pcm + total : nullptr, std::max<int64_t>(0, cap - total));
+        total += n;
+    }
+    return total;
+}
+
 int64_t Engine::codec_decode_host(const int64_t* codes, int F, float* pcm, int64_t cap) {
     if (!finalized) throw Error("weights not finalized");
     if (F < 1 || F > max_frames_cap) throw Error("codec_decode: F out of range");

@@ -44,6 +44,7 @@ TTSEngine::TTSEngine(const std::string& model_dir) {
         if (q3tts_load_weights_file(h_, path.c_str()) != 0) { error_msg_ = q3tts_last_error(h_); return; }
     }
     spk_dim_ = cfg.spk_enc_dim;
+    cfg_hidden_ = cfg.hidden;
     // tokenizer files: where the reference looks (tts_onnx.cpp:110-121: <parent of model_dir>/models/
     // Qwen3-TTS-12Hz-0.6B-Base/{vocab.json,merges.txt}), then model_dir itself.  Present but unreadable is
     // an error, absent is a warning and text synthesis stays unavailable — as in the reference.
@@ -191,6 +192,40 @@ std::vector<std::vector<float>> TTSEngine::synthesize_tokens_batch(const std::ve
     }
     for (size_t i = 0; i < out.size(); ++i) out[i].resize((size_t)std::min<int64_t>(lens[i], cap));
     return out;
+}
+
+int TTSEngine::synthesize_tokens_streaming(const std::vector<int64_t>& token_ids, Language lang, const SamplingParams& params, int chunk_frames,
+                                           int left_context_frames, const std::function<void(const float*, size_t)>& on_audio) {
+    if (!ready_ || chunk_frames < 1) return -1;
+    q3tts_config cfg;
+    q3tts_default_config("0.6b", &cfg);
+    const int H = cfg_hidden_;
+    std::vector<float> prompt((size_t)16 * H), trailing((size_t)1024 * H);
+    int S = 0, nt = 0;
+    q3tts_sampling sp{ params.temperature, params.top_p, params.top_k, params.repetition_penalty, params.max_new_tokens };
+    auto fail = [&]() { std::cerr << "[TTSEngine] Synthesis error: " << q3tts_last_error(h_) << std::endl; (void)q3tts_slot_release(h_, 0); return -1; };
+    for (int b = 0; b < max_batch_; ++b) (void)q3tts_slot_release(h_, b);
+    if (q3tts_build_prompt_host(h_, token_ids.data(), (int)token_ids.size(), lang_index(lang), nullptr, prompt.data(), &S, trailing.data(), 1024, &nt) != 0) return fail();
+    if (q3tts_slot_begin(h_, 0, prompt.data(), S, trailing.data(), nt, &sp, seed_, 0, 0) != 0) return fail();
+    std::vector<float> pcm((size_t)chunk_frames * 1920 + 1920);
+    int done = 0;
+    for (;;) {
+        const int want = std::min(chunk_frames, params.max_new_tokens - done);
+        const int active = want > 0 ? q3tts_decode_steps(h_, want) : 0;
+        if (active < 0) return fail();
+        int nf = 0, fin = 0;
+        if (q3tts_slot_status(h_, 0, &nf, &fin) != 0) return fail();
+        if (nf > done) {
+            int64_t n = 0;
+            const int ctx = left_context_frames < 0 ? nf : left_context_frames;
+            if (q3tts_slot_codec_decode_range_host(h_, 0, done, nf, ctx, pcm.data(), (int64_t)pcm.size(), &n) != 0) return fail();
+            on_audio(pcm.data(), (size_t)std::min<int64_t>(n, (int64_t)pcm.size()));
+            done = nf;
+        }
+        if (active == 0 || want <= 0) break;
+    }
+    (void)q3tts_slot_release(h_, 0);
+    return done;
 }
 
 std::vector<float> TTSEngine::synthesize_tokens(const std::vector<int64_t>& token_ids, Language lang, const SamplingParams& params) {

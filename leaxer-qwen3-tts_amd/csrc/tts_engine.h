@@ -7,6 +7,7 @@
 #define LEAXER_QWEN_TTS_ENGINE_H
 
 #include <cstdint>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -68,6 +69,11 @@ public:
                                                             const SamplingParams& params = SamplingParams());
     std::vector<std::vector<float>> synthesize_batch(const std::vector<std::string>& texts, Language lang = Language::Auto,
                                                      const SamplingParams& params = SamplingParams());
+    // streaming extension: `on_audio` receives each chunk's samples as soon as its frames exist (exactly the
+    // samples the whole-utterance decode would return for them when left_context_frames covers the history; < 0 = all of it).
+    // Returns the number of frames generated, -1 on error.
+    int synthesize_tokens_streaming(const std::vector<int64_t>& token_ids, Language lang, const SamplingParams& params, int chunk_frames,
+                                    int left_context_frames, const std::function<void(const float*, size_t)>& on_audio);
     void set_seed(uint64_t seed) { seed_ = seed; }
     // ids of `text` from the loaded tokenizer (reference io::tokenize, src/io/tokenizer.h:22)
     std::vector<int32_t> tokenize(const std::string& text) const;
@@ -88,6 +94,7 @@ private:
     uint64_t seed_ = 0;
     int max_batch_ = 1;
     int spk_dim_ = 0;
+    int cfg_hidden_ = 1024;
 };
 
 inline int64_t language_to_codec_id(Language lang) { // reference src/tts_onnx.h:230-238

@@ -84,6 +84,7 @@ EXPORTS = [
     "q3tts_tokenizer_ready", "q3tts_tokenize",
     "q3tts_synthesize_clone_batch_host", "q3tts_read_wav_host", "q3tts_resample_host", "q3tts_mel_host",
     "q3tts_has_speaker_encoder", "q3tts_speaker_encoder_host", "q3tts_extract_speaker_embedding_host",
+    "q3tts_codec_decode_chunked_host", "q3tts_slot_codec_decode_range_host",
 ]
 
 _lib = None
@@ -146,6 +147,8 @@ def lib():
     L.q3tts_has_speaker_encoder.argtypes = [vp]
     L.q3tts_speaker_encoder_host.argtypes = [vp, vp, i32, vp]
     L.q3tts_extract_speaker_embedding_host.argtypes = [vp, C.c_char_p, vp]
+    L.q3tts_codec_decode_chunked_host.argtypes = [vp, vp, i32, i32, i32, vp, i64, C.POINTER(i64)]
+    L.q3tts_slot_codec_decode_range_host.argtypes = [vp, i32, i32, i32, i32, vp, i64, C.POINTER(i64)]
     L.q3tts_tokenizer_create.restype = vp
     L.q3tts_tokenizer_create.argtypes = []
     L.q3tts_tokenizer_destroy.restype = None
@@ -284,6 +287,23 @@ class Engine:
         pcm = np.empty(n, np.float32)
         out_len = C.c_int64(0)
         self._ck(self.L.q3tts_codec_decode_host(self.h, _p(c), c.shape[0], _p(pcm), n, C.byref(out_len)))
+        return pcm[: out_len.value]
+
+    def codec_decode_chunked(self, codes, chunk_frames, left_context):
+        """exact chunked decode: equals codec_decode(codes) when left_context covers the history"""
+        c = np.ascontiguousarray(codes, dtype=np.int64)
+        n = max(self.codec_decode_len(c.shape[0]), 1)
+        pcm = np.empty(n, np.float32)
+        out_len = C.c_int64(0)
+        self._ck(self.L.q3tts_codec_decode_chunked_host(self.h, _p(c), c.shape[0], chunk_frames, left_context, _p(pcm), n, C.byref(out_len)))
+        return pcm[: out_len.value]
+
+    def slot_codec_decode_range(self, slot, frame_begin, frame_end, left_context):
+        """samples owned by frames [frame_begin, frame_end) of a slot (streaming while it generates)"""
+        n = self.codec_decode_len(frame_end) - (self.codec_decode_len(frame_begin) if frame_begin > 0 else 0)
+        pcm = np.empty(max(n, 1), np.float32)
+        out_len = C.c_int64(0)
+        self._ck(self.L.q3tts_slot_codec_decode_range_host(self.h, slot, frame_begin, frame_end, left_context, _p(pcm), n, C.byref(out_len)))
         return pcm[: out_len.value]
 
     def sample(self, logits, sp, u, suppress=False):

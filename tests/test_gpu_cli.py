@@ -99,6 +99,24 @@ def test_cli_text_prompt_uses_the_tokenizer(tmp_path):
     assert r.returncode == 1 and "Failed to load tokenizer" in r.stderr
 
 
+def test_cli_streaming_equals_one_shot(tmp_path):
+    """--stream-chunk N: audio delivered in chunks while the frames are generated is the one-shot decode, sample for sample."""
+    eng, orc, _ = tiny_pair(seed=6, max_batch=1, max_ctx=96)
+    mdir = tmp_path / "m"
+    mdir.mkdir()
+    eng.save_weights(str(mdir / "model.q3w"))
+    eng.close()
+    orc.close()
+    common = ["-m", str(mdir), "--tokens", "3,1,4,1,5,9", "--max-tokens", "23", "--seed", "8"]
+    a, b = str(tmp_path / "a.wav"), str(tmp_path / "b.wav")
+    r = subprocess.run([CLI, "-o", a] + common, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    r = subprocess.run([CLI, "-o", b, "--stream-chunk", "5"] + common, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "First" in r.stdout and "chunks" in r.stdout, r.stdout + r.stderr
+    wa, wb = read_wav16(a), read_wav16(b)
+    assert wa.shape == wb.shape and wa.size > 0 and np.abs(wa.astype(int) - wb.astype(int)).max() <= 1
+
+
 def test_cli_errors_like_the_reference(tmp_path):
     r = subprocess.run([CLI, "-p", "hello"], capture_output=True, text=True)
     assert r.returncode == 1 and "required" in r.stderr

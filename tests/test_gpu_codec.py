@@ -66,3 +66,55 @@ def test_synthesize_batch_vs_oracle(pair):
         ref_pcm = orc.vocoder(ref_codes)
         assert pcm[u].shape == ref_pcm.shape
         assert float(np.sqrt(np.mean((pcm[u] - ref_pcm) ** 2))) < 1e-4
+
+
+def test_chunked_decode_equals_whole_decode(pair):
+    """frames [a, b) own samples [L(a), L(b)); decoding chunk by chunk with the full history as left
+    context reproduces the whole-utterance decode (what the reference computes, tts_onnx.cpp:430) — also against the
+    oracle.  The tiny config's attention window is 4 frames x 2 layers, so a short context is already exact-ish."""
+    eng, orc, _ = pair
+    F = 37
+    codes = np.random.default_rng(21).integers(0, eng.cfg.cd_codebook, (F, eng.cfg.n_groups)).astype(np.int64)
+    whole = eng.codec_decode(codes)
+    ref = orc.vocoder(codes)
+    for chunk in (1, 5, 16, 37, 100):
+        got = eng.codec_decode_chunked(codes, chunk, left_context=F)
+        assert got.shape == whole.shape, chunk
+        assert float(np.abs(got - whole).max()) < 2e-5, (chunk, float(np.abs(got - whole).max()))
+        assert float(np.sqrt(np.mean((got - ref) ** 2))) < 1e-4
+    # a bounded history is an approximation whose error shrinks as the context grows past the receptive field
+    e_small = float(np.abs(eng.codec_decode_chunked(codes, 5, left_context=1) - whole).max())
+    e_big = float(np.abs(eng.codec_decode_chunked(codes, 5, left_context=16) - whole).max())
+    assert e_big < 1e-3 and e_big < e_small, (e_small, e_big)
+    with pytest.raises(RuntimeError, match="chunk must be positive"):
+        eng.codec_decode_chunked(codes, 0, 4)
+
+
+def test_streaming_decode_while_generating(pair):
+    """Audio for the frames generated so far is final: chunks pulled from a slot between decode_steps calls concatenate
+    to exactly what the whole-utterance decode returns at the end."""
+    import q3tts
+    eng, orc, _ = pair
+    ids = frame_tokens([9, 8, 7, 6, 5])
+    sp = q3tts.Sampling(temperature=0.8, top_p=0.95, top_k=50, max_new_tokens=24)
+    prompt, trailing = eng.build_prompt(ids, 0)
+    for b in range(3):
+        eng.slot_release(b)
+    eng.slot_begin(0, prompt, trailing, sp, seed=5, stream_id=0, ignore_eos=True)
+    parts, done = [], 0
+    for step in (3, 8, 1, 12):
+        eng.decode_steps(step)
+        nf, _ = eng.slot_status(0)
+        assert nf == done + step
+        with pytest.raises(RuntimeError, match="not generated yet"):
+            eng.slot_codec_decode_range(0, done, nf + 1, left_context=nf)
+        parts.append(eng.slot_codec_decode_range(0, done, nf, left_context=nf))
+        assert parts[-1].size == eng.codec_decode_len(nf) - (eng.codec_decode_len(done) if done else 0)
+        done = nf
+    whole = eng.slot_codec_decode(0)
+    got = np.concatenate(parts)
+    assert got.shape == whole.shape and float(np.abs(got - whole).max()) < 2e-5
+    codes = eng.slot_codes(0)
+    ref = orc.vocoder(codes)
+    assert float(np.sqrt(np.mean((got - ref) ** 2))) < 1e-4
+    eng.slot_release(0)

@@ -120,6 +120,17 @@ def test_codec_split_precision_matrix_path_full_size(full):
     print("codec rms error vs oracle: split-bf16 %.3g, fp32-mfma %.3g, signal rms %.3g" % (err, err32, rms_ref))
 
 
+def test_chunked_codec_full_size(full):
+    """0.6B dims: 40 frames in chunks of 16 with the full history == one decode of all 40 (8 layers x 72-frame window > 40)."""
+    eng, _ = full
+    codes = np.random.default_rng(6).integers(0, 2048, (40, 16)).astype(np.int64)
+    whole = eng.codec_decode(codes)
+    got = eng.codec_decode_chunked(codes, 16, left_context=40)
+    assert got.shape == whole.shape and float(np.abs(got - whole).max()) < 1e-5 + 1e-3 * float(np.abs(whole).max())
+    first = eng.codec_decode_chunked(codes[:16], 16, left_context=0)          # first chunk needs no history at all
+    assert np.array_equal(first, got[: first.size]) or float(np.abs(first - got[: first.size]).max()) < 1e-6
+
+
 def test_talker_decode_across_split_boundary_full_size(full):
     """140 talker decode steps at 0.6B dims: the context crosses the first 128-token attention split."""
     eng, orc = full
