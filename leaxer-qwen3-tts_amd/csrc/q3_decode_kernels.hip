@@ -724,8 +724,18 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
             O += w * co[g][h][e];
         }
         const int head = kvh * grp + h;
-        if (a.po == nullptr) a.out[(size_t)row * a.ld_out + head * D + e] = O / L;
-        else {
+        if (a.po == nullptr) {
+            const float o = O / L;
+            if (a.out) a.out[(size_t)row * a.ld_out + head * D + e] = o;
+            if (a.oh) { // (hi, lo) bf16 planes for the MFMA o_proj: a one-split attention needs no combine launch
+                const uint32_t u = __float_as_uint(o);
+                const bf16_t hi = (bf16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+                const float rem = o - __uint_as_float((uint32_t)hi << 16);
+                const uint32_t v = __float_as_uint(rem);
+                a.oh[(size_t)row * a.ldp + head * D + e] = hi;
+                a.ol[(size_t)row * a.ldp + head * D + e] = (bf16_t)((v + 0x7FFFu + ((v >> 16) & 1u)) >> 16);
+            }
+        } else {
             const size_t pi = ((size_t)row * a.nq + head) * S + split;
             a.po[pi * D + e] = O;
             if (e == 0) { a.pm[pi] = mx; a.pl[pi] = L; }

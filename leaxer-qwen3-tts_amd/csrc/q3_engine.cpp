@@ -408,10 +408,14 @@ bool Engine::run_layers(const DecStack& W, float* x, int ldx, int nb, int n_new,
         a.slot_offset = slot_offset; a.nb = nb; a.n_new = n_new; a.nq = W.nq; a.nkv = W.nkv; a.d = W.d;
         a.scale = 1.0f / sqrtf((float)W.d); a.window = 0; a.new_from_raw = 1;
         a.n_splits = W.n_splits; a.chunk = W.chunk; a.po = W.po; a.pm = W.pm; a.pl = W.pl;
+        const bool direct_planes = mfma && W.n_splits == 1;     // one split: the attention kernel normalises and writes the planes itself
+        if (direct_planes) { a.out = nullptr; a.po = nullptr; a.pm = nullptr; a.pl = nullptr; a.oh = pl1h; a.ol = pl1l; a.ldp = ldp; }
         launch_attn(a, stream);
         if (mfma) {
-            a.out = nullptr; a.oh = pl1h; a.ol = pl1l; a.ldp = ldp;
-            launch_attn_combine(a, stream);                      // partials -> (hi, lo) planes
+            if (!direct_planes) {
+                a.out = nullptr; a.oh = pl1h; a.ol = pl1l; a.ldp = ldp;
+                launch_attn_combine(a, stream);                  // partials -> (hi, lo) planes
+            }
             const int ks_o = pick_ksplit(AO), ks_d = pick_ksplit(W.ffn);
             GemmArgs o;
             o.W = w.o; o.xh = pl1h; o.xl = pl1l; o.ldx = ldp; o.out = slab_d; o.ldo = W.H; o.M = M; o.N = W.H; o.K = AO; o.epi = EPI_SLAB;
