@@ -215,17 +215,24 @@ int q3tts_synthesize_clone_batch_host(q3tts_engine* h, int n_utt, const int64_t*
     Q3_API_BEGIN(h)
     Engine& e = *h->e;
     const int H = e.c.hidden, G = e.c.n_groups;
-    std::vector<float> prompt((size_t)16 * H), trailing((size_t)e.max_trailing * H);
+    std::vector<float> prompts((size_t)e.B * 16 * H), trailing;
+    std::vector<Engine::SlotInit> init((size_t)e.B);
     for (int u0 = 0; u0 < n_utt; u0 += e.B) {
         const int nb = std::min(e.B, n_utt - u0);
         for (int b = 0; b < e.B; ++b) e.slot_release(b);
+        size_t trows = 0;                                 // trailing rows of utterance u: its text tokens minus the first, plus tts_eos
+        std::vector<size_t> toff((size_t)nb);
+        for (int b = 0; b < nb; ++b) { toff[(size_t)b] = trows; trows += (size_t)std::max(1, offsets[u0 + b + 1] - offsets[u0 + b] - 3); }
+        trailing.resize(trows * H);
         for (int b = 0; b < nb; ++b) {
             const int u = u0 + b;
-            int S = 0, nt = 0;
-            e.build_prompt(ids + offsets[u], offsets[u + 1] - offsets[u], lang, speakers ? speakers[u] : nullptr, prompt.data(), &S, trailing.data(),
-                           e.max_trailing, &nt);
-            e.slot_begin(b, prompt.data(), S, trailing.data(), nt, *p, seed, (uint32_t)u, ignore_eos);
+            Engine::SlotInit& q = init[(size_t)b];
+            const int cap_rows = std::max(1, offsets[u + 1] - offsets[u] - 3);
+            q.slot = b; q.prompt = prompts.data() + (size_t)b * 16 * H; q.trailing = trailing.data() + toff[(size_t)b] * H; q.stream_id = (uint32_t)u;
+            e.build_prompt(ids + offsets[u], offsets[u + 1] - offsets[u], lang, speakers ? speakers[u] : nullptr, const_cast<float*>(q.prompt), &q.S,
+                           const_cast<float*>(q.trailing), std::min(cap_rows, e.max_trailing), &q.n_trailing);
         }
+        e.slots_begin(init.data(), nb, *p, seed, ignore_eos);   // equal-length prompts share one pass through the talker stack
         int left = p->max_new_tokens;
         while (left > 0) {
             const int chunk = std::min(left, 32);

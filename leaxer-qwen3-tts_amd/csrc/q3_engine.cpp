@@ -186,8 +186,8 @@ Engine::Engine(const q3tts_config& cfg, int device_, int max_batch, int max_ctx_
     x_cp = fm((size_t)B * 2 * H);
     x_cp1 = fm((size_t)B * H);
     sum = fm((size_t)B * H);
-    xp = fm((size_t)16 * H);
-    hn = fm((size_t)16 * H);
+    xp = fm((size_t)std::max(16, rows_max) * H);   // one prefill group: up to rows_max prompt rows
+    hn = fm((size_t)std::max(16, rows_max) * H);
     logits_p = fm((size_t)16 * std::max(c.vocab, c.sub_vocab));
     trailing_d = fm((size_t)B * max_trailing * H);
     tts_pad_d = fm(H);
@@ -672,17 +672,57 @@ int Engine::nb_in_use() const {
 
 void Engine::slot_begin(int slot, const float* prompt, int S, const float* trailing, int n_trailing,
                         const q3tts_sampling& p, uint64_t seed, uint32_t stream_id, int ignore_eos) {
-    if (slot < 0 || slot >= B) throw Error("slot out of range");
-    if (n_trailing < 0 || n_trailing > max_trailing) throw Error("too many trailing text rows");
-    if (p.max_new_tokens < 1 || S + p.max_new_tokens > max_ctx) throw Error("prompt + max_new_tokens exceeds max_ctx");
-    const int H = c.hidden;
-    talker_prefill(slot, prompt, S, nullptr, nullptr);
-    if (n_trailing > 0)
-        Q3_HIP_CHECK(hipMemcpyAsync(trailing_d + (size_t)slot * max_trailing * H, trailing, (size_t)n_trailing * H * sizeof(float), hipMemcpyHostToDevice, stream));
-    SlotState& s = st_h[slot];
-    s.n_frames = 0; s.finished = 0; s.active = 1; s.prompt_len = S; s.trailing_len = n_trailing; s.max_frames = p.max_new_tokens;
-    s.top_k = p.top_k; s.ignore_eos = ignore_eos; s.temperature = p.temperature; s.top_p = p.top_p; s.stream_id = stream_id; s.pad0 = 0; s.seed = seed;
-    Q3_HIP_CHECK(hipMemcpyAsync(st_d + slot, &s, sizeof(SlotState), hipMemcpyHostToDevice, stream));
+    SlotInit in;
+    in.slot = slot; in.prompt = prompt; in.S = S; in.trailing = trailing; in.n_trailing = n_trailing; in.stream_id = stream_id;
+    slots_begin(&in, 1, p, seed, ignore_eos);
+}
+
+// Prefill of several slots at once: slots with equal prompt length share one pass through the talker stack (rows = slots x S,
+// groups of at most 128 rows on the MFMA path), only the last row of each prompt goes through the codec head.  One
+// synchronisation for the whole set instead of two per slot.
+void Engine::slots_begin(const SlotInit* in, int n, const q3tts_sampling& p, uint64_t seed, int ignore_eos) {
+    if (!finalized) throw Error("weights not finalized");
+    const int H = c.hidden, V = c.vocab;
+    for (int i = 0; i < n; ++i) {
+        if (in[i].slot < 0 || in[i].slot >= B) throw Error("slot out of range");
+        if (in[i].n_trailing < 0 || in[i].n_trailing > max_trailing) throw Error("too many trailing text rows");
+        if (in[i].S < 1 || in[i].S > 16) throw Error("prefill length must be 1..16 rows");
+        if (p.max_new_tokens < 1 || in[i].S + p.max_new_tokens > max_ctx) throw Error("prompt + max_new_tokens exceeds max_ctx");
+    }
+    int i0 = 0;
+    while (i0 < n) {
+        // a group: consecutive slots (slot ids increasing by one) with the same S, at most rows_max / S of them (and <= 128 rows)
+        const bool mfma_ok = H % 128 == 0 && (c.n_heads * c.head_dim) % 128 == 0 && c.ffn % 128 == 0 && H <= 4096;   // run_layers' MFMA condition
+        const int S = in[i0].S, cap = mfma_ok ? std::max(1, std::min(rows_max, 128) / S) : 1;
+        int g = 1;
+        while (i0 + g < n && g < cap && in[i0 + g].S == S && in[i0 + g].slot == in[i0].slot + g) ++g;
+        if (g == 1 || g * S <= 8) {
+            for (int k = 0; k < g; ++k) talker_prefill(in[i0 + k].slot, in[i0 + k].prompt, S, nullptr, nullptr);
+        } else {
+            const int slot0 = in[i0].slot, M = g * S;
+            for (int k = 0; k < g; ++k)
+                Q3_HIP_CHECK(hipMemcpyAsync(xp + (size_t)k * S * H, in[i0 + k].prompt, (size_t)S * H * sizeof(float), hipMemcpyHostToDevice, stream));
+            const bool pr = run_layers(talker, xp, H, g, S, slot0, nullptr, 0, talker_norm, c.rms_eps, hn, H);
+            if (!pr) throw Error("batched prefill expects the MFMA path");   // M = g*S > 8 rows by construction (g >= 2, S >= 5)
+            // codec head on the last row of every prompt straight into the fused path's logits; normalised last rows -> predictor input
+            head_proj(codec_head, xp, H, talker_norm, c.rms_eps, nullptr, 0, logits_t + (size_t)slot0 * V, V, g, V, H, true, true, S - 1, S);
+            launch_copy_rows(hn + (size_t)(S - 1) * H, S * H, x_cp + (size_t)slot0 * 2 * H, 2 * H, g, H, stream);
+            std::vector<int32_t> pos((size_t)g, S);
+            Q3_HIP_CHECK(hipMemcpyAsync(talker_pos_d + slot0, pos.data(), (size_t)g * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+            sync();   // pos is a stack buffer
+            (void)M;
+        }
+        i0 += g;
+    }
+    for (int i = 0; i < n; ++i) {
+        const SlotInit& q = in[i];
+        if (q.n_trailing > 0)
+            Q3_HIP_CHECK(hipMemcpyAsync(trailing_d + (size_t)q.slot * max_trailing * H, q.trailing, (size_t)q.n_trailing * H * sizeof(float), hipMemcpyHostToDevice, stream));
+        SlotState& s = st_h[q.slot];
+        s.n_frames = 0; s.finished = 0; s.active = 1; s.prompt_len = q.S; s.trailing_len = q.n_trailing; s.max_frames = p.max_new_tokens;
+        s.top_k = p.top_k; s.ignore_eos = ignore_eos; s.temperature = p.temperature; s.top_p = p.top_p; s.stream_id = q.stream_id; s.pad0 = 0; s.seed = seed;
+        Q3_HIP_CHECK(hipMemcpyAsync(st_d + q.slot, &s, sizeof(SlotState), hipMemcpyHostToDevice, stream));
+    }
     sync();
 }
 

@@ -82,6 +82,8 @@ public:
     int64_t codec_decode_chunked_host(const int64_t* codes, int F, int chunk, int left_context, float* pcm, int64_t cap);
 
     // ---- fused generation ----
+    struct SlotInit { int slot = 0; const float* prompt = nullptr; int S = 0; const float* trailing = nullptr; int n_trailing = 0; uint32_t stream_id = 0; };
+    void slots_begin(const SlotInit* in, int n, const q3tts_sampling& p, uint64_t seed, int ignore_eos); // batched prefill of equal-length prompts
     void slot_begin(int slot, const float* prompt, int S, const float* trailing, int n_trailing,
                     const q3tts_sampling& p, uint64_t seed, uint32_t stream_id, int ignore_eos);
     int decode_steps(int n_steps);
