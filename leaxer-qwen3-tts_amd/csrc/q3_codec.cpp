@@ -33,10 +33,10 @@ struct CodecW {
     struct Planes { bf16_t* hi; bf16_t* lo; float scale_inv; };
     std::unordered_map<const float*, Planes> planes;
     // run-time workspace: one bump arena per codec stream (lane 0 = the engine's own stream)
-    static constexpr int NLANE = 4;
-    char* arena[NLANE] = {nullptr, nullptr, nullptr, nullptr}; size_t arena_bytes[NLANE] = {0, 0, 0, 0};
-    hipStream_t lane_stream[NLANE] = {nullptr, nullptr, nullptr, nullptr};
-    float* pinned[NLANE] = {nullptr, nullptr, nullptr, nullptr}; size_t pinned_floats[NLANE] = {0, 0, 0, 0};
+    static constexpr int NLANE = 8;
+    char* arena[NLANE] = {}; size_t arena_bytes[NLANE] = {};
+    hipStream_t lane_stream[NLANE] = {};
+    float* pinned[NLANE] = {}; size_t pinned_floats[NLANE] = {};
     float *rope_cos = nullptr, *rope_sin = nullptr; int rope_P = 0;
     int* page_table = nullptr;
 };
