@@ -131,6 +131,37 @@ def test_chunked_codec_full_size(full):
     assert np.array_equal(first, got[: first.size]) or float(np.abs(first - got[: first.size]).max()) < 1e-6
 
 
+def test_baseline_size_run_properties():
+    """BASELINE.json configs[1] at full size (0.6B, b=1, sampled, 2048 frames, EOS suppressed) — too long for the CPU oracle, so the
+    size-independent properties: every code in its codebook, the same seed reproduces the run bit for bit, graph replay == eager
+    launches over the first 384 frames (three attention splits), PCM finite, in [-1, 1], of the formula's length, and the first
+    25 frames decoded alone are a prefix of it (causality of the codec = what streaming relies on)."""
+    import q3tts
+    cfg = q3tts.default_config("0.6b")
+    F = 2048
+    ids = frame_tokens(np.random.default_rng(1).integers(0, 151643, 16))
+    sp = q3tts.Sampling(temperature=0.8, top_p=0.95, top_k=50, max_new_tokens=F)
+    eng = q3tts.Engine(cfg, device=0, max_batch=1, max_ctx=F + 32)
+    eng.fill_synthetic(seed=0)
+    pcm, codes, nfr = eng.synthesize_batch([ids], sp, lang=0, seed=100, ignore_eos=True)
+    assert nfr[0] == F and codes[0].shape == (F, 16)
+    assert codes[0].min() >= 0 and codes[0][:, 0].max() < 2048 and codes[0][:, 1:].max() < 2048      # code0 never a control token
+    assert pcm[0].shape == (eng.codec_decode_len(F),) and np.isfinite(pcm[0]).all() and np.abs(pcm[0]).max() <= 1.0
+    pcm2, codes2, _ = eng.synthesize_batch([ids], sp, lang=0, seed=100, ignore_eos=True)
+    assert np.array_equal(codes2[0], codes[0]) and np.array_equal(pcm2[0], pcm[0])
+    _, codes3, _ = eng.synthesize_batch([ids], sp, lang=0, seed=101, ignore_eos=True)
+    assert not np.array_equal(codes3[0][:64], codes[0][:64])                                         # the seed matters
+    first = eng.codec_decode(codes[0][:25])
+    assert float(np.abs(first - pcm[0][: first.size]).max()) < 1e-5
+    eng.close()
+    eager = q3tts.Engine(cfg, device=0, max_batch=1, max_ctx=F + 32, flags=q3tts.FLAG_NO_GRAPH)
+    eager.fill_synthetic(seed=0)
+    sp384 = q3tts.Sampling(temperature=0.8, top_p=0.95, top_k=50, max_new_tokens=384)
+    _, ce, _ = eager.synthesize_batch([ids], sp384, lang=0, seed=100, ignore_eos=True)
+    eager.close()
+    assert np.array_equal(ce[0], codes[0][:384])
+
+
 def test_talker_decode_across_split_boundary_full_size(full):
     """140 talker decode steps at 0.6B dims: the context crosses the first 128-token attention split."""
     eng, orc = full
