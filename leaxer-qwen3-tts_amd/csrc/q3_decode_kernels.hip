@@ -14,6 +14,7 @@
 // Built with -ffp-contract=off: elementwise math rounds like the fp32 oracle; dot products use
 // explicit fmaf.
 #include "q3_common.h"
+#include "q3_wave_sort.h"
 
 namespace q3 {
 
@@ -1050,19 +1051,26 @@ static __device__ __forceinline__ float wave_scan_f(float v, int lane) {
     return v;
 }
 
-// k-th largest of one value per lane (ties allowed), -inf when fewer than k lanes hold a finite value:
-// 64 scalar broadcasts, no LDS.
+// k-th largest of one value per lane (ties allowed), -inf when fewer than k lanes hold a finite value: the wave sorts its 64
+// values in registers (q3_wave_sort.h) and reads rank k-1.  (A 64-broadcast rank count did the same in 1.4 us; this is ~0.3.)
 static __device__ __forceinline__ float kth_largest_of_lanes(float v, int k) {
-    int gt = 0, ge = 0;
-#pragma unroll 8
-    for (int o2 = 0; o2 < 64; ++o2) { const float w = lane_bcast(v, o2); gt += w > v ? 1 : 0; ge += w >= v ? 1 : 0; }
-    return wave_max((gt < k && k <= ge) ? v : -INFINITY);
+    const int lane = threadIdx.x & 63;
+    const float sorted = wave_sort_desc(v, lane);
+    const int r = __builtin_amdgcn_readfirstlane(k) - 1;
+    return lane_bcast(sorted, r < 0 ? 0 : (r > 63 ? 63 : r));
 }
 
 // Four waves per utterance: wave w owns the 64-element slices j = w, w+4, ... of the logits row (registers),
 // the few cross-wave hand-offs go through LDS; the serial tail (threshold rounds, top-p, draw) runs on wave 0
 // only, the embedding epilogue on all 256 threads.
 #define SAMP_PERW (SAMP_MAXV / 256)
+#ifdef Q3_SAMPLE_PROF
+__device__ long long g_sample_prof[16];
+#define SP_MARK(k) do { if (threadIdx.x == 0) g_sample_prof[k] = wall_clock64(); } while (0)
+void sample_prof_read(long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sample_prof), sizeof(long long) * 16); }
+#else
+#define SP_MARK(k) do { } while (0)
+#endif
 __global__ __launch_bounds__(256) void k_sample(SampleArgs a) {
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1079,6 +1087,7 @@ __global__ __launch_bounds__(256) void k_sample(SampleArgs a) {
     __shared__ float sh_f[4];
     __shared__ int sh_i[4];
 
+    SP_MARK(0);
     // ---- round trip 1: slot state (one 64-byte struct) and this wave's logits slices, all in flight ----
     float temperature = a.temperature, top_p = a.top_p, u = a.u;
     int top_k = a.top_k, suppress = a.suppress, keep_eos = 1;
@@ -1108,6 +1117,7 @@ __global__ __launch_bounds__(256) void k_sample(SampleArgs a) {
         suppress = a.group == 0;
         keep_eos = !sl.ignore_eos;
     }
+    SP_MARK(1);
     const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
 
     // suppress (:803-807) + temperature (:882-884)
@@ -1129,6 +1139,7 @@ __global__ __launch_bounds__(256) void k_sample(SampleArgs a) {
     // 64 group maxima (group = lane, over all four waves) -> global max and the prefilter bound
     const float gm = fmaxf(fmaxf(gmax[0][lane], gmax[1][lane]), fmaxf(gmax[2][lane], gmax[3][lane]));
     const float mx = wave_max(gm);
+    SP_MARK(2);
 
     // ---- top-k threshold = k-th largest value, ties kept (:917-927) ----
     float thr = -INFINITY;
@@ -1140,6 +1151,7 @@ __global__ __launch_bounds__(256) void k_sample(SampleArgs a) {
             // largest overall, so only elements >= L can matter (~100 of 3072); wave 0 re-deals the survivors
             // over its lanes and repeats until at most one candidate per lane is left, ranked exactly.
             const float L1 = kth_largest_of_lanes(gm, top_k);   // every wave computes the same L1
+            SP_MARK(3);
             int nw = 0;
 #pragma unroll
             for (int jj = 0; jj < SAMP_PERW; ++jj) {
@@ -1151,6 +1163,7 @@ __global__ __launch_bounds__(256) void k_sample(SampleArgs a) {
             }
             if (lane == 0) svn[wave] = nw;
             __syncthreads();
+            SP_MARK(4);
             if (wave == 0) {
                 const int n0 = svn[0], n1 = svn[1], n2 = svn[2], n3 = svn[3];
                 int n = n0 + n1 + n2 + n3;
@@ -1188,6 +1201,7 @@ __global__ __launch_bounds__(256) void k_sample(SampleArgs a) {
                 if (lane == 0) { sh_f[0] = thr; sh_i[0] = done ? 1 : 0; }
             }
             __syncthreads();
+            SP_MARK(5);
             thr = sh_f[0];
             done = sh_i[0] != 0;
         }
@@ -1221,7 +1235,7 @@ __global__ __launch_bounds__(256) void k_sample(SampleArgs a) {
     __syncthreads();
     // exclusive prefix of the per-slice counts (slice order = index order); lane j holds slice j
     const int cmine = lane < PER ? cnt_s[lane] : 0;
-    const int cincl = wave_scan_i(cmine, lane);
+    const int cincl = wave_scan_incl_i(cmine);
     const int n_kept = lane_bcast_i(cincl, 63);
     float esum = 0.f;
 #pragma unroll
@@ -1241,6 +1255,7 @@ __global__ __launch_bounds__(256) void k_sample(SampleArgs a) {
     if (lane == 0) esum_s[wave] = esum;
     __syncthreads();
     esum = ((esum_s[0] + esum_s[1]) + esum_s[2]) + esum_s[3];
+    SP_MARK(6);
 
     int tok = 0;
     if (wave == 0) {
@@ -1250,26 +1265,25 @@ __global__ __launch_bounds__(256) void k_sample(SampleArgs a) {
             float p = have ? cand_p[lane] / esum : 0.f;
             const int myidx = have ? cand_idx[lane] : 0;
             if (top_p < 1.0f) { // :929-950 — order by (p desc, index asc); keep through the first cumulative sum > top_p
-                int rank = 0;      // candidates ordered strictly before this one
-                float cum = 0.f;   // sum of every candidate ordered at or before this one
-#pragma unroll 4
-                for (int o2 = 0; o2 < n_kept; ++o2) {
-                    const float po = lane_bcast(p, o2);
-                    const bool before = po > p || (po == p && o2 < lane);
-                    rank += before ? 1 : 0;
-                    cum += (before || o2 == lane) ? po : 0.f;
-                }
-                int rcut = (have && cum > top_p) ? rank : 0x7FFFFFFF;
-#pragma unroll
-                for (int off = 32; off >= 1; off >>= 1) { const int t = __shfl_xor(rcut, off, 64); rcut = t < rcut ? t : rcut; }
-                if (!(have && rank <= rcut)) p = 0.f;
+                // sort (p, position) pairs across the lanes, scan the sorted probabilities, cut, and send every keep flag back to
+                // the lane it came from (ds_permute pushes; the tags are a permutation of 0..63)
+                float sk = have ? p : -INFINITY;
+                int tag = lane;
+                wave_sort_desc_kv(sk, tag, lane);
+                const float cum = wave_scan_incl_f(lane < n_kept ? sk : 0.f);
+                const unsigned long long over = __ballot(lane < n_kept && cum > top_p);
+                const int rcut = over ? __ffsll((long long)over) - 1 : 0x7FFFFFFF;
+                const int keep_rank = (lane < n_kept && lane <= rcut) ? 1 : 0;
+                const int keep_here = __builtin_amdgcn_ds_permute(tag << 2, keep_rank);
+                if (!(have && keep_here)) p = 0.f;
                 const float s2 = wave_sum(p);
                 if (s2 > 0.f) p = p / s2; // :893-898
             }
+            SP_MARK(7);
             // draw: inverse CDF in index order
             const float total = wave_sum(p);
             const float target = u * total;
-            const float cum = wave_scan_f(p, lane);
+            const float cum = wave_scan_incl_f(p);
             const unsigned long long hit = __ballot(p > 0.f && cum > target);
             const unsigned long long pos_mask = __ballot(p > 0.f);
             int pick;
@@ -1333,6 +1347,7 @@ __global__ __launch_bounds__(256) void k_sample(SampleArgs a) {
     }
     __syncthreads();
     tok = sh_i[3];
+    SP_MARK(8);
 
     if (!st) { if (tid == 0) a.token_out[b] = tok; return; }
 
