@@ -18,6 +18,15 @@
 
 namespace q3 {
 
+// -DQ3_SAMPLE_PROF: phase timestamps (100 MHz wall clock) of the last workgroup-0 run of an instrumented kernel; tools/ only
+#ifdef Q3_SAMPLE_PROF
+__device__ long long g_kernel_prof[32];
+void sample_prof_read(long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_kernel_prof), sizeof(long long) * 32); }
+#define KP_MARK(k) do { if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) g_kernel_prof[k] = wall_clock64(); } while (0)
+#else
+#define KP_MARK(k) do { } while (0)
+#endif
+
 // Cross-lane reductions on the DPP path (no LDS round trip; __shfl_xor lowers to ds_bpermute + a full
 // lgkmcnt wait per step).  quad_perm / row_ror stay inside a 16-lane row; row_bcast15/31 carry the
 // row totals up to lane 63, which is broadcast through an SGPR.
@@ -250,6 +259,7 @@ __global__ __launch_bounds__(256) void k_gemv1(GemvArgs a) {
     const int N = a.N, M = a.M;
     __shared__ float xs[COMB ? MT * K : 1];
 
+    KP_MARK(8);
     // 1. weights: everything this wave will ever read, in flight at once
     uint4 w[RW][NCH], w2[RW][NCH];
 #pragma unroll
@@ -347,6 +357,7 @@ __global__ __launch_bounds__(256) void k_gemv1(GemvArgs a) {
             g[c][0] = g0.x; g[c][1] = g0.y; g[c][2] = g0.z; g[c][3] = g0.w; g[c][4] = g1.x; g[c][5] = g1.y; g[c][6] = g1.z; g[c][7] = g1.w;
         }
     }
+    KP_MARK(9);
     __builtin_amdgcn_sched_barrier(0); // all loads of the kernel are in flight past this point
     if (NORM) {
 #pragma unroll
@@ -372,6 +383,7 @@ __global__ __launch_bounds__(256) void k_gemv1(GemvArgs a) {
             }
         }
     }
+    KP_MARK(10);
     // 3. dot products
     float mine = 0.f, mine2 = 0.f;
 #pragma unroll
@@ -394,6 +406,7 @@ __global__ __launch_bounds__(256) void k_gemv1(GemvArgs a) {
             if (lane == m * RW + r) mine = s1;
             if (EPI == EPI_SWIGLU) { s2 = wave_sum(s2); if (lane == m * RW + r) mine2 = s2; }
         }
+    KP_MARK(11);
     if (lane < MT * RW) {
         const int m = lane / RW, r = lane % RW, n = n0 + r;
         if (m < M && n < N) {
@@ -832,11 +845,10 @@ __global__ __launch_bounds__(512) void k_cp_attn_oproj(CpAttnOprojArgs a) {
     __shared__ float q_s[NKV][NEW][G][D];
     __shared__ float knew[NKV][NEW][D];
     __shared__ float vnew[NKV][NEW][D];
-    __shared__ float cm[NKV][NEW][G][4], cl[NKV][NEW][G][4];
-    __shared__ float co[NKV][NEW][G][4][D];
     __shared__ float attn_s[NEW][K];
     __shared__ float part[NEW][8];
 
+    KP_MARK(16);
     // ---- the one memory round: o_proj weights, residual, q/k/v rows + their norm / RoPE operands, cached K/V ----
     const int orow = blockIdx.x * 4 + (wave & 3), khalf = wave >> 2;
     const int orow_c = orow < a.N ? orow : a.N - 1;
@@ -879,6 +891,7 @@ __global__ __launch_bounds__(512) void k_cp_attn_oproj(CpAttnOprojArgs a) {
     }
     __builtin_amdgcn_sched_barrier(0);
 
+    KP_MARK(17);
     // ---- 1. q / k RMSNorm + RoPE (reference graphs: per-head norm, rotate-half RoPE), new K/V to LDS and the cache ----
 #pragma unroll
     for (int v = 0; v < NVEC; ++v) {
@@ -902,6 +915,7 @@ __global__ __launch_bounds__(512) void k_cp_attn_oproj(CpAttnOprojArgs a) {
     }
     __syncthreads();
 
+    KP_MARK(18);
     // ---- 2. scores and weighted values: token group tg owns cached tokens tg, tg+4, ... and new token j if (j & 3) == tg ----
 #pragma unroll
     for (int inew = 0; inew < NEW; ++inew) {
@@ -948,28 +962,26 @@ __global__ __launch_bounds__(512) void k_cp_attn_oproj(CpAttnOprojArgs a) {
 #pragma unroll
                 for (int e = 0; e < EPL; ++e) o[e] = fmaf(pw, vn[j][e], o[e]);
             }
-            if (sub == 0) { cm[kvh][inew][h][tg] = mx; cl[kvh][inew][h][tg] = l; }
+            // merge the wave's 4 token groups in registers: lanes {sub, sub+16, sub+32, sub+48} hold the same 8 dims of different groups
+            const float mall = wave_max(mx);                                  // every group's max is replicated over its 16 lanes
+            const float wgt = mx == -INFINITY ? 0.f : __expf(mx - mall);
+            l *= wgt;
 #pragma unroll
-            for (int e = 0; e < EPL; ++e) co[kvh][inew][h][tg][sub * EPL + e] = o[e];
+            for (int e = 0; e < EPL; ++e) o[e] *= wgt;
+            l += wave_xor_lane_f<16>(l, lane);
+            l += wave_xor_lane_f<32>(l, lane);
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) { o[e] += wave_xor_lane_f<16>(o[e], lane); o[e] += wave_xor_lane_f<32>(o[e], lane); }
+            if (tg == 0) {
+                const float il = 1.0f / l;
+                float* dst = &attn_s[inew][(kvh * G + h) * D + sub * EPL];
+                *reinterpret_cast<float4*>(dst) = make_float4(o[0] * il, o[1] * il, o[2] * il, o[3] * il);
+                *reinterpret_cast<float4*>(dst + 4) = make_float4(o[4] * il, o[5] * il, o[6] * il, o[7] * il);
+            }
         }
     }
     __syncthreads();
-    // ---- 3. merge the 4 token groups of every head -> attention rows in LDS ----
-    for (int idx = tid; idx < NEW * K; idx += 512) {
-        const int inew = idx / K, k = idx % K, head = k / D, e = k % D, kv = head / G, h = head % G;
-        float mx = -INFINITY;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) mx = fmaxf(mx, cm[kv][inew][h][g]);
-        float L = 0.f, O = 0.f;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const float wgt = cm[kv][inew][h][g] == -INFINITY ? 0.f : expf(cm[kv][inew][h][g] - mx);
-            L += wgt * cl[kv][inew][h][g];
-            O += wgt * co[kv][inew][h][g][e];
-        }
-        attn_s[inew][k] = O / L;
-    }
-    __syncthreads();
+    KP_MARK(20);
     // ---- 4. o_proj: wave (row = wave & 3, K half = wave >> 2), residual add ----
 #pragma unroll
     for (int m = 0; m < NEW; ++m) {
@@ -987,6 +999,7 @@ __global__ __launch_bounds__(512) void k_cp_attn_oproj(CpAttnOprojArgs a) {
         if (lane == 0) part[m][wave] = s1;
     }
     __syncthreads();
+    KP_MARK(21);
     if (wave < 4 && lane < NEW && orow < a.N) {
         float r = resid[0];
         if (NEW > 1 && lane == 1) r = resid[NEW - 1];
@@ -1065,9 +1078,7 @@ static __device__ __forceinline__ float kth_largest_of_lanes(float v, int k) {
 // only, the embedding epilogue on all 256 threads.
 #define SAMP_PERW (SAMP_MAXV / 256)
 #ifdef Q3_SAMPLE_PROF
-__device__ long long g_sample_prof[16];
-#define SP_MARK(k) do { if (threadIdx.x == 0) g_sample_prof[k] = wall_clock64(); } while (0)
-void sample_prof_read(long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sample_prof), sizeof(long long) * 16); }
+#define SP_MARK(k) do { if (threadIdx.x == 0) g_kernel_prof[k] = wall_clock64(); } while (0)
 #else
 #define SP_MARK(k) do { } while (0)
 #endif

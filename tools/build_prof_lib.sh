@@ -1,0 +1,17 @@
+#!/bin/bash
+# Builds tools/exp/libprof.so = libq3tts_hip.so with -DQ3_SAMPLE_PROF (phase timestamps inside k_sample / k_gemv1 / k_cp_attn_oproj) plus
+# an accessor; use with Q3TTS_LIB=$PWD/tools/exp/libprof.so python tools/kernel_phases.py.  Needs a prior `python leaxer-qwen3-tts_amd/build.py`.
+set -e
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+mkdir -p "$ROOT/tools/exp" /tmp/q3prof
+cd /tmp/q3prof
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -DQ3_SAMPLE_PROF -x hip -c "$ROOT/leaxer-qwen3-tts_amd/csrc/q3_decode_kernels.hip" -o dk_prof.o
+cat > prof_api.cpp <<'EOC'
+namespace q3 { void sample_prof_read(long long* out); }
+extern "C" void q3_kernel_prof(long long* out) { q3::sample_prof_read(out); }
+EOC
+hipcc --offload-arch=gfx950 -O2 -std=c++17 -fPIC -x hip -c prof_api.cpp -o prof_api.o
+B="$ROOT/leaxer-qwen3-tts_amd/build"
+hipcc --offload-arch=gfx950 -shared -fPIC -o "$ROOT/tools/exp/libprof.so" dk_prof.o prof_api.o "$B/q3_gemm_kernels.hip.o" "$B/q3_codec_kernels.hip.o" \
+    "$B/q3_speaker_kernels.hip.o" "$B/q3_engine.cpp.o" "$B/q3_codec.cpp.o" "$B/q3_speaker.cpp.o" "$B/q3_audio.cpp.o" "$B/q3_bpe.cpp.o" "$B/q3_capi.cpp.o"
+echo "$ROOT/tools/exp/libprof.so"
