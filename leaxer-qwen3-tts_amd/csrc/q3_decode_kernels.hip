@@ -250,15 +250,20 @@ static __device__ __forceinline__ uint4 ldw_rt(const bf16_t* p, bool nt) {
     return make_uint4(v.x, v.y, v.z, v.w);
 }
 
+// The leading scalar parameters repeat the fields the first loads need: the file is built with -amdgpu-kernarg-preload-count=16, so the
+// command processor hands them to the wave in SGPRs at launch instead of the wave fetching its kernarg segment first (~0.35 us per
+// launch on a chain of dependent GEMVs; a by-value struct is not preloadable).
 template <int MT, int NCH, int RW, int EPI, bool NORM, bool COMB>
-__global__ __launch_bounds__(256) void k_gemv1(GemvArgs a) {
+__global__ __launch_bounds__(256) void k_gemv1(const bf16_t* pW, const bf16_t* pW2, const float* px, const float* pgamma, const float* pepi,
+                                                int pN, int pM, int pldx, int pldepi, int pnt, GemvArgs a) {
     constexpr int K = NCH * 512;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // provably wave-uniform: row addresses stay scalar
     const int n0 = (blockIdx.x * 4 + wave) * RW;
-    const int N = a.N, M = a.M;
+    const int N = pN, M = pM;
     __shared__ float xs[COMB ? MT * K : 1];
 
+    KP_MARK(30); KP_MARK(31);   // back to back: the first one absorbs the kernarg fetch, their distance is the cost of a mark
     KP_MARK(8);
     // 1. weights: everything this wave will ever read, in flight at once
     uint4 w[RW][NCH], w2[RW][NCH];
@@ -267,8 +272,8 @@ __global__ __launch_bounds__(256) void k_gemv1(GemvArgs a) {
         const int n = n0 + r < N ? n0 + r : N - 1;
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
-            w[r][c] = ldw_rt(a.W + (size_t)n * K + c * 512 + lane * 8, a.nt);
-            if (EPI == EPI_SWIGLU) w2[r][c] = ldw_rt(a.W2 + (size_t)n * K + c * 512 + lane * 8, a.nt);
+            w[r][c] = ldw_rt(pW + (size_t)n * K + c * 512 + lane * 8, pnt != 0);
+            if (EPI == EPI_SWIGLU) w2[r][c] = ldw_rt(pW2 + (size_t)n * K + c * 512 + lane * 8, pnt != 0);
         }
     }
     __builtin_amdgcn_sched_barrier(0); // keep the weight loads ahead of everything below (hipcc sinks them otherwise)
@@ -277,7 +282,7 @@ __global__ __launch_bounds__(256) void k_gemv1(GemvArgs a) {
     if (EPI == EPI_RESIDUAL || EPI == EPI_BIAS || EPI == EPI_BIAS_SILU) {
         if (lane < MT * RW) {
             const int m = lane / RW, n = n0 + lane % RW;
-            if (m < M && n < N) epi_in = EPI == EPI_RESIDUAL ? a.res[(size_t)m * a.ldres + n] : a.bias[n];
+            if (m < M && n < N) epi_in = EPI == EPI_RESIDUAL ? pepi[(size_t)m * pldepi + n] : pepi[n];
         }
     }
     // 2. activations
@@ -341,7 +346,7 @@ __global__ __launch_bounds__(256) void k_gemv1(GemvArgs a) {
         for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
-                const float* xr = a.x + (size_t)(m < M ? m : 0) * a.ldx + c * 512 + lane * 8;
+                const float* xr = px + (size_t)(m < M ? m : 0) * pldx + c * 512 + lane * 8;
                 const float4 x0 = *reinterpret_cast<const float4*>(xr);
                 const float4 x1 = *reinterpret_cast<const float4*>(xr + 4);
                 xv[m][c][0] = x0.x; xv[m][c][1] = x0.y; xv[m][c][2] = x0.z; xv[m][c][3] = x0.w;
@@ -352,8 +357,8 @@ __global__ __launch_bounds__(256) void k_gemv1(GemvArgs a) {
     if (NORM) {
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
-            const float4 g0 = *reinterpret_cast<const float4*>(a.gamma + c * 512 + lane * 8);
-            const float4 g1 = *reinterpret_cast<const float4*>(a.gamma + c * 512 + lane * 8 + 4);
+            const float4 g0 = *reinterpret_cast<const float4*>(pgamma + c * 512 + lane * 8);
+            const float4 g1 = *reinterpret_cast<const float4*>(pgamma + c * 512 + lane * 8 + 4);
             g[c][0] = g0.x; g[c][1] = g0.y; g[c][2] = g0.z; g[c][3] = g0.w; g[c][4] = g1.x; g[c][5] = g1.y; g[c][6] = g1.z; g[c][7] = g1.w;
         }
     }
@@ -441,7 +446,8 @@ bool gemv_fast_path(const GemvArgs& a) {
 template <int MT, int NCH, int RW>
 static void gemv1_launch(const GemvArgs& a, int grid, hipStream_t s) {
     const bool norm = a.gamma != nullptr, comb = a.po != nullptr;
-#define Q3_G1(EPI, NORM, COMB) hipLaunchKernelGGL((k_gemv1<MT, NCH, RW, EPI, NORM, COMB>), dim3(grid), dim3(256), 0, s, a)
+#define Q3_G1(EPI, NORM, COMB) hipLaunchKernelGGL((k_gemv1<MT, NCH, RW, EPI, NORM, COMB>), dim3(grid), dim3(256), 0, s, a.W, a.W2, a.x, a.gamma, \
+        (a.epi == EPI_RESIDUAL ? a.res : a.bias), a.N, a.M, a.ldx, a.ldres, (int)a.nt, a)
     if (comb) { Q3_G1(EPI_RESIDUAL, false, true); return; }
     switch (a.epi) {
     case EPI_STORE: if (norm) Q3_G1(EPI_STORE, true, false); else Q3_G1(EPI_STORE, false, false); break;
@@ -503,11 +509,13 @@ void launch_gemv(const GemvArgs& a0, hipStream_t s) {
 #define ATT_MAX_GRP 4
 
 template <int D, int U, int G>
-__global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
+__global__ __launch_bounds__(256) void k_attn(const int* ppage_table, const int* ppos_dev, const float* pqkv, const float* pkcache, const float* pvcache,
+                                               const float* pcos, const float* psin, int ppos_scalar, int pn_splits, AttnArgs a) {
+    // leading scalars: preloaded into SGPRs, so the first memory round (page ids, position) leaves at once (see k_gemv1)
     constexpr int EPL = D / 16;
     constexpr int HALF = D / 2;
     const int kvh = blockIdx.x, bi = blockIdx.z;
-    const int S = a.n_splits;
+    const int S = pn_splits;
     const int inew = blockIdx.y / S, split = blockIdx.y % S;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); // provably wave-uniform: pointer selects stay scalar
@@ -522,17 +530,19 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
     __shared__ float cm[16][G], cl[16][G];
     __shared__ float co[16][G][D];
 
+    KP_MARK(24);
     // ---- round 1: position of new token 0 and the (at most 4) page ids this split can touch ----
-    const int* pt = a.page_table + (size_t)slot * a.pages_per_slot;
+    const int* pt = ppage_table + (size_t)slot * a.pages_per_slot;
     const int pbase = (split * a.chunk) >> pshift;
     int pg[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) { const int pi = pbase + q < a.pages_per_slot ? pbase + q : a.pages_per_slot - 1; pg[q] = pt[pi]; }
-    int base = a.pos_scalar;
-    if (a.pos_dev) base = a.pos_dev[slot];
+    int base = ppos_scalar;
+    if (ppos_dev) base = ppos_dev[slot];
     const int pos = base + inew;
     __builtin_amdgcn_sched_barrier(0);
 
+    KP_MARK(25);
     // token range of this split
     int lo = split * a.chunk;
     int hi = lo + a.chunk < pos + 1 ? lo + a.chunk : pos + 1;
@@ -561,14 +571,14 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
             if (EPL >= 4) {
 #pragma unroll
                 for (int e = 0; e < EPL; e += 4) {
-                    const float4 k4 = *reinterpret_cast<const float4*>(a.kcache + off + e);
-                    const float4 v4 = *reinterpret_cast<const float4*>(a.vcache + off + e);
+                    const float4 k4 = *reinterpret_cast<const float4*>(pkcache + off + e);
+                    const float4 v4 = *reinterpret_cast<const float4*>(pvcache + off + e);
                     kr[u][e] = k4.x; kr[u][e + 1] = k4.y; kr[u][e + 2] = k4.z; kr[u][e + 3] = k4.w;
                     vr[u][e] = v4.x; vr[u][e + 1] = v4.y; vr[u][e + 2] = v4.z; vr[u][e + 3] = v4.w;
                 }
             } else {
 #pragma unroll
-                for (int e = 0; e < EPL; ++e) { kr[u][e] = a.kcache[off + e]; vr[u][e] = a.vcache[off + e]; }
+                for (int e = 0; e < EPL; ++e) { kr[u][e] = pkcache[off + e]; vr[u][e] = pvcache[off + e]; }
             }
         }
     };
@@ -583,7 +593,7 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
     auto load_vec = [&](int v) -> VecOps {
         const bool is_q = v < grp;
         const int j = is_q ? inew : jlo + (v - grp);
-        const float* rowp = a.qkv + (size_t)(bi * a.n_new + j) * a.ld_qkv;
+        const float* rowp = pqkv + (size_t)(bi * a.n_new + j) * a.ld_qkv;
         const float* src = rowp + (is_q ? (kvh * grp + v) * D : (a.nq + kvh) * D);
         const float* vs = rowp + (a.nq + a.nkv + kvh) * D;
         const int p = base + j;
@@ -599,7 +609,7 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
         r.n0 = 1.f; r.n1 = 1.f; r.cs = 1.f; r.sn = 0.f;
         if (a.new_from_raw) {
             if (nw != nullptr) { r.n0 = nw[hl]; r.n1 = nw[hl + HALF]; }
-            r.cs = a.rope_cos[(size_t)p * HALF + hl]; r.sn = a.rope_sin[(size_t)p * HALF + hl];
+            r.cs = pcos[(size_t)p * HALF + hl]; r.sn = psin[(size_t)p * HALF + hl];
         }
         return r;
     };
@@ -633,6 +643,7 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
             }
         }
     };
+    KP_MARK(26);
     const VecOps first = load_vec(wave < nvec ? wave : 0);
     __builtin_amdgcn_sched_barrier(0);
     load_batch(lo + tg);
@@ -641,6 +652,7 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
     for (int v = wave + 4; v < nvec; v += 4) finish_vec(v, load_vec(v)); // prefill only (more than 4 vectors)
     __syncthreads();
 
+    KP_MARK(27);
     // ---- 2. online softmax ----
     float qr[G][EPL], o[G][EPL], mrun[G], lrun[G];
 #pragma unroll
@@ -715,6 +727,7 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
         for (int e = 0; e < EPL; ++e) { kv[e] = knew[j][sub * EPL + e]; vv[e] = vnew[j][sub * EPL + e]; }
         consume(kv, vv);
     }
+    KP_MARK(28);
     // ---- 3. combine the 16 token groups ----
 #pragma unroll
     for (int h = 0; h < G; ++h) {
@@ -755,6 +768,7 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
             if (e == 0) { a.pm[pi] = mx; a.pl[pi] = L; }
         }
     }
+    KP_MARK(29);
 }
 
 void launch_attn(const AttnArgs& a, hipStream_t s) {
@@ -765,9 +779,10 @@ void launch_attn(const AttnArgs& a, hipStream_t s) {
     if ((size_t)a.n_new * a.n_splits > 65535) throw Error("attn: grid too large");
     if (a.n_splits > 1 && (a.chunk >> a.page_shift) + 1 > 4) throw Error("attn: a split may touch at most 4 KV pages");
     dim3 grid(a.nkv, a.n_new * a.n_splits, a.nb);
-#define Q3_ATT(D, U) do { if (grp == 1) hipLaunchKernelGGL((k_attn<D, U, 1>), grid, dim3(256), 0, s, a); \
-        else if (grp == 2) hipLaunchKernelGGL((k_attn<D, U, 2>), grid, dim3(256), 0, s, a); \
-        else hipLaunchKernelGGL((k_attn<D, U, 4>), grid, dim3(256), 0, s, a); } while (0)
+#define Q3_ATT_ARGS a.page_table, a.pos_dev, a.qkv, (const float*)a.kcache, (const float*)a.vcache, a.rope_cos, a.rope_sin, a.pos_scalar, a.n_splits, a
+#define Q3_ATT(D, U) do { if (grp == 1) hipLaunchKernelGGL((k_attn<D, U, 1>), grid, dim3(256), 0, s, Q3_ATT_ARGS); \
+        else if (grp == 2) hipLaunchKernelGGL((k_attn<D, U, 2>), grid, dim3(256), 0, s, Q3_ATT_ARGS); \
+        else hipLaunchKernelGGL((k_attn<D, U, 4>), grid, dim3(256), 0, s, Q3_ATT_ARGS); } while (0)
     const bool tiny_ctx = a.n_splits == 1 && a.window == 0 && (a.pages_per_slot << a.page_shift) <= 32; // code predictor
     if (a.d == 128 && tiny_ctx) Q3_ATT(128, 2);
     else if (a.d == 128) Q3_ATT(128, 8);
@@ -835,12 +850,17 @@ void launch_attn_combine(const AttnArgs& a, hipStream_t s) {
 // U = cached tokens per 16-lane group in flight (cached tokens <= 4 U).
 // ================================================================================================
 template <int NEW, int U>
-__global__ __launch_bounds__(512) void k_cp_attn_oproj(CpAttnOprojArgs a) {
+__global__ __launch_bounds__(512) void k_cp_attn_oproj(const bf16_t* pW, const float* pqkv, const float* pkc, const float* pvc, const float* px,
+                                                        const float* pcos, const float* psin, uint32_t pk0, uint32_t pk1, CpAttnOprojArgs a) {
+    // leading scalars = everything the first memory round's addresses need, preloaded into SGPRs (see k_gemv1); 16 dwords at most, so the
+    // small integers travel packed: pk0 = base | page_tokens << 16, pk1 = N | ldx << 16 (ld_qkv is (16 + 2*8) * 128 by construction)
+    const int pbase = (int)(pk0 & 0xFFFFu), ppage_tokens = (int)(pk0 >> 16), pN = (int)(pk1 & 0xFFFFu), pldx = (int)(pk1 >> 16);
+    constexpr int LDQ = 4096;
     constexpr int D = 128, HALF = 64, EPL = 8, G = 2, NKV = 8, K = 2048;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kvh = wave;
-    const int base = a.base;
+    const int base = pbase;
 
     __shared__ float q_s[NKV][NEW][G][D];
     __shared__ float knew[NKV][NEW][D];
@@ -851,13 +871,13 @@ __global__ __launch_bounds__(512) void k_cp_attn_oproj(CpAttnOprojArgs a) {
     KP_MARK(16);
     // ---- the one memory round: o_proj weights, residual, q/k/v rows + their norm / RoPE operands, cached K/V ----
     const int orow = blockIdx.x * 4 + (wave & 3), khalf = wave >> 2;
-    const int orow_c = orow < a.N ? orow : a.N - 1;
+    const int orow_c = orow < pN ? orow : pN - 1;
     uint4 w4[2];
 #pragma unroll
-    for (int c = 0; c < 2; ++c) w4[c] = ldw_rt(a.W + (size_t)orow_c * K + (khalf * 2 + c) * 512 + lane * 8, false);
+    for (int c = 0; c < 2; ++c) w4[c] = ldw_rt(pW + (size_t)orow_c * K + (khalf * 2 + c) * 512 + lane * 8, false);
     float resid[NEW];
 #pragma unroll
-    for (int m = 0; m < NEW; ++m) resid[m] = a.x[(size_t)m * a.ldx + orow_c];
+    for (int m = 0; m < NEW; ++m) resid[m] = px[(size_t)m * pldx + orow_c];
     __builtin_amdgcn_sched_barrier(0);
 
     struct VecOps { float x0, x1, v0, v1, n0, n1, cs, sn; };
@@ -867,14 +887,14 @@ __global__ __launch_bounds__(512) void k_cp_attn_oproj(CpAttnOprojArgs a) {
     for (int v = 0; v < NVEC; ++v) {
         const bool is_q = v < NEW * G;
         const int j = is_q ? v / G : v - NEW * G;
-        const float* rowp = a.qkv + (size_t)j * a.ld_qkv;
+        const float* rowp = pqkv + (size_t)j * LDQ;
         const float* src = rowp + (is_q ? (kvh * G + v % G) * D : (NKV * G + kvh) * D);
         const float* vs = rowp + (NKV * G + NKV + kvh) * D;
         const float* nw = is_q ? a.q_norm : a.k_norm;
         vec[v].x0 = src[lane]; vec[v].x1 = src[lane + HALF];
         vec[v].v0 = vs[lane]; vec[v].v1 = vs[lane + HALF];
         vec[v].n0 = nw[lane]; vec[v].n1 = nw[lane + HALF];
-        vec[v].cs = a.rope_cos[(size_t)(base + j) * HALF + lane]; vec[v].sn = a.rope_sin[(size_t)(base + j) * HALF + lane];
+        vec[v].cs = pcos[(size_t)(base + j) * HALF + lane]; vec[v].sn = psin[(size_t)(base + j) * HALF + lane];
     }
     const int tg = lane >> 4, sub = lane & 15;
     float kr[U][EPL], vr[U][EPL];
@@ -883,9 +903,9 @@ __global__ __launch_bounds__(512) void k_cp_attn_oproj(CpAttnOprojArgs a) {
         int t = tg + 4 * u;                      // clamped, unconditional (a conditional load is a serial round trip)
         t = t < base ? t : base - 1;
         t = t > 0 ? t : 0;
-        const size_t off = ((size_t)kvh * a.page_tokens + t) * D + sub * EPL;
-        const float4 k0 = *reinterpret_cast<const float4*>(a.kc + off), k1 = *reinterpret_cast<const float4*>(a.kc + off + 4);
-        const float4 v0 = *reinterpret_cast<const float4*>(a.vc + off), v1 = *reinterpret_cast<const float4*>(a.vc + off + 4);
+        const size_t off = ((size_t)kvh * ppage_tokens + t) * D + sub * EPL;
+        const float4 k0 = *reinterpret_cast<const float4*>(pkc + off), k1 = *reinterpret_cast<const float4*>(pkc + off + 4);
+        const float4 v0 = *reinterpret_cast<const float4*>(pvc + off), v1 = *reinterpret_cast<const float4*>(pvc + off + 4);
         kr[u][0] = k0.x; kr[u][1] = k0.y; kr[u][2] = k0.z; kr[u][3] = k0.w; kr[u][4] = k1.x; kr[u][5] = k1.y; kr[u][6] = k1.z; kr[u][7] = k1.w;
         vr[u][0] = v0.x; vr[u][1] = v0.y; vr[u][2] = v0.z; vr[u][3] = v0.w; vr[u][4] = v1.x; vr[u][5] = v1.y; vr[u][6] = v1.z; vr[u][7] = v1.w;
     }
@@ -1011,7 +1031,8 @@ void launch_cp_attn_oproj(const CpAttnOprojArgs& a, int n_new, hipStream_t s) {
     if (!cp_attn_oproj_ok(a, n_new)) throw Error("cp_attn_oproj: unsupported shape");
     const int U = a.base <= 4 ? 1 : (a.base <= 8 ? 2 : (a.base <= 12 ? 3 : 4));
     const dim3 grid((a.N + 3) / 4), block(512);
-#define Q3_CAO(NEW, UU) hipLaunchKernelGGL((k_cp_attn_oproj<NEW, UU>), grid, block, 0, s, a)
+#define Q3_CAO(NEW, UU) hipLaunchKernelGGL((k_cp_attn_oproj<NEW, UU>), grid, block, 0, s, a.W, a.qkv, (const float*)a.kc, (const float*)a.vc, (const float*)a.x, \
+        a.rope_cos, a.rope_sin, (uint32_t)a.base | (uint32_t)a.page_tokens << 16, (uint32_t)a.N | (uint32_t)a.ldx << 16, a)
     if (n_new == 1) { if (U == 1) Q3_CAO(1, 1); else if (U == 2) Q3_CAO(1, 2); else if (U == 3) Q3_CAO(1, 3); else Q3_CAO(1, 4); }
     else { if (U == 1) Q3_CAO(2, 1); else if (U == 2) Q3_CAO(2, 2); else if (U == 3) Q3_CAO(2, 3); else Q3_CAO(2, 4); }
 #undef Q3_CAO
@@ -1019,7 +1040,7 @@ void launch_cp_attn_oproj(const CpAttnOprojArgs& a, int n_new, hipStream_t s) {
 }
 bool cp_attn_oproj_ok(const CpAttnOprojArgs& a, int n_new) {
     return (n_new == 1 || n_new == 2) && a.nq == 16 && a.nkv == 8 && a.d == 128 && a.K == 2048 && a.base >= 0 && a.base <= 16 &&
-           a.base + n_new <= a.page_tokens && a.q_norm && a.k_norm && a.ld_qkv >= 4096 && a.N >= 1;
+           a.base + n_new <= a.page_tokens && a.q_norm && a.k_norm && a.ld_qkv == 4096 && a.N >= 1 && a.N < 65536 && a.ldx < 65536 && a.page_tokens < 65536;
 }
 
 // ================================================================================================
@@ -1082,10 +1103,10 @@ static __device__ __forceinline__ float kth_largest_of_lanes(float v, int k) {
 #else
 #define SP_MARK(k) do { } while (0)
 #endif
-__global__ __launch_bounds__(256) void k_sample(SampleArgs a) {
+__global__ __launch_bounds__(256) void k_sample(const float* plogits, SlotState* pst, int pld, int pV, SampleArgs a) {   // leading scalars: preloaded (see k_gemv1)
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int V = a.V;
+    const int V = pV;
     __shared__ float gmax[4][64];                // per-wave lane maxima
     __shared__ float svw[4][256 + 64];           // per-wave survivor staging (+64 dump slots)
     __shared__ int svn[4];
@@ -1103,14 +1124,14 @@ __global__ __launch_bounds__(256) void k_sample(SampleArgs a) {
     float temperature = a.temperature, top_p = a.top_p, u = a.u;
     int top_k = a.top_k, suppress = a.suppress, keep_eos = 1;
     int frame = 0;
-    SlotState* st = a.st ? a.st + b : nullptr;
+    SlotState* st = pst ? pst + b : nullptr;
     SlotState sl;
     if (st) {
         const uint4* sp = reinterpret_cast<const uint4*>(st);
         uint4 raw[4] = { sp[0], sp[1], sp[2], sp[3] };
         __builtin_memcpy(&sl, raw, sizeof sl);
     }
-    const float* lg = a.logits + (size_t)b * a.ld;
+    const float* lg = plogits + (size_t)b * pld;
     const int PER = (V + 63) / 64;               // 64-element slices in the row
     float x[SAMP_PERW];
 #pragma unroll
@@ -1408,7 +1429,7 @@ __global__ __launch_bounds__(256) void k_sample(SampleArgs a) {
 
 void launch_sample(const SampleArgs& a, hipStream_t s) {
     if (a.V > SAMP_MAXV) throw Error("sample: vocabulary larger than 4096");
-    hipLaunchKernelGGL(k_sample, dim3(a.nb), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_sample, dim3(a.nb), dim3(256), 0, s, a.logits, a.st, a.ld, a.V, a);
 }
 
 // ================================================================================================
