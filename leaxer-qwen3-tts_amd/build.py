@@ -32,7 +32,7 @@ def _compile(src, hdr_digest, force):
     dg = _digest([path]) + hdr_digest
     if not force and os.path.exists(obj) and os.path.exists(tag) and open(tag).read() == dg:
         return obj, False
-    extra = ["-mllvm", "-amdgpu-kernarg-preload-count=16"] if src == "q3_decode_kernels.hip" else []   # leading scalar kernel args arrive in SGPRs
+    extra = ["-mllvm", "-amdgpu-kernarg-preload-count=16"] if src in ("q3_decode_kernels.hip", "q3_gemm_kernels.hip") else []   # leading scalar kernel args arrive in SGPRs
     cmd = ["hipcc"] + FLAGS + extra + ["-x", "hip", "-c", path, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:

@@ -188,21 +188,22 @@ void launch_rmsnorm_split(const float* x, int ldx, const float* gamma, float eps
 #define G2_LD (G2_KC + 8)
 
 template <int MTILES, int EPI, int NW>
-__global__ __launch_bounds__(NW * 64) void k_gemm2(GemmArgs a) {
+__global__ __launch_bounds__(NW * 64) void k_gemm2(const bf16_t* pW, const bf16_t* pW2, const bf16_t* pxh, const bf16_t* pxl, int pldx, int pM, int pN, int pK,
+                                                     GemmArgs a) {   // leading scalars: kernarg-preloaded, see k_gemv1 in q3_decode_kernels.hip
     constexpr bool DUAL = EPI == EPI_SWIGLU || EPI == EPI_SLAB2;
     constexpr int NT = NW * 64;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r16 = lane & 15, q = lane >> 4;
     const int n0 = (blockIdx.x * NW + wave) * 16;
-    const int K = a.K, M = a.M;
+    const int K = pK, M = pM;
     const int kslice = K / gridDim.y, kbeg = blockIdx.y * kslice;
     __shared__ __attribute__((aligned(16))) bf16_t xs[2][MTILES * 16][G2_LD];
 
     int nrow = n0 + r16;
-    nrow = nrow < a.N ? nrow : a.N - 1;
-    const bf16_t* wp = a.W + (size_t)nrow * K + q * 8;
-    const bf16_t* wp2 = DUAL ? a.W2 + (size_t)nrow * K + q * 8 : nullptr;
+    nrow = nrow < pN ? nrow : pN - 1;
+    const bf16_t* wp = pW + (size_t)nrow * K + q * 8;
+    const bf16_t* wp2 = DUAL ? pW2 + (size_t)nrow * K + q * 8 : nullptr;
     f32x4 acc[MTILES], acc2[MTILES];
 #pragma unroll
     for (int mt = 0; mt < MTILES; ++mt) { acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[mt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -224,8 +225,8 @@ __global__ __launch_bounds__(NW * 64) void k_gemm2(GemmArgs a) {
         for (int p = 0; p < PASSES; ++p) {
             int row = srow + p * RPP;
             row = row < M ? row : M - 1;
-            S.sh[p] = *reinterpret_cast<const uint4*>(a.xh + (size_t)row * a.ldx + k0 + scol);
-            S.sl[p] = *reinterpret_cast<const uint4*>(a.xl + (size_t)row * a.ldx + k0 + scol);
+            S.sh[p] = *reinterpret_cast<const uint4*>(pxh + (size_t)row * pldx + k0 + scol);
+            S.sl[p] = *reinterpret_cast<const uint4*>(pxl + (size_t)row * pldx + k0 + scol);
         }
     };
     auto consume = [&](Stage& S) {
@@ -290,10 +291,10 @@ template <int MTILES, int NW>
 static void gemm2_epi(const GemmArgs& a, int ksplit, hipStream_t s) {
     const dim3 grid((a.N + NW * 16 - 1) / (NW * 16), ksplit), block(NW * 64);
     switch (a.epi) {
-    case EPI_STORE: hipLaunchKernelGGL((k_gemm2<MTILES, EPI_STORE, NW>), grid, block, 0, s, a); break;
-    case EPI_SWIGLU: hipLaunchKernelGGL((k_gemm2<MTILES, EPI_SWIGLU, NW>), grid, block, 0, s, a); break;
-    case EPI_SLAB: hipLaunchKernelGGL((k_gemm2<MTILES, EPI_SLAB, NW>), grid, block, 0, s, a); break;
-    case EPI_SLAB2: hipLaunchKernelGGL((k_gemm2<MTILES, EPI_SLAB2, NW>), grid, block, 0, s, a); break;
+    case EPI_STORE: hipLaunchKernelGGL((k_gemm2<MTILES, EPI_STORE, NW>), grid, block, 0, s, a.W, a.W2, a.xh, a.xl, a.ldx, a.M, a.N, a.K, a); break;
+    case EPI_SWIGLU: hipLaunchKernelGGL((k_gemm2<MTILES, EPI_SWIGLU, NW>), grid, block, 0, s, a.W, a.W2, a.xh, a.xl, a.ldx, a.M, a.N, a.K, a); break;
+    case EPI_SLAB: hipLaunchKernelGGL((k_gemm2<MTILES, EPI_SLAB, NW>), grid, block, 0, s, a.W, a.W2, a.xh, a.xl, a.ldx, a.M, a.N, a.K, a); break;
+    case EPI_SLAB2: hipLaunchKernelGGL((k_gemm2<MTILES, EPI_SLAB2, NW>), grid, block, 0, s, a.W, a.W2, a.xh, a.xl, a.ldx, a.M, a.N, a.K, a); break;
     default: throw Error("gemm2: unsupported epilogue");
     }
 }
