@@ -843,53 +843,51 @@ void launch_attn_combine(const AttnArgs& a, hipStream_t s) {
 // The predictor context is at most 17 tokens, so attention is a few KB of L2-resident K/V per head; what a
 // separate attention launch costs is its dependent-launch slot (~4.6 us of the 2.67 ms step, 75 per frame).
 // Here every workgroup of the o_proj GEMV (4 output rows x K) recomputes the whole attention vector itself:
-// wave w = kv head w (both of its query heads), all addresses known at launch (contiguous per-slot cache,
-// host-known position), so weights, q/k/v rows, norm/RoPE operands and the cached K/V are ONE memory round.
-// The 4 token groups of a wave meet in LDS, the 8 heads meet in LDS, then 2 waves per output row split K.
-// Workgroup 0 appends the new K/V rows to the cache.  NEW = new rows (1, or 2 for the predictor's first pass),
-// U = cached tokens per 16-lane group in flight (cached tokens <= 4 U).
+// 16 waves, wave w = query head w (the two heads of a kv group both redo its new key), all addresses known at launch
+// (contiguous per-slot cache, host-known position), so weights, q/k/v rows, norm/RoPE operands and the cached K/V are ONE
+// memory round.  The 4 token groups of a wave meet in registers (permlane swaps), the 16 heads meet in LDS, then 4 waves
+// per output row split K.  Workgroup 0 appends the new K/V rows to the cache.  NEW = new rows (1, or 2 for the predictor's
+// first pass), U = cached tokens per 16-lane group in flight (cached tokens <= 4 U).
 // ================================================================================================
 template <int NEW, int U>
-__global__ __launch_bounds__(512) void k_cp_attn_oproj(const bf16_t* pW, const float* pqkv, const float* pkc, const float* pvc, const float* px,
-                                                        const float* pcos, const float* psin, uint32_t pk0, uint32_t pk1, CpAttnOprojArgs a) {
+__global__ __launch_bounds__(1024) void k_cp_attn_oproj(const bf16_t* pW, const float* pqkv, const float* pkc, const float* pvc, const float* px,
+                                                         const float* pcos, const float* psin, uint32_t pk0, uint32_t pk1, CpAttnOprojArgs a) {
     // leading scalars = everything the first memory round's addresses need, preloaded into SGPRs (see k_gemv1); 16 dwords at most, so the
     // small integers travel packed: pk0 = base | page_tokens << 16, pk1 = N | ldx << 16 (ld_qkv is (16 + 2*8) * 128 by construction)
     const int pbase = (int)(pk0 & 0xFFFFu), ppage_tokens = (int)(pk0 >> 16), pN = (int)(pk1 & 0xFFFFu), pldx = (int)(pk1 >> 16);
     constexpr int LDQ = 4096;
-    constexpr int D = 128, HALF = 64, EPL = 8, G = 2, NKV = 8, K = 2048;
+    constexpr int D = 128, HALF = 64, EPL = 8, G = 2, NKV = 8, NQ = 16, K = 2048;
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int kvh = wave;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // 16 waves: one query head each (both heads of a kv group redo its new key)
+    const int head = wave, kvh = wave / G;
     const int base = pbase;
 
-    __shared__ float q_s[NKV][NEW][G][D];
-    __shared__ float knew[NKV][NEW][D];
-    __shared__ float vnew[NKV][NEW][D];
+    __shared__ float q_s[NQ][NEW][D];      // wave-private staging: (lane, lane+64) layout -> 8 contiguous dims per lane
+    __shared__ float knew[NQ][NEW][D];
+    __shared__ float vnew[NQ][NEW][D];
     __shared__ float attn_s[NEW][K];
-    __shared__ float part[NEW][8];
+    __shared__ float part[NEW][16];
 
     KP_MARK(16);
     // ---- the one memory round: o_proj weights, residual, q/k/v rows + their norm / RoPE operands, cached K/V ----
-    const int orow = blockIdx.x * 4 + (wave & 3), khalf = wave >> 2;
+    const int orow = blockIdx.x * 4 + (wave & 3), kq = wave >> 2;
     const int orow_c = orow < pN ? orow : pN - 1;
-    uint4 w4[2];
-#pragma unroll
-    for (int c = 0; c < 2; ++c) w4[c] = ldw_rt(pW + (size_t)orow_c * K + (khalf * 2 + c) * 512 + lane * 8, false);
+    const uint4 w4 = ldw_rt(pW + (size_t)orow_c * K + kq * 512 + lane * 8, false);
     float resid[NEW];
 #pragma unroll
     for (int m = 0; m < NEW; ++m) resid[m] = px[(size_t)m * pldx + orow_c];
     __builtin_amdgcn_sched_barrier(0);
 
     struct VecOps { float x0, x1, v0, v1, n0, n1, cs, sn; };
-    constexpr int NVEC = NEW * G + NEW;          // q vectors (row-major over (row, head)), then the new keys
+    constexpr int NVEC = 2 * NEW;                // this head's query rows, then the new keys of its kv group
     VecOps vec[NVEC];
 #pragma unroll
     for (int v = 0; v < NVEC; ++v) {
-        const bool is_q = v < NEW * G;
-        const int j = is_q ? v / G : v - NEW * G;
+        const bool is_q = v < NEW;
+        const int j = is_q ? v : v - NEW;
         const float* rowp = pqkv + (size_t)j * LDQ;
-        const float* src = rowp + (is_q ? (kvh * G + v % G) * D : (NKV * G + kvh) * D);
-        const float* vs = rowp + (NKV * G + NKV + kvh) * D;
+        const float* src = rowp + (is_q ? head * D : (NQ + kvh) * D);
+        const float* vs = rowp + (NQ + NKV + kvh) * D;
         const float* nw = is_q ? a.q_norm : a.k_norm;
         vec[v].x0 = src[lane]; vec[v].x1 = src[lane + HALF];
         vec[v].v0 = vs[lane]; vec[v].v1 = vs[lane + HALF];
@@ -912,109 +910,110 @@ __global__ __launch_bounds__(512) void k_cp_attn_oproj(const bf16_t* pW, const f
     __builtin_amdgcn_sched_barrier(0);
 
     KP_MARK(17);
-    // ---- 1. q / k RMSNorm + RoPE (reference graphs: per-head norm, rotate-half RoPE), new K/V to LDS and the cache ----
+    // ---- 1. q / k RMSNorm + RoPE (reference graphs: per-head norm, rotate-half RoPE); the staging is wave-private, so the
+    // wave's in-order LDS queue is all the synchronisation it needs.  The even head of workgroup 0 appends K/V to the cache. ----
 #pragma unroll
     for (int v = 0; v < NVEC; ++v) {
-        const bool is_q = v < NEW * G;
-        const int j = is_q ? v / G : v - NEW * G;
+        const bool is_q = v < NEW;
+        const int j = is_q ? v : v - NEW;
         const float ss = wave_sum(vec[v].x0 * vec[v].x0 + vec[v].x1 * vec[v].x1);
         const float rr = 1.0f / sqrtf(ss / (float)D + a.eps);
         const float x0 = vec[v].n0 * (vec[v].x0 * rr), x1 = vec[v].n1 * (vec[v].x1 * rr);
         const float y0 = x0 * vec[v].cs + (-x1) * vec[v].sn;
         const float y1 = x1 * vec[v].cs + x0 * vec[v].sn;
-        if (is_q) { q_s[kvh][j][v % G][lane] = y0; q_s[kvh][j][v % G][lane + HALF] = y1; }
+        if (is_q) { q_s[head][j][lane] = y0; q_s[head][j][lane + HALF] = y1; }
         else {
-            knew[kvh][j][lane] = y0; knew[kvh][j][lane + HALF] = y1;
-            vnew[kvh][j][lane] = vec[v].v0; vnew[kvh][j][lane + HALF] = vec[v].v1;
-            if (blockIdx.x == 0) {
+            knew[head][j][lane] = y0; knew[head][j][lane + HALF] = y1;
+            vnew[head][j][lane] = vec[v].v0; vnew[head][j][lane + HALF] = vec[v].v1;
+            if (blockIdx.x == 0 && (head & 1) == 0) {
                 const size_t off = ((size_t)kvh * a.page_tokens + base + j) * D;
                 a.kc[off + lane] = y0; a.kc[off + lane + HALF] = y1;
                 a.vc[off + lane] = vec[v].v0; a.vc[off + lane + HALF] = vec[v].v1;
             }
         }
     }
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
     KP_MARK(18);
     // ---- 2. scores and weighted values: token group tg owns cached tokens tg, tg+4, ... and new token j if (j & 3) == tg ----
+    float kn[NEW][EPL], vn[NEW][EPL];
+#pragma unroll
+    for (int j = 0; j < NEW; ++j)
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) { kn[j][e] = knew[head][j][sub * EPL + e]; vn[j][e] = vnew[head][j][sub * EPL + e]; }
 #pragma unroll
     for (int inew = 0; inew < NEW; ++inew) {
+        float qr[EPL];
 #pragma unroll
-        for (int h = 0; h < G; ++h) {
-            float qr[EPL];
+        for (int e = 0; e < EPL; ++e) qr[e] = q_s[head][inew][sub * EPL + e];
+        float sc[U + NEW];
 #pragma unroll
-            for (int e = 0; e < EPL; ++e) qr[e] = q_s[kvh][inew][h][sub * EPL + e];
-            float sc[U + NEW];
+        for (int u = 0; u < U; ++u) {
+            float sdot = 0.f;
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                float sdot = 0.f;
+            for (int e = 0; e < EPL; ++e) sdot = fmaf(qr[e], kr[u][e], sdot);
+            sdot = row_sum16(sdot) * a.scale;
+            sc[u] = tg + 4 * u < base ? sdot : -INFINITY;
+        }
 #pragma unroll
-                for (int e = 0; e < EPL; ++e) sdot = fmaf(qr[e], kr[u][e], sdot);
-                sdot = row_sum16(sdot) * a.scale;
-                sc[u] = tg + 4 * u < base ? sdot : -INFINITY;
-            }
-            float kn[NEW][EPL], vn[NEW][EPL];
+        for (int j = 0; j < NEW; ++j) {
+            float sdot = 0.f;
 #pragma unroll
-            for (int j = 0; j < NEW; ++j) {
-                float sdot = 0.f;
+            for (int e = 0; e < EPL; ++e) sdot = fmaf(qr[e], kn[j][e], sdot);
+            sdot = row_sum16(sdot) * a.scale;
+            sc[U + j] = (j <= inew && (j & 3) == tg) ? sdot : -INFINITY;   // causal among the new rows
+        }
+        float mx = -INFINITY;
 #pragma unroll
-                for (int e = 0; e < EPL; ++e) { kn[j][e] = knew[kvh][j][sub * EPL + e]; vn[j][e] = vnew[kvh][j][sub * EPL + e]; sdot = fmaf(qr[e], kn[j][e], sdot); }
-                sdot = row_sum16(sdot) * a.scale;
-                sc[U + j] = (j <= inew && (j & 3) == tg) ? sdot : -INFINITY;   // causal among the new rows
-            }
-            float mx = -INFINITY;
+        for (int i = 0; i < U + NEW; ++i) mx = fmaxf(mx, sc[i]);
+        float l = 0.f, o[EPL];
 #pragma unroll
-            for (int i = 0; i < U + NEW; ++i) mx = fmaxf(mx, sc[i]);
-            float l = 0.f, o[EPL];
+        for (int e = 0; e < EPL; ++e) o[e] = 0.f;
 #pragma unroll
-            for (int e = 0; e < EPL; ++e) o[e] = 0.f;
+        for (int u = 0; u < U; ++u) {
+            const float pw = mx == -INFINITY ? 0.f : __expf(sc[u] - mx);
+            l += pw;
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const float pw = mx == -INFINITY ? 0.f : __expf(sc[u] - mx);
-                l += pw;
+            for (int e = 0; e < EPL; ++e) o[e] = fmaf(pw, tg + 4 * u < base ? vr[u][e] : 0.f, o[e]);   // never-written cache rows may hold NaN
+        }
 #pragma unroll
-                for (int e = 0; e < EPL; ++e) o[e] = fmaf(pw, tg + 4 * u < base ? vr[u][e] : 0.f, o[e]);   // never-written cache rows may hold NaN
-            }
+        for (int j = 0; j < NEW; ++j) {
+            const float pw = mx == -INFINITY ? 0.f : __expf(sc[U + j] - mx);
+            l += pw;
 #pragma unroll
-            for (int j = 0; j < NEW; ++j) {
-                const float pw = mx == -INFINITY ? 0.f : __expf(sc[U + j] - mx);
-                l += pw;
+            for (int e = 0; e < EPL; ++e) o[e] = fmaf(pw, vn[j][e], o[e]);
+        }
+        // merge the wave's 4 token groups in registers: lanes {sub, sub+16, sub+32, sub+48} hold the same 8 dims of different groups
+        const float mall = wave_max(mx);                                  // every group's max is replicated over its 16 lanes
+        const float wgt = mx == -INFINITY ? 0.f : __expf(mx - mall);
+        l *= wgt;
 #pragma unroll
-                for (int e = 0; e < EPL; ++e) o[e] = fmaf(pw, vn[j][e], o[e]);
-            }
-            // merge the wave's 4 token groups in registers: lanes {sub, sub+16, sub+32, sub+48} hold the same 8 dims of different groups
-            const float mall = wave_max(mx);                                  // every group's max is replicated over its 16 lanes
-            const float wgt = mx == -INFINITY ? 0.f : __expf(mx - mall);
-            l *= wgt;
+        for (int e = 0; e < EPL; ++e) o[e] *= wgt;
+        l += wave_xor_lane_f<16>(l, lane);
+        l += wave_xor_lane_f<32>(l, lane);
 #pragma unroll
-            for (int e = 0; e < EPL; ++e) o[e] *= wgt;
-            l += wave_xor_lane_f<16>(l, lane);
-            l += wave_xor_lane_f<32>(l, lane);
-#pragma unroll
-            for (int e = 0; e < EPL; ++e) { o[e] += wave_xor_lane_f<16>(o[e], lane); o[e] += wave_xor_lane_f<32>(o[e], lane); }
-            if (tg == 0) {
-                const float il = 1.0f / l;
-                float* dst = &attn_s[inew][(kvh * G + h) * D + sub * EPL];
-                *reinterpret_cast<float4*>(dst) = make_float4(o[0] * il, o[1] * il, o[2] * il, o[3] * il);
-                *reinterpret_cast<float4*>(dst + 4) = make_float4(o[4] * il, o[5] * il, o[6] * il, o[7] * il);
-            }
+        for (int e = 0; e < EPL; ++e) { o[e] += wave_xor_lane_f<16>(o[e], lane); o[e] += wave_xor_lane_f<32>(o[e], lane); }
+        if (tg == 0) {
+            const float il = 1.0f / l;
+            float* dst = &attn_s[inew][head * D + sub * EPL];
+            *reinterpret_cast<float4*>(dst) = make_float4(o[0] * il, o[1] * il, o[2] * il, o[3] * il);
+            *reinterpret_cast<float4*>(dst + 4) = make_float4(o[4] * il, o[5] * il, o[6] * il, o[7] * il);
         }
     }
     __syncthreads();
     KP_MARK(20);
-    // ---- 4. o_proj: wave (row = wave & 3, K half = wave >> 2), residual add ----
+    // ---- 3. o_proj: wave (row = wave & 3, K quarter = wave >> 2), residual add ----
 #pragma unroll
     for (int m = 0; m < NEW; ++m) {
+        const float* xr = &attn_s[m][kq * 512 + lane * 8];
+        const float4 x0 = *reinterpret_cast<const float4*>(xr), x1 = *reinterpret_cast<const float4*>(xr + 4);
+        const float xv[8] = { x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w };
+        const uint32_t wu[4] = { w4.x, w4.y, w4.z, w4.w };
         float s1 = 0.f;
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const float* xr = &attn_s[m][(khalf * 2 + c) * 512 + lane * 8];
-            const float4 x0 = *reinterpret_cast<const float4*>(xr), x1 = *reinterpret_cast<const float4*>(xr + 4);
-            const float xv[8] = { x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w };
-            const uint32_t wu[4] = { w4[c].x, w4[c].y, w4[c].z, w4[c].w };
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { s1 = fmaf(xv[2 * j], bf_lo(wu[j]), s1); s1 = fmaf(xv[2 * j + 1], bf_hi(wu[j]), s1); }
-        }
+        for (int j = 0; j < 4; ++j) { s1 = fmaf(xv[2 * j], bf_lo(wu[j]), s1); s1 = fmaf(xv[2 * j + 1], bf_hi(wu[j]), s1); }
         s1 = wave_sum(s1);
         if (lane == 0) part[m][wave] = s1;
     }
@@ -1023,14 +1022,14 @@ __global__ __launch_bounds__(512) void k_cp_attn_oproj(const bf16_t* pW, const f
     if (wave < 4 && lane < NEW && orow < a.N) {
         float r = resid[0];
         if (NEW > 1 && lane == 1) r = resid[NEW - 1];
-        a.x[(size_t)lane * a.ldx + orow] = r + (part[lane][wave] + part[lane][wave + 4]);
+        a.x[(size_t)lane * a.ldx + orow] = r + (((part[lane][wave] + part[lane][wave + 4]) + part[lane][wave + 8]) + part[lane][wave + 12]);
     }
 }
 
 void launch_cp_attn_oproj(const CpAttnOprojArgs& a, int n_new, hipStream_t s) {
     if (!cp_attn_oproj_ok(a, n_new)) throw Error("cp_attn_oproj: unsupported shape");
     const int U = a.base <= 4 ? 1 : (a.base <= 8 ? 2 : (a.base <= 12 ? 3 : 4));
-    const dim3 grid((a.N + 3) / 4), block(512);
+    const dim3 grid((a.N + 3) / 4), block(1024);
 #define Q3_CAO(NEW, UU) hipLaunchKernelGGL((k_cp_attn_oproj<NEW, UU>), grid, block, 0, s, a.W, a.qkv, (const float*)a.kc, (const float*)a.vc, (const float*)a.x, \
         a.rope_cos, a.rope_sin, (uint32_t)a.base | (uint32_t)a.page_tokens << 16, (uint32_t)a.N | (uint32_t)a.ldx << 16, a)
     if (n_new == 1) { if (U == 1) Q3_CAO(1, 1); else if (U == 2) Q3_CAO(1, 2); else if (U == 3) Q3_CAO(1, 3); else Q3_CAO(1, 4); }
