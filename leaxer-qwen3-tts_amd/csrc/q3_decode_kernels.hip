@@ -1165,216 +1165,291 @@ __global__ __launch_bounds__(256) void k_sample(const float* plogits, SlotState*
         x[jj] = v;
         lmax = fmaxf(lmax, v);
     }
-    gmax[wave][lane] = lmax;
-    __syncthreads();
-    // 64 group maxima (group = lane, over all four waves) -> global max and the prefilter bound
-    const float gm = fmaxf(fmaxf(gmax[0][lane], gmax[1][lane]), fmaxf(gmax[2][lane], gmax[3][lane]));
-    const float mx = wave_max(gm);
-    SP_MARK(2);
-
-    // ---- top-k threshold = k-th largest value, ties kept (:917-927) ----
-    float thr = -INFINITY;
-    if (top_k > 0 && top_k < V) {
-        bool done = false;
-        if (top_k == 1) { thr = mx; done = true; }
-        else if (top_k <= 64) {
-            // Iterated prefilter: the k-th largest of the 64 group maxima is a lower bound L of the k-th
-            // largest overall, so only elements >= L can matter (~100 of 3072); wave 0 re-deals the survivors
-            // over its lanes and repeats until at most one candidate per lane is left, ranked exactly.
-            const float L1 = kth_largest_of_lanes(gm, top_k);   // every wave computes the same L1
-            SP_MARK(3);
-            int nw = 0;
-#pragma unroll
-            for (int jj = 0; jj < SAMP_PERW; ++jj) {
-                const bool sv = x[jj] >= L1 && x[jj] != -INFINITY;
-                const unsigned long long m = __ballot(sv);
-                const int ppos = nw + __popcll(m & lt_mask);
-                svw[wave][(sv && ppos < 256) ? ppos : 256 + lane] = x[jj];
-                nw += __popcll(m);
-            }
-            if (lane == 0) svn[wave] = nw;
-            __syncthreads();
-            SP_MARK(4);
-            if (wave == 0) {
-                const int n0 = svn[0], n1 = svn[1], n2 = svn[2], n3 = svn[3];
-                int n = n0 + n1 + n2 + n3;
-                bool ok = L1 != -INFINITY && n <= 256;
-                if (ok) { // gather the four wave-local lists into svb[0..n)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int i = q * 64 + lane;
-                        float v = -INFINITY;
-                        if (i < n0) v = svw[0][i];
-                        else if (i < n0 + n1) v = svw[1][i - n0];
-                        else if (i < n0 + n1 + n2) v = svw[2][i - n0 - n1];
-                        else if (i < n) v = svw[3][i - n0 - n1 - n2];
-                        svb[i] = v;
-                    }
-                }
-                for (int round = 0; ok && round < 8; ++round) {
-                    float s4[4];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) { const float v = svb[q * 64 + lane]; s4[q] = q * 64 + lane < n ? v : -INFINITY; }
-                    if (n <= 64) { thr = kth_largest_of_lanes(s4[0], top_k); done = thr != -INFINITY; break; }
-                    const float L2 = kth_largest_of_lanes(fmaxf(fmaxf(s4[0], s4[1]), fmaxf(s4[2], s4[3])), top_k);
-                    int n2c = 0;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const bool sv = s4[q] >= L2 && s4[q] != -INFINITY;
-                        const unsigned long long m = __ballot(sv);
-                        const int ppos = n2c + __popcll(m & lt_mask);
-                        svb[sv ? ppos : 256 + lane] = s4[q];
-                        n2c += __popcll(m);
-                    }
-                    ok = L2 != -INFINITY && n2c < n; // no progress (mass ties): exact fallback below
-                    n = n2c;
-                }
-                if (lane == 0) { sh_f[0] = thr; sh_i[0] = done ? 1 : 0; }
-            }
-            __syncthreads();
-            SP_MARK(5);
-            thr = sh_f[0];
-            done = sh_i[0] != 0;
-        }
-        if (!done) { // rare fallback (top_k > 64, or pathological ties): bitwise search of the k-th largest key
-            uint32_t prefix = 0;
-            for (int bit = 31; bit >= 0; --bit) {
-                const uint32_t cand = prefix | (1u << bit);
-                int c = 0;
-#pragma unroll
-                for (int jj = 0; jj < SAMP_PERW; ++jj) c += ((jj * 4 + wave) * 64 + lane < V && fkey(x[jj]) >= cand) ? 1 : 0;
-                c = wave_sum_i(c);
-                __syncthreads();
-                if (lane == 0) svn[wave] = c;
-                __syncthreads();
-                if (svn[0] + svn[1] + svn[2] + svn[3] >= top_k) prefix = cand;
-            }
-            const uint32_t ku = (prefix & 0x80000000u) ? (prefix & 0x7FFFFFFFu) : ~prefix;
-            thr = __uint_as_float(ku);
-        }
-    }
-
-    // ---- index-ordered compaction of the kept entries; softmax numerators exp(x - max) (:907-915) ----
-    unsigned long long km[SAMP_PERW];
-#pragma unroll
-    for (int jj = 0; jj < SAMP_PERW; ++jj) {
-        const bool keep = x[jj] >= thr && x[jj] != -INFINITY;
-        km[jj] = __ballot(keep);
-        const int j = jj * 4 + wave;
-        if (lane == 0 && j < PER) cnt_s[j] = __popcll(km[jj]);
-    }
-    __syncthreads();
-    // exclusive prefix of the per-slice counts (slice order = index order); lane j holds slice j
-    const int cmine = lane < PER ? cnt_s[lane] : 0;
-    const int cincl = wave_scan_incl_i(cmine);
-    const int n_kept = lane_bcast_i(cincl, 63);
-    float esum = 0.f;
-#pragma unroll
-    for (int jj = 0; jj < SAMP_PERW; ++jj) {
-        const int j = jj * 4 + wave;
-        if (km[jj]) { // wave-uniform: most slices hold no survivor
-            const int base = lane_bcast_i(cincl, j) - lane_bcast_i(cmine, j);
-            const bool keep = (km[jj] >> lane) & 1ull;
-            const int wpos = keep ? base + __popcll(km[jj] & lt_mask) : SAMP_MAXV + lane;
-            const float e = keep ? expf(x[jj] - mx) : 0.f;
-            cand_idx[wpos] = j * 64 + lane;
-            cand_p[wpos] = e;
-            esum += e;
-        }
-    }
-    esum = wave_sum(esum);
-    if (lane == 0) esum_s[wave] = esum;
-    __syncthreads();
-    esum = ((esum_s[0] + esum_s[1]) + esum_s[2]) + esum_s[3];
-    SP_MARK(6);
-
     int tok = 0;
-    if (wave == 0) {
-        if (n_kept <= 64) {
-            // ---- wave path: one candidate per lane, everything in registers ----
-            const bool have = lane < n_kept;
-            float p = have ? cand_p[lane] / esum : 0.f;
-            const int myidx = have ? cand_idx[lane] : 0;
-            if (top_p < 1.0f) { // :929-950 — order by (p desc, index asc); keep through the first cumulative sum > top_p
-                // sort (p, position) pairs across the lanes, scan the sorted probabilities, cut, and send every keep flag back to
-                // the lane it came from (ds_permute pushes; the tags are a permutation of 0..63)
-                float sk = have ? p : -INFINITY;
-                int tag = lane;
-                wave_sort_desc_kv(sk, tag, lane);
-                const float cum = wave_scan_incl_f(lane < n_kept ? sk : 0.f);
-                const unsigned long long over = __ballot(lane < n_kept && cum > top_p);
-                const int rcut = over ? __ffsll((long long)over) - 1 : 0x7FFFFFFF;
-                const int keep_rank = (lane < n_kept && lane <= rcut) ? 1 : 0;
-                const int keep_here = __builtin_amdgcn_ds_permute(tag << 2, keep_rank);
-                if (!(have && keep_here)) p = 0.f;
-                const float s2 = wave_sum(p);
-                if (s2 > 0.f) p = p / s2; // :893-898
-            }
-            SP_MARK(7);
-            // draw: inverse CDF in index order
-            const float total = wave_sum(p);
-            const float target = u * total;
-            const float cum = wave_scan_incl_f(p);
-            const unsigned long long hit = __ballot(p > 0.f && cum > target);
-            const unsigned long long pos_mask = __ballot(p > 0.f);
-            int pick;
-            if (hit) pick = __ffsll((long long)hit) - 1;
-            else pick = pos_mask ? 63 - __clzll((long long)pos_mask) : 0;
-            tok = lane_bcast_i(myidx, pick);
-        } else {
-            // ---- general path (top_k == 0 or > 64, or many ties): LDS-resident candidates, wave 0 only ----
-            for (int c = lane; c < n_kept; c += 64) cand_p[c] = cand_p[c] / esum;
-            if (top_p < 1.0f) {
-                for (int c = lane; c < n_kept; c += 64) {
-                    const float pc = cand_p[c];
-                    int rank = 0;
-                    for (int o2 = 0; o2 < n_kept; ++o2) {
-                        const float po = cand_p[o2];
-                        rank += (po > pc || (po == pc && o2 < c)) ? 1 : 0;
-                    }
-                    sorted_p[rank] = pc;
-                }
-                int cutoff = n_kept;
-                if (lane == 0) {
-                    float cum = 0.f;
-                    for (int i = 0; i < n_kept; ++i) { cum += sorted_p[i]; if (cum > top_p) { cutoff = i + 1; break; } }
-                }
-                cutoff = lane_bcast_i(cutoff, 0);
-                const float pcut = sorted_p[cutoff - 1]; // probability of the last kept rank
-                int n_gt = 0;
-                for (int c = lane; c < n_kept; c += 64) n_gt += cand_p[c] > pcut ? 1 : 0;
-                n_gt = wave_sum_i(n_gt);
-                const int n_eq_keep = cutoff - n_gt; // equal-p candidates kept, lowest indices first
-                if (lane == 0) {
-                    int seen = 0;
-                    for (int c = 0; c < n_kept; ++c) {
-                        const float pc = cand_p[c];
-                        if (pc > pcut) continue;
-                        if (pc == pcut && seen < n_eq_keep) { ++seen; continue; }
-                        cand_p[c] = 0.f;
-                    }
-                }
-                float s2 = 0.f;
-                for (int c = lane; c < n_kept; c += 64) s2 += cand_p[c];
-                s2 = wave_sum(s2);
-                if (s2 > 0.f) for (int c = lane; c < n_kept; c += 64) cand_p[c] = cand_p[c] / s2;
-            }
-            int picked = 0;
-            if (lane == 0) {
-                float total = 0.f;
-                for (int c = 0; c < n_kept; ++c) total += cand_p[c];
-                const float target = u * total;
-                float cum = 0.f;
-                int pick = -1, last = -1;
-                for (int c = 0; c < n_kept; ++c) {
-                    if (cand_p[c] > 0.f) { last = c; cum += cand_p[c]; if (cum > target) { pick = c; break; } }
-                }
-                if (pick < 0) pick = last;
-                picked = pick >= 0 ? cand_idx[pick] : 0;
-            }
-            tok = lane_bcast_i(picked, 0);
+    // ---- fast path (2 <= top_k <= 64): one bound, one survivor list, two register sorts ----
+    // The k-th largest logit is at least B = the k-th largest of the 64 values {16 largest THREAD maxima of each wave} (a subset of
+    // the logits, so its k-th largest cannot exceed theirs).  Thread maxima are a much tighter net than the 64 lane-group maxima:
+    // typically k+5..k+10 values survive, i.e. they fit one value per lane of wave 0, where a (value desc, index asc) sort yields
+    // the threshold, the kept set and the top-p order at once, and a second sort by index restores the order the draw walks in.
+    bool fast_done = false;
+    if (top_k >= 2 && top_k <= 64 && top_k < V) {
+        const float tsort = wave_sort_desc(lmax, lane);
+        if (lane < 16) svb[wave * 16 + lane] = tsort;
+        __syncthreads();
+        const float msort = wave_sort_desc(svb[lane], lane);                  // every wave redoes the 64-value merge: no second barrier
+        const float B = lane_bcast(msort, __builtin_amdgcn_readfirstlane(top_k) - 1);
+        const float mxf = lane_bcast(msort, 0);
+        SP_MARK(3);
+        int nw = 0;
+#pragma unroll
+        for (int jj = 0; jj < SAMP_PERW; ++jj) {
+            const bool sv = x[jj] >= B && x[jj] != -INFINITY;
+            const unsigned long long m = __ballot(sv);
+            const int ppos = nw + __popcll(m & lt_mask);
+            const int slot = (sv && ppos < 256) ? ppos : 256 + lane;
+            svw[wave][slot] = x[jj];
+            cand_idx[wave * (256 + 64) + slot] = (jj * 4 + wave) * 64 + lane;
+            nw += __popcll(m);
         }
-        if (lane == 0) sh_i[3] = tok;
+        if (lane == 0) svn[wave] = nw;
+        __syncthreads();
+        SP_MARK(4);
+        const int n0 = svn[0], n1 = svn[1], n2 = svn[2], n3 = svn[3], n = n0 + n1 + n2 + n3;
+        if (B != -INFINITY && n >= 1 && n <= 64) {       // block-uniform
+            fast_done = true;
+            if (wave == 0) {
+                float v = -INFINITY;
+                int id = 0x7FFFFFFF;
+                const int w = lane < n0 ? 0 : (lane < n0 + n1 ? 1 : (lane < n0 + n1 + n2 ? 2 : 3));
+                const int off = lane - (w == 0 ? 0 : (w == 1 ? n0 : (w == 2 ? n0 + n1 : n0 + n1 + n2)));
+                if (lane < n) { v = svw[w][off]; id = cand_idx[w * (256 + 64) + off]; }
+                wave_sort_desc_kv(v, id, lane);
+                const int kk = __builtin_amdgcn_readfirstlane(top_k);
+                const float thrf = n >= kk ? lane_bcast(v, kk - 1) : -INFINITY;     // ties at the threshold stay (:917-927)
+                const bool kept = lane < n && v >= thrf;
+                SP_MARK(5);
+                const float e = kept ? expf(v - mxf) : 0.f;                          // softmax over the kept entries (:907-915)
+                float p = e / wave_sum(e);
+                SP_MARK(6);
+                if (top_p < 1.0f) { // :929-950 — already in (p desc, index asc) order: keep through the first cumulative sum > top_p
+                    const float cum = wave_scan_incl_f(p);
+                    const unsigned long long over = __ballot(kept && cum > top_p);
+                    const int rcut = over ? __ffsll((long long)over) - 1 : 0x7FFFFFFF;
+                    if (lane > rcut) p = 0.f;
+                    const float s2 = wave_sum(p);
+                    if (s2 > 0.f) p = p / s2; // :893-898
+                }
+                SP_MARK(7);
+                // back to index order for the draw: sort by index, pull (p, index) along with a backward permute
+                float key = kept ? -(float)id : -INFINITY;
+                int from = lane;
+                wave_sort_desc_kv(key, from, lane);
+                const float pi = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(from << 2, __builtin_bit_cast(int, p)));
+                const int idi = __builtin_amdgcn_ds_bpermute(from << 2, id);
+                const float total = wave_sum(pi);
+                const float target = u * total;
+                const float cum = wave_scan_incl_f(pi);
+                const unsigned long long hit = __ballot(pi > 0.f && cum > target);
+                const unsigned long long pos_mask = __ballot(pi > 0.f);
+                int pick;
+                if (hit) pick = __ffsll((long long)hit) - 1;
+                else pick = pos_mask ? 63 - __clzll((long long)pos_mask) : 0;
+                tok = lane_bcast_i(idi, pick);
+                if (lane == 0) sh_i[3] = tok;
+            }
+        }
+    }
+    if (!fast_done) {   // top_k == 1, 0 or > 64, or more than 64 survivors (mass ties): the general machinery
+        gmax[wave][lane] = lmax;
+        __syncthreads();
+        // 64 group maxima (group = lane, over all four waves) -> global max and the prefilter bound
+        const float gm = fmaxf(fmaxf(gmax[0][lane], gmax[1][lane]), fmaxf(gmax[2][lane], gmax[3][lane]));
+        const float mx = wave_max(gm);
+        SP_MARK(2);
+
+        // ---- top-k threshold = k-th largest value, ties kept (:917-927) ----
+        float thr = -INFINITY;
+        if (top_k > 0 && top_k < V) {
+            bool done = false;
+            if (top_k == 1) { thr = mx; done = true; }
+            else if (top_k <= 64) {
+                // Iterated prefilter: the k-th largest of the 64 group maxima is a lower bound L of the k-th
+                // largest overall, so only elements >= L can matter (~100 of 3072); wave 0 re-deals the survivors
+                // over its lanes and repeats until at most one candidate per lane is left, ranked exactly.
+                const float L1 = kth_largest_of_lanes(gm, top_k);   // every wave computes the same L1
+                SP_MARK(3);
+                int nw = 0;
+    #pragma unroll
+                for (int jj = 0; jj < SAMP_PERW; ++jj) {
+                    const bool sv = x[jj] >= L1 && x[jj] != -INFINITY;
+                    const unsigned long long m = __ballot(sv);
+                    const int ppos = nw + __popcll(m & lt_mask);
+                    svw[wave][(sv && ppos < 256) ? ppos : 256 + lane] = x[jj];
+                    nw += __popcll(m);
+                }
+                if (lane == 0) svn[wave] = nw;
+                __syncthreads();
+                SP_MARK(4);
+                if (wave == 0) {
+                    const int n0 = svn[0], n1 = svn[1], n2 = svn[2], n3 = svn[3];
+                    int n = n0 + n1 + n2 + n3;
+                    bool ok = L1 != -INFINITY && n <= 256;
+                    if (ok) { // gather the four wave-local lists into svb[0..n)
+    #pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int i = q * 64 + lane;
+                            float v = -INFINITY;
+                            if (i < n0) v = svw[0][i];
+                            else if (i < n0 + n1) v = svw[1][i - n0];
+                            else if (i < n0 + n1 + n2) v = svw[2][i - n0 - n1];
+                            else if (i < n) v = svw[3][i - n0 - n1 - n2];
+                            svb[i] = v;
+                        }
+                    }
+                    for (int round = 0; ok && round < 8; ++round) {
+                        float s4[4];
+    #pragma unroll
+                        for (int q = 0; q < 4; ++q) { const float v = svb[q * 64 + lane]; s4[q] = q * 64 + lane < n ? v : -INFINITY; }
+                        if (n <= 64) { thr = kth_largest_of_lanes(s4[0], top_k); done = thr != -INFINITY; break; }
+                        const float L2 = kth_largest_of_lanes(fmaxf(fmaxf(s4[0], s4[1]), fmaxf(s4[2], s4[3])), top_k);
+                        int n2c = 0;
+    #pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const bool sv = s4[q] >= L2 && s4[q] != -INFINITY;
+                            const unsigned long long m = __ballot(sv);
+                            const int ppos = n2c + __popcll(m & lt_mask);
+                            svb[sv ? ppos : 256 + lane] = s4[q];
+                            n2c += __popcll(m);
+                        }
+                        ok = L2 != -INFINITY && n2c < n; // no progress (mass ties): exact fallback below
+                        n = n2c;
+                    }
+                    if (lane == 0) { sh_f[0] = thr; sh_i[0] = done ? 1 : 0; }
+                }
+                __syncthreads();
+                SP_MARK(5);
+                thr = sh_f[0];
+                done = sh_i[0] != 0;
+            }
+            if (!done) { // rare fallback (top_k > 64, or pathological ties): bitwise search of the k-th largest key
+                uint32_t prefix = 0;
+                for (int bit = 31; bit >= 0; --bit) {
+                    const uint32_t cand = prefix | (1u << bit);
+                    int c = 0;
+    #pragma unroll
+                    for (int jj = 0; jj < SAMP_PERW; ++jj) c += ((jj * 4 + wave) * 64 + lane < V && fkey(x[jj]) >= cand) ? 1 : 0;
+                    c = wave_sum_i(c);
+                    __syncthreads();
+                    if (lane == 0) svn[wave] = c;
+                    __syncthreads();
+                    if (svn[0] + svn[1] + svn[2] + svn[3] >= top_k) prefix = cand;
+                }
+                const uint32_t ku = (prefix & 0x80000000u) ? (prefix & 0x7FFFFFFFu) : ~prefix;
+                thr = __uint_as_float(ku);
+            }
+        }
+
+        // ---- index-ordered compaction of the kept entries; softmax numerators exp(x - max) (:907-915) ----
+        unsigned long long km[SAMP_PERW];
+    #pragma unroll
+        for (int jj = 0; jj < SAMP_PERW; ++jj) {
+            const bool keep = x[jj] >= thr && x[jj] != -INFINITY;
+            km[jj] = __ballot(keep);
+            const int j = jj * 4 + wave;
+            if (lane == 0 && j < PER) cnt_s[j] = __popcll(km[jj]);
+        }
+        __syncthreads();
+        // exclusive prefix of the per-slice counts (slice order = index order); lane j holds slice j
+        const int cmine = lane < PER ? cnt_s[lane] : 0;
+        const int cincl = wave_scan_incl_i(cmine);
+        const int n_kept = lane_bcast_i(cincl, 63);
+        float esum = 0.f;
+    #pragma unroll
+        for (int jj = 0; jj < SAMP_PERW; ++jj) {
+            const int j = jj * 4 + wave;
+            if (km[jj]) { // wave-uniform: most slices hold no survivor
+                const int base = lane_bcast_i(cincl, j) - lane_bcast_i(cmine, j);
+                const bool keep = (km[jj] >> lane) & 1ull;
+                const int wpos = keep ? base + __popcll(km[jj] & lt_mask) : SAMP_MAXV + lane;
+                const float e = keep ? expf(x[jj] - mx) : 0.f;
+                cand_idx[wpos] = j * 64 + lane;
+                cand_p[wpos] = e;
+                esum += e;
+            }
+        }
+        esum = wave_sum(esum);
+        if (lane == 0) esum_s[wave] = esum;
+        __syncthreads();
+        esum = ((esum_s[0] + esum_s[1]) + esum_s[2]) + esum_s[3];
+        SP_MARK(6);
+
+        if (wave == 0) {
+            if (n_kept <= 64) {
+                // ---- wave path: one candidate per lane, everything in registers ----
+                const bool have = lane < n_kept;
+                float p = have ? cand_p[lane] / esum : 0.f;
+                const int myidx = have ? cand_idx[lane] : 0;
+                if (top_p < 1.0f) { // :929-950 — order by (p desc, index asc); keep through the first cumulative sum > top_p
+                    // sort (p, position) pairs across the lanes, scan the sorted probabilities, cut, and send every keep flag back to
+                    // the lane it came from (ds_permute pushes; the tags are a permutation of 0..63)
+                    float sk = have ? p : -INFINITY;
+                    int tag = lane;
+                    wave_sort_desc_kv(sk, tag, lane);
+                    const float cum = wave_scan_incl_f(lane < n_kept ? sk : 0.f);
+                    const unsigned long long over = __ballot(lane < n_kept && cum > top_p);
+                    const int rcut = over ? __ffsll((long long)over) - 1 : 0x7FFFFFFF;
+                    const int keep_rank = (lane < n_kept && lane <= rcut) ? 1 : 0;
+                    const int keep_here = __builtin_amdgcn_ds_permute(tag << 2, keep_rank);
+                    if (!(have && keep_here)) p = 0.f;
+                    const float s2 = wave_sum(p);
+                    if (s2 > 0.f) p = p / s2; // :893-898
+                }
+                SP_MARK(7);
+                // draw: inverse CDF in index order
+                const float total = wave_sum(p);
+                const float target = u * total;
+                const float cum = wave_scan_incl_f(p);
+                const unsigned long long hit = __ballot(p > 0.f && cum > target);
+                const unsigned long long pos_mask = __ballot(p > 0.f);
+                int pick;
+                if (hit) pick = __ffsll((long long)hit) - 1;
+                else pick = pos_mask ? 63 - __clzll((long long)pos_mask) : 0;
+                tok = lane_bcast_i(myidx, pick);
+            } else {
+                // ---- general path (top_k == 0 or > 64, or many ties): LDS-resident candidates, wave 0 only ----
+                for (int c = lane; c < n_kept; c += 64) cand_p[c] = cand_p[c] / esum;
+                if (top_p < 1.0f) {
+                    for (int c = lane; c < n_kept; c += 64) {
+                        const float pc = cand_p[c];
+                        int rank = 0;
+                        for (int o2 = 0; o2 < n_kept; ++o2) {
+                            const float po = cand_p[o2];
+                            rank += (po > pc || (po == pc && o2 < c)) ? 1 : 0;
+                        }
+                        sorted_p[rank] = pc;
+                    }
+                    int cutoff = n_kept;
+                    if (lane == 0) {
+                        float cum = 0.f;
+                        for (int i = 0; i < n_kept; ++i) { cum += sorted_p[i]; if (cum > top_p) { cutoff = i + 1; break; } }
+                    }
+                    cutoff = lane_bcast_i(cutoff, 0);
+                    const float pcut = sorted_p[cutoff - 1]; // probability of the last kept rank
+                    int n_gt = 0;
+                    for (int c = lane; c < n_kept; c += 64) n_gt += cand_p[c] > pcut ? 1 : 0;
+                    n_gt = wave_sum_i(n_gt);
+                    const int n_eq_keep = cutoff - n_gt; // equal-p candidates kept, lowest indices first
+                    if (lane == 0) {
+                        int seen = 0;
+                        for (int c = 0; c < n_kept; ++c) {
+                            const float pc = cand_p[c];
+                            if (pc > pcut) continue;
+                            if (pc == pcut && seen < n_eq_keep) { ++seen; continue; }
+                            cand_p[c] = 0.f;
+                        }
+                    }
+                    float s2 = 0.f;
+                    for (int c = lane; c < n_kept; c += 64) s2 += cand_p[c];
+                    s2 = wave_sum(s2);
+                    if (s2 > 0.f) for (int c = lane; c < n_kept; c += 64) cand_p[c] = cand_p[c] / s2;
+                }
+                int picked = 0;
+                if (lane == 0) {
+                    float total = 0.f;
+                    for (int c = 0; c < n_kept; ++c) total += cand_p[c];
+                    const float target = u * total;
+                    float cum = 0.f;
+                    int pick = -1, last = -1;
+                    for (int c = 0; c < n_kept; ++c) {
+                        if (cand_p[c] > 0.f) { last = c; cum += cand_p[c]; if (cum > target) { pick = c; break; } }
+                    }
+                    if (pick < 0) pick = last;
+                    picked = pick >= 0 ? cand_idx[pick] : 0;
+                }
+                tok = lane_bcast_i(picked, 0);
+            }
+            if (lane == 0) sh_i[3] = tok;
+        }
     }
     __syncthreads();
     tok = sh_i[3];
