@@ -598,13 +598,19 @@ __global__ __launch_bounds__(256) void k_attn(const int* ppage_table, const int*
         const float* vs = rowp + (a.nq + a.nkv + kvh) * D;
         const int p = base + j;
         VecOps r;
-        r.x0 = src[hl]; r.x1 = src[hl + HALF];
-        r.v0 = vs[hl]; r.v1 = vs[hl + HALF];
-        for (int sb = 1; sb < a.qkv_nslab; ++sb) { // split-K partial slabs of the QKV projection, fixed order
-            const size_t so = sb * a.qkv_slab_stride;
-            r.x0 += src[so + hl]; r.x1 += src[so + hl + HALF];
-            r.v0 += vs[so + hl]; r.v1 += vs[so + hl + HALF];
+        // split-K partial slabs of the QKV projection (at most 4): every load first, summed in slab order — a runtime-count
+        // load-then-add loop costs one L2 round trip per slab
+        float px0[4], px1[4], pv0[4], pv1[4];
+#pragma unroll
+        for (int sb = 0; sb < 4; ++sb) {
+            const size_t so = (size_t)(sb < a.qkv_nslab ? sb : 0) * a.qkv_slab_stride;
+            px0[sb] = src[so + hl]; px1[sb] = src[so + hl + HALF];
+            pv0[sb] = vs[so + hl]; pv1[sb] = vs[so + hl + HALF];
         }
+        r.x0 = px0[0]; r.x1 = px1[0]; r.v0 = pv0[0]; r.v1 = pv1[0];
+#pragma unroll
+        for (int sb = 1; sb < 4; ++sb)
+            if (sb < a.qkv_nslab) { r.x0 += px0[sb]; r.x1 += px1[sb]; r.v0 += pv0[sb]; r.v1 += pv1[sb]; }
         const float* nw = is_q ? a.q_norm : a.k_norm;
         r.n0 = 1.f; r.n1 = 1.f; r.cs = 1.f; r.sn = 0.f;
         if (a.new_from_raw) {

@@ -314,6 +314,27 @@ void launch_gemm2(const GemmArgs& a, int ksplit, int nw, hipStream_t s) {
 
 // x[m][:] += sum_ks slab[ks][m][:] (fixed order), then RMSNorm(gamma) -> (hi, lo) planes (+ optional fp32 rows).
 // One workgroup per row.  nslab == 0: plain RMSNorm + split.  gamma == null: residual update only.
+static __device__ __forceinline__ void split_store4(const float (&y)[4], bf16_t* hi, bf16_t* lo) {   // 4 values -> one 8-byte store per plane
+    bf16_t h[4], l[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { h[j] = bf16_rne(y[j]); l[j] = bf16_rne(y[j] - __uint_as_float((uint32_t)h[j] << 16)); }
+    *reinterpret_cast<uint2*>(hi) = make_uint2((uint32_t)h[0] | (uint32_t)h[1] << 16, (uint32_t)h[2] | (uint32_t)h[3] << 16);
+    *reinterpret_cast<uint2*>(lo) = make_uint2((uint32_t)l[0] | (uint32_t)l[1] << 16, (uint32_t)l[2] | (uint32_t)l[3] << 16);
+}
+static __device__ __forceinline__ float wave_sum_dpp(float v) {   // DPP path (see q3_decode_kernels.hip); __shfl_xor costs an LDS round trip per step
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xF, 0xF, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xA, 0xF, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xC, 0xF, false));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+// All slab loads of a thread are issued before the first add (clamped slab index, the sum itself runs in slab order over the first
+// `nslab` only): a runtime-count loop of load-then-add had cost one L2 round trip per slab, 12 in a row after the down projection.
+#define FIN_MAXS 16
+template <int NS>   // slabs held in registers at once (>= nslab)
 __global__ __launch_bounds__(256) void k_finish(float* x, int ldx, const float* slab, int nslab, size_t slab_stride, int ld_slab,
                                                  const float* gamma, float eps, int K, bf16_t* oh, bf16_t* ol, int ldp,
                                                  float* xn_out, int ld_xn) {
@@ -324,21 +345,28 @@ __global__ __launch_bounds__(256) void k_finish(float* x, int ldx, const float* 
     float ss = 0.f;
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
-        const int k = (it * 256 + threadIdx.x) * 4;
-        if (k < K) {
-            float4 t = *reinterpret_cast<const float4*>(xr + k);
-            for (int sidx = 0; sidx < nslab; ++sidx) {
-                const float4 p = *reinterpret_cast<const float4*>(slab + sidx * slab_stride + (size_t)m * ld_slab + k);
-                t.x += p.x; t.y += p.y; t.z += p.z; t.w += p.w;
-            }
-            if (nslab > 0) *reinterpret_cast<float4*>(xr + k) = t;
-            v[it] = t;
-            ss = fmaf(t.x, t.x, ss); ss = fmaf(t.y, t.y, ss); ss = fmaf(t.z, t.z, ss); ss = fmaf(t.w, t.w, ss);
+        int k = (it * 256 + threadIdx.x) * 4;
+        if (it * 1024 >= K) { v[it] = make_float4(0.f, 0.f, 0.f, 0.f); continue; }   // workgroup-uniform
+        const bool inr = k < K;
+        k = inr ? k : K - 4;
+        float4 t = *reinterpret_cast<const float4*>(xr + k);
+        float4 p[NS > 0 ? NS : 1];
+#pragma unroll
+        for (int sidx = 0; sidx < NS; ++sidx) {
+            const int sc = sidx < nslab ? sidx : nslab - 1;
+            p[sidx] = *reinterpret_cast<const float4*>(slab + sc * slab_stride + (size_t)m * ld_slab + k);
         }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int sidx = 0; sidx < NS; ++sidx)
+            if (sidx < nslab) { t.x += p[sidx].x; t.y += p[sidx].y; t.z += p[sidx].z; t.w += p[sidx].w; }
+        if (NS > 0 && inr) *reinterpret_cast<float4*>(xr + k) = t;
+        if (!inr) t = make_float4(0.f, 0.f, 0.f, 0.f);
+        v[it] = t;
+        ss = fmaf(t.x, t.x, ss); ss = fmaf(t.y, t.y, ss); ss = fmaf(t.z, t.z, ss); ss = fmaf(t.w, t.w, ss);
     }
     if (gamma == nullptr) return;
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) ss += __shfl_xor(ss, off, 64);
+    ss = wave_sum_dpp(ss);
     if (lane == 0) red[wave] = ss;
     __syncthreads();
     const float r = 1.0f / sqrtf((((red[0] + red[1]) + red[2]) + red[3]) / (float)K + eps);
@@ -348,38 +376,47 @@ __global__ __launch_bounds__(256) void k_finish(float* x, int ldx, const float* 
         if (k < K) {
             const float4 g = *reinterpret_cast<const float4*>(gamma + k);
             const float y[4] = { g.x * (v[it].x * r), g.y * (v[it].y * r), g.z * (v[it].z * r), g.w * (v[it].w * r) };
-#pragma unroll
-            for (int j = 0; j < 4; ++j) split_store(y[j], oh + (size_t)m * ldp + k + j, ol + (size_t)m * ldp + k + j);
+            split_store4(y, oh + (size_t)m * ldp + k, ol + (size_t)m * ldp + k);
             if (xn_out) *reinterpret_cast<float4*>(xn_out + (size_t)m * ld_xn + k) = make_float4(y[0], y[1], y[2], y[3]);
         }
     }
 }
 void launch_finish(float* x, int ldx, const float* slab, int nslab, size_t slab_stride, int ld_slab, const float* gamma, float eps,
                    int rows, int K, bf16_t* oh, bf16_t* ol, int ldp, float* xn_out, int ld_xn, hipStream_t s) {
-    if (K % 4 || K > 4096) throw Error("finish: K must be a multiple of 4 and <= 4096");
-    if (rows > 0) hipLaunchKernelGGL(k_finish, dim3(rows), dim3(256), 0, s, x, ldx, slab, nslab, slab_stride, ld_slab, gamma, eps, K, oh, ol, ldp, xn_out, ld_xn);
+    if (K % 4 || K > 4096 || nslab > FIN_MAXS) throw Error("finish: K must be a multiple of 4 and <= 4096, at most 16 slabs");
+    if (rows <= 0) return;
+#define Q3_FIN(NS) hipLaunchKernelGGL(k_finish<NS>, dim3(rows), dim3(256), 0, s, x, ldx, slab, nslab, slab_stride, ld_slab, gamma, eps, K, oh, ol, ldp, xn_out, ld_xn)
+    if (nslab <= 0) Q3_FIN(0); else if (nslab <= 4) Q3_FIN(4); else if (nslab <= 8) Q3_FIN(8); else if (nslab <= 12) Q3_FIN(12); else Q3_FIN(16);
+#undef Q3_FIN
 }
 
 // act = silu(sum gate slabs) * (sum up slabs) -> (hi, lo) planes; one workgroup per row
 __global__ __launch_bounds__(256) void k_finish_swiglu(const float* gs, const float* us, int nslab, size_t slab_stride, int N,
                                                         bf16_t* oh, bf16_t* ol, int ldp) {
     const int m = blockIdx.x;
-    for (int n = threadIdx.x * 4; n < N; n += 1024) {
-        float4 g = make_float4(0.f, 0.f, 0.f, 0.f), u = g;
-        for (int sidx = 0; sidx < nslab; ++sidx) {
-            const float4 pg = *reinterpret_cast<const float4*>(gs + sidx * slab_stride + (size_t)m * N + n);
-            const float4 pu = *reinterpret_cast<const float4*>(us + sidx * slab_stride + (size_t)m * N + n);
-            g.x += pg.x; g.y += pg.y; g.z += pg.z; g.w += pg.w;
-            u.x += pu.x; u.y += pu.y; u.z += pu.z; u.w += pu.w;
-        }
-        const float o[4] = { silu_g(g.x) * u.x, silu_g(g.y) * u.y, silu_g(g.z) * u.z, silu_g(g.w) * u.w };
+    for (int n0 = threadIdx.x * 4; n0 < N; n0 += 1024) {
+        float4 pg[4], pu[4];   // split-K of gate/up is at most 4 (Engine::run_layers): every load first, sums in slab order
 #pragma unroll
-        for (int j = 0; j < 4; ++j) split_store(o[j], oh + (size_t)m * ldp + n + j, ol + (size_t)m * ldp + n + j);
+        for (int sidx = 0; sidx < 4; ++sidx) {
+            const int sc = sidx < nslab ? sidx : nslab - 1;
+            pg[sidx] = *reinterpret_cast<const float4*>(gs + sc * slab_stride + (size_t)m * N + n0);
+            pu[sidx] = *reinterpret_cast<const float4*>(us + sc * slab_stride + (size_t)m * N + n0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f), u = g;
+#pragma unroll
+        for (int sidx = 0; sidx < 4; ++sidx)
+            if (sidx < nslab) {
+                g.x += pg[sidx].x; g.y += pg[sidx].y; g.z += pg[sidx].z; g.w += pg[sidx].w;
+                u.x += pu[sidx].x; u.y += pu[sidx].y; u.z += pu[sidx].z; u.w += pu[sidx].w;
+            }
+        const float o[4] = { silu_g(g.x) * u.x, silu_g(g.y) * u.y, silu_g(g.z) * u.z, silu_g(g.w) * u.w };
+        split_store4(o, oh + (size_t)m * ldp + n0, ol + (size_t)m * ldp + n0);
     }
 }
 void launch_finish_swiglu(const float* gs, const float* us, int nslab, size_t slab_stride, int rows, int N,
                           bf16_t* oh, bf16_t* ol, int ldp, hipStream_t s) {
-    if (N % 4) throw Error("finish_swiglu: N must be a multiple of 4");
+    if (N % 4 || nslab < 1 || nslab > 4) throw Error("finish_swiglu: N must be a multiple of 4 and 1 <= nslab <= 4");
     if (rows > 0) hipLaunchKernelGGL(k_finish_swiglu, dim3(rows), dim3(256), 0, s, gs, us, nslab, slab_stride, N, oh, ol, ldp);
 }
 
