@@ -17,6 +17,17 @@ namespace q3 {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// -DQ3_SAMPLE_PROF: wall-clock stamps inside k_conv_split (workgroup (0,0,0), thread 0), tools/ only
+#ifdef Q3_SAMPLE_PROF
+__device__ long long g_conv_prof[64];
+void conv_prof_read(long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_conv_prof), sizeof(long long) * 64); }
+// the stamped launch: the pre-transformer's down projection (C_in 3072 -> C_out 1024, one tap), i.e. the longest serial K walk
+#define CP_MARK(k) do { if ((k) < 64 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0 && a.taps == 1 && a.C_in == 3072 && a.C_out == 1024) \
+        g_conv_prof[k] = wall_clock64(); } while (0)
+#else
+#define CP_MARK(k) do { } while (0)
+#endif
+
 static __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 static __device__ __forceinline__ float silu2_f(float x) { return x / (1.0f + expf(-x)); }
 // sin(x)^2 for SnakeBeta: three-term FMA reduction by pi/2 (exact products; good to |x| ~ 1e5, far past anything a*x reaches here),
@@ -236,23 +247,29 @@ static __device__ __forceinline__ void split_epilogue_block(const ConvKArgs& a, 
     }
 }
 
-template <int MB, int NB, int WM, int WN, int PA>
-__global__ __launch_bounds__(256, (MB * NB <= 6 ? 2 : 1)) void k_conv_split(ConvKArgs a) {   // <= 96 accumulator registers: two workgroups per CU
+// KC = C_in columns per staged chunk (32, or 128 for the short-and-wide GEMMs of the pre-transformer, whose few workgroups walk K
+// serially: a chunk costs one memory latency whatever its size, so 4x wider chunks are 4x fewer latencies); NBUF = weight-tile buffers.
+template <int MB, int NB, int WM, int WN, int PA, int KC = 32, int NBUF = 2>
+// <= 96 accumulator registers and 32-column chunks: two workgroups per CU (256 registers each); otherwise ONE wave per SIMD with the
+// whole 512-register file — said explicitly, or hipcc still budgets 256 and spills the prefetch registers right behind their loads
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MB * NB <= 6 && KC == 32 ? 2 : 1), (MB * NB <= 6 && KC == 32 ? 2 : 1))))
+void k_conv_split(ConvKArgs a) {
     constexpr int TM = WM * MB * 32, TN = WN * NB * 32, AROWS = PA * 32;
-    constexpr int PB = TN * 8 / 256;                 // 16-B segments per thread of one weight tile (2 planes x TN rows x 4 segments)
-    constexpr int A_BYTES = 2 * AROWS * B3_LD * 2, B_BYTES = 2 * 2 * TN * B3_LD * 2;
+    constexpr int CB = KC / 32, SEG = KC / 8, LD = KC + 8;       // 32-column blocks, 16-byte segments and padded halves per staged row
+    constexpr int PB = TN * SEG * 2 / 256;                       // 16-B segments per thread of one weight tile (2 planes x TN rows x SEG)
+    constexpr int A_BYTES = 2 * AROWS * LD * 2, B_BYTES = NBUF * 2 * TN * LD * 2;
     constexpr int E_BYTES = 4 * 32 * (NB * 32 + 8) * 4;          // epilogue staging: 32 rows per wave
     constexpr int SM_BYTES = A_BYTES + B_BYTES > E_BYTES ? A_BYTES + B_BYTES : E_BYTES;
     __shared__ __attribute__((aligned(16))) unsigned char smem[SM_BYTES];
-    _Float16 (*As)[AROWS][B3_LD] = reinterpret_cast<_Float16 (*)[AROWS][B3_LD]>(smem);
-    _Float16 (*Bs)[2][TN][B3_LD] = reinterpret_cast<_Float16 (*)[2][TN][B3_LD]>(smem + A_BYTES);
+    _Float16 (*As)[AROWS][LD] = reinterpret_cast<_Float16 (*)[AROWS][LD]>(smem);
+    _Float16 (*Bs)[2][TN][LD] = reinterpret_cast<_Float16 (*)[2][TN][LD]>(smem + A_BYTES);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int m0 = blockIdx.x * TM, co0 = blockIdx.y * TN, phase = blockIdx.z;
     const int NT = a.transposed ? a.taps / a.stride : a.taps;
     const int halo = a.transposed ? NT - 1 : (a.taps - 1) * a.dil;
-    const int n_chunks = a.C_in / 32, total = n_chunks * NT;
+    const int n_chunks = a.C_in / KC, total = n_chunks * NT;
 
     f32x16 acc[MB][NB];
     const f32x16 zero16 = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
@@ -262,24 +279,27 @@ __global__ __launch_bounds__(256, (MB * NB <= 6 ? 2 : 1)) void k_conv_split(Conv
         for (int j = 0; j < NB; ++j) acc[i][j] = zero16;
 
     const int arow = tid >> 3, acol = (tid & 7) * 4;
-    float4 areg[PA];
-    uint4 breg[PB];
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    typedef float f32x4v __attribute__((ext_vector_type(4)));
+    f32x4v areg[PA][CB];   // native vector types: hipcc keeps arrays of the HIP uint4 / float4 structs beyond 128 bytes in scratch
+    u32x4 breg[PB];
     auto loadA = [&](int ci0) {
 #pragma unroll
         for (int i = 0; i < PA; ++i) {
             const int src = m0 - halo + arow + 32 * i;
             const int sc = src < 0 ? 0 : (src < a.T_in ? src : a.T_in - 1);      // clamped address; out-of-range rows are zeroed in storeA
-            areg[i] = *reinterpret_cast<const float4*>(a.in + (size_t)sc * a.C_in + ci0 + acol);
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) areg[i][cb] = *reinterpret_cast<const f32x4v*>(a.in + (size_t)sc * a.C_in + ci0 + cb * 32 + acol);
         }
     };
     auto loadB = [&](int ci0, int ti) {
         const int wtap = a.transposed ? phase + ti * a.stride : ti;
 #pragma unroll
         for (int i = 0; i < PB; ++i) {
-            const int idx = tid + 256 * i, plane = idx / (TN * 4), rem = idx % (TN * 4), brow = rem >> 2, bseg = rem & 3;
+            const int idx = tid + 256 * i, plane = idx / (TN * SEG), rem = idx % (TN * SEG), brow = rem / SEG, bseg = rem % SEG;
             const int co = co0 + brow;
             const int cc = co < a.C_out ? co : a.C_out - 1;               // rows past C_out repeat the last one; their columns are never stored
-            breg[i] = *reinterpret_cast<const uint4*>((plane ? a.Wl : a.Wh) + ((size_t)wtap * a.C_out + cc) * a.C_in + ci0 + bseg * 8);
+            breg[i] = *reinterpret_cast<const u32x4*>((plane ? a.Wl : a.Wh) + ((size_t)wtap * a.C_out + cc) * a.C_in + ci0 + bseg * 8);
         }
     };
     auto storeA = [&]() {
@@ -287,38 +307,48 @@ __global__ __launch_bounds__(256, (MB * NB <= 6 ? 2 : 1)) void k_conv_split(Conv
         for (int i = 0; i < PA; ++i) {
             const int src = m0 - halo + arow + 32 * i;
             const bool inr = src >= 0 && src < a.T_in;
-            const float4 v = make_float4(inr ? areg[i].x : 0.f, inr ? areg[i].y : 0.f, inr ? areg[i].z : 0.f, inr ? areg[i].w : 0.f);
-            const float h0 = f16_hi_of(v.x), h1 = f16_hi_of(v.y), h2 = f16_hi_of(v.z), h3 = f16_hi_of(v.w);
-            *reinterpret_cast<uint2*>(&As[0][arow + 32 * i][acol]) = pack_f16x4(h0, h1, h2, h3);
-            *reinterpret_cast<uint2*>(&As[1][arow + 32 * i][acol]) = pack_f16x4(f16_hi_of(v.x - h0), f16_hi_of(v.y - h1), f16_hi_of(v.z - h2), f16_hi_of(v.w - h3));
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) {
+                const f32x4v r = areg[i][cb];
+                const float4 v = make_float4(inr ? r.x : 0.f, inr ? r.y : 0.f, inr ? r.z : 0.f, inr ? r.w : 0.f);
+                const float h0 = f16_hi_of(v.x), h1 = f16_hi_of(v.y), h2 = f16_hi_of(v.z), h3 = f16_hi_of(v.w);
+                *reinterpret_cast<uint2*>(&As[0][arow + 32 * i][cb * 32 + acol]) = pack_f16x4(h0, h1, h2, h3);
+                *reinterpret_cast<uint2*>(&As[1][arow + 32 * i][cb * 32 + acol]) =
+                    pack_f16x4(f16_hi_of(v.x - h0), f16_hi_of(v.y - h1), f16_hi_of(v.z - h2), f16_hi_of(v.w - h3));
+            }
         }
     };
     auto storeB = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < PB; ++i) {
-            const int idx = tid + 256 * i, plane = idx / (TN * 4), rem = idx % (TN * 4), brow = rem >> 2, bseg = rem & 3;
-            *reinterpret_cast<uint4*>(&Bs[buf][plane][brow][bseg * 8]) = breg[i];
+            const int idx = tid + 256 * i, plane = idx / (TN * SEG), rem = idx % (TN * SEG), brow = rem / SEG, bseg = rem % SEG;
+            *reinterpret_cast<u32x4*>(&Bs[buf][plane][brow][bseg * 8]) = breg[i];
         }
     };
 
+    CP_MARK(0);
     loadA(0);
     loadB(0, 0);
     int chunk = 0, ti = 0;
     for (int it = 0; it < total; ++it) {
-        if (ti == 0) { __syncthreads(); storeA(); }          // every wave is done with the previous chunk's rows
-        storeB(it & 1);                                       // this buffer was last read two taps ago
+        const int buf = NBUF == 2 ? (it & 1) : 0;
+        CP_MARK(1 + it * 4);
+        if (ti == 0 || NBUF == 1) __syncthreads();            // every wave is done with the rows (and, single-buffered, the weight tile) it read last
+        if (ti == 0) storeA();
+        storeB(buf);                                          // double-buffered: this buffer was last read two taps ago
+        CP_MARK(2 + it * 4);
         __syncthreads();
+        CP_MARK(3 + it * 4);
         int nchunk = chunk, nti = ti + 1;
         if (nti == NT) { nti = 0; ++nchunk; }
         if (it + 1 < total) {                                 // next tap's weights (and next chunk's rows) fly during the MFMAs below
-            loadB(nchunk * 32, nti);
-            if (nti == 0) loadA(nchunk * 32);
+            loadB(nchunk * KC, nti);
+            if (nti == 0) loadA(nchunk * KC);
         }
         const int shift = a.transposed ? ti : (a.taps - 1 - ti) * a.dil;
         const int roff = halo - shift + wm * MB * 32 + (lane & 31);
-        const int buf = it & 1;
-#pragma unroll
-        for (int st = 0; st < 2; ++st) {
+#pragma unroll 2   // not more: fully unrolled, the scheduler hoists every fragment read of a 128-column chunk and spills the prefetch registers
+        for (int st = 0; st < KC / 16; ++st) {
             const int kof = st * 16 + 8 * (lane >> 5);
             f16x8 ah[MB], al[MB], bh[NB], bl[NB];
 #pragma unroll
@@ -342,12 +372,15 @@ __global__ __launch_bounds__(256, (MB * NB <= 6 ? 2 : 1)) void k_conv_split(Conv
                 }
         }
         chunk = nchunk; ti = nti;
+        CP_MARK(4 + it * 4);
     }
+    CP_MARK(62);
     __syncthreads();                                          // the staging slices below overlay the operand tiles
     float* stage = reinterpret_cast<float*>(smem) + wave * 32 * (NB * 32 + 8);
     // statically indexed row blocks (a rolled loop would give the accumulators a scratch home that the main loop keeps in sync)
     split_epilogue_block<NB>(a, acc[0], stage, m0 + wm * MB * 32, co0 + wn * NB * 32, lane, phase, NT);
     if (MB > 1) split_epilogue_block<NB>(a, acc[MB - 1], stage, m0 + wm * MB * 32 + 32, co0 + wn * NB * 32, lane, phase, NT);
+    CP_MARK(63);
 }
 
 // fp32 weights * scale -> (hi, lo) fp16 planes; absmax for choosing the power-of-two scale
@@ -442,7 +475,14 @@ void launch_conv(const ConvArgs& c, hipStream_t s) {
         // 256-row tiles when the grid still fills the chip a few times over and K is deep enough to be compute-bound; 128-row tiles
         // (2-3 workgroups per CU) for bandwidth-bound or mid-sized launches; 64-row tiles for the short pre-transformer GEMMs
         const bool deep = NTt * c.C_in > 512;
-        if (n_thin < 512) launch_split_pa<2, 1, 1, 4>(a, dim3((rows + 63) / 64, (c.C_out + 127) / 128, z), extra, s);
+        if (n_thin < 512) {   // few workgroups, each walking K alone: 128-column chunks when the channel count allows
+            const dim3 g((rows + 63) / 64, (c.C_out + 127) / 128, z);
+            if (c.C_in % 128 == 0) {
+                if (extra == 0) hipLaunchKernelGGL((k_conv_split<2, 1, 1, 4, 2, 128, 1>), g, dim3(256), 0, s, a);
+                else if (extra == 1) hipLaunchKernelGGL((k_conv_split<2, 1, 1, 4, 3, 128, 1>), g, dim3(256), 0, s, a);
+                else hipLaunchKernelGGL((k_conv_split<2, 1, 1, 4, 4, 128, 1>), g, dim3(256), 0, s, a);
+            } else launch_split_pa<2, 1, 1, 4>(a, g, extra, s);
+        }
         else if (!deep || n_big < 1024) {
             if (n96) launch_split_pa<1, 3, 4, 1>(a, dim3((rows + 127) / 128, ntile, z), extra, s);
             else launch_split_pa<1, 4, 4, 1>(a, dim3((rows + 127) / 128, ntile, z), extra, s);
