@@ -356,7 +356,7 @@ void k_conv_split(ConvKArgs a) {
         }
         const int shift = a.transposed ? ti : (a.taps - 1 - ti) * a.dil;
         const int roff = halo - shift + wm * MB * 32 + (lane & 31);
-#pragma unroll 2   // not more: fully unrolled, the scheduler hoists every fragment read of a 128-column chunk and spills the prefetch registers
+#pragma unroll
         for (int st = 0; st < KC / 16; ++st) {
             const int kof = st * 16 + 8 * (lane >> 5);
             f16x8 ah[MB], al[MB], bh[NB], bl[NB];
