@@ -214,7 +214,8 @@ __global__ __launch_bounds__(NW * 64) void k_gemm2(const bf16_t* pW, const bf16_
 
     // Two register sets: while chunk c is multiplied out of LDS, chunk c+1's weight fragments (HBM) and
     // activation slice (L2) are already in flight.
-    struct Stage { bf16x8 b[G2_KC / 32], b2[G2_KC / 32]; uint4 sh[PASSES], sl[PASSES]; };
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // native vectors: arrays of the HIP uint4 struct end up in scratch (prefetch spilled behind its loads)
+    struct Stage { bf16x8 b[G2_KC / 32], b2[G2_KC / 32]; u32x4 sh[PASSES], sl[PASSES]; };
     auto issue = [&](Stage& S, int k0) {
 #pragma unroll
         for (int st = 0; st < G2_KC / 32; ++st) {
@@ -225,8 +226,8 @@ __global__ __launch_bounds__(NW * 64) void k_gemm2(const bf16_t* pW, const bf16_
         for (int p = 0; p < PASSES; ++p) {
             int row = srow + p * RPP;
             row = row < M ? row : M - 1;
-            S.sh[p] = *reinterpret_cast<const uint4*>(pxh + (size_t)row * pldx + k0 + scol);
-            S.sl[p] = *reinterpret_cast<const uint4*>(pxl + (size_t)row * pldx + k0 + scol);
+            S.sh[p] = *reinterpret_cast<const u32x4*>(pxh + (size_t)row * pldx + k0 + scol);
+            S.sl[p] = *reinterpret_cast<const u32x4*>(pxl + (size_t)row * pldx + k0 + scol);
         }
     };
     auto consume = [&](Stage& S) {
@@ -235,8 +236,8 @@ __global__ __launch_bounds__(NW * 64) void k_gemm2(const bf16_t* pW, const bf16_
         for (int p = 0; p < PASSES; ++p) {
             const int row = srow + p * RPP;
             if (row < ROWS) {
-                *reinterpret_cast<uint4*>(&xs[0][row][scol]) = S.sh[p];
-                *reinterpret_cast<uint4*>(&xs[1][row][scol]) = S.sl[p];
+                *reinterpret_cast<u32x4*>(&xs[0][row][scol]) = S.sh[p];
+                *reinterpret_cast<u32x4*>(&xs[1][row][scol]) = S.sl[p];
             }
         }
         __syncthreads();
