@@ -41,6 +41,10 @@ typedef struct q3tts_config {
      * (C, C, C, C, 3C), kernels (5,3,3,3,1), dilations (1,2,3,4,1).  spk_enc_dim == 0: no speaker encoder
      * (has_speaker_encoder() false, as when the reference finds no speaker_encoder.onnx). */
     int32_t spk_enc_dim, spk_mel, spk_channels, spk_scale, spk_se, spk_att;
+    /* width of the code predictor's layers; 0 (or == hidden): the talker's width, as in the 0.6B export.  Otherwise (1.7B: hidden 2048,
+     * cp_hidden 1024) every predictor input row passes through cp.proj (Linear + bias, [HINT] Qwen3-TTS small_to_mtp_projection) first;
+     * the predictor's code embeddings stay talker-wide.  The code_predictor session contract (tts_onnx.cpp:734-757) is unchanged. */
+    int32_t cp_hidden;
 } q3tts_config;
 
 /* SamplingParams, reference src/tts_onnx.h:99-105 (repetition_penalty is never read there) */
@@ -59,7 +63,7 @@ typedef struct q3tts_engine q3tts_engine;
 #define Q3TTS_FLAG_FP32_CODEC 4u  /* codec decoder on the exact-fp32 matrix-core path instead of the bf16 hi/lo split path */
 
 /* ---- lifecycle (replaces TTSEngine ctor / load_model, tts_onnx.cpp:84-232) ---- */
-int q3tts_default_config(const char* name /* "0.6b" */, q3tts_config* out);
+int q3tts_default_config(const char* name /* "0.6b" | "1.7b" */, q3tts_config* out);
 q3tts_engine* q3tts_create(const q3tts_config* cfg, int device, int max_batch, int max_ctx, uint32_t flags);
 void q3tts_destroy(q3tts_engine* e);
 const char* q3tts_last_error(q3tts_engine* e); /* e may be NULL: error of the last failed create */

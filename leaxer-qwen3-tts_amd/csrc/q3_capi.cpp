@@ -30,7 +30,8 @@ extern "C" {
 
 int q3tts_default_config(const char* name, q3tts_config* o) {
     if (!o || !name) return -1;
-    if (strcmp(name, "0.6b") != 0 && strcmp(name, "0.6B") != 0) return -1;
+    const bool big = strcmp(name, "1.7b") == 0 || strcmp(name, "1.7B") == 0;
+    if (!big && strcmp(name, "0.6b") != 0 && strcmp(name, "0.6B") != 0) return -1;
     memset(o, 0, sizeof *o);
     // talker dims: reference src/tts_onnx.h:31-37; the rest [HINT]
     o->hidden = 1024; o->n_layers = 28; o->n_heads = 16; o->n_kv_heads = 8; o->head_dim = 128; o->ffn = 3072; o->vocab = 3072;
@@ -47,6 +48,10 @@ int q3tts_default_config(const char* name, q3tts_config* o) {
     o->codec_eos = 2150; o->suppress_begin = 2048; o->suppress_end = 3072;
     // speaker encoder of the Base checkpoints [HINT: Qwen3-TTS speaker_encoder_config]: ECAPA-TDNN 512/1536 channels -> hidden
     o->spk_enc_dim = 1024; o->spk_mel = 128; o->spk_channels = 512; o->spk_scale = 8; o->spk_se = 128; o->spk_att = 128;
+    if (big) { // [HINT: the public 1.7B checkpoints] talker twice as wide, predictor at the 0.6B width behind cp.proj, speaker row talker-wide.
+               // Beyond the reference: README.md:125 lists 1.7B as planned and tts_onnx.h:31-37 hard-codes the 0.6B dims.
+        o->hidden = 2048; o->ffn = 6144; o->cp_hidden = 1024; o->spk_enc_dim = 2048;
+    }
     return 0;
 }
 
@@ -354,6 +359,7 @@ void read_header(FILE* f, q3tts_config* cfg, uint32_t* n) {
     if (cfg_bytes > sizeof(q3tts_config) || cfg_bytes < offsetof(q3tts_config, spk_enc_dim)) throw q3::Error("weights file: config struct size mismatch");
     memset(cfg, 0, sizeof *cfg);
     rd(f, cfg, cfg_bytes);
+    if (cfg->cp_hidden == cfg->hidden) cfg->cp_hidden = 0; // one spelling of "same width" (the engine normalises likewise)
     rd(f, n, 4);
 }
 } // namespace

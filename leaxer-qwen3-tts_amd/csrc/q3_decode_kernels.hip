@@ -431,11 +431,12 @@ static int gemv1_rw(const GemvArgs& a) {
     if (rw < 1) rw = 1;
     if (rw > 4) rw = 4;
     if (a.epi == EPI_SWIGLU && rw > 3) rw = 3;
+    if (a.K > 3072 && rw > 2) rw = 2;   // 12 chunks per row: two rows of weights + the activation row fill the register file
     return rw;
 }
 bool gemv_fast_path(const GemvArgs& a) {
     if (a.M < 1 || a.M > 2) return false;
-    if (a.K != 1024 && a.K != 2048 && a.K != 3072) return false;
+    if (a.K != 1024 && a.K != 2048 && a.K != 3072 && !(a.K == 6144 && a.M == 1)) return false;   // 6144: the 1.7B talker's down projection
     if (a.ldx % 4 != 0 && !a.po) return false;
     const bool norm = a.gamma != nullptr, comb = a.po != nullptr;
     if (comb && (norm || a.epi != EPI_RESIDUAL || a.pd % 8 != 0 || a.pheads * a.pd != a.K)) return false;
@@ -471,7 +472,9 @@ template <int MT>
 static void gemv1_nch(const GemvArgs& a, hipStream_t s) {
     if (a.K == 1024) gemv1_rwsel<MT, 2>(a, s);
     else if (a.K == 2048) gemv1_rwsel<MT, 4>(a, s);
-    else gemv1_rwsel<MT, 6>(a, s);
+    else if (a.K == 3072) gemv1_rwsel<MT, 6>(a, s);
+    else if constexpr (MT == 1) gemv1_rwsel<1, 12>(a, s);
+    else throw Error("gemv: K = 6144 fast path is single-row");
 }
 
 void launch_gemv(const GemvArgs& a0, hipStream_t s) {

@@ -49,7 +49,9 @@ Tensor& Engine::T(const std::string& n) {
 Engine::Engine(const q3tts_config& cfg, int device_, int max_batch, int max_ctx_, uint32_t flags_)
     : c(cfg), device(device_), B(max_batch), max_ctx(max_ctx_), flags(flags_) {
     if (B < 1 || B > 1024) throw Error("max_batch out of range");
-    if (c.hidden % 8 || c.ffn % 8 || c.text_hidden % 8 || c.cp_ffn % 8) throw Error("hidden/ffn sizes must be multiples of 8");
+    if (c.cp_hidden < 0) throw Error("cp_hidden must be >= 0");
+    if (c.cp_hidden == c.hidden) c.cp_hidden = 0;
+    if (c.hidden % 8 || c.ffn % 8 || c.text_hidden % 8 || c.cp_ffn % 8 || cp_width() % 8) throw Error("hidden/ffn sizes must be multiples of 8");
     if (c.vocab > 4096 || c.sub_vocab > 4096) throw Error("codec vocabularies larger than 4096 are not supported");
     if (c.n_groups < 2 || c.n_groups > 32) throw Error("n_groups out of range");
     Q3_HIP_CHECK(hipSetDevice(device));
@@ -97,9 +99,12 @@ Engine::Engine(const q3tts_config& cfg, int device_, int max_batch, int max_ctx_
     add("text.fc1.b", {c.text_hidden}, TK_BIAS, false);
     add("text.fc2.w", {H, c.text_hidden}, TK_W, true);
     add("text.fc2.b", {H}, TK_BIAS, false);
-    add_layers("cp", c.cp_layers, H, c.cp_heads, c.cp_kv_heads, c.cp_head_dim, c.cp_ffn, true, false, true);
-    add("cp.norm", {H}, TK_NORM, false);
-    for (int j = 0; j < c.n_groups - 1; ++j) add("cp.head." + std::to_string(j), {c.sub_vocab, H}, TK_W, true);
+    // predictor width: the talker's (0.6B) or narrower behind cp.proj (1.7B: 2048 -> 1024); its embeddings stay talker-wide
+    const int Hc = cp_width();
+    add_layers("cp", c.cp_layers, Hc, c.cp_heads, c.cp_kv_heads, c.cp_head_dim, c.cp_ffn, true, false, true);
+    add("cp.norm", {Hc}, TK_NORM, false);
+    if (cp_projected()) { add("cp.proj.w", {Hc, H}, TK_W, true); add("cp.proj.b", {Hc}, TK_BIAS, false); }
+    for (int j = 0; j < c.n_groups - 1; ++j) add("cp.head." + std::to_string(j), {c.sub_vocab, Hc}, TK_W, true);
     for (int j = 0; j < c.n_groups - 1; ++j) add("cp.embed." + std::to_string(j), {c.sub_vocab, H}, TK_W, true);
     const int CH = c.cd_hidden;
     add_layers("cd", c.cd_layers, CH, c.cd_heads, c.cd_heads, c.cd_head_dim, c.cd_ffn, false, true, false);
@@ -185,6 +190,7 @@ Engine::Engine(const q3tts_config& cfg, int device_, int max_batch, int max_ctx_
     logits_cp = fm((size_t)B * c.sub_vocab);
     x_cp = fm((size_t)B * 2 * H);
     x_cp1 = fm((size_t)B * H);
+    if (cp_projected()) x_cpp = fm((size_t)std::max(rows_max, 16) * Hc);
     sum = fm((size_t)B * H);
     xp = fm((size_t)std::max(16, rows_max) * H);   // one prefill group: up to rows_max prompt rows
     hn = fm((size_t)std::max(16, rows_max) * H);
@@ -239,7 +245,7 @@ Engine::Engine(const q3tts_config& cfg, int device_, int max_batch, int max_ctx_
         Q3_HIP_CHECK(hipMemcpy(S.rope_sin, sn.data(), sn.size() * sizeof(float), hipMemcpyHostToDevice));
     };
     setup_stack(talker, H, c.n_layers, c.n_heads, c.n_kv_heads, c.head_dim, c.ffn, c.rms_eps, 6, max_ctx, c.rope_theta, true);
-    setup_stack(cp, H, c.cp_layers, c.cp_heads, c.cp_kv_heads, c.cp_head_dim, c.cp_ffn, c.cp_rms_eps, 5, 32, c.cp_rope_theta, false);
+    setup_stack(cp, Hc, c.cp_layers, c.cp_heads, c.cp_kv_heads, c.cp_head_dim, c.cp_ffn, c.cp_rms_eps, 5, 32, c.cp_rope_theta, false);
     // split-T attention: 128 cache tokens per workgroup (16 lane groups x 8 tokens in flight)
     talker.chunk = 128;
     talker.n_splits = (max_ctx + 127) / 128;
@@ -331,6 +337,8 @@ void Engine::finalize() {
     talker_norm = fp("talker.norm"); codec_head = bp("talker.codec_head"); codec_embed_w = bp("talker.codec_embed");
     text_embed = bp("text.embed"); fc1_w = bp("text.fc1.w"); fc2_w = bp("text.fc2.w"); fc1_b = fp("text.fc1.b"); fc2_b = fp("text.fc2.b");
     cp_norm = fp("cp.norm");
+    cp_proj_w = cp_projected() ? bp("cp.proj.w") : nullptr;
+    cp_proj_b = cp_projected() ? fp("cp.proj.b") : nullptr;
     cp_head.clear(); cp_embed_w.clear();
     for (int j = 0; j < c.n_groups - 1; ++j) { cp_head.push_back(bp("cp.head." + std::to_string(j))); cp_embed_w.push_back(bp("cp.embed." + std::to_string(j))); }
     codec_finalize();
@@ -569,12 +577,13 @@ void Engine::talker_decode(int slot, const float* embed, float* logits, float* l
 void Engine::code_predictor(const float* seq, int n, int step, float* logits) {
     if (!finalized) throw Error("weights not finalized");
     if (n < 1 || n > 16 || step < 0 || step >= c.n_groups - 1) throw Error("code_predictor arguments out of range");
-    const int H = c.hidden, SV = c.sub_vocab;
+    const int H = c.hidden, Hc = cp_width(), SV = c.sub_vocab;
     Q3_HIP_CHECK(hipMemcpyAsync(xp, seq, (size_t)n * H * sizeof(float), hipMemcpyHostToDevice, stream));
-    run_layers(cp, xp, H, 1, n, 0, nullptr, 0); // full causal re-run over the n rows (reference call pattern)
+    float* xc = cp_project(xp, H, n);
+    run_layers(cp, xc, Hc, 1, n, 0, nullptr, 0); // full causal re-run over the n rows (reference call pattern)
     GemvArgs g;
-    g.W = cp_head[step]; g.x = xp + (size_t)(n - 1) * H; g.ldx = H; g.gamma = cp_norm; g.eps = c.cp_rms_eps;
-    g.out = logits_p; g.ldo = SV; g.M = 1; g.N = SV; g.K = H; g.epi = EPI_STORE;
+    g.W = cp_head[step]; g.x = xc + (size_t)(n - 1) * Hc; g.ldx = Hc; g.gamma = cp_norm; g.eps = c.cp_rms_eps;
+    g.out = logits_p; g.ldo = SV; g.M = 1; g.N = SV; g.K = Hc; g.epi = EPI_STORE;
     launch_gemv(g, stream);
     Q3_HIP_CHECK(hipMemcpyAsync(logits, logits_p, (size_t)SV * sizeof(float), hipMemcpyDeviceToHost, stream));
     sync();
@@ -639,8 +648,17 @@ void Engine::build_prompt(const int64_t* ids, int n_ids, int lang, const float* 
 // ------------------------------------------------------------------------------------------------
 // fused generation: one frame = sampler + (n_groups-1) predictor passes + talker decode
 // ------------------------------------------------------------------------------------------------
+// predictor input rows: talker-width rows through cp.proj (bias) when the predictor is narrower, else the rows themselves
+float* Engine::cp_project(float* rows, int ld, int M) {
+    if (!cp_projected()) return rows;
+    GemvArgs g;
+    g.W = cp_proj_w; g.x = rows; g.ldx = ld; g.bias = cp_proj_b; g.out = x_cpp; g.ldo = cp_width(); g.M = M; g.N = cp_width(); g.K = c.hidden; g.epi = EPI_BIAS;
+    launch_gemv(g, stream);
+    return x_cpp;
+}
+
 void Engine::record_step(int nb) {
-    const int H = c.hidden, V = c.vocab, SV = c.sub_vocab, G = c.n_groups;
+    const int H = c.hidden, Hc = cp_width(), V = c.vocab, SV = c.sub_vocab, G = c.n_groups;
     SampleArgs s0;
     s0.logits = logits_t; s0.ld = V; s0.V = V; s0.nb = nb; s0.sup_begin = c.suppress_begin; s0.sup_end = c.suppress_end; s0.eos_id = c.codec_eos;
     s0.group = 0; s0.n_groups = G; s0.st = st_d; s0.embed = codec_embed_w; s0.H = H;
@@ -648,12 +666,13 @@ void Engine::record_step(int nb) {
     s0.tts_pad = tts_pad_d; s0.codes = codes_d; s0.max_frames_cap = max_frames_cap; s0.talker_pos = talker_pos_d;
     launch_sample(s0, stream);                                  // code0 (tts_onnx.cpp:803-812)
     for (int j = 0; j < G - 1; ++j) {                           // predict_subcodes (:851-872), KV-cached
-        float* xin = j == 0 ? x_cp : x_cp1;
+        // pass 0: rows [last_hidden, embed(code0)] of every utterance; later passes: the embedding of the code just sampled
+        float* xin = j == 0 ? cp_project(x_cp, H, nb * 2) : cp_project(x_cp1, H, nb);
         bool pr;
-        if (j == 0) pr = run_layers(cp, x_cp, H, nb, 2, 0, nullptr, 0, cp_norm, c.cp_rms_eps);        // rows [last_hidden, embed(code0)]
-        else pr = run_layers(cp, x_cp1, H, nb, 1, 0, nullptr, j + 1, cp_norm, c.cp_rms_eps);
+        if (j == 0) pr = run_layers(cp, xin, Hc, nb, 2, 0, nullptr, 0, cp_norm, c.cp_rms_eps);
+        else pr = run_layers(cp, xin, Hc, nb, 1, 0, nullptr, j + 1, cp_norm, c.cp_rms_eps);
         // head j on the last row of every utterance (pass 0 holds two rows per utterance: planes row b*2+1)
-        head_proj(cp_head[j], j == 0 ? xin + H : xin, j == 0 ? 2 * H : H, cp_norm, c.cp_rms_eps, nullptr, 0, logits_cp, SV, nb, SV, H, false,
+        head_proj(cp_head[j], j == 0 ? xin + Hc : xin, j == 0 ? 2 * Hc : Hc, cp_norm, c.cp_rms_eps, nullptr, 0, logits_cp, SV, nb, SV, Hc, false,
                   pr, j == 0 ? 1 : 0, j == 0 ? 2 : 1);
         SampleArgs s = s0;
         s.logits = logits_cp; s.ld = SV; s.V = SV; s.group = j + 1; s.embed = cp_embed_w[j];
@@ -881,11 +900,11 @@ int64_t Engine::codec_decode_host(const int64_t* codes, int F, float* pcm, int64
 // Algorithmic bytes of one decode step: every talker weight once, every
 // predictor weight once per pass, plus the KV entries the attention kernels read.
 void Engine::step_bytes(double* wbytes, double* kvbytes) {
-    const double H = c.hidden;
-    auto layer = [&](int nq, int nkv, int d, int ffn) { return 2.0 * (H * (nq + 2.0 * nkv) * d + H * nq * d + 3.0 * H * ffn); };
-    double w = c.n_layers * layer(c.n_heads, c.n_kv_heads, c.head_dim, c.ffn) + 2.0 * H * c.vocab;
+    const double H = c.hidden, Hc = cp_width();
+    auto layer = [&](double Hw, int nq, int nkv, int d, int ffn) { return 2.0 * (Hw * (nq + 2.0 * nkv) * d + Hw * nq * d + 3.0 * Hw * ffn); };
+    double w = c.n_layers * layer(H, c.n_heads, c.n_kv_heads, c.head_dim, c.ffn) + 2.0 * H * c.vocab;
     const int P = c.n_groups - 1;
-    w += P * (c.cp_layers * layer(c.cp_heads, c.cp_kv_heads, c.cp_head_dim, c.cp_ffn) + 2.0 * H * c.sub_vocab);
+    w += P * (c.cp_layers * layer(Hc, c.cp_heads, c.cp_kv_heads, c.cp_head_dim, c.cp_ffn) + 2.0 * Hc * c.sub_vocab + (cp_projected() ? 2.0 * H * Hc : 0.0));
     double kv = 0;
     for (int b = 0; b < B; ++b) {
         if (!st_h[b].active) continue;

@@ -119,6 +119,11 @@ public:
     const float* talker_norm = nullptr; const bf16_t* codec_head = nullptr; const bf16_t* codec_embed_w = nullptr;
     const bf16_t *text_embed = nullptr, *fc1_w = nullptr, *fc2_w = nullptr; const float *fc1_b = nullptr, *fc2_b = nullptr;
     const float* cp_norm = nullptr;
+    const bf16_t* cp_proj_w = nullptr; const float* cp_proj_b = nullptr; // talker width -> predictor width (1.7B), null when equal
+    float* x_cpp = nullptr;                                               // projected predictor input rows [<= rows_max][cp_width]
+    int cp_width() const { return c.cp_hidden > 0 ? c.cp_hidden : c.hidden; }
+    bool cp_projected() const { return cp_width() != c.hidden; }
+    float* cp_project(float* rows, int ld, int M);
     std::vector<const bf16_t*> cp_head, cp_embed_w;
 
     int rows_max = 0, max_trailing = 0, max_frames_cap = 0;

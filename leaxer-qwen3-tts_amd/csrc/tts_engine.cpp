@@ -31,11 +31,12 @@ TTSEngine::TTSEngine(const std::string& model_dir) {
     const int device = std::getenv("Q3TTS_DEVICE") ? std::atoi(std::getenv("Q3TTS_DEVICE")) : 0;
     const int max_ctx = config::MAX_NEW_TOKENS + 64;
     q3tts_config cfg;
-    if (model_dir.rfind("synthetic:", 0) == 0) {
-        q3tts_default_config("0.6b", &cfg);
+    if (model_dir.rfind("synthetic:", 0) == 0 || model_dir.rfind("synthetic-1.7b:", 0) == 0) {   // seeded weights at the 0.6B / 1.7B dims
+        const bool big = model_dir[9] == '-';
+        q3tts_default_config(big ? "1.7b" : "0.6b", &cfg);
         h_ = q3tts_create(&cfg, device, max_batch_, max_ctx, 0);
         if (!h_) { error_msg_ = q3tts_last_error(nullptr); return; }
-        if (q3tts_fill_synthetic(h_, std::strtoull(model_dir.c_str() + 10, nullptr, 10)) != 0 || q3tts_finalize(h_) != 0) { error_msg_ = q3tts_last_error(h_); return; }
+        if (q3tts_fill_synthetic(h_, std::strtoull(model_dir.c_str() + (big ? 15 : 10), nullptr, 10)) != 0 || q3tts_finalize(h_) != 0) { error_msg_ = q3tts_last_error(h_); return; }
     } else {
         const std::string path = model_dir + "/model.q3w";
         if (q3tts_read_weights_config(path.c_str(), &cfg) != 0) { error_msg_ = std::string("Failed to load ") + path + ": " + q3tts_last_error(nullptr); return; }

@@ -29,6 +29,7 @@ _CFG_FIELDS = [
     ("codec_eos", C.c_int32), ("suppress_begin", C.c_int32), ("suppress_end", C.c_int32),
     ("spk_enc_dim", C.c_int32), ("spk_mel", C.c_int32), ("spk_channels", C.c_int32), ("spk_scale", C.c_int32),
     ("spk_se", C.c_int32), ("spk_att", C.c_int32),
+    ("cp_hidden", C.c_int32),
 ]
 
 
@@ -46,7 +47,7 @@ class Config(C.Structure):
     def from_dict(cls, d):
         c = cls()
         for n, t in _CFG_FIELDS:
-            v = d[n] if n in d or not n.startswith("spk_") else 0
+            v = d[n] if n in d or not (n.startswith("spk_") or n == "cp_hidden") else 0
             if hasattr(t, "_length_"):
                 arr = t()
                 for i, x in enumerate(v):

@@ -115,7 +115,8 @@ struct q3o_model {
     /* predictor */
     layer_w* pl;
     float* p_norm;
-    float **p_head, **p_embed; /* [G-1] x [SV][H] */
+    float **p_head, **p_embed; /* [G-1] x [SV][Hc] heads, [SV][H] embeddings (talker width) */
+    float *p_proj_w, *p_proj_b; /* talker width -> predictor width (cp_hidden != hidden: the 1.7B export), else NULL */
     float *pkc, *pvc;          /* [cp_layers][cp_kv][32][d] */
     /* codec decoder */
     layer_w* cl;
@@ -130,6 +131,11 @@ struct q3o_model {
     float *last_hidden, *trailing, *tts_pad;
     int trailing_len;
 };
+
+/* predictor width: the 0.6B predictor runs at the talker's width; the 1.7B one is narrower and puts a Linear (with bias) in front of
+ * its layers [HINT: Qwen3-TTS `small_to_mtp_projection`, applied to every input row of the predictor; the reference's
+ * code_predictor.onnx would hold it inside the graph, its I/O contract (tts_onnx.cpp:734-757) is unchanged] */
+static int cp_width(const q3o_config* c) { return c->cp_hidden > 0 ? c->cp_hidden : c->hidden; }
 
 static float* zalloc(size_t n) {
     float* p = (float*)calloc(n ? n : 1, sizeof(float));
@@ -179,10 +185,12 @@ q3o_model* q3o_create(const q3o_config* cfg, int max_ctx) {
     size_t kvn = (size_t)c->n_layers * c->n_kv_heads * max_ctx * c->head_dim;
     m->kc = zalloc(kvn); m->vc = zalloc(kvn);
     m->pl = (layer_w*)calloc(c->cp_layers, sizeof(layer_w));
-    alloc_layers(m->pl, c->cp_layers, H, c->cp_heads, c->cp_kv_heads, c->cp_head_dim, c->cp_ffn, 1, 0);
-    m->p_norm = zalloc(H);
+    int Hc = cp_width(c);
+    alloc_layers(m->pl, c->cp_layers, Hc, c->cp_heads, c->cp_kv_heads, c->cp_head_dim, c->cp_ffn, 1, 0);
+    m->p_norm = zalloc(Hc);
+    if (Hc != H) { m->p_proj_w = zalloc((size_t)Hc * H); m->p_proj_b = zalloc(Hc); }
     m->p_head = (float**)calloc(G, sizeof(float*)); m->p_embed = (float**)calloc(G, sizeof(float*));
-    for (int j = 0; j < G - 1; ++j) { m->p_head[j] = zalloc((size_t)c->sub_vocab * H); m->p_embed[j] = zalloc((size_t)c->sub_vocab * H); }
+    for (int j = 0; j < G - 1; ++j) { m->p_head[j] = zalloc((size_t)c->sub_vocab * Hc); m->p_embed[j] = zalloc((size_t)c->sub_vocab * H); }
     size_t pkvn = (size_t)c->cp_layers * c->cp_kv_heads * 32 * c->cp_head_dim;
     m->pkc = zalloc(pkvn); m->pvc = zalloc(pkvn);
     int CH = c->cd_hidden;
@@ -236,7 +244,7 @@ void q3o_destroy(q3o_model* m) {
     free_layers(m->tl, c->n_layers); free_layers(m->pl, c->cp_layers); free_layers(m->cl, c->cd_layers);
     free(m->t_norm); free(m->codec_head); free(m->codec_embed); free(m->text_embed);
     free(m->fc1_w); free(m->fc1_b); free(m->fc2_w); free(m->fc2_b); free(m->kc); free(m->vc);
-    free(m->p_norm);
+    free(m->p_norm); free(m->p_proj_w); free(m->p_proj_b);
     for (int j = 0; j < c->n_groups - 1; ++j) { free(m->p_head[j]); free(m->p_embed[j]); }
     free(m->p_head); free(m->p_embed); free(m->pkc); free(m->pvc);
     free(m->c_norm); free(m->code_embed);
@@ -325,9 +333,11 @@ static int resolve(q3o_model* m, const char* name, slot* s) {
     if (!strcmp(name, "text.fc2.w")) { s->p = m->fc2_w; s->n = (int64_t)H * c->text_hidden; return 0; }
     if (!strcmp(name, "text.fc2.b")) { s->p = m->fc2_b; s->n = H; return 0; }
     if (sscanf(name, "cp.layers.%d.%63s", &i, f) == 2 && i >= 0 && i < c->cp_layers)
-        return layer_slot(&m->pl[i], f, H, c->cp_heads, c->cp_kv_heads, c->cp_head_dim, c->cp_ffn, s);
-    if (!strcmp(name, "cp.norm")) { s->p = m->p_norm; s->n = H; return 0; }
-    if (idx_suffix(name, "cp.head.", &j) && j < c->n_groups - 1) { s->p = m->p_head[j]; s->n = (int64_t)c->sub_vocab * H; return 0; }
+        return layer_slot(&m->pl[i], f, cp_width(c), c->cp_heads, c->cp_kv_heads, c->cp_head_dim, c->cp_ffn, s);
+    if (!strcmp(name, "cp.norm")) { s->p = m->p_norm; s->n = cp_width(c); return 0; }
+    if (!strcmp(name, "cp.proj.w") && m->p_proj_w) { s->p = m->p_proj_w; s->n = (int64_t)cp_width(c) * H; return 0; }
+    if (!strcmp(name, "cp.proj.b") && m->p_proj_b) { s->p = m->p_proj_b; s->n = cp_width(c); return 0; }
+    if (idx_suffix(name, "cp.head.", &j) && j < c->n_groups - 1) { s->p = m->p_head[j]; s->n = (int64_t)c->sub_vocab * cp_width(c); return 0; }
     if (idx_suffix(name, "cp.embed.", &j) && j < c->n_groups - 1) { s->p = m->p_embed[j]; s->n = (int64_t)c->sub_vocab * H; return 0; }
     int CH = c->cd_hidden;
     if (sscanf(name, "cd.layers.%d.%63s", &i, f) == 2 && i >= 0 && i < c->cd_layers)
@@ -495,7 +505,7 @@ static dec_dims talker_dims(const q3o_config* c) {
     return D;
 }
 static dec_dims cp_dims(const q3o_config* c) {
-    dec_dims D = { c->hidden, c->cp_layers, c->cp_heads, c->cp_kv_heads, c->cp_head_dim, c->cp_ffn, c->cp_rope_theta, c->cp_rms_eps, 0, 1, 0 };
+    dec_dims D = { cp_width(c), c->cp_layers, c->cp_heads, c->cp_kv_heads, c->cp_head_dim, c->cp_ffn, c->cp_rope_theta, c->cp_rms_eps, 0, 1, 0 };
     return D;
 }
 static dec_dims cd_dims(const q3o_config* c) {
@@ -579,20 +589,28 @@ int q3o_decode(q3o_model* m, const float* embed, float* logits, float* last_hidd
     return 0;
 }
 
+/* rows [n][H] at talker width -> predictor input [n][Hc] (caller frees) */
+static float* cp_input(q3o_model* m, const float* rows, int n) {
+    int H = m->c.hidden, Hc = cp_width(&m->c);
+    float* x = zalloc((size_t)n * Hc);
+    if (m->p_proj_w) linear(rows, n, H, m->p_proj_w, m->p_proj_b, Hc, x, Hc);
+    else memcpy(x, rows, (size_t)n * H * sizeof(float));
+    return x;
+}
+
 /* code_predictor.onnx {inputs_embeds [1,n,H], generation_step -> logits} (tts_onnx.cpp:734-757):
  * full causal re-run over the n rows, final norm, head #step applied to the LAST row
  * (the reference consumes the first SV floats, :755-756). */
 int q3o_code_predictor(q3o_model* m, const float* seq, int n, int step, float* logits) {
     const q3o_config* c = &m->c;
-    int H = c->hidden;
     if (n < 1 || n > 32 || step < 0 || step >= c->n_groups - 1) FAIL("code_predictor(n=%d, step=%d) out of range", n, step);
     dec_dims D = cp_dims(c);
-    float* x = zalloc((size_t)n * H);
-    memcpy(x, seq, (size_t)n * H * sizeof(float));
+    int Hc = cp_width(c);
+    float* x = cp_input(m, seq, n);
     dec_forward(&D, m->pl, m->pkc, m->pvc, 32, x, n, 0);
-    float* hn = zalloc(H);
-    rmsnorm(x + (size_t)(n - 1) * H, m->p_norm, H, c->cp_rms_eps, hn);
-    linear(hn, 1, H, m->p_head[step], NULL, c->sub_vocab, logits, c->sub_vocab);
+    float* hn = zalloc(Hc);
+    rmsnorm(x + (size_t)(n - 1) * Hc, m->p_norm, Hc, c->cp_rms_eps, hn);
+    linear(hn, 1, Hc, m->p_head[step], NULL, c->sub_vocab, logits, c->sub_vocab);
     free(x); free(hn);
     return 0;
 }
@@ -600,14 +618,14 @@ int q3o_code_predictor(q3o_model* m, const float* seq, int n, int step, float* l
 /* KV-cached variant of the same computation: rows [from, n) are new, cache holds rows [0, from). */
 static void cp_cached_step(q3o_model* m, const float* rows, int from, int n, int step, float* logits) {
     const q3o_config* c = &m->c;
-    int H = c->hidden, M = n - from;
+    int M = n - from;
     dec_dims D = cp_dims(c);
-    float* x = zalloc((size_t)M * H);
-    memcpy(x, rows, (size_t)M * H * sizeof(float));
+    int Hc = cp_width(c);
+    float* x = cp_input(m, rows, M);
     dec_forward(&D, m->pl, m->pkc, m->pvc, 32, x, M, from);
-    float* hn = zalloc(H);
-    rmsnorm(x + (size_t)(M - 1) * H, m->p_norm, H, c->cp_rms_eps, hn);
-    linear(hn, 1, H, m->p_head[step], NULL, c->sub_vocab, logits, c->sub_vocab);
+    float* hn = zalloc(Hc);
+    rmsnorm(x + (size_t)(M - 1) * Hc, m->p_norm, Hc, c->cp_rms_eps, hn);
+    linear(hn, 1, Hc, m->p_head[step], NULL, c->sub_vocab, logits, c->sub_vocab);
     free(x); free(hn);
 }
 

@@ -55,6 +55,9 @@ typedef struct q3o_config {
      * [HINT: transformers qwen2_5_omni ECAPA_TimeDelayNet].  spk_enc_dim == 0: no speaker encoder.
      * Channel plan (C, C, C, C, 3C), kernels (5,3,3,3,1), dilations (1,2,3,4,1). */
     int32_t spk_enc_dim, spk_mel, spk_channels, spk_scale, spk_se, spk_att;
+    /* width of the code predictor's layers; 0 or == hidden: same as the talker (0.6B).  Otherwise (1.7B: 2048 -> 1024) every predictor
+     * input row goes through cp.proj (Linear with bias) first; predictor embeddings stay at the talker's width. */
+    int32_t cp_hidden;
 } q3o_config;
 
 /* src/tts_onnx.h:99-105 */

@@ -29,6 +29,7 @@ _CFG_FIELDS = [
     ("codec_eos", C.c_int32), ("suppress_begin", C.c_int32), ("suppress_end", C.c_int32),
     ("spk_enc_dim", C.c_int32), ("spk_mel", C.c_int32), ("spk_channels", C.c_int32), ("spk_scale", C.c_int32),
     ("spk_se", C.c_int32), ("spk_att", C.c_int32),
+    ("cp_hidden", C.c_int32),
 ]
 
 
@@ -46,7 +47,7 @@ class Config(C.Structure):
     def from_dict(cls, d):
         c = cls()
         for n, t in _CFG_FIELDS:
-            v = d[n] if n in d or not n.startswith("spk_") else 0   # configs saved before the speaker rows existed
+            v = d[n] if n in d or not (n.startswith("spk_") or n == "cp_hidden") else 0   # configs saved before these fields existed
             if hasattr(t, "_length_"):
                 arr = t()
                 for i, x in enumerate(v):
@@ -82,6 +83,15 @@ def config_06b():
         spk_enc_dim=1024, spk_mel=128, spk_channels=512, spk_scale=8, spk_se=128, spk_att=128))
 
 
+def config_17b():
+    """Qwen3-TTS-1.7B dims [HINT: the public 1.7B checkpoints' config.json]: talker twice as wide, the code predictor keeps the 0.6B
+    width behind a 2048 -> 1024 projection; the speaker embedding is a talker-width row.  Beyond what the reference runs
+    (README.md:125 lists 1.7B as planned; tts_onnx.h:31-37 hard-codes the 0.6B talker dims)."""
+    d = config_06b().to_dict()
+    d.update(hidden=2048, ffn=6144, cp_hidden=1024, spk_enc_dim=2048)
+    return Config.from_dict(d)
+
+
 def config_tiny():
     """Small config with the same structure; every kernel path is exercised in seconds on CPU.
     The codec vocabulary keeps the real control-token ids (2148..2157, tts_onnx.h:50-56) so prompt
@@ -106,6 +116,20 @@ def config_medium():
     d = config_tiny().to_dict()
     d.update(hidden=128, n_layers=2, n_heads=2, n_kv_heads=1, head_dim=64, ffn=256,
              cp_layers=2, cp_heads=2, cp_kv_heads=1, cp_head_dim=64, cp_ffn=256, text_hidden=64, spk_enc_dim=128)
+    return Config.from_dict(d)
+
+
+def config_tiny_proj():
+    """config_tiny with a narrower predictor behind cp.proj (the 1.7B structure)."""
+    d = config_tiny().to_dict()
+    d.update(cp_hidden=48)
+    return Config.from_dict(d)
+
+
+def config_medium_proj():
+    """config_medium with the 1.7B structure: talker 256 wide, predictor 128 wide behind cp.proj."""
+    d = config_medium().to_dict()
+    d.update(hidden=256, ffn=384, cp_hidden=128, spk_enc_dim=256)
     return Config.from_dict(d)
 
 
@@ -144,10 +168,14 @@ def tensor_specs(cfg):
     out.append(("text.fc1.b", (c.text_hidden,), "b"))
     out.append(("text.fc2.w", (H, c.text_hidden), "w"))
     out.append(("text.fc2.b", (H,), "b"))
-    layers("cp", c.cp_layers, H, c.cp_heads, c.cp_kv_heads, c.cp_head_dim, c.cp_ffn, True, False)
-    out.append(("cp.norm", (H,), "norm"))
+    Hc = c.cp_hidden if c.cp_hidden > 0 else H          # 1.7B: narrower predictor behind cp.proj
+    layers("cp", c.cp_layers, Hc, c.cp_heads, c.cp_kv_heads, c.cp_head_dim, c.cp_ffn, True, False)
+    out.append(("cp.norm", (Hc,), "norm"))
+    if Hc != H:
+        out.append(("cp.proj.w", (Hc, H), "w"))
+        out.append(("cp.proj.b", (Hc,), "b"))
     for j in range(c.n_groups - 1):
-        out.append((f"cp.head.{j}", (c.sub_vocab, H), "w"))
+        out.append((f"cp.head.{j}", (c.sub_vocab, Hc), "w"))
     for j in range(c.n_groups - 1):
         out.append((f"cp.embed.{j}", (c.sub_vocab, H), "w"))
     CH = c.cd_hidden

@@ -131,6 +131,36 @@ def test_default_config_matches_reference_constants():
     assert c.to_dict() == qo.config_06b().to_dict()
 
 
+def test_wide_config_and_predictor_projection():
+    """1.7B structure: the C-ABI's "1.7b" dims equal the oracle's, the predictor is narrower than the talker and
+    sits behind cp.proj, and the reference call pattern (re-run, no cache, tts_onnx.cpp:851-872) still equals the KV-cached one."""
+    import q3tts
+    c = q3tts.default_config("1.7b")
+    assert c.to_dict() == qo.config_17b().to_dict()
+    assert (c.hidden, c.ffn, c.cp_hidden, c.spk_enc_dim) == (2048, 6144, 1024, 2048)
+    specs = {n: s for n, s, _ in qo.tensor_specs(qo.config_17b())}
+    assert specs["cp.proj.w"] == (1024, 2048) and specs["cp.proj.b"] == (1024,)
+    assert specs["cp.embed.3"] == (2048, 2048) and specs["cp.head.3"] == (2048, 1024) and specs["cp.layers.0.q_proj"] == (2048, 1024)
+    assert "cp.proj.w" not in {n for n, _, _ in qo.tensor_specs(qo.config_06b())}
+    cfg = qo.config_tiny_proj()
+    w = qo.random_weights(cfg, 3)
+    o = qo.Oracle(cfg, max_ctx=64, weights=w)
+    p = o.build_prompt(frame_tokens([9, 8, 7, 6]), 0)
+    sp = qo.Sampling(temperature=1.0, top_p=1.0, top_k=0, max_new_tokens=12)
+    a = o.generate(p, sp, seed=5, stream=0, cp_cached=True, ignore_eos=True)
+    b = o.generate(p, sp, seed=5, stream=0, cp_cached=False, ignore_eos=True)
+    assert len(a) == 12 and np.array_equal(a, b)
+    # the projection is what the predictor sees: numpy restatement of pass 0 on two rows
+    seq = np.random.default_rng(0).standard_normal((2, cfg.hidden)).astype(np.float32)
+    lg = o.code_predictor(seq, 0)
+    w2 = dict(w)
+    w2["cp.proj.b"] = w["cp.proj.b"] + np.float32(0.5)
+    o2 = qo.Oracle(cfg, max_ctx=64, weights=w2)
+    assert np.abs(o2.code_predictor(seq, 0) - lg).max() > 1e-4     # the bias is live
+    o.close()
+    o2.close()
+
+
 def test_no_cpu_fallback():
     import q3tts
     import torch

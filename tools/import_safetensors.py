@@ -2,7 +2,7 @@
 
     python tools/import_safetensors.py --out model_dir/model.q3w main.safetensors [speech_tokenizer.safetensors ...] \\
         [--prefix talker=talker. --prefix predictor=talker.code_predictor. --prefix code2wav=decoder. --prefix speaker=speaker_encoder.]
-        [--map extra_rules.json] [--config 0.6b | --config cfg.json] [--allow-missing]
+        [--map extra_rules.json] [--config 0.6b | 1.7b | cfg.json] [--allow-missing]
 
 The reference ships no converter: it consumes seven pre-exported .onnx graphs (src/tts_onnx.cpp:91-107).  This tool
 maps parameter NAMES onto the tensor registry shared by the engine and the oracle (q3_oracle.tensor_specs).  The
@@ -50,6 +50,7 @@ RULES = {
         (r"model\.norm\.weight", "cp.norm"),
         (r"lm_head\.(\d+)\.weight", r"cp.head.\1"),
         (r"model\.codec_embedding\.(\d+)\.weight", r"cp.embed.\1"),
+        (r"small_to_mtp_projection\.(weight|bias)", lambda m: f"cp.proj.{m.group(1)[0]}"),                  # [HINT] 1.7B only
     ],
     "code2wav": _layers(r"pre_transformer\.", "cd.") + [
         (r"pre_transformer\.norm\.weight", "cd.norm"),
@@ -193,7 +194,7 @@ def main():
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     ap.add_argument("files", nargs="+")
     ap.add_argument("--out")
-    ap.add_argument("--config", default="0.6b", help='"0.6b" or a JSON file of q3tts_config fields')
+    ap.add_argument("--config", default="0.6b", help='"0.6b", "1.7b" or a JSON file of q3tts_config fields')
     ap.add_argument("--prefix", action="append", default=[], help="component=prefix (talker, predictor, code2wav, speaker)")
     ap.add_argument("--map", help='JSON list of [regex, replacement] applied to the full checkpoint name first')
     ap.add_argument("--allow-missing", action="store_true")
@@ -202,7 +203,8 @@ def main():
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     sys.path.insert(0, ROOT)
     import q3_oracle as qo
-    cfg = qo.config_06b() if a.config.lower() == "0.6b" else qo.Config.from_dict(json.load(open(a.config)))
+    named = {"0.6b": qo.config_06b, "1.7b": qo.config_17b}
+    cfg = named[a.config.lower()]() if a.config.lower() in named else qo.Config.from_dict(json.load(open(a.config)))
     prefixes = dict(p.split("=", 1) for p in a.prefix)
     extra = [tuple(r) for r in json.load(open(a.map))] if a.map else []
     if a.list:
