@@ -36,12 +36,13 @@ def algorithmic_step_bytes(cfg, batch, avg_ctx):
     """talker weights once + predictor weights once per pass (bf16) + bf16-equivalent
     KV bytes the attention must read (B x T x 2 x L x n_kv x d x 2 B)."""
     H = cfg.hidden
+    Hc = cfg.cp_hidden or H        # 1.7B: narrower predictor behind cp.proj
 
-    def layer(nq, nkv, d, ffn):
-        return 2.0 * (H * (nq + 2 * nkv) * d + H * nq * d + 3 * H * ffn)
-    w = cfg.n_layers * layer(cfg.n_heads, cfg.n_kv_heads, cfg.head_dim, cfg.ffn) + 2.0 * H * cfg.vocab
-    w += (cfg.n_groups - 1) * (cfg.cp_layers * layer(cfg.cp_heads, cfg.cp_kv_heads, cfg.cp_head_dim, cfg.cp_ffn)
-                               + 2.0 * H * cfg.sub_vocab)
+    def layer(Hw, nq, nkv, d, ffn):
+        return 2.0 * (Hw * (nq + 2 * nkv) * d + Hw * nq * d + 3 * Hw * ffn)
+    w = cfg.n_layers * layer(H, cfg.n_heads, cfg.n_kv_heads, cfg.head_dim, cfg.ffn) + 2.0 * H * cfg.vocab
+    w += (cfg.n_groups - 1) * (cfg.cp_layers * layer(Hc, cfg.cp_heads, cfg.cp_kv_heads, cfg.cp_head_dim, cfg.cp_ffn)
+                               + 2.0 * Hc * cfg.sub_vocab + (2.0 * H * Hc if Hc != H else 0.0))
     kv = batch * avg_ctx * cfg.n_layers * 2.0 * cfg.n_kv_heads * cfg.head_dim * 2.0
     return w + kv
 
@@ -79,6 +80,7 @@ def main():
     ap.add_argument("--batch", type=int, default=1, help="utterances per GPU per step (configs[1]: 1, configs[2]: 64)")
     ap.add_argument("--frames", type=int, default=2048, help="max-tokens per utterance")
     ap.add_argument("--greedy", action="store_true", help="top_k=1 instead of the sampled default")
+    ap.add_argument("--model", default="0.6b", choices=["0.6b", "1.7b"], help="model dims (the headline is 0.6b; 1.7b = configs[4] dims)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay (rocprofv3 kernel tracing "
                                                              "crashes inside hipGraphLaunch on this ROCm; same kernels either way)")
@@ -97,7 +99,8 @@ def main():
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))  # RCCL on ROCm
 
     import q3tts
-    cfg = q3tts.default_config("0.6b")
+    cfg = q3tts.default_config(args.model)
+    MODEL = "Qwen3-TTS-" + args.model.upper()
     B, F = args.batch, args.frames
     eng = q3tts.Engine(cfg, device=local_rank, max_batch=B, max_ctx=F + 32, flags=q3tts.FLAG_NO_GRAPH if args.no_graph else 0)
     eng.fill_synthetic(seed=0)
@@ -166,18 +169,18 @@ def main():
         tf = os.path.join(ROOT, "profiles", "decode_step_traffic.json")
         if os.path.exists(tf):
             try:
-                traffic = json.load(open(tf)).get(f"b{B}")
+                traffic = json.load(open(tf)).get(f"b{B}") if args.model == "0.6b" else None
             except Exception:
                 traffic = None
         out = {
-            "metric": "real-time factor (24 kHz audio sec / wall sec), Qwen3-TTS-0.6B",
+            "metric": f"real-time factor (24 kHz audio sec / wall sec), {MODEL}",
             "value": round(frames * FRAME_SECONDS / dt, 3),
             "unit": "x real-time (audio s / wall s)",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16 weights, fp32 activations/accumulate (codec decoder: fp16 hi/lo split operands, fp32 accumulate)", "data": "synthetic",
-            "config": {"workload": f"Qwen3-TTS-0.6B, batch={B}/GPU, 16-token prompt, "
+            "config": {"workload": f"{MODEL}, batch={B}/GPU, 16-token prompt, "
                                    + ("greedy top_k=1" if args.greedy else "sampled temp=0.8 top-k=50 top-p=0.95")
                                    + f", max-tokens={F} (EOS suppressed), synthetic seeded weights",
                        "batch_per_gpu": B, "frames_per_utterance": F, "parallelism": f"dp{world} (independent utterances)"},

@@ -57,6 +57,7 @@ Engine::Engine(const q3tts_config& cfg, int device_, int max_batch, int max_ctx_
     Q3_HIP_CHECK(hipSetDevice(device));
     // Q3TTS_NULL_STREAM=1 (profiling aid): rocprofv3 --pmc crashes on user-created streams on this ROCm; run on the
     // default stream instead (forces eager launches: the default stream cannot be captured)
+    if (const char* mr = getenv("Q3TTS_MFMA_MIN_ROWS")) mfma_min_rows = std::max(3, atoi(mr));   // A/B knob for the GEMV <-> GEMM crossover
     null_stream = getenv("Q3TTS_NULL_STREAM") && getenv("Q3TTS_NULL_STREAM")[0] == '1';
     if (null_stream) { stream = nullptr; flags |= Q3TTS_FLAG_NO_GRAPH; }
     else Q3_HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
@@ -369,8 +370,8 @@ static int pick_ksplit(int K) { // K slices per GEMM: 256 (two LDS chunks) per w
 bool Engine::run_layers(const DecStack& W, float* x, int ldx, int nb, int n_new, int slot_offset, const int* pos_dev, int pos_scalar,
                         const float* final_gamma, float final_eps, float* final_xn, int final_ld_xn) {
     const int M = nb * n_new, QKV = (W.nq + 2 * W.nkv) * W.d, AO = W.nq * W.d;
-    // M > 8 rows: bf16-MFMA skinny GEMM over (hi, lo) activation planes; else the GEMV family
-    const bool mfma = M > 8 && M <= 128 && W.H % 128 == 0 && AO % 128 == 0 && W.ffn % 128 == 0 && W.H <= 4096;
+    // M >= mfma_min_rows: bf16-MFMA skinny GEMM over (hi, lo) activation planes; below it the single-pass GEMV family
+    const bool mfma = M >= mfma_min_rows && M <= 128 && W.H % 128 == 0 && AO % 128 == 0 && W.ffn % 128 == 0 && W.H <= 4096;
     const int ks_q = mfma ? std::min(4, pick_ksplit(W.H)) : 1;
     if (mfma) // planes0 = RMSNorm(in_norm[0])(x)
         launch_finish(x, ldx, nullptr, 0, 0, 0, W.layers[0].in_norm, W.eps, M, W.H, pl0h, pl0l, ldp, nullptr, 0, stream);
@@ -470,7 +471,7 @@ bool Engine::run_layers(const DecStack& W, float* x, int ldx, int nb, int n_new,
 // final RMSNorm + output head (codec_head / cp.head.j); optionally keeps the normalised rows
 void Engine::head_proj(const bf16_t* Wm, const float* x, int ldx, const float* gamma, float eps, float* xn_out, int ld_xn,
                        float* out, int ldo, int M, int N, int K, bool nt, bool planes_ready, int plane_row0, int plane_row_stride) {
-    if (planes_ready || (M > 8 && M <= 128 && K % 128 == 0 && K <= 4096)) {
+    if (planes_ready || (M >= mfma_min_rows && M <= 128 && K % 128 == 0 && K <= 4096)) {
         if (!planes_ready) {
             launch_finish(const_cast<float*>(x), ldx, nullptr, 0, 0, 0, gamma, eps, M, K, pl0h, pl0l, ldp, xn_out, ld_xn, stream);
             plane_row0 = 0; plane_row_stride = 1;
