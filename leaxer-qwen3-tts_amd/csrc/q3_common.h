@@ -69,6 +69,8 @@ struct GemvArgs {
 };
 void launch_gemv(const GemvArgs& a, hipStream_t s);
 bool gemv_fast_path(const GemvArgs& a); // single-pass kernel available (M <= 2, K in {1024,2048,3072})
+bool gemv16_ok(const GemvArgs& a);        // 3..16 rows on the matrix cores, same contract (q3_gemm_kernels.hip); launch_gemv picks it
+void launch_gemv16(const GemvArgs& a, hipStream_t s);
 
 // Decode-time attention over a paged fp32 KV cache with the new tokens' q/k-norm + RoPE + append fused.
 struct AttnArgs {

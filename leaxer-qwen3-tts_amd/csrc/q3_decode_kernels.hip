@@ -482,6 +482,7 @@ void launch_gemv(const GemvArgs& a0, hipStream_t s) {
         if (a0.M == 1) gemv1_nch<1>(a0, s); else gemv1_nch<2>(a0, s);
         return;
     }
+    if (gemv16_ok(a0)) { launch_gemv16(a0, s); return; }
     if (a0.po) throw Error("gemv: attention-partials prologue needs the fast path (combine separately)");
     if (a0.K % 8 != 0 || a0.ldx % 4 != 0) throw Error("gemv: K must be a multiple of 8 and ldx of 4");
     if ((a0.epi == EPI_RESIDUAL || a0.epi == EPI_BIAS || a0.epi == EPI_BIAS_SILU) && a0.gamma) throw Error("gemv: norm+epilogue combination not built");

@@ -419,6 +419,8 @@ bool Engine::run_layers(const DecStack& W, float* x, int ldx, int nb, int n_new,
         a.n_splits = W.n_splits; a.chunk = W.chunk; a.po = W.po; a.pm = W.pm; a.pl = W.pl;
         const bool direct_planes = mfma && W.n_splits == 1;     // one split: the attention kernel normalises and writes the planes itself
         if (direct_planes) { a.out = nullptr; a.po = nullptr; a.pm = nullptr; a.pl = nullptr; a.oh = pl1h; a.ol = pl1l; a.ldp = ldp; }
+        const bool direct_rows = !mfma && W.n_splits == 1;      // likewise for the GEMV family: normalised fp32 rows, nothing to combine
+        if (direct_rows) { a.po = nullptr; a.pm = nullptr; a.pl = nullptr; }
         launch_attn(a, stream);
         if (mfma) {
             if (!direct_planes) {
@@ -451,7 +453,8 @@ bool Engine::run_layers(const DecStack& W, float* x, int ldx, int nb, int n_new,
         o.M = M; o.N = W.H; o.K = AO; o.epi = EPI_RESIDUAL; o.nt = W.nt;
         o.po = W.po; o.pm = W.pm; o.pl = W.pl; o.pS = W.n_splits; o.pchunk = W.chunk; o.pn_new = n_new; o.pslot_offset = slot_offset;
         o.pheads = W.nq; o.pd = W.d; o.ppos_dev = pos_dev; o.ppos_scalar = pos_scalar;
-        if (!gemv_fast_path(o)) { // partials -> attn rows, then the generic GEMV
+        if (direct_rows) { o.po = nullptr; o.pm = nullptr; o.pl = nullptr; }
+        else if (!gemv_fast_path(o)) { // partials -> attn rows, then a GEMV without the combine prologue
             launch_attn_combine(a, stream);
             o.po = nullptr; o.pm = nullptr; o.pl = nullptr;
         }
@@ -716,14 +719,14 @@ void Engine::slots_begin(const SlotInit* in, int n, const q3tts_sampling& p, uin
         const int S = in[i0].S, cap = mfma_ok ? std::max(1, std::min(rows_max, 128) / S) : 1;
         int g = 1;
         while (i0 + g < n && g < cap && in[i0 + g].S == S && in[i0 + g].slot == in[i0].slot + g) ++g;
-        if (g == 1 || g * S <= 8) {
+        if (g == 1 || g * S < mfma_min_rows) {
             for (int k = 0; k < g; ++k) talker_prefill(in[i0 + k].slot, in[i0 + k].prompt, S, nullptr, nullptr);
         } else {
             const int slot0 = in[i0].slot, M = g * S;
             for (int k = 0; k < g; ++k)
                 Q3_HIP_CHECK(hipMemcpyAsync(xp + (size_t)k * S * H, in[i0 + k].prompt, (size_t)S * H * sizeof(float), hipMemcpyHostToDevice, stream));
             const bool pr = run_layers(talker, xp, H, g, S, slot0, nullptr, 0, talker_norm, c.rms_eps, hn, H);
-            if (!pr) throw Error("batched prefill expects the MFMA path");   // M = g*S > 8 rows by construction (g >= 2, S >= 5)
+            if (!pr) throw Error("batched prefill expects the MFMA path");   // M = g*S >= mfma_min_rows by construction
             // codec head on the last row of every prompt straight into the fused path's logits; normalised last rows -> predictor input
             head_proj(codec_head, xp, H, talker_norm, c.rms_eps, nullptr, 0, logits_t + (size_t)slot0 * V, V, g, V, H, true, true, S - 1, S);
             launch_copy_rows(hn + (size_t)(S - 1) * H, S * H, x_cp + (size_t)slot0 * 2 * H, 2 * H, g, H, stream);

@@ -127,7 +127,9 @@ public:
     std::vector<const bf16_t*> cp_head, cp_embed_w;
 
     int rows_max = 0, max_trailing = 0, max_frames_cap = 0;
-    int mfma_min_rows = 3; // rows from which a projection runs on the matrix cores (1-2 rows: single-pass GEMV; 3-8 on the chunked GEMV was 2x slower)
+    // rows from which a projection takes the split-K slab GEMM (k_gemm2 + finish kernels, 8 launches per layer).  Below it the GEMV-family
+    // contract holds (5 launches per layer): 1-2 rows single-pass GEMV, 3-16 rows k_gemv16 on the matrix cores.
+    int mfma_min_rows = 17;
     float *x_talk = nullptr, *qkv = nullptr, *attn = nullptr, *act = nullptr, *logits_t = nullptr, *logits_cp = nullptr;
     float *x_cp = nullptr, *x_cp1 = nullptr, *sum = nullptr, *xp = nullptr, *hn = nullptr, *logits_p = nullptr;
     float *trailing_d = nullptr, *tts_pad_d = nullptr, *text_tmp = nullptr, *text_tmp2 = nullptr;

@@ -313,6 +313,214 @@ void launch_gemm2(const GemmArgs& a, int ksplit, int nw, hipStream_t s) {
     else gemm2_nw<8>(a, ksplit, nw, s);
 }
 
+// ================================================================================================
+// k_gemv16 — 3..16 activation rows, the GEMV family's contract (fp32 rows in, fused RMSNorm, fused epilogue, ONE launch per
+// projection) on the matrix cores.  Workgroup = one 16-column tile of N over the full K; its NWV waves split K and meet in LDS in
+// wave order (deterministic).  A wave issues every weight fragment of its K slice before anything else (HBM stream, one latency
+// deep), then walks its slice of the fp32 activation rows (L2) in batches of AB k-steps: gamma, sum of squares, split into
+// (hi, lo) bf16 with the hardware RNE convert, two MFMAs per k-step.  The row scale 1/rms is applied to the finished sums
+// (sum_k (x*gamma)*W * inv == sum_k ((x*inv)*gamma)*W up to fp32 rounding), so no pass over x precedes the products and the
+// split-K slabs + finish kernels of k_gemm2 (3 extra launches per layer) are not needed at these row counts.
+// ================================================================================================
+typedef unsigned g16_u32x4 __attribute__((ext_vector_type(4)));
+typedef float g16_f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 g16_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float g16_f32x2 __attribute__((ext_vector_type(2)));
+
+static __device__ __forceinline__ g16_u32x4 g16_ldw(const bf16_t* p, bool nt) {
+    if (nt) return __builtin_nontemporal_load(reinterpret_cast<const g16_u32x4*>(p));
+    return *reinterpret_cast<const g16_u32x4*>(p);
+}
+// 8 fp32 -> hi and lo planes (4 dwords each); v - hi is exact in fp32
+static __device__ __forceinline__ void g16_split8(const float (&y)[8], bf16x8& hi, bf16x8& lo) {
+    g16_u32x4 h, l;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const g16_f32x2 v = { y[2 * j], y[2 * j + 1] };
+        const uint32_t hp = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, g16_bf16x2));
+        const g16_f32x2 r = { y[2 * j] - __uint_as_float(hp << 16), y[2 * j + 1] - __uint_as_float(hp & 0xFFFF0000u) };
+        h[j] = hp;
+        l[j] = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, g16_bf16x2));
+    }
+    hi = __builtin_bit_cast(bf16x8, h);
+    lo = __builtin_bit_cast(bf16x8, l);
+}
+
+#define G16_AB 4
+template <int KWMAX, int NWV, int EPI, bool NORM>
+__global__ __launch_bounds__(NWV * 64) void k_gemv16(const bf16_t* pW, const bf16_t* pW2, const float* px, const float* pgamma, const float* pepi,
+                                                      int pN, int pM, int pldx, int pldepi, uint32_t pKnt /* K | nt << 31 */, GemvArgs a) {   // leading scalars: kernarg-preloaded
+    constexpr bool DUAL = EPI == EPI_SWIGLU;
+    constexpr int NG = (KWMAX + G16_AB - 1) / G16_AB;       // groups of AB k-steps
+    constexpr int PREG = NG < (NORM ? 2 : 3) ? NG : (NORM ? 2 : 3);   // groups whose activation loads are issued BEFORE the weights
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, q = lane >> 4;
+    const int n0 = blockIdx.x * 16;
+    const int K = (int)(pKnt & 0x7FFFFFFFu), M = pM, N = pN;
+    const bool nt = (pKnt >> 31) != 0;
+    const int kslice = K / NWV, kw = kslice >> 5;   // k-steps of 32 this wave owns (1..KWMAX)
+    const int kbeg = wave * kslice;
+    __shared__ float red[DUAL ? 2 : 1][NWV][16][17];
+    __shared__ float ssq[NWV][16];
+
+    // Loads return in issue order, so what is issued before the weight stream can be converted while the weights are in flight:
+    // the first PREG groups of activation k-steps go first, the rest follow the weights one group at a time into a freed buffer.
+    const float* xr = px + (size_t)(r16 < M ? r16 : M - 1) * pldx + kbeg + q * 8;   // lane (r16, q): row r16, 8 consecutive k per k-step
+    const float* gr = NORM ? pgamma + kbeg + q * 8 : nullptr;
+    g16_f32x4 xa[PREG][G16_AB][2], ga[NORM ? PREG : 1][G16_AB][2];
+    const bool row_live = r16 < M;   // lanes of rows past M issue no activation loads (their outputs are never stored)
+    auto issue = [&](int buf, int g) {
+#pragma unroll
+        for (int j = 0; j < G16_AB; ++j) {
+            const int ks = g * G16_AB + j;
+            const int kk = ks < kw ? ks : kw - 1;   // k-steps past kw repeat the last one; their fragment is zeroed below
+            xa[buf][j][0] = g16_f32x4{ 0.f, 0.f, 0.f, 0.f };
+            xa[buf][j][1] = g16_f32x4{ 0.f, 0.f, 0.f, 0.f };
+            if (row_live) {
+                xa[buf][j][0] = *reinterpret_cast<const g16_f32x4*>(xr + kk * 32);
+                xa[buf][j][1] = *reinterpret_cast<const g16_f32x4*>(xr + kk * 32 + 4);
+            }
+            if (NORM) {
+                ga[buf][j][0] = *reinterpret_cast<const g16_f32x4*>(gr + kk * 32);
+                ga[buf][j][1] = *reinterpret_cast<const g16_f32x4*>(gr + kk * 32 + 4);
+            }
+        }
+    };
+#pragma unroll
+    for (int g = 0; g < PREG; ++g) issue(g, g);
+    __builtin_amdgcn_sched_barrier(0);
+    // weights: the whole K slice of this wave's 16 rows in flight at once
+    const int nrow = n0 + r16 < N ? n0 + r16 : N - 1;
+    const bf16_t* wp = pW + (size_t)nrow * K + kbeg + q * 8;
+    const bf16_t* wp2 = DUAL ? pW2 + (size_t)nrow * K + kbeg + q * 8 : nullptr;
+    g16_u32x4 w[KWMAX], w2[DUAL ? KWMAX : 1];
+#pragma unroll
+    for (int ks = 0; ks < KWMAX; ++ks) {
+        const int kk = ks < kw ? ks : kw - 1;
+        w[ks] = g16_ldw(wp + kk * 32, nt);
+        if (DUAL) w2[ks] = g16_ldw(wp2 + kk * 32, nt);
+    }
+    // epilogue operand (residual / bias) of the output this thread finishes: (m, n) = (tid / 16, tid % 16)
+    const int em = tid >> 4, en = n0 + (tid & 15);
+    float epi_in = 0.f;
+    if (EPI == EPI_RESIDUAL || EPI == EPI_BIAS || EPI == EPI_BIAS_SILU) {
+        if (tid < 256 && em < M && en < N) epi_in = EPI == EPI_RESIDUAL ? pepi[(size_t)em * pldepi + en] : pepi[en];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    f32x4 acc = { 0.f, 0.f, 0.f, 0.f }, acc2 = { 0.f, 0.f, 0.f, 0.f };
+    float ss = 0.f;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+#pragma unroll
+        for (int j = 0; j < G16_AB; ++j) {
+            const int ks = g * G16_AB + j;
+            if (ks >= KWMAX) continue;
+            const float live = ks < kw ? 1.0f : 0.0f;
+            float y[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float xv = xa[g % PREG][j][e >> 2][e & 3] * live;
+                if (NORM) { ss = fmaf(xv, xv, ss); y[e] = xv * ga[g % PREG][j][e >> 2][e & 3]; }
+                else y[e] = xv;
+            }
+            bf16x8 ah, al;
+            g16_split8(y, ah, al);
+            const bf16x8 bw = __builtin_bit_cast(bf16x8, w[ks]);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bw, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bw, acc, 0, 0, 0);
+            if (DUAL) {
+                const bf16x8 bw2 = __builtin_bit_cast(bf16x8, w2[ks]);
+                acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bw2, acc2, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bw2, acc2, 0, 0, 0);
+            }
+        }
+        if (g + PREG < NG) {   // refill the buffer just consumed; the next group's conversion covers this L2 round trip
+            __builtin_amdgcn_sched_barrier(0);
+            issue(g % PREG, g + PREG);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // meet in LDS: D layout col = lane & 15 (n), row = q * 4 + reg (m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        red[0][wave][q * 4 + r][r16] = acc[r];
+        if (DUAL) red[DUAL ? 1 : 0][wave][q * 4 + r][r16] = acc2[r];
+    }
+    if (NORM) {   // the four lanes of a row (q = 0..3) hold disjoint k: sum them, one value per (wave, row)
+        ss += __shfl_xor(ss, 16);
+        ss += __shfl_xor(ss, 32);
+        if (q == 0) ssq[wave][r16] = ss;
+    }
+    __syncthreads();
+    if (tid < 256) {
+        float v = 0.f, v2 = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < NWV; ++wv) { v += red[0][wv][em][tid & 15]; if (DUAL) v2 += red[DUAL ? 1 : 0][wv][em][tid & 15]; }
+        if (NORM) {
+            float t = 0.f;
+#pragma unroll
+            for (int wv = 0; wv < NWV; ++wv) t += ssq[wv][em];
+            const float inv = 1.0f / sqrtf(t / (float)K + a.eps);
+            v *= inv; v2 *= inv;
+        }
+        if (em < M && en < N) {
+            float o;
+            if (EPI == EPI_STORE) o = v;
+            else if (EPI == EPI_RESIDUAL) o = epi_in + v;
+            else if (EPI == EPI_SWIGLU) o = silu_g(v) * v2;
+            else if (EPI == EPI_BIAS) o = v + epi_in;
+            else o = silu_g(v + epi_in);
+            a.out[(size_t)em * a.ldo + en] = o;
+        }
+    }
+    // optional fp32 copy of the normalised rows (the talker head keeps them as the predictor's first input row)
+    if (NORM && a.xn_out != nullptr && blockIdx.x == 0) {
+        for (int m = 0; m < M; ++m) {
+            float t = 0.f;
+#pragma unroll
+            for (int wv = 0; wv < NWV; ++wv) t += ssq[wv][m];
+            const float im = 1.0f / sqrtf(t / (float)K + a.eps);
+            for (int k = tid; k < K; k += NWV * 64) a.xn_out[(size_t)m * a.ld_xn + k] = pgamma[k] * (px[(size_t)m * pldx + k] * im);
+        }
+    }
+}
+
+bool gemv16_ok(const GemvArgs& a) {
+    if (a.M < 3 || a.M > 16 || a.po != nullptr) return false;
+    if (a.K % 128 != 0 || a.K > 6144 || a.ldx % 4 != 0) return false;
+    if (a.K > 1024 && a.K % 256 != 0) return false;   // 8 waves from there on
+    if (a.gamma && a.epi != EPI_STORE && a.epi != EPI_SWIGLU) return false;
+    return true;
+}
+
+template <int KWMAX, int NWV>
+static void gemv16_epi(const GemvArgs& a, hipStream_t s) {
+    const dim3 grid((a.N + 15) / 16), block(NWV * 64);
+    const bool norm = a.gamma != nullptr;
+#define Q3_G16(EPI, NORM) hipLaunchKernelGGL((k_gemv16<KWMAX, NWV, EPI, NORM>), grid, block, 0, s, a.W, a.W2, a.x, a.gamma, \
+        (a.epi == EPI_RESIDUAL ? a.res : a.bias), a.N, a.M, a.ldx, a.ldres, (uint32_t)a.K | (a.nt ? 0x80000000u : 0u), a)
+    switch (a.epi) {
+    case EPI_STORE: if (norm) Q3_G16(EPI_STORE, true); else Q3_G16(EPI_STORE, false); break;
+    case EPI_SWIGLU: if (norm) Q3_G16(EPI_SWIGLU, true); else Q3_G16(EPI_SWIGLU, false); break;
+    case EPI_RESIDUAL: Q3_G16(EPI_RESIDUAL, false); break;
+    case EPI_BIAS: Q3_G16(EPI_BIAS, false); break;
+    case EPI_BIAS_SILU: Q3_G16(EPI_BIAS_SILU, false); break;
+    default: throw Error("gemv16: bad epilogue");
+    }
+#undef Q3_G16
+}
+void launch_gemv16(const GemvArgs& a, hipStream_t s) {
+    if (!gemv16_ok(a)) throw Error("gemv16: unsupported shape");
+    // K <= 1024: 4 waves x <= 8 k-steps.  Wider K: 8 waves, so that at K <= 3072 every activation group is issued ahead of the weights
+    // (converted while they stream) and the serial tail per wave after the last weight fragment stays at a few MFMAs.
+    if (a.K <= 1024) gemv16_epi<8, 4>(a, s);
+    else if (a.K <= 2048) gemv16_epi<8, 8>(a, s);
+    else if (a.K <= 3072) gemv16_epi<12, 8>(a, s);
+    else gemv16_epi<24, 8>(a, s);
+}
+
 // x[m][:] += sum_ks slab[ks][m][:] (fixed order), then RMSNorm(gamma) -> (hi, lo) planes (+ optional fp32 rows).
 // One workgroup per row.  nslab == 0: plain RMSNorm + split.  gamma == null: residual update only.
 static __device__ __forceinline__ void split_store4(const float (&y)[4], bf16_t* hi, bf16_t* lo) {   // 4 values -> one 8-byte store per plane
