@@ -58,6 +58,7 @@ def build(force=False, verbose=False):
         if verbose:
             print("linked", LIB)
     _build_cli(force)
+    _build_pmc_driver(force)
     return LIB
 
 
@@ -75,6 +76,23 @@ def _build_cli(force=False):
     if r.returncode != 0:
         raise RuntimeError("building leaxer-tts failed:\n" + r.stderr[-4000:])
     return CLI
+
+
+def _build_pmc_driver(force=False):
+    """tools/pmc_bisect: a C driver of the decode step for the rocprofv3 --pmc passes (the program after `--` must be the program
+    itself, not python).  It holds a q3tts_config on its stack, so it is rebuilt whenever the C-ABI header changes."""
+    root = os.path.join(HERE, "..")
+    src, out = os.path.join(root, "tools", "pmc_bisect.cpp"), os.path.join(root, "tools", "pmc_bisect")
+    deps = [src, os.path.join(root, "include", "q3tts.h"), LIB]
+    if not os.path.exists(src):
+        return None
+    if not force and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps):
+        return out
+    cmd = ["g++", "-O2", "-std=c++17", "-o", out, src, "-L" + HERE, "-lq3tts_hip", "-Wl,-rpath,$ORIGIN/../leaxer-qwen3-tts_amd"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("building tools/pmc_bisect failed:\n" + r.stderr[-4000:])
+    return out
 
 
 if __name__ == "__main__":

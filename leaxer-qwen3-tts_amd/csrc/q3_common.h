@@ -135,15 +135,11 @@ struct GemmArgs {
     bf16_t* oh = nullptr; bf16_t* ol = nullptr; int ldp = 0; // optional plane outputs (input of the next GEMM)
     int M = 0, N = 0, K = 0, epi = EPI_STORE;
 };
-bool gemm_mfma_ok(int M, int K);
-void launch_gemm_mfma(const GemmArgs& a, hipStream_t s);
 void launch_gemm2(const GemmArgs& a, int ksplit, int nw, hipStream_t s); // EPI_SLAB: out = slabs [ksplit][M][ldo]
 void launch_finish(float* x, int ldx, const float* slab, int nslab, size_t slab_stride, int ld_slab, const float* gamma, float eps,
                    int rows, int K, bf16_t* oh, bf16_t* ol, int ldp, float* xn_out, int ld_xn, hipStream_t s);
 void launch_finish_swiglu(const float* gs, const float* us, int nslab, size_t slab_stride, int rows, int N,
                           bf16_t* oh, bf16_t* ol, int ldp, hipStream_t s);
-void launch_rmsnorm_split(const float* x, int ldx, const float* gamma, float eps, int rows, int K,
-                          bf16_t* oh, bf16_t* ol, int ldp, float* xn_out, int ld_xn, hipStream_t s);
 
 struct SlotState { // device-resident per-slot generation state
     int32_t n_frames;     // frames recorded so far

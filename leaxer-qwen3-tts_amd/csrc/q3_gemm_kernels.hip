@@ -1,17 +1,17 @@
-// q3_gemm_kernels.hip — skinny-M GEMM for batched decode (9 <= M <= 128 rows) on the bf16 matrix cores.
+// q3_gemm_kernels.hip — skinny-M projections for batched decode on the bf16 matrix cores.
 //
 // out[M][N] = epi(X[M][K] . W[N][K]^T): the weights (bf16, nn.Linear layout) are streamed exactly once per
 // launch and every M row reuses them — the batch dimension is what lifts the decode step off the
 // launch-latency floor of the b=1 path.  Parity with the fp32 oracle is kept by feeding the activations
 // as TWO bf16 planes, x = hi + lo (|x - hi - lo| <= 2^-18 |x|): bf16 x bf16 products are exact in the
 // fp32 accumulator, so two v_mfma_f32_16x16x32_bf16 per tile give fp32-grade dot products at 1/8 of the
-// fp32-MFMA cost.  The planes are written by the producers (k_rmsnorm_split, k_attn_combine, the SwiGLU
-// epilogue), so the GEMM's operand loads are plain 16-byte loads straight into MFMA fragments:
-//   A (x):  lane l -> row m0 + (l&15), k0 + 8*(l>>4) .. +7        (L2-resident planes)
+// fp32-MFMA cost.  Fragment layout of both kernels:
+//   A (x):  lane l -> row m0 + (l&15), k0 + 8*(l>>4) .. +7
 //   B (W):  lane l -> weight row n0 + (l&15), same k              (HBM stream)
-// One workgroup = one 16-column tile of N; its 4 waves split K and meet in LDS, so N/16 workgroups
-// stream disjoint weight rows (256 for the QKV projection).  Summation order is fixed: results are
-// bit-reproducible run to run.
+//   k_gemv16 (3..16 rows):   one launch per projection, fp32 rows in, RMSNorm and epilogue fused, hi/lo split in registers
+//   k_gemm2  (17..128 rows): planes written by the producers (k_finish*, k_attn), activation slice staged through LDS and
+//                            shared by 64 columns, split-K slabs reduced in fixed order by k_finish / k_finish_swiglu
+// Summation order is fixed everywhere: results are bit-reproducible run to run.
 #include "q3_common.h"
 
 namespace q3 {
@@ -29,152 +29,6 @@ static __device__ __forceinline__ void split_store(float v, bf16_t* hi, bf16_t* 
     *hi = h;
     *lo = bf16_rne(v - __uint_as_float((uint32_t)h << 16)); // v - hi is exact in fp32
 }
-
-template <int MTILES, int EPI>
-__global__ __launch_bounds__(256) void k_gemm_mfma(GemmArgs a) {
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int r16 = lane & 15, q = lane >> 4;
-    const int n0 = blockIdx.x * 16;
-    const int K = a.K, M = a.M;
-    const int kq = K / 4, kbeg = wave * kq;
-    __shared__ float red[4][MTILES][4][64];
-
-    int nrow = n0 + r16;
-    nrow = nrow < a.N ? nrow : a.N - 1;
-    const bf16_t* wp = a.W + (size_t)nrow * K + q * 8;
-    const bf16_t* wp2 = EPI == EPI_SWIGLU ? a.W2 + (size_t)nrow * K + q * 8 : nullptr;
-    const bf16_t* xh[MTILES];
-    const bf16_t* xl[MTILES];
-#pragma unroll
-    for (int mt = 0; mt < MTILES; ++mt) {
-        int row = mt * 16 + r16;
-        row = row < M ? row : M - 1; // clamped: the extra rows are computed and dropped
-        xh[mt] = a.xh + (size_t)row * a.ldx + q * 8;
-        xl[mt] = a.xl + (size_t)row * a.ldx + q * 8;
-    }
-    f32x4 acc[MTILES], acc2[MTILES];
-#pragma unroll
-    for (int mt = 0; mt < MTILES; ++mt) { acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[mt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-
-#pragma unroll 2
-    for (int k0 = kbeg; k0 < kbeg + kq; k0 += 32) {
-        const bf16x8 b = *reinterpret_cast<const bf16x8*>(wp + k0);
-        bf16x8 b2;
-        if (EPI == EPI_SWIGLU) b2 = *reinterpret_cast<const bf16x8*>(wp2 + k0);
-#pragma unroll
-        for (int mt = 0; mt < MTILES; ++mt) {
-            const bf16x8 ah = *reinterpret_cast<const bf16x8*>(xh[mt] + k0);
-            const bf16x8 al = *reinterpret_cast<const bf16x8*>(xl[mt] + k0);
-            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, b, acc[mt], 0, 0, 0);
-            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, b, acc[mt], 0, 0, 0);
-            if (EPI == EPI_SWIGLU) {
-                acc2[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, b2, acc2[mt], 0, 0, 0);
-                acc2[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, b2, acc2[mt], 0, 0, 0);
-            }
-        }
-    }
-
-    // ---- cross-wave K reduction (fixed order), then the epilogue: wave w owns m-tiles w, w+4 ----
-    auto reduce = [&](f32x4 (&src)[MTILES], float (&dst)[2][4]) {
-#pragma unroll
-        for (int mt = 0; mt < MTILES; ++mt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) red[wave][mt][r][lane] = src[mt][r];
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int mt = wave + 4 * i;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float s = 0.f;
-                if (mt < MTILES) s = ((red[0][mt < MTILES ? mt : 0][r][lane] + red[1][mt < MTILES ? mt : 0][r][lane]) + red[2][mt < MTILES ? mt : 0][r][lane]) + red[3][mt < MTILES ? mt : 0][r][lane];
-                dst[i][r] = s;
-            }
-        }
-        __syncthreads();
-    };
-    float v1[2][4], v2[2][4];
-    reduce(acc, v1);
-    if (EPI == EPI_SWIGLU) reduce(acc2, v2);
-
-    const int n = n0 + r16;
-    if (n >= a.N) return;
-    const float bias = (EPI == EPI_BIAS || EPI == EPI_BIAS_SILU) ? a.bias[n] : 0.f;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int mt = wave + 4 * i;
-        if (mt >= MTILES) continue;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int m = mt * 16 + q * 4 + r; // D layout: col = lane&15, row = (lane>>4)*4 + reg
-            if (m >= M) continue;
-            float o = v1[i][r];
-            if (EPI == EPI_RESIDUAL) o = a.res[(size_t)m * a.ldres + n] + o;
-            else if (EPI == EPI_SWIGLU) o = silu_g(o) * v2[i][r];
-            else if (EPI == EPI_BIAS) o = o + bias;
-            else if (EPI == EPI_BIAS_SILU) o = silu_g(o + bias);
-            if (a.out) a.out[(size_t)m * a.ldo + n] = o;
-            if (a.oh) split_store(o, a.oh + (size_t)m * a.ldp + n, a.ol + (size_t)m * a.ldp + n);
-        }
-    }
-}
-
-template <int MTILES>
-static void gemm_epi(const GemmArgs& a, hipStream_t s) {
-    const dim3 grid((a.N + 15) / 16), block(256);
-    switch (a.epi) {
-    case EPI_STORE: hipLaunchKernelGGL((k_gemm_mfma<MTILES, EPI_STORE>), grid, block, 0, s, a); break;
-    case EPI_RESIDUAL: hipLaunchKernelGGL((k_gemm_mfma<MTILES, EPI_RESIDUAL>), grid, block, 0, s, a); break;
-    case EPI_SWIGLU: hipLaunchKernelGGL((k_gemm_mfma<MTILES, EPI_SWIGLU>), grid, block, 0, s, a); break;
-    case EPI_BIAS: hipLaunchKernelGGL((k_gemm_mfma<MTILES, EPI_BIAS>), grid, block, 0, s, a); break;
-    default: hipLaunchKernelGGL((k_gemm_mfma<MTILES, EPI_BIAS_SILU>), grid, block, 0, s, a); break;
-    }
-}
-
-bool gemm_mfma_ok(int M, int K) { return M >= 1 && M <= 128 && K % 128 == 0; }
-
-void launch_gemm_mfma(const GemmArgs& a, hipStream_t s) {
-    if (!gemm_mfma_ok(a.M, a.K) || a.ldx % 8 != 0) throw Error("gemm_mfma: unsupported shape");
-    if (a.M <= 16) gemm_epi<1>(a, s);
-    else if (a.M <= 32) gemm_epi<2>(a, s);
-    else if (a.M <= 64) gemm_epi<4>(a, s);
-    else gemm_epi<8>(a, s);
-}
-
-// RMSNorm of fp32 rows -> (hi, lo) bf16 planes (+ optional fp32 copy of the normalised rows)
-__global__ __launch_bounds__(256) void k_rmsnorm_split(const float* x, int ldx, const float* gamma, float eps, int K,
-                                                        bf16_t* oh, bf16_t* ol, int ldp, float* xn_out, int ld_xn) {
-    __shared__ float red[4];
-    const int m = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const float* xr = x + (size_t)m * ldx;
-    float ss = 0.f;
-    for (int k = threadIdx.x * 4; k < K; k += 1024) {
-        const float4 v = *reinterpret_cast<const float4*>(xr + k);
-        ss = fmaf(v.x, v.x, ss); ss = fmaf(v.y, v.y, ss); ss = fmaf(v.z, v.z, ss); ss = fmaf(v.w, v.w, ss);
-    }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) ss += __shfl_xor(ss, off, 64);
-    if (lane == 0) red[wave] = ss;
-    __syncthreads();
-    const float r = 1.0f / sqrtf((((red[0] + red[1]) + red[2]) + red[3]) / (float)K + eps);
-    for (int k = threadIdx.x * 4; k < K; k += 1024) {
-        const float4 v = *reinterpret_cast<const float4*>(xr + k);
-        const float4 g = gamma ? *reinterpret_cast<const float4*>(gamma + k) : make_float4(1.f, 1.f, 1.f, 1.f);
-        float y[4];
-        if (gamma) { y[0] = g.x * (v.x * r); y[1] = g.y * (v.y * r); y[2] = g.z * (v.z * r); y[3] = g.w * (v.w * r); }
-        else { y[0] = v.x; y[1] = v.y; y[2] = v.z; y[3] = v.w; }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) split_store(y[j], oh + (size_t)m * ldp + k + j, ol + (size_t)m * ldp + k + j);
-        if (xn_out) *reinterpret_cast<float4*>(xn_out + (size_t)m * ld_xn + k) = make_float4(y[0], y[1], y[2], y[3]);
-    }
-}
-void launch_rmsnorm_split(const float* x, int ldx, const float* gamma, float eps, int rows, int K,
-                          bf16_t* oh, bf16_t* ol, int ldp, float* xn_out, int ld_xn, hipStream_t s) {
-    if (K % 4) throw Error("rmsnorm_split: K must be a multiple of 4");
-    if (rows > 0) hipLaunchKernelGGL(k_rmsnorm_split, dim3(rows), dim3(256), 0, s, x, ldx, gamma, eps, K, oh, ol, ldp, xn_out, ld_xn);
-}
-
 
 // ================================================================================================
 // k_gemm2 — second-generation batched-decode GEMM.  Workgroup = (n-group of NW*16 columns, K slice):
