@@ -47,6 +47,53 @@ def algorithmic_step_bytes(cfg, batch, avg_ctx):
     return w + kv
 
 
+CODEC_GFLOP_PER_FRAME = 5.0     # SURVEY.md section 8d / DESIGN.md section 4
+MFMA_16BIT_DENSE_TFLOPS = 2500.0
+
+
+def stage_report(eng, q3tts, cfg, toks, sp, B, F, ctr):
+    """north_star: achieved fraction of the HBM / MFMA roofline per stage.  Arms the B slots again, advances them to mid-utterance with
+    graph replays, then runs 16 EAGER steps with HIP events at the stage boundaries (q3tts_stage_profile); eager launches carry a
+    little more launch gap than the graph replay the headline times.  Codec numbers come from the timed region's counters."""
+    H, Hc = cfg.hidden, cfg.cp_hidden or cfg.hidden
+
+    def layer(Hw, nq, nkv, d, ffn):
+        return 2.0 * (Hw * (nq + 2 * nkv) * d + Hw * nq * d + 3 * Hw * ffn)
+    for b in range(B):
+        eng.slot_release(b)
+    t0 = time.perf_counter()
+    for b in range(B):
+        p, tr = eng.build_prompt(toks[b], 0)
+        eng.slot_begin(b, p, tr, sp, seed=5, stream_id=b, ignore_eos=True)
+    prefill_ms = (time.perf_counter() - t0) * 1e3 / B
+    mid = max(1, min(F // 2, F - 20))
+    eng.decode_steps(mid)
+    st = eng.stage_profile(16)
+    ctx = 9 + mid + 8
+    talker_bytes = cfg.n_layers * layer(H, cfg.n_heads, cfg.n_kv_heads, cfg.head_dim, cfg.ffn) + 2.0 * H * cfg.vocab \
+        + B * ctx * cfg.n_layers * 2.0 * cfg.n_kv_heads * cfg.head_dim * 2.0
+    pred_bytes = (cfg.n_groups - 1) * (cfg.cp_layers * layer(Hc, cfg.cp_heads, cfg.cp_kv_heads, cfg.cp_head_dim, cfg.cp_ffn)
+                                       + 2.0 * Hc * cfg.sub_vocab + (2.0 * H * Hc if Hc != H else 0.0))
+    for b in range(B):
+        eng.slot_release(b)
+
+    def hbm(ms, nbytes):
+        gbs = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        return {"ms_per_step": round(ms, 4), "algorithmic_bytes": int(nbytes), "GB/s": round(gbs, 1), "frac_hbm": round(gbs / HBM_PEAK_GBS, 4)}
+    codec_ms = ctr["codec_ms"] / max(ctr["codec_frames"], 1)
+    tf = CODEC_GFLOP_PER_FRAME * 1e9 / (codec_ms * 1e-3) / 1e12 if codec_ms > 0 else 0.0
+    return {
+        "talker_decode": dict(hbm(st["talker_decode_ms"], talker_bytes), context=ctx),
+        "code_predictor": hbm(st["code_predictor_ms"], pred_bytes),
+        "sampler": {"ms_per_step": round(st["sampler_ms"], 4), "launches_per_step": cfg.n_groups, "bound": "latency"},
+        "codec_decode": {"ms_per_frame": round(codec_ms, 5), "GFLOP_per_frame": CODEC_GFLOP_PER_FRAME, "TFLOP/s": round(tf, 1),
+                         "frac_mfma_16bit_dense": round(tf / MFMA_16BIT_DENSE_TFLOPS, 4),
+                         "note": "fp32 products as 3 fp16 MFMA passes: matrix-core issue is 3x the algorithmic rate"},
+        "prompt_and_prefill": {"ms_per_utterance_wall": round(prefill_ms, 3), "note": "host prompt assembly (text_project calls) + talker prefill"},
+        "eager_step_ms": round(st["step_ms"], 4),
+    }
+
+
 def cpu_baseline(eng, cfg, ids, sp_kwargs, frames):
     """Times the CPU oracle (oracle/, fp32, OpenMP) on a bounded sample of the same workload: prompt
     assembly + prefill + `frames` frames in the REFERENCE's call pattern (predictor re-run without a
@@ -161,6 +208,13 @@ def main():
             ts.append((time.perf_counter() - t1) * 1e3)
         first_audio = round(min(ts), 2)
 
+    stages = None
+    if world == 1 and dist is None and not args.no_graph:
+        try:
+            stages = stage_report(eng, q3tts, cfg, toks, sp, B, F, ctr)
+        except Exception as ex:   # a reported extra, never the measurement
+            stages = {"error": str(ex)}
+
     if rank == 0:
         step_ms = ctr["decode_ms"] / max(ctr["decode_steps"], 1)
         abytes = algorithmic_step_bytes(cfg, B, 8 + F / 2.0)
@@ -196,6 +250,8 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "algorithmic_bytes_per_launch": int(abytes), "launch_ms": round(step_ms, 4)},
         }
+        if stages is not None:
+            out["stages"] = stages
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(eng, cfg, toks[0], sp_kwargs, args.cpu_frames)

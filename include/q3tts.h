@@ -191,6 +191,10 @@ int q3tts_last_codec_ms(q3tts_engine* e, float* ms);
 /* accumulated device time since the last reset: decode steps (HIP events around the graph
  * replays, on the engine's stream) and codec decodes */
 int q3tts_counters(q3tts_engine* e, double* decode_ms, int64_t* decode_steps, double* codec_ms, int64_t* codec_frames, int reset);
+/* Per-stage device time of the decode step: runs n_steps EAGER steps of the armed slots (they advance like q3tts_decode_steps) with HIP
+ * events at the stage boundaries.  out_ms[0] sampler (n_groups launches), [1] code predictor (layer passes + heads; predict_subcodes,
+ * tts_onnx.cpp:851-872), [2] talker decode (layers + codec head; run_decode :667-732), [3] their sum — milliseconds per step. */
+int q3tts_stage_profile(q3tts_engine* e, int n_steps, double* out_ms /* [4] */);
 /* algorithmic bytes one decode step streams (weights + KV at the slots' current contexts) */
 int q3tts_decode_step_bytes(q3tts_engine* e, double* weight_bytes, double* kv_bytes);
 

@@ -333,6 +333,13 @@ int q3tts_counters(q3tts_engine* h, double* dms, int64_t* dsteps, double* cms, i
     return 0;
     Q3_API_END(h)
 }
+int q3tts_stage_profile(q3tts_engine* h, int n_steps, double* out_ms) {
+    Q3_API_BEGIN(h)
+    if (!out_ms) throw q3::Error("stage_profile: null output");
+    h->e->stage_profile(n_steps, out_ms);
+    return 0;
+    Q3_API_END(h)
+}
 int q3tts_decode_step_bytes(q3tts_engine* h, double* wb, double* kvb) {
     Q3_API_BEGIN(h) h->e->step_bytes(wb, kvb); return 0; Q3_API_END(h)
 }

@@ -33,7 +33,8 @@ struct CodecW {
     struct Planes { bf16_t* hi; bf16_t* lo; float scale_inv; };
     std::unordered_map<const float*, Planes> planes;
     // run-time workspace: one bump arena per codec stream (lane 0 = the engine's own stream)
-    static constexpr int NLANE = 8;
+    static constexpr int NLANE = 32;   // capacity; `nlane` of them are used (Q3TTS_CODEC_LANES, default 8)
+    int nlane = 8;
     char* arena[NLANE] = {}; size_t arena_bytes[NLANE] = {};
     hipStream_t lane_stream[NLANE] = {};
     float* pinned[NLANE] = {}; size_t pinned_floats[NLANE] = {};
@@ -141,6 +142,7 @@ void Engine::codec_finalize() {
         pc(W.conv_in);
         for (const CodecW::Block& B : W.blocks) { pc(B.tconv); for (int u = 0; u < 3; ++u) { pc(B.res[u].c1); pc(B.res[u].c2); } }
     }
+    if (const char* ev = getenv("Q3TTS_CODEC_LANES")) W.nlane = std::max(1, std::min((int)CodecW::NLANE, atoi(ev)));
     W.lane_stream[0] = stream;
     for (int i = 1; i < CodecW::NLANE; ++i) {
         if (null_stream) W.lane_stream[i] = nullptr;
@@ -321,9 +323,9 @@ void Engine::codec_decode_slots(int nb, float* const* pcm_out, int64_t cap, int6
     hipEvent_t e0, e1;
     Q3_HIP_CHECK(hipEventCreate(&e0)); Q3_HIP_CHECK(hipEventCreate(&e1));
     Q3_HIP_CHECK(hipEventRecord(e0, stream));
-    for (int i = 1; i < CodecW::NLANE; ++i) Q3_HIP_CHECK(hipStreamWaitEvent(W.lane_stream[i], e0, 0));
-    std::vector<int> pending(CodecW::NLANE, -1);
-    std::vector<int64_t> pending_n(CodecW::NLANE, 0);
+    for (int i = 1; i < W.nlane; ++i) Q3_HIP_CHECK(hipStreamWaitEvent(W.lane_stream[i], e0, 0));
+    std::vector<int> pending(W.nlane, -1);
+    std::vector<int64_t> pending_n(W.nlane, 0);
     auto drain = [&](int lane) {
         if (pending[lane] < 0) return;
         Q3_HIP_CHECK(hipStreamSynchronize(W.lane_stream[lane]));
@@ -334,7 +336,7 @@ void Engine::codec_decode_slots(int nb, float* const* pcm_out, int64_t cap, int6
     };
     int64_t frames = 0;
     for (int b = 0; b < nb; ++b) {
-        const int lane = b % CodecW::NLANE;
+        const int lane = b % W.nlane;
         drain(lane);
         const int nf = st[b].n_frames;
         if (lens) lens[b] = 0;
@@ -352,8 +354,8 @@ void Engine::codec_decode_slots(int nb, float* const* pcm_out, int64_t cap, int6
         if (m > 0) Q3_HIP_CHECK(hipMemcpyAsync(W.pinned[lane], pcm_d, (size_t)m * sizeof(float), hipMemcpyDeviceToHost, W.lane_stream[lane]));
         pending[lane] = b; pending_n[lane] = n;
     }
-    for (int i = 0; i < CodecW::NLANE; ++i) drain(i);
-    for (int i = 1; i < CodecW::NLANE; ++i) { Q3_HIP_CHECK(hipEventRecord(e1, W.lane_stream[i])); Q3_HIP_CHECK(hipStreamWaitEvent(stream, e1, 0)); }
+    for (int i = 0; i < W.nlane; ++i) drain(i);
+    for (int i = 1; i < W.nlane; ++i) { Q3_HIP_CHECK(hipEventRecord(e1, W.lane_stream[i])); Q3_HIP_CHECK(hipStreamWaitEvent(stream, e1, 0)); }
     Q3_HIP_CHECK(hipEventRecord(e1, stream));
     sync();
     float ms = 0.f;

@@ -668,7 +668,12 @@ void Engine::record_step(int nb) {
     s0.group = 0; s0.n_groups = G; s0.st = st_d; s0.embed = codec_embed_w; s0.H = H;
     s0.x_next = x_cp + H; s0.ld_xnext = 2 * H; s0.sum = sum; s0.x_talk = x_talk; s0.trailing = trailing_d; s0.max_trailing = max_trailing;
     s0.tts_pad = tts_pad_d; s0.codes = codes_d; s0.max_frames_cap = max_frames_cap; s0.talker_pos = talker_pos_d;
+    // stage_profile(): events between the stages of the step (eager launches only)
+    size_t mk = 0;
+    auto mark = [&]() { if (!stage_ev.empty()) Q3_HIP_CHECK(hipEventRecord(stage_ev[mk++], stream)); };
+    mark();
     launch_sample(s0, stream);                                  // code0 (tts_onnx.cpp:803-812)
+    mark();
     for (int j = 0; j < G - 1; ++j) {                           // predict_subcodes (:851-872), KV-cached
         // pass 0: rows [last_hidden, embed(code0)] of every utterance; later passes: the embedding of the code just sampled
         float* xin = j == 0 ? cp_project(x_cp, H, nb * 2) : cp_project(x_cp1, H, nb);
@@ -678,13 +683,46 @@ void Engine::record_step(int nb) {
         // head j on the last row of every utterance (pass 0 holds two rows per utterance: planes row b*2+1)
         head_proj(cp_head[j], j == 0 ? xin + Hc : xin, j == 0 ? 2 * Hc : Hc, cp_norm, c.cp_rms_eps, nullptr, 0, logits_cp, SV, nb, SV, Hc, false,
                   pr, j == 0 ? 1 : 0, j == 0 ? 2 : 1);
+        mark();
         SampleArgs s = s0;
         s.logits = logits_cp; s.ld = SV; s.V = SV; s.group = j + 1; s.embed = cp_embed_w[j];
         s.x_next = j + 1 < G - 1 ? x_cp1 : nullptr; s.ld_xnext = H;
         launch_sample(s, stream);
+        mark();
     }
     const bool pr = run_layers(talker, x_talk, H, nb, 1, 0, talker_pos_d, 0, talker_norm, c.rms_eps, x_cp, 2 * H);  // run_decode (:845)
     head_proj(codec_head, x_talk, H, talker_norm, c.rms_eps, x_cp, 2 * H, logits_t, V, nb, V, H, true, pr);
+    mark();
+}
+
+// Per-stage device time of the decode step (north_star: "achieved fraction of roofline reported per stage"): n_steps eager steps of the
+// armed slots with HIP events at the stage boundaries.  out[0] sampler (n_groups launches), out[1] code predictor (layer passes + heads),
+// out[2] talker decode (layers + codec head), out[3] the whole step — milliseconds per step.  Eager launches carry a little more launch
+// gap than the hipGraph replay bench.py times, so out[3] reads slightly above decode_ms_per_frame_step.
+void Engine::stage_profile(int n_steps, double* out) {
+    if (!finalized) throw Error("weights not finalized");
+    const int nb = nb_in_use(), G = c.n_groups;
+    if (nb == 0 || n_steps < 1) throw Error("stage_profile: no armed slot");
+    const size_t n_marks = 2 + 2 * (size_t)(G - 1) + 1;   // before/after sample0, after each {predictor pass, its sample}, after the talker
+    stage_ev.resize(n_marks);
+    for (auto& e : stage_ev) Q3_HIP_CHECK(hipEventCreate(&e));
+    double acc[3] = { 0.0, 0.0, 0.0 };
+    try {
+        for (int i = 0; i < n_steps; ++i) {
+            record_step(nb);
+            sync();
+            for (size_t k = 0; k + 1 < n_marks; ++k) {
+                float ms = 0.f;
+                Q3_HIP_CHECK(hipEventElapsedTime(&ms, stage_ev[k], stage_ev[k + 1]));
+                const int kind = k + 2 == n_marks ? 2 : (k % 2 == 0 ? 0 : 1);   // S, (P, S) x (G-1), T
+                acc[kind] += ms;
+            }
+        }
+    } catch (...) { for (auto& e : stage_ev) (void)hipEventDestroy(e); stage_ev.clear(); throw; }
+    for (auto& e : stage_ev) (void)hipEventDestroy(e);
+    stage_ev.clear();
+    for (int k = 0; k < 3; ++k) out[k] = acc[k] / n_steps;
+    out[3] = out[0] + out[1] + out[2];
 }
 
 int Engine::nb_in_use() const {

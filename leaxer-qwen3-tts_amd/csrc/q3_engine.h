@@ -92,6 +92,8 @@ public:
     int64_t slot_codec_decode(int slot, float* pcm, int64_t cap);
     void slot_release(int slot);
     void step_bytes(double* wbytes, double* kvbytes);
+    void stage_profile(int n_steps, double* out_ms4);   // eager steps with events at the stage boundaries (diagnostic)
+    std::vector<hipEvent_t> stage_ev;
 
     float last_decode_ms = 0.f;
     int last_decode_steps = 0;

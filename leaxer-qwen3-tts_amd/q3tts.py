@@ -80,7 +80,7 @@ EXPORTS = [
     "q3tts_sample_host", "q3tts_rng_uniform", "q3tts_build_prompt_host", "q3tts_slot_begin", "q3tts_decode_steps",
     "q3tts_slot_status", "q3tts_slot_codes_host", "q3tts_slot_codec_decode_host", "q3tts_slot_release",
     "q3tts_synthesize_batch_host", "q3tts_last_decode_ms", "q3tts_last_codec_ms", "q3tts_decode_step_bytes",
-    "q3tts_counters", "q3tts_read_weights_config", "q3tts_load_weights_file", "q3tts_save_weights_file",
+    "q3tts_counters", "q3tts_stage_profile", "q3tts_read_weights_config", "q3tts_load_weights_file", "q3tts_save_weights_file",
     "q3tts_tokenizer_create", "q3tts_tokenizer_destroy", "q3tts_tokenizer_load_vocab", "q3tts_tokenizer_load_merges",
     "q3tts_tokenizer_ready", "q3tts_tokenize",
     "q3tts_synthesize_clone_batch_host", "q3tts_read_wav_host", "q3tts_resample_host", "q3tts_mel_host",
@@ -135,6 +135,7 @@ def lib():
                                               vp, i64, vp, vp, vp]
     L.q3tts_last_decode_ms.argtypes = [vp, C.POINTER(f32), C.POINTER(i32)]
     L.q3tts_last_codec_ms.argtypes = [vp, C.POINTER(f32)]
+    L.q3tts_stage_profile.argtypes = [vp, i32, C.POINTER(C.c_double)]
     L.q3tts_counters.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(C.c_double), C.POINTER(i64), i32]
     L.q3tts_decode_step_bytes.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.q3tts_read_weights_config.argtypes = [C.c_char_p, C.POINTER(Config)]
@@ -425,6 +426,12 @@ class Engine:
         ds, cf = C.c_int64(0), C.c_int64(0)
         self._ck(self.L.q3tts_counters(self.h, C.byref(dms), C.byref(ds), C.byref(cms), C.byref(cf), int(reset)))
         return dict(decode_ms=dms.value, decode_steps=ds.value, codec_ms=cms.value, codec_frames=cf.value)
+
+    def stage_profile(self, n_steps=32):
+        """ms per step of {sampler, code predictor, talker decode, sum}: eager steps with events at the stage boundaries."""
+        out = (C.c_double * 4)()
+        self._ck(self.L.q3tts_stage_profile(self.h, int(n_steps), out))
+        return dict(sampler_ms=out[0], code_predictor_ms=out[1], talker_decode_ms=out[2], step_ms=out[3])
 
     def decode_step_bytes(self):
         w, kv = C.c_double(0), C.c_double(0)

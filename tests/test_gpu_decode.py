@@ -197,3 +197,27 @@ def test_long_context_crosses_attention_splits():
     assert first_bad.size == 0, ("first diverging frame", int(first_bad[0]))
     eng.close()
     orc.close()
+
+
+def test_stage_profile_steps_are_real_steps():
+    """q3tts_stage_profile advances the armed slots with eager launches and events between the stages: the frames it produces are the
+    same frames, and the three stage times add up to its step time."""
+    import q3tts
+    eng, orc, _ = tiny_pair(seed=15, max_batch=2, max_ctx=96)
+    sp = q3tts.Sampling(temperature=0.8, top_p=0.95, top_k=50, max_new_tokens=12)
+    toks = [frame_tokens([3, 1, 4, 1, 5]), frame_tokens([9, 2, 6])]
+    for b, t in enumerate(toks):
+        p, tr = eng.build_prompt(t, 0)
+        eng.slot_begin(b, p, tr, sp, seed=8, stream_id=b, ignore_eos=True)
+    eng.decode_steps(3)
+    st = eng.stage_profile(5)
+    assert st["sampler_ms"] > 0 and st["code_predictor_ms"] > 0 and st["talker_decode_ms"] > 0
+    assert abs(st["step_ms"] - (st["sampler_ms"] + st["code_predictor_ms"] + st["talker_decode_ms"])) < 1e-9
+    assert eng.decode_steps(4) == 0
+    for b, t in enumerate(toks):
+        ref = orc.generate(orc.build_prompt(t, 0), to_osampling(sp), seed=8, stream=b, cp_cached=True, ignore_eos=True)
+        assert np.array_equal(eng.slot_codes(b), ref), b
+    with pytest.raises(RuntimeError, match="no armed slot"):
+        eng.slot_release(0), eng.slot_release(1), eng.stage_profile(1)
+    eng.close()
+    orc.close()
