@@ -69,6 +69,10 @@ void q3tts_destroy(q3tts_engine* e);
 const char* q3tts_last_error(q3tts_engine* e); /* e may be NULL: error of the last failed create */
 
 /* ---- weights: tensors by name (names = the oracle's / DESIGN.md section 3) ---- */
+/* The registry a config implies, without an engine (host-only, no GPU needed): what a checkpoint converter must provide.
+ * kind: 0 matrix / conv weight, 1 norm weight, 2 bias, 3 LayerScale / gamma, 4 SnakeBeta alpha / beta. */
+int q3tts_config_num_tensors(const q3tts_config* cfg);
+int q3tts_config_tensor_info(const q3tts_config* cfg, int index, char* name, int name_cap, int64_t* shape4, int* ndim, int* kind);
 int q3tts_num_tensors(q3tts_engine* e);
 int q3tts_tensor_info(q3tts_engine* e, int index, char* name, int name_cap, int64_t* shape4, int* ndim);
 int q3tts_set_tensor_host(q3tts_engine* e, const char* name, const float* data, int64_t numel);

@@ -55,6 +55,24 @@ int q3tts_default_config(const char* name, q3tts_config* o) {
     return 0;
 }
 
+int q3tts_config_num_tensors(const q3tts_config* cfg) {
+    if (!cfg) return -1;
+    try { return (int)q3::tensor_specs(*cfg).size(); } catch (...) { return -1; }
+}
+int q3tts_config_tensor_info(const q3tts_config* cfg, int index, char* name, int name_cap, int64_t* shape4, int* ndim, int* kind) {
+    if (!cfg) return -1;
+    try {
+        const std::vector<q3::TensorSpec> specs = q3::tensor_specs(*cfg);
+        if (index < 0 || index >= (int)specs.size()) return -1;
+        const q3::TensorSpec& t = specs[index];
+        if (name && name_cap > 0) { snprintf(name, (size_t)name_cap, "%s", t.name.c_str()); }
+        if (shape4) for (int i = 0; i < 4; ++i) shape4[i] = t.shape[i];
+        if (ndim) *ndim = t.ndim;
+        if (kind) *kind = t.kind;
+        return 0;
+    } catch (...) { return -1; }
+}
+
 q3tts_engine* q3tts_create(const q3tts_config* cfg, int device, int max_batch, int max_ctx, uint32_t flags) {
     if (!cfg) { g_create_err = "null config"; return nullptr; }
     try {

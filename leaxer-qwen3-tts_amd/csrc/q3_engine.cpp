@@ -44,43 +44,27 @@ Tensor& Engine::T(const std::string& n) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// construction: tensor registry (names/shapes shared with the oracle and DESIGN.md section 3)
+// tensor registry (names/shapes shared with the oracle and DESIGN.md section 3) — host-only, no HIP call: the importer and
+// q3tts_config_tensor_info walk it without a GPU; the engine allocates from it.
 // ------------------------------------------------------------------------------------------------
-Engine::Engine(const q3tts_config& cfg, int device_, int max_batch, int max_ctx_, uint32_t flags_)
-    : c(cfg), device(device_), B(max_batch), max_ctx(max_ctx_), flags(flags_) {
-    if (B < 1 || B > 1024) throw Error("max_batch out of range");
-    if (c.cp_hidden < 0) throw Error("cp_hidden must be >= 0");
-    if (c.cp_hidden == c.hidden) c.cp_hidden = 0;
-    if (c.hidden % 8 || c.ffn % 8 || c.text_hidden % 8 || c.cp_ffn % 8 || cp_width() % 8) throw Error("hidden/ffn sizes must be multiples of 8");
-    if (c.vocab > 4096 || c.sub_vocab > 4096) throw Error("codec vocabularies larger than 4096 are not supported");
-    if (c.n_groups < 2 || c.n_groups > 32) throw Error("n_groups out of range");
-    Q3_HIP_CHECK(hipSetDevice(device));
-    // Q3TTS_NULL_STREAM=1 (profiling aid): rocprofv3 --pmc crashes on user-created streams on this ROCm; run on the
-    // default stream instead (forces eager launches: the default stream cannot be captured)
-    if (const char* mr = getenv("Q3TTS_MFMA_MIN_ROWS")) mfma_min_rows = std::max(3, atoi(mr));   // A/B knob for the GEMV <-> GEMM crossover
-    null_stream = getenv("Q3TTS_NULL_STREAM") && getenv("Q3TTS_NULL_STREAM")[0] == '1';
-    if (null_stream) { stream = nullptr; flags |= Q3TTS_FLAG_NO_GRAPH; }
-    else Q3_HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-    Q3_HIP_CHECK(hipEventCreate(&ev0));
-    Q3_HIP_CHECK(hipEventCreate(&ev1));
-
-    auto add = [&](const std::string& name, std::vector<int64_t> shape, int kind, bool bf, void* dev = nullptr, float sstd = 0.02f) {
-        Tensor t;
-        t.name = name; t.ndim = (int)shape.size(); t.kind = kind; t.bf16 = bf; t.numel = 1; t.synth_std = sstd;
-        for (int i = 0; i < t.ndim; ++i) { t.shape[i] = shape[i]; t.numel *= shape[i]; }
-        t.dev = dev ? dev : dmalloc((size_t)t.numel * (bf ? 2 : 4));
-        tindex[name] = (int)tensors.size();
-        tensors.push_back(t);
+std::vector<TensorSpec> tensor_specs(const q3tts_config& c) {
+    std::vector<TensorSpec> out;
+    // counts that index fixed arrays or drive loops: an out-of-range config has no registry (callers report it)
+    if (c.n_layers < 0 || c.n_layers > 1024 || c.cp_layers < 0 || c.cp_layers > 1024 || c.cd_layers < 0 || c.cd_layers > 1024 ||
+        c.n_groups < 2 || c.n_groups > 32 || c.cd_n_up < 0 || c.cd_n_up > 4 || c.cd_n_blocks < 0 || c.cd_n_blocks > 8 || c.spk_scale > 64) return out;
+    auto add = [&](const std::string& name, std::vector<int64_t> shape, int kind, bool bf, int fuse = 0, float sstd = 0.02f) {
+        TensorSpec t;
+        t.name = name; t.ndim = (int)shape.size(); t.kind = kind; t.bf16 = bf; t.fuse = fuse; t.synth_std = sstd;
+        for (int i = 0; i < t.ndim; ++i) t.shape[i] = shape[i];
+        out.push_back(t);
     };
     auto add_layers = [&](const std::string& prefix, int n, int H, int nq, int nkv, int d, int ffn, bool qk, bool ls, bool bf) {
-        const size_t es = bf ? 2 : 4;
         for (int i = 0; i < n; ++i) {
             const std::string p = prefix + ".layers." + std::to_string(i) + ".";
             add(p + "input_norm", {H}, TK_NORM, false);
-            char* fused = (char*)dmalloc((size_t)(nq + 2 * nkv) * d * H * es); // q|k|v rows contiguous: one GEMV
-            add(p + "q_proj", {(int64_t)nq * d, H}, TK_W, bf, fused);
-            add(p + "k_proj", {(int64_t)nkv * d, H}, TK_W, bf, fused + (size_t)nq * d * H * es);
-            add(p + "v_proj", {(int64_t)nkv * d, H}, TK_W, bf, fused + (size_t)(nq + nkv) * d * H * es);
+            add(p + "q_proj", {(int64_t)nq * d, H}, TK_W, bf, 1);   // q | k | v rows contiguous in HBM: one GEMV
+            add(p + "k_proj", {(int64_t)nkv * d, H}, TK_W, bf, 2);
+            add(p + "v_proj", {(int64_t)nkv * d, H}, TK_W, bf, 3);
             add(p + "o_proj", {H, (int64_t)nq * d}, TK_W, bf);
             if (qk) { add(p + "q_norm", {d}, TK_NORM, false); add(p + "k_norm", {d}, TK_NORM, false); }
             add(p + "post_norm", {H}, TK_NORM, false);
@@ -101,10 +85,10 @@ Engine::Engine(const q3tts_config& cfg, int device_, int max_batch, int max_ctx_
     add("text.fc2.w", {H, c.text_hidden}, TK_W, true);
     add("text.fc2.b", {H}, TK_BIAS, false);
     // predictor width: the talker's (0.6B) or narrower behind cp.proj (1.7B: 2048 -> 1024); its embeddings stay talker-wide
-    const int Hc = cp_width();
+    const int Hc = c.cp_hidden > 0 ? c.cp_hidden : c.hidden;
     add_layers("cp", c.cp_layers, Hc, c.cp_heads, c.cp_kv_heads, c.cp_head_dim, c.cp_ffn, true, false, true);
     add("cp.norm", {Hc}, TK_NORM, false);
-    if (cp_projected()) { add("cp.proj.w", {Hc, H}, TK_W, true); add("cp.proj.b", {Hc}, TK_BIAS, false); }
+    if (Hc != H) { add("cp.proj.w", {Hc, H}, TK_W, true); add("cp.proj.b", {Hc}, TK_BIAS, false); }
     for (int j = 0; j < c.n_groups - 1; ++j) add("cp.head." + std::to_string(j), {c.sub_vocab, Hc}, TK_W, true);
     for (int j = 0; j < c.n_groups - 1; ++j) add("cp.embed." + std::to_string(j), {c.sub_vocab, H}, TK_W, true);
     const int CH = c.cd_hidden;
@@ -151,14 +135,13 @@ Engine::Engine(const q3tts_config& cfg, int device_, int max_batch, int max_ctx_
     const int OD = D >> c.cd_n_blocks;
     add("cd.dec.snake_out.alpha", {OD}, TK_SNAKE, false);
     add("cd.dec.snake_out.beta", {OD}, TK_SNAKE, false);
-    add("cd.dec.conv_out.w", {1, OD, 7}, TK_W, false, nullptr, 0.002f);
+    add("cd.dec.conv_out.w", {1, OD, 7}, TK_W, false, 0, 0.002f);
     add("cd.dec.conv_out.b", {1}, TK_BIAS, false);
     if (c.spk_enc_dim > 0) { // ECAPA-TDNN speaker encoder (clone path), torch Conv1d layout [out][in][k], fp32
-        if (c.spk_scale < 2 || c.spk_scale > 16 || c.spk_channels % c.spk_scale || c.spk_mel < 1 || c.spk_se < 1 || c.spk_att < 1)
-            throw Error("speaker encoder dims out of range");
+        if (c.spk_scale < 1 || c.spk_channels < 1) return out;   // malformed: the engine constructor reports it
         const int SC = c.spk_channels, sub = SC / c.spk_scale;
         auto conv = [&](const std::string& n, int cout, int cin, int k) {
-            add(n + ".w", {cout, cin, k}, TK_W, false, nullptr, 1.0f / sqrtf((float)(cin * k)));
+            add(n + ".w", {cout, cin, k}, TK_W, false, 0, 1.0f / sqrtf((float)(cin * k)));
             add(n + ".b", {cout}, TK_BIAS, false);
         };
         conv("spk.tdnn0", SC, c.spk_mel, 5);
@@ -175,6 +158,58 @@ Engine::Engine(const q3tts_config& cfg, int device_, int max_batch, int max_ctx_
         conv("spk.asp.conv", 3 * SC, c.spk_att, 1);
         conv("spk.fc", c.spk_enc_dim, 6 * SC, 1);
     }
+    return out;
+}
+
+// ------------------------------------------------------------------------------------------------
+// construction
+// ------------------------------------------------------------------------------------------------
+Engine::Engine(const q3tts_config& cfg, int device_, int max_batch, int max_ctx_, uint32_t flags_)
+    : c(cfg), device(device_), B(max_batch), max_ctx(max_ctx_), flags(flags_) {
+    if (B < 1 || B > 1024) throw Error("max_batch out of range");
+    if (c.cp_hidden < 0) throw Error("cp_hidden must be >= 0");
+    if (c.cp_hidden == c.hidden) c.cp_hidden = 0;
+    if (c.hidden % 8 || c.ffn % 8 || c.text_hidden % 8 || c.cp_ffn % 8 || cp_width() % 8) throw Error("hidden/ffn sizes must be multiples of 8");
+    if (c.vocab > 4096 || c.sub_vocab > 4096) throw Error("codec vocabularies larger than 4096 are not supported");
+    if (c.n_groups < 2 || c.n_groups > 32) throw Error("n_groups out of range");
+    Q3_HIP_CHECK(hipSetDevice(device));
+    // Q3TTS_NULL_STREAM=1 (profiling aid): rocprofv3 --pmc crashes on user-created streams on this ROCm; run on the
+    // default stream instead (forces eager launches: the default stream cannot be captured)
+    if (const char* mr = getenv("Q3TTS_MFMA_MIN_ROWS")) mfma_min_rows = std::max(3, atoi(mr));   // A/B knob for the GEMV <-> GEMM crossover
+    null_stream = getenv("Q3TTS_NULL_STREAM") && getenv("Q3TTS_NULL_STREAM")[0] == '1';
+    if (null_stream) { stream = nullptr; flags |= Q3TTS_FLAG_NO_GRAPH; }
+    else Q3_HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    Q3_HIP_CHECK(hipEventCreate(&ev0));
+    Q3_HIP_CHECK(hipEventCreate(&ev1));
+
+    if (c.spk_enc_dim > 0 && (c.spk_scale < 2 || c.spk_scale > 16 || c.spk_channels % c.spk_scale || c.spk_mel < 1 || c.spk_se < 1 || c.spk_att < 1))
+        throw Error("speaker encoder dims out of range");
+    {   // allocate the registry (q | k | v of a layer share one block so that their rows are contiguous)
+        char* fused = nullptr; size_t fused_off = 0;
+        const std::vector<TensorSpec> specs = tensor_specs(c);
+        if (specs.empty()) throw Error("model config out of range (layer / group / block counts)");
+        for (size_t i = 0; i < specs.size(); ++i) {
+            const TensorSpec& sp = specs[i];
+            Tensor t;
+            t.name = sp.name; t.ndim = sp.ndim; t.kind = sp.kind; t.bf16 = sp.bf16; t.synth_std = sp.synth_std; t.numel = 1;
+            for (int k = 0; k < sp.ndim; ++k) { t.shape[k] = sp.shape[k]; t.numel *= sp.shape[k]; }
+            const size_t bytes = (size_t)t.numel * (sp.bf16 ? 2 : 4);
+            if (sp.fuse == 1) {
+                size_t total = bytes;
+                for (size_t k = i + 1; k < specs.size() && specs[k].fuse > 1; ++k) {
+                    size_t n = 1;
+                    for (int d = 0; d < specs[k].ndim; ++d) n *= (size_t)specs[k].shape[d];
+                    total += n * (specs[k].bf16 ? 2 : 4);
+                }
+                fused = (char*)dmalloc(total); fused_off = 0;
+            }
+            if (sp.fuse > 0) { t.dev = fused + fused_off; fused_off += bytes; }
+            else t.dev = dmalloc(bytes);
+            tindex[t.name] = (int)tensors.size();
+            tensors.push_back(t);
+        }
+    }
+    const int H = c.hidden, Hc = cp_width();
 
     // ---- workspaces ----
     rows_max = std::max(2 * B, 16);

@@ -22,6 +22,16 @@ struct Tensor {
     float synth_std = 0.02f;
 };
 
+struct TensorSpec { // registry entry without storage
+    std::string name;
+    int64_t shape[4] = {0, 0, 0, 0};
+    int ndim = 0, kind = TK_W;
+    bool bf16 = false;
+    int fuse = 0;           // 1/2/3: q/k/v of a layer, allocated as one block
+    float synth_std = 0.02f;
+};
+std::vector<TensorSpec> tensor_specs(const q3tts_config& c); // host-only
+
 struct DecLayerW { // one decoder layer, bf16 matrices
     const float *in_norm = nullptr, *post_norm = nullptr, *q_norm = nullptr, *k_norm = nullptr;
     const bf16_t *qkv = nullptr, *o = nullptr, *gate = nullptr, *up = nullptr, *down = nullptr;

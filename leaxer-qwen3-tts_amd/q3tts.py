@@ -80,7 +80,7 @@ EXPORTS = [
     "q3tts_sample_host", "q3tts_rng_uniform", "q3tts_build_prompt_host", "q3tts_slot_begin", "q3tts_decode_steps",
     "q3tts_slot_status", "q3tts_slot_codes_host", "q3tts_slot_codec_decode_host", "q3tts_slot_release",
     "q3tts_synthesize_batch_host", "q3tts_last_decode_ms", "q3tts_last_codec_ms", "q3tts_decode_step_bytes",
-    "q3tts_counters", "q3tts_stage_profile", "q3tts_read_weights_config", "q3tts_load_weights_file", "q3tts_save_weights_file",
+    "q3tts_counters", "q3tts_stage_profile", "q3tts_config_num_tensors", "q3tts_config_tensor_info", "q3tts_read_weights_config", "q3tts_load_weights_file", "q3tts_save_weights_file",
     "q3tts_tokenizer_create", "q3tts_tokenizer_destroy", "q3tts_tokenizer_load_vocab", "q3tts_tokenizer_load_merges",
     "q3tts_tokenizer_ready", "q3tts_tokenize",
     "q3tts_synthesize_clone_batch_host", "q3tts_read_wav_host", "q3tts_resample_host", "q3tts_mel_host",
@@ -162,6 +162,25 @@ def lib():
     L.q3tts_tokenize.argtypes = [vp, C.c_char_p, i64, C.POINTER(C.c_int32), i64]
     _lib = L
     return L
+
+
+_KINDS = ("w", "norm", "b", "scale", "snake")
+
+
+def tensor_specs(cfg):
+    """(name, shape, kind) of every tensor the config implies — the engine's registry, from the library, no GPU needed."""
+    L = lib()
+    L.q3tts_config_num_tensors.argtypes = [C.c_void_p]
+    L.q3tts_config_tensor_info.argtypes = [C.c_void_p, C.c_int32, C.c_char_p, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    n = L.q3tts_config_num_tensors(C.byref(cfg))
+    if n <= 0:
+        raise ValueError("model config out of range")
+    out, name, shape, nd, kind = [], C.create_string_buffer(256), (C.c_int64 * 4)(), C.c_int32(0), C.c_int32(0)
+    for i in range(n):
+        if L.q3tts_config_tensor_info(C.byref(cfg), i, name, 256, shape, C.byref(nd), C.byref(kind)) != 0:
+            raise RuntimeError("q3tts_config_tensor_info failed")
+        out.append((name.value.decode(), tuple(int(shape[k]) for k in range(nd.value)), _KINDS[kind.value]))
+    return out
 
 
 def default_config(name="0.6b"):

@@ -87,3 +87,30 @@ def test_shape_mismatch_and_missing_are_errors(tmp_path):
     write_safetensors(p, {"talker.model.norm.weight": np.zeros(cfg.hidden, np.float32)})
     with pytest.raises(ValueError, match="not found"):
         import_checkpoint([p], cfg)
+
+
+def test_registry_from_the_library_equals_the_oracles():
+    """q3tts_config_tensor_info (host-only) lists the tensors the engine allocates; same names, shapes, kinds and order as the oracle's."""
+    sys.path.insert(0, os.path.join(ROOT, "leaxer-qwen3-tts_amd"))
+    import q3tts
+    for mk in (qo.config_tiny, qo.config_tiny_proj, qo.config_medium, qo.config_medium_proj, qo.config_06b, qo.config_17b):
+        oc = mk()
+        got = q3tts.tensor_specs(q3tts.Config.from_dict(oc.to_dict()))
+        want = [(n, tuple(s), k) for n, s, k in qo.tensor_specs(oc)]
+        assert got == want, mk.__name__
+    bad = q3tts.Config.from_dict(qo.config_tiny().to_dict())
+    bad.cd_n_blocks = 99
+    import pytest
+    with pytest.raises(ValueError, match="out of range"):
+        q3tts.tensor_specs(bad)
+
+
+def test_importer_does_not_touch_the_oracle(tmp_path):
+    """The converter is product code: it must work from the library alone (oracle/ is test infrastructure)."""
+    import subprocess
+    code = ("import sys, json; sys.path.insert(0, %r); import tools.import_safetensors as t; q = t._binding(); "
+            "c = q.default_config('1.7b'); n = len(q.tensor_specs(c)); "
+            "assert not any('oracle' in m for m in sys.modules), [m for m in sys.modules if 'oracle' in m]; print(n)") % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr
+    assert int(r.stdout.strip()) == 710

@@ -5,7 +5,7 @@
         [--map extra_rules.json] [--config 0.6b | 1.7b | cfg.json] [--allow-missing]
 
 The reference ships no converter: it consumes seven pre-exported .onnx graphs (src/tts_onnx.cpp:91-107).  This tool
-maps parameter NAMES onto the tensor registry shared by the engine and the oracle (q3_oracle.tensor_specs).  The
+maps parameter NAMES onto the engine's tensor registry (q3tts.tensor_specs = q3tts_config_tensor_info, host-only).  The
 rule tables below are the state_dict naming of the `transformers` modules the architecture was pinned against
 (Qwen3 decoder, Qwen3-Omni talker code predictor, Code2Wav, ECAPA_TimeDelayNet — tests/golden/hf_state_dict_keys.json
 holds the generated key list they were derived from).  Where each component sits inside a real Qwen3-TTS checkpoint
@@ -162,11 +162,17 @@ def map_names(names, prefixes=None, extra_rules=()):
     return out
 
 
+def _binding():
+    """The product's ctypes binding: configs and the tensor registry come from libq3tts_hip.so (host-only calls, no GPU needed)."""
+    sys.path.insert(0, os.path.join(ROOT, "leaxer-qwen3-tts_amd"))
+    import q3tts
+    return q3tts
+
+
 def import_checkpoint(paths, cfg, prefixes=None, extra_rules=(), allow_missing=False):
     """-> {registry name: float32 array} with shapes checked against tensor_specs(cfg)."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import q3_oracle as qo
-    specs = {n: tuple(s) for n, s, _ in qo.tensor_specs(cfg)}
+    q3tts = _binding()
+    specs = {n: tuple(s) for n, s, _ in q3tts.tensor_specs(cfg)}
     src = {}
     for p in paths:
         src.update(read_safetensors(p))
@@ -200,11 +206,9 @@ def main():
     ap.add_argument("--allow-missing", action="store_true")
     ap.add_argument("--list", action="store_true", help="print the checkpoint's tensor names with their mapping and exit")
     a = ap.parse_args()
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
     sys.path.insert(0, ROOT)
-    import q3_oracle as qo
-    named = {"0.6b": qo.config_06b, "1.7b": qo.config_17b}
-    cfg = named[a.config.lower()]() if a.config.lower() in named else qo.Config.from_dict(json.load(open(a.config)))
+    q3tts = _binding()
+    cfg = q3tts.default_config(a.config.lower()) if a.config.lower() in ("0.6b", "1.7b") else q3tts.Config.from_dict(json.load(open(a.config)))
     prefixes = dict(p.split("=", 1) for p in a.prefix)
     extra = [tuple(r) for r in json.load(open(a.map))] if a.map else []
     if a.list:

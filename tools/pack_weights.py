@@ -3,7 +3,7 @@
     from tools.pack_weights import write_q3w
     write_q3w("model/model.q3w", cfg, {"talker.layers.0.q_proj": np.ndarray, ...})
 
-Tensor names / shapes: q3_oracle.tensor_specs(cfg) (same registry as csrc/q3_engine.cpp).  Matrices of
+Tensor names / shapes: q3tts.tensor_specs(cfg) (q3tts_config_tensor_info: the registry of csrc/q3_engine.cpp).  Matrices of
 the talker / predictor / text stacks may be stored bf16 (dtype code 1), everything else fp32 (0).
 Converting a real checkpoint = mapping its parameter names onto this registry.
 """
@@ -21,7 +21,7 @@ def _bf16_bits(a):
 
 
 def write_q3w(path, cfg, tensors, bf16_prefixes=("talker.", "cp.", "text.")):
-    """cfg: a ctypes Config (q3tts.Config or q3_oracle.Config); tensors: dict name -> array."""
+    """cfg: a ctypes q3tts.Config; tensors: dict name -> array."""
     with open(path, "wb") as f:
         f.write(MAGIC)
         raw = bytes(ctypes.string_at(ctypes.addressof(cfg), ctypes.sizeof(cfg)))
