@@ -8,10 +8,13 @@ import sys
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-for p in ("leaxer-qwen3-tts_amd", "oracle", "tests"):
-    sys.path.insert(0, os.path.join(ROOT, p))
+sys.path.insert(0, os.path.join(ROOT, "leaxer-qwen3-tts_amd"))
 import q3tts  # noqa: E402
-from util import frame_tokens  # noqa: E402
+
+
+def frame_tokens(text_ids):   # token framing of TTSEngine::synthesize (reference src/tts_onnx.cpp:244-259)
+    return np.array([151644, 77091, 151672] + list(text_ids) + [151673, 151645], np.int64)
+
 
 L = C.CDLL(os.environ["Q3TTS_LIB"])
 
