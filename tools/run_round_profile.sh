@@ -37,3 +37,8 @@ ls gpurun_out/$TAG/pmc_fetch gpurun_out/$TAG/pmc_write
 python tools/pmc_traffic.py gpurun_out/$TAG/pmc_fetch/f_counter_collection.csv gpurun_out/$TAG/pmc_write/w_counter_collection.csv 12 1 > gpurun_out/$TAG/pmc_traffic_b1.json
 cat gpurun_out/$TAG/pmc_traffic_b1.json
 rm -rf gpurun_out/$TAG/pmc_fetch gpurun_out/$TAG/pmc_write
+# 5. matrix-core issue rate of the codec decoder from hardware counters (SQ_INSTS_VALU_MFMA_MOPS_*: FLOP / 512), default stream
+Q3TTS_NULL_STREAM=1 timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_VALU_MFMA_MOPS_F32 -d gpurun_out/$TAG/pmc_mfma -o m --output-format csv -- python tools/codec_bench.py --frames 2048 --reps 1 > gpurun_out/$TAG/pmc_mfma.log 2>&1
+python tools/pmc_mfma.py gpurun_out/$TAG/pmc_mfma/m_counter_collection.csv 4096 > gpurun_out/$TAG/pmc_mfma_codec.json
+cat gpurun_out/$TAG/pmc_mfma_codec.json
+rm -rf gpurun_out/$TAG/pmc_mfma
