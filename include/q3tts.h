@@ -106,6 +106,12 @@ int q3tts_code_predictor_host(q3tts_engine* e, const float* seq, int n, int gene
 /* run_vocoder, tts_onnx.cpp:759-776: codes[F][n_groups] (frame-major) -> pcm; *out_len = lengths[0] */
 int q3tts_codec_decode_host(q3tts_engine* e, const int64_t* codes, int F, float* pcm, int64_t cap, int64_t* out_len);
 int64_t q3tts_codec_decode_len(const q3tts_config* cfg, int F);
+/* the same with both ends in HBM: codes_dev int32 [F][n_groups] and pcm_dev float [cap] are DEVICE pointers on the engine's GPU (any
+ * allocator: hipMalloc, a torch tensor's data_ptr); values outside [0, codebook) are clamped.  Returns after the work has completed. */
+int q3tts_codec_decode_dev(q3tts_engine* e, const int32_t* codes_dev, int F, float* pcm_dev, int64_t cap, int64_t* out_len);
+/* the engine's HIP stream as an opaque pointer (hipStream_t): every launch of this handle is ordered on it, so a host application can
+ * record events on / wait for it instead of relying on the blocking entry points */
+void* q3tts_stream(q3tts_engine* e);
 /* Streaming / chunked decode (the reference decodes the whole utterance in one run_vocoder call, tts_onnx.cpp:430).
  * The decoder is causal: frames [a, b) own the samples [L(a), L(b)) of the full decode (L = q3tts_codec_decode_len, L(0) = 0), and
  * they are final as soon as frame b-1 exists.  Each call decodes the window [a - left_context, b) and returns exactly those

@@ -149,6 +149,15 @@ int q3tts_codec_decode_host(q3tts_engine* h, const int64_t* codes, int F, float*
     Q3_API_END(h)
 }
 
+int q3tts_codec_decode_dev(q3tts_engine* h, const int32_t* codes_dev, int F, float* pcm_dev, int64_t cap, int64_t* out_len) {
+    Q3_API_BEGIN(h)
+    const int64_t n = h->e->codec_decode_dev(codes_dev, F, pcm_dev, cap);
+    if (out_len) *out_len = n;
+    return 0;
+    Q3_API_END(h)
+}
+void* q3tts_stream(q3tts_engine* h) { return h && h->e ? (void*)h->e->stream : nullptr; }
+
 int q3tts_codec_decode_chunked_host(q3tts_engine* h, const int64_t* codes, int F, int chunk_frames, int left_context, float* pcm, int64_t cap,
                                     int64_t* out_len) {
     Q3_API_BEGIN(h)

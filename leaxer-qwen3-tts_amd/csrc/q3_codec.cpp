@@ -144,7 +144,7 @@ void Engine::codec_finalize() {
     }
     if (const char* ev = getenv("Q3TTS_CODEC_LANES")) W.nlane = std::max(1, std::min((int)CodecW::NLANE, atoi(ev)));
     W.lane_stream[0] = stream;
-    for (int i = 1; i < CodecW::NLANE; ++i) {
+    for (int i = 1; i < W.nlane; ++i) {
         if (null_stream) W.lane_stream[i] = nullptr;
         else Q3_HIP_CHECK(hipStreamCreateWithFlags(&W.lane_stream[i], hipStreamNonBlocking));
     }
@@ -163,14 +163,14 @@ static int tconv_out_len(const q3tts_config& c, int T, int k, int s, int* left_o
 int64_t Engine::codec_run(const int32_t* codes_dev, int F, float** pcm_dev, int lane) {
     if (!codec) throw Error("codec decoder not finalized");
     CodecW& W = *codec;
-    if (lane < 0 || lane >= CodecW::NLANE) throw Error("codec: bad lane");
+    if (lane < 0 || lane >= W.nlane) throw Error("codec: bad lane");
     hipStream_t stream = W.lane_stream[lane]; // shadows the engine stream for every launch below
     const int CH = c.cd_hidden, NH = c.cd_heads, HD = c.cd_head_dim, FF = c.cd_ffn, D = c.cd_decoder_dim;
     if (NH * HD != CH) throw Error("codec: heads*head_dim must equal hidden");
     int P = 1, pshift = 0;
     while (P < F) { P <<= 1; ++pshift; }
     if (W.rope_P < P) { // RoPE tables, oracle formula (fp32 libm)
-        for (int i = 0; i < CodecW::NLANE; ++i) Q3_HIP_CHECK(hipStreamSynchronize(W.lane_stream[i])); // tables may be in use
+        for (int i = 0; i < W.nlane; ++i) Q3_HIP_CHECK(hipStreamSynchronize(W.lane_stream[i])); // tables may be in use
         if (W.rope_cos) (void)hipFree(W.rope_cos);
         if (W.rope_sin) (void)hipFree(W.rope_sin);
         const int half = HD / 2;

@@ -525,7 +525,11 @@ __global__ void k_code_embed_mean(const float* table, const int32_t* codes, int 
     const int t = blockIdx.x;
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
         float s = 0.f;
-        for (int g = 0; g < G; ++g) s += table[((size_t)g * codebook + codes[(size_t)t * G + g]) * C + c];
+        for (int g = 0; g < G; ++g) {
+            int code = codes[(size_t)t * G + g];
+            code = code < 0 ? 0 : (code < codebook ? code : codebook - 1);   // device-resident codes are not validated on the host: never index outside the table
+            s += table[((size_t)g * codebook + code) * C + c];
+        }
         out[(size_t)t * C + c] = s / (float)G;
     }
 }

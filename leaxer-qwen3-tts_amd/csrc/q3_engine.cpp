@@ -974,6 +974,24 @@ int64_t Engine::codec_decode_host(const int64_t* codes, int F, float* pcm, int64
     return n;
 }
 
+// run_vocoder with everything already in HBM: codes int32 [F][n_groups] and the PCM destination are device pointers of the caller
+// (e.g. torch tensors); out-of-range codes are clamped by the gather kernel (the host entry rejects them instead).
+int64_t Engine::codec_decode_dev(const int32_t* codes_dev, int F, float* pcm_dev, int64_t cap) {
+    if (!finalized) throw Error("weights not finalized");
+    if (!codes_dev) throw Error("codec_decode_dev: null codes");
+    if (F < 1 || F > max_frames_cap) throw Error("codec_decode: F out of range");
+    float* pcm_d = nullptr;
+    Q3_HIP_CHECK(hipEventRecord(ev0, stream));
+    const int64_t n = codec_run(codes_dev, F, &pcm_d);
+    Q3_HIP_CHECK(hipEventRecord(ev1, stream));
+    const int64_t m = std::min(n, cap);
+    if (m > 0 && pcm_dev) Q3_HIP_CHECK(hipMemcpyAsync(pcm_dev, pcm_d, (size_t)m * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    sync();
+    Q3_HIP_CHECK(hipEventElapsedTime(&last_codec_ms, ev0, ev1));
+    total_codec_ms += last_codec_ms; total_codec_frames += F;
+    return n;
+}
+
 // Algorithmic bytes of one decode step: every talker weight once, every
 // predictor weight once per pass, plus the KV entries the attention kernels read.
 void Engine::step_bytes(double* wbytes, double* kvbytes) {

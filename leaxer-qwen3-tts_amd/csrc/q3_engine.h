@@ -86,6 +86,7 @@ public:
     void build_prompt(const int64_t* ids, int n_ids, int lang, const float* speaker, float* prompt, int* S,
                       float* trailing, int cap_rows, int* n_trailing);
     int64_t codec_decode_host(const int64_t* codes, int F, float* pcm, int64_t cap);
+    int64_t codec_decode_dev(const int32_t* codes_dev, int F, float* pcm_dev, int64_t cap);
     // exact chunked / streaming decode: samples owned by frames [a, b), decoded from the window [a - left_context, b)
     int64_t codec_decode_range_dev(const int32_t* codes_dev, int a, int b, int left_context, float* pcm, int64_t cap);
     int64_t slot_codec_decode_range(int slot, int a, int b, int left_context, float* pcm, int64_t cap);

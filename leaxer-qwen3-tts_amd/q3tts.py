@@ -80,7 +80,7 @@ EXPORTS = [
     "q3tts_sample_host", "q3tts_rng_uniform", "q3tts_build_prompt_host", "q3tts_slot_begin", "q3tts_decode_steps",
     "q3tts_slot_status", "q3tts_slot_codes_host", "q3tts_slot_codec_decode_host", "q3tts_slot_release",
     "q3tts_synthesize_batch_host", "q3tts_last_decode_ms", "q3tts_last_codec_ms", "q3tts_decode_step_bytes",
-    "q3tts_counters", "q3tts_stage_profile", "q3tts_config_num_tensors", "q3tts_config_tensor_info", "q3tts_read_weights_config", "q3tts_load_weights_file", "q3tts_save_weights_file",
+    "q3tts_codec_decode_dev", "q3tts_stream", "q3tts_counters", "q3tts_stage_profile", "q3tts_config_num_tensors", "q3tts_config_tensor_info", "q3tts_read_weights_config", "q3tts_load_weights_file", "q3tts_save_weights_file",
     "q3tts_tokenizer_create", "q3tts_tokenizer_destroy", "q3tts_tokenizer_load_vocab", "q3tts_tokenizer_load_merges",
     "q3tts_tokenizer_ready", "q3tts_tokenize",
     "q3tts_synthesize_clone_batch_host", "q3tts_read_wav_host", "q3tts_resample_host", "q3tts_mel_host",
@@ -445,6 +445,19 @@ class Engine:
         ds, cf = C.c_int64(0), C.c_int64(0)
         self._ck(self.L.q3tts_counters(self.h, C.byref(dms), C.byref(ds), C.byref(cms), C.byref(cf), int(reset)))
         return dict(decode_ms=dms.value, decode_steps=ds.value, codec_ms=cms.value, codec_frames=cf.value)
+
+    def codec_decode_dev(self, codes_ptr, F, pcm_ptr, cap):
+        """codes_ptr: device address of int32 [F][n_groups]; pcm_ptr: device address of float [cap] (e.g. torch tensors' data_ptr())."""
+        n = C.c_int64(0)
+        self.L.q3tts_codec_decode_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+        self._ck(self.L.q3tts_codec_decode_dev(self.h, C.c_void_p(codes_ptr), int(F), C.c_void_p(pcm_ptr), int(cap), C.byref(n)))
+        return n.value
+
+    @property
+    def stream(self):
+        self.L.q3tts_stream.restype = C.c_void_p
+        self.L.q3tts_stream.argtypes = [C.c_void_p]
+        return self.L.q3tts_stream(self.h)
 
     def stage_profile(self, n_steps=32):
         """ms per step of {sampler, code predictor, talker decode, sum}: eager steps with events at the stage boundaries."""

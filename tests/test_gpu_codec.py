@@ -118,3 +118,50 @@ def test_streaming_decode_while_generating(pair):
     ref = orc.vocoder(codes)
     assert float(np.sqrt(np.mean((got - ref) ** 2))) < 1e-4
     eng.slot_release(0)
+
+
+def test_codec_decode_with_device_resident_ends():
+    """q3tts_codec_decode_dev: codes and PCM live in HBM (buffers of the caller, here plain hipMalloc through the same HIP runtime the
+    library uses) — same samples as the host entry; out-of-range codes are clamped instead of indexing outside the embedding table."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so.7")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipFree.argtypes = [C.c_void_p]
+    H2D, D2H = 1, 2
+
+    def dmalloc(nbytes):
+        p = C.c_void_p()
+        assert hip.hipMalloc(C.byref(p), nbytes) == 0
+        return p
+
+    eng, orc, _ = tiny_pair(seed=21, max_batch=1, max_ctx=64)
+    F, G, CB = 9, eng.cfg.n_groups, eng.cfg.cd_codebook
+    codes = np.random.default_rng(3).integers(0, CB, (F, G)).astype(np.int64)
+    want = eng.codec_decode(codes)
+    n = eng.codec_decode_len(F)
+    codes_d, pcm_d = dmalloc(F * G * 4), dmalloc((n + 16) * 4)
+
+    def run(c64):
+        c32 = np.ascontiguousarray(c64.astype(np.int32))
+        fill = np.full(n + 16, 7.0, np.float32)
+        assert hip.hipMemcpy(codes_d, c32.ctypes.data_as(C.c_void_p), c32.nbytes, H2D) == 0
+        assert hip.hipMemcpy(pcm_d, fill.ctypes.data_as(C.c_void_p), fill.nbytes, H2D) == 0
+        got_n = eng.codec_decode_dev(codes_d.value, F, pcm_d.value, n)
+        out = np.empty(n + 16, np.float32)
+        assert hip.hipMemcpy(out.ctypes.data_as(C.c_void_p), pcm_d, out.nbytes, D2H) == 0
+        return got_n, out
+
+    got_n, got = run(codes)
+    assert got_n == n and eng.stream
+    assert np.array_equal(got[:n], want) and (got[n:] == 7.0).all()          # bit-identical, nothing written past cap
+    bad = codes.copy()
+    bad[2, 5] = CB + 1000
+    bad[4, 0] = -3
+    _, got = run(bad)
+    assert np.array_equal(got[:n], eng.codec_decode(np.clip(bad, 0, CB - 1)))
+    with pytest.raises(RuntimeError, match="out of range"):
+        eng.codec_decode(bad)
+    hip.hipFree(codes_d), hip.hipFree(pcm_d)
+    eng.close()
+    orc.close()
