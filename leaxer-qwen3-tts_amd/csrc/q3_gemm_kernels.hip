@@ -16,6 +16,15 @@
 
 namespace q3 {
 
+// -DQ3_SAMPLE_PROF: wall-clock stamps (100 MHz) inside the gate/up k_gemm2 launch and k_finish, workgroup 0 / thread 0; tools/ only
+#ifdef Q3_SAMPLE_PROF
+__device__ long long g_gemm_prof[32];
+void gemm_prof_read(long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gemm_prof), sizeof(long long) * 32); }
+#define GP_MARK(cond, k) do { if ((cond) && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_gemm_prof[k] = wall_clock64(); } while (0)
+#else
+#define GP_MARK(cond, k) do { } while (0)
+#endif
+
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -84,6 +93,8 @@ __global__ __launch_bounds__(NW * 64) void k_gemm2(const bf16_t* pW, const bf16_
             S.sl[p] = *reinterpret_cast<const u32x4*>(pxl + (size_t)row * pldx + k0 + scol);
         }
     };
+    int pm = 2;   // Q3_SAMPLE_PROF mark cursor
+    (void)pm;
     auto consume = [&](Stage& S) {
         __syncthreads(); // previous chunk's fragment reads are done
 #pragma unroll
@@ -95,6 +106,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm2(const bf16_t* pW, const bf16_
             }
         }
         __syncthreads();
+        GP_MARK(EPI == EPI_SLAB2, pm++);   // this chunk's operands have landed and sit in LDS
 #pragma unroll
         for (int st = 0; st < G2_KC / 32; ++st) {
 #pragma unroll
@@ -109,13 +121,16 @@ __global__ __launch_bounds__(NW * 64) void k_gemm2(const bf16_t* pW, const bf16_
                 }
             }
         }
+        GP_MARK(EPI == EPI_SLAB2, pm++);   // its MFMAs are issued
     };
     Stage s0, s1;
     const int kend = kbeg + kslice;
+    GP_MARK(EPI == EPI_SLAB2, 0);
     issue(s0, kbeg);
     for (int k0 = kbeg; k0 < kend; k0 += 2 * G2_KC) {
         if (k0 + G2_KC < kend) issue(s1, k0 + G2_KC);
         __builtin_amdgcn_sched_barrier(0);
+        GP_MARK(EPI == EPI_SLAB2 && k0 == kbeg, 1);   // both chunks' loads issued
         consume(s0);
         if (k0 + G2_KC < kend) {
             if (k0 + 2 * G2_KC < kend) issue(s0, k0 + 2 * G2_KC);
@@ -140,6 +155,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm2(const bf16_t* pW, const bf16_
             if (a.oh) split_store(o, a.oh + (size_t)m * a.ldp + n, a.ol + (size_t)m * a.ldp + n);
         }
     }
+    GP_MARK(EPI == EPI_SLAB2, 15);   // epilogue stores issued
 }
 
 template <int MTILES, int NW>

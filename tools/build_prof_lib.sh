@@ -7,13 +7,15 @@ mkdir -p "$ROOT/tools/exp" /tmp/q3prof
 cd /tmp/q3prof
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -DQ3_SAMPLE_PROF -mllvm -amdgpu-kernarg-preload-count=16 -x hip -c "$ROOT/leaxer-qwen3-tts_amd/csrc/q3_decode_kernels.hip" -o dk_prof.o
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -DQ3_SAMPLE_PROF -x hip -c "$ROOT/leaxer-qwen3-tts_amd/csrc/q3_codec_kernels.hip" -o ck_prof.o
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -DQ3_SAMPLE_PROF -mllvm -amdgpu-kernarg-preload-count=16 -x hip -c "$ROOT/leaxer-qwen3-tts_amd/csrc/q3_gemm_kernels.hip" -o gk_prof.o
 cat > prof_api.cpp <<'EOC'
-namespace q3 { void sample_prof_read(long long* out); void conv_prof_read(long long* out); }
+namespace q3 { void sample_prof_read(long long* out); void conv_prof_read(long long* out); void gemm_prof_read(long long* out); }
 extern "C" void q3_kernel_prof(long long* out) { q3::sample_prof_read(out); }
 extern "C" void q3_conv_prof(long long* out) { q3::conv_prof_read(out); }
+extern "C" void q3_gemm_prof(long long* out) { q3::gemm_prof_read(out); }
 EOC
 hipcc --offload-arch=gfx950 -O2 -std=c++17 -fPIC -x hip -c prof_api.cpp -o prof_api.o
 B="$ROOT/leaxer-qwen3-tts_amd/build"
-hipcc --offload-arch=gfx950 -shared -fPIC -o "$ROOT/tools/exp/libprof.so" dk_prof.o ck_prof.o prof_api.o "$B/q3_gemm_kernels.hip.o" \
+hipcc --offload-arch=gfx950 -shared -fPIC -o "$ROOT/tools/exp/libprof.so" dk_prof.o ck_prof.o gk_prof.o prof_api.o \
     "$B/q3_speaker_kernels.hip.o" "$B/q3_engine.cpp.o" "$B/q3_codec.cpp.o" "$B/q3_speaker.cpp.o" "$B/q3_audio.cpp.o" "$B/q3_bpe.cpp.o" "$B/q3_capi.cpp.o"
 echo "$ROOT/tools/exp/libprof.so"
