@@ -164,6 +164,13 @@ int q3tts_synthesize_clone_batch_host(q3tts_engine* e, int n_utt, const int64_t*
                                       const float* const* speakers, const q3tts_sampling* p, uint64_t seed, int ignore_eos,
                                       float* const* pcm_out, int64_t pcm_cap, int64_t* pcm_len, int32_t* n_frames,
                                       int64_t* codes_out);
+/* The scheduler behind both: n_utt may exceed max_batch — utterances queue for the slots, a slot that finishes is re-armed with the
+ * next one (continuous batching) while its codes are vocoded on a side stream.  max_new_per_utt (NULL: p->max_new_tokens for all) caps
+ * each utterance separately: with ignore_eos it fixes ragged lengths for benchmarks.  Results do not depend on
+ * the schedule (RNG stream = utterance index). */
+int q3tts_synthesize_schedule_host(q3tts_engine* e, int n_utt, const int64_t* ids, const int32_t* offsets, int lang,
+                                   const float* const* speakers, const q3tts_sampling* p, const int32_t* max_new_per_utt, uint64_t seed, int ignore_eos,
+                                   float* const* pcm_out, int64_t pcm_cap, int64_t* pcm_len, int32_t* n_frames, int64_t* codes_out);
 /* io::read_wav (src/io/wav_reader.h:13, wav_reader.cpp:28-143): mono float samples; -1 when the reference
  * returns an empty vector.  Call with out == NULL to learn *n_samples. */
 int q3tts_read_wav_host(const char* path, float* out, int64_t cap, int64_t* n_samples, int32_t* sample_rate);

@@ -240,48 +240,112 @@ int q3tts_synthesize_batch_host(q3tts_engine* h, int n_utt, const int64_t* ids, 
     return q3tts_synthesize_clone_batch_host(h, n_utt, ids, offsets, lang, nullptr, p, seed, ignore_eos, pcm_out, pcm_cap, pcm_len, n_frames, codes_out);
 }
 
+// Continuous batching: utterances queue for the engine's max_batch slots; a slot that finishes (EOS or max_new_tokens) stashes its codes
+// and is re-armed with the next utterance at the following look, so ragged lengths do not idle the batch; the vocoder runs over the
+// side lanes once the decode queue is empty.  Results do not depend on the schedule: the RNG stream of an utterance is its index,
+// never its slot.
 int q3tts_synthesize_clone_batch_host(q3tts_engine* h, int n_utt, const int64_t* ids, const int32_t* offsets, int lang,
                                       const float* const* speakers, const q3tts_sampling* p, uint64_t seed, int ignore_eos,
                                       float* const* pcm_out, int64_t pcm_cap, int64_t* pcm_len, int32_t* n_frames,
                                       int64_t* codes_out) {
+    return q3tts_synthesize_schedule_host(h, n_utt, ids, offsets, lang, speakers, p, nullptr, seed, ignore_eos, pcm_out, pcm_cap, pcm_len, n_frames, codes_out);
+}
+
+int q3tts_synthesize_schedule_host(q3tts_engine* h, int n_utt, const int64_t* ids, const int32_t* offsets, int lang,
+                                   const float* const* speakers, const q3tts_sampling* p, const int32_t* max_new_per_utt, uint64_t seed, int ignore_eos,
+                                   float* const* pcm_out, int64_t pcm_cap, int64_t* pcm_len, int32_t* n_frames,
+                                   int64_t* codes_out) {
     Q3_API_BEGIN(h)
     Engine& e = *h->e;
-    const int H = e.c.hidden, G = e.c.n_groups;
-    std::vector<float> prompts((size_t)e.B * 16 * H), trailing;
-    std::vector<Engine::SlotInit> init((size_t)e.B);
-    for (int u0 = 0; u0 < n_utt; u0 += e.B) {
-        const int nb = std::min(e.B, n_utt - u0);
-        for (int b = 0; b < e.B; ++b) e.slot_release(b);
-        size_t trows = 0;                                 // trailing rows of utterance u: its text tokens minus the first, plus tts_eos
-        std::vector<size_t> toff((size_t)nb);
-        for (int b = 0; b < nb; ++b) { toff[(size_t)b] = trows; trows += (size_t)std::max(1, offsets[u0 + b + 1] - offsets[u0 + b] - 3); }
-        trailing.resize(trows * H);
-        for (int b = 0; b < nb; ++b) {
-            const int u = u0 + b;
-            Engine::SlotInit& q = init[(size_t)b];
+    const int H = e.c.hidden, G = e.c.n_groups, B = e.B;
+    if (n_utt <= 0) return 0;
+    if (!ids || !offsets || !p) throw q3::Error("synthesize: null argument");
+    for (int b = 0; b < B; ++b) e.slot_release(b);
+    const int row_frames = std::max(1, std::min(p->max_new_tokens, e.max_frames_cap));
+    e.codec_async_prepare(row_frames, n_utt);
+    std::vector<int32_t> got_frames((size_t)n_utt, 0);
+    // Prompt rows of every utterance are assembled before the first step: prompt assembly is a handful of small synchronous device
+    // round trips per utterance, cheap on an idle GPU and slow once vocoder lanes keep it busy.
+    struct Prep { int S = 0, nt = 0; size_t poff = 0, toff = 0; };
+    std::vector<Prep> prep((size_t)n_utt);
+    std::vector<float> prompts, trailing;
+    {
+        size_t prow = 0, trow = 0;
+        for (int u = 0; u < n_utt; ++u) {
+            prep[(size_t)u].poff = prow; prep[(size_t)u].toff = trow;
+            prow += 16; trow += (size_t)std::max(1, offsets[u + 1] - offsets[u] - 3);   // trailing rows: text tokens minus the first, plus tts_eos
+        }
+        prompts.resize(prow * H); trailing.resize(trow * H);
+        for (int u = 0; u < n_utt; ++u) {
+            Prep& q = prep[(size_t)u];
             const int cap_rows = std::max(1, offsets[u + 1] - offsets[u] - 3);
-            q.slot = b; q.prompt = prompts.data() + (size_t)b * 16 * H; q.trailing = trailing.data() + toff[(size_t)b] * H; q.stream_id = (uint32_t)u;
-            e.build_prompt(ids + offsets[u], offsets[u + 1] - offsets[u], lang, speakers ? speakers[u] : nullptr, const_cast<float*>(q.prompt), &q.S,
-                           const_cast<float*>(q.trailing), std::min(cap_rows, e.max_trailing), &q.n_trailing);
+            e.build_prompt(ids + offsets[u], offsets[u + 1] - offsets[u], lang, speakers ? speakers[u] : nullptr, prompts.data() + q.poff * H, &q.S,
+                           trailing.data() + q.toff * H, std::min(cap_rows, e.max_trailing), &q.nt);
         }
-        e.slots_begin(init.data(), nb, *p, seed, ignore_eos);   // equal-length prompts share one pass through the talker stack
-        int left = p->max_new_tokens;
-        while (left > 0) {
-            const int chunk = std::min(left, 32);
-            const int active = e.decode_steps(chunk);
-            left -= chunk;
-            if (active == 0) break;
-        }
-        for (int b = 0; b < nb; ++b) {
-            const int u = u0 + b;
-            int nf = 0;
-            e.slot_status(b, &nf, nullptr);
-            if (n_frames) n_frames[u] = nf;
-            if (codes_out) e.slot_codes(b, codes_out + (size_t)u * p->max_new_tokens * G, p->max_new_tokens);
-        }
-        e.codec_decode_slots(nb, pcm_out ? pcm_out + u0 : nullptr, pcm_cap, pcm_len ? pcm_len + u0 : nullptr);
-        for (int b = 0; b < nb; ++b) e.slot_release(b);
     }
+    std::vector<Engine::SlotInit> init;
+    std::vector<int> slot_utt((size_t)B, -1), done_frames((size_t)B, 0), fresh, retired;
+    std::vector<q3::SlotState> st;
+    int next = 0, live = 0;
+    try {
+        while (next < n_utt || live > 0) {
+            fresh.clear();
+            for (int b = 0; b < B && next < n_utt; ++b)
+                if (slot_utt[(size_t)b] < 0) { slot_utt[(size_t)b] = next++; fresh.push_back(b); }
+            if (!fresh.empty()) {
+                init.assign(fresh.size(), Engine::SlotInit());
+                for (size_t i = 0; i < fresh.size(); ++i) {
+                    const int b = fresh[i], u = slot_utt[(size_t)b];
+                    const Prep& pr = prep[(size_t)u];
+                    Engine::SlotInit& q = init[i];
+                    q.slot = b; q.prompt = prompts.data() + pr.poff * H; q.S = pr.S; q.trailing = trailing.data() + pr.toff * H; q.n_trailing = pr.nt;
+                    q.stream_id = (uint32_t)u;
+                    q.max_frames = max_new_per_utt ? std::max(1, (int)max_new_per_utt[u]) : 0;
+                }
+                e.slots_begin(init.data(), (int)init.size(), *p, seed, ignore_eos);   // equal-length prompts in consecutive slots share one prefill pass
+                live += (int)fresh.size();
+            }
+            // steps until the next look: never past the earliest slot that can reach max_new_tokens, short when few utterances are live
+            int rem = p->max_new_tokens;
+            for (int b = 0; b < B; ++b) {
+                const int u = slot_utt[(size_t)b];
+                if (u < 0) continue;
+                const int cap_u = max_new_per_utt ? std::min(std::max(1, (int)max_new_per_utt[u]), p->max_new_tokens) : p->max_new_tokens;
+                rem = std::min(rem, cap_u - done_frames[(size_t)b]);
+            }
+            // (with EOS suppressed nothing can finish earlier than that, so the look-ahead only bounds how long the host is away)
+            e.decode_steps(std::max(1, std::min(rem, ignore_eos ? 64 : (live <= 16 ? 4 : 8))));
+            e.slots_state(B, st);
+            retired.clear();
+            for (int b = 0; b < B; ++b) {
+                const int u = slot_utt[(size_t)b];
+                if (u < 0) continue;
+                const q3::SlotState& s = st[(size_t)b];
+                done_frames[(size_t)b] = s.n_frames;
+                if (!(s.finished || s.n_frames >= s.max_frames)) continue;
+                got_frames[(size_t)u] = s.n_frames;
+                if (n_frames) n_frames[u] = s.n_frames;
+                e.codec_stash(b, s.n_frames, u, row_frames);
+                retired.push_back(b);
+            }
+            for (int b : retired) {
+                const int u = slot_utt[(size_t)b];
+                if (codes_out) e.slot_codes(b, codes_out + (size_t)u * p->max_new_tokens * G, p->max_new_tokens);
+                e.slot_release(b);
+                slot_utt[(size_t)b] = -1; done_frames[(size_t)b] = 0;
+                --live;
+            }
+        }
+    } catch (...) {
+        try { e.codec_async_drain(); } catch (...) { }
+        for (int b = 0; b < B; ++b) { try { e.slot_release(b); } catch (...) { } }
+        throw;
+    }
+    for (int u = 0; u < n_utt; ++u) {   // vocoder: every utterance of the job over the side lanes, once the decode queue is empty
+        if (pcm_len) pcm_len[u] = 0;
+        e.codec_async_submit_dev(e.codec_job_codes(u, row_frames), got_frames[(size_t)u], pcm_out ? pcm_out[u] : nullptr, pcm_cap, pcm_len ? pcm_len + u : nullptr);
+    }
+    e.codec_async_drain();
     return 0;
     Q3_API_END(h)
 }

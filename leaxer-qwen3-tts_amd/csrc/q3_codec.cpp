@@ -33,13 +33,21 @@ struct CodecW {
     struct Planes { bf16_t* hi; bf16_t* lo; float scale_inv; };
     std::unordered_map<const float*, Planes> planes;
     // run-time workspace: one bump arena per codec stream (lane 0 = the engine's own stream)
-    static constexpr int NLANE = 32;   // capacity; `nlane` of them are used (Q3TTS_CODEC_LANES, default 8)
-    int nlane = 8;
+    static constexpr int NLANE = 32;   // capacity; `nlane` of them are used (Q3TTS_CODEC_LANES)
+    int nlane = 9;                      // lane 0 = the engine's stream (synchronous entry points), the others decode asynchronously
     char* arena[NLANE] = {}; size_t arena_bytes[NLANE] = {};
     hipStream_t lane_stream[NLANE] = {};
     float* pinned[NLANE] = {}; size_t pinned_floats[NLANE] = {};
     float *rope_cos = nullptr, *rope_sin = nullptr; int rope_P = 0;
     int* page_table = nullptr;
+    // asynchronous per-utterance decodes over the side lanes: result parked in the lane's pinned buffer until the lane is drained
+    struct Pending { float* user = nullptr; int64_t n = 0, cap = 0; int64_t* len = nullptr; int frames = 0; bool busy = false; };
+    Pending pend[NLANE];
+    int32_t* job_codes = nullptr; size_t job_codes_n = 0;   // codes of a scheduler job's finished utterances, [utterance][max_new][groups]
+    hipEvent_t lane_done[NLANE] = {};
+    hipEvent_t fork = nullptr, win0 = nullptr, win1 = nullptr;
+    bool window_open = false;
+    int rr = 0;
 };
 
 void Engine::codec_free() {
@@ -49,8 +57,11 @@ void Engine::codec_free() {
     for (int i = 0; i < CodecW::NLANE; ++i) {
         if (codec->arena[i]) (void)hipFree(codec->arena[i]);
         if (codec->pinned[i]) (void)hipHostFree(codec->pinned[i]);
+        if (codec->lane_done[i]) (void)hipEventDestroy(codec->lane_done[i]);
         if (i > 0 && codec->lane_stream[i] && !null_stream) (void)hipStreamDestroy(codec->lane_stream[i]);
     }
+    for (hipEvent_t ev : { codec->fork, codec->win0, codec->win1 }) if (ev) (void)hipEventDestroy(ev);
+    if (codec->job_codes) (void)hipFree(codec->job_codes);
     if (codec->rope_cos) (void)hipFree(codec->rope_cos);
     if (codec->rope_sin) (void)hipFree(codec->rope_sin);
     if (codec->page_table) (void)hipFree(codec->page_table);
@@ -146,7 +157,11 @@ void Engine::codec_finalize() {
     W.lane_stream[0] = stream;
     for (int i = 1; i < W.nlane; ++i) {
         if (null_stream) W.lane_stream[i] = nullptr;
-        else Q3_HIP_CHECK(hipStreamCreateWithFlags(&W.lane_stream[i], hipStreamNonBlocking));
+        else {
+            int lo = 0, hi = 0;
+            Q3_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+            Q3_HIP_CHECK(hipStreamCreateWithPriority(&W.lane_stream[i], hipStreamNonBlocking, lo));
+        }
     }
     int zero = 0;
     Q3_HIP_CHECK(hipMalloc((void**)&W.page_table, sizeof(int)));
@@ -302,66 +317,101 @@ int64_t Engine::codec_run(const int32_t* codes_dev, int F, float** pcm_dev, int 
 }
 
 
-// Vocoder for slots [0, nb): utterances are independent, so their (small-grid) conv kernels are spread
-// over NLANE HIP streams with private arenas; PCM leaves through per-lane pinned staging buffers.
-void Engine::codec_decode_slots(int nb, float* const* pcm_out, int64_t cap, int64_t* lens) {
+// ------------------------------------------------------------------------------------------------
+// Vocoder side of the scheduler (q3tts_synthesize_schedule_host).  A slot that finishes copies its codes into the job's buffer on the
+// engine stream (codec_stash) and is free at once; when the decode queue has run dry the utterances are vocoded over the side lanes
+// (codec_async_submit_dev / codec_async_drain), their small-grid kernels overlapping each other.  Vocoding while other slots still
+// decode was measured and dropped: the conv kernels own whole CUs and stream gigabytes through L2 / MALL, so every decode step of the
+// latency-bound chain got 12 % longer and the job 10 % slower than with the two phases back to back (profiles/r01_negative_results.txt).
+// ------------------------------------------------------------------------------------------------
+void Engine::codec_async_prepare(int max_frames, int n_utt) {
     if (!codec) throw Error("codec decoder not finalized");
     CodecW& W = *codec;
-    const int G = c.n_groups;
-    sync();
-    std::vector<SlotState> st(nb);
-    Q3_HIP_CHECK(hipMemcpy(st.data(), st_d, (size_t)nb * sizeof(SlotState), hipMemcpyDeviceToHost));
-    int maxF = 1;
-    for (int b = 0; b < nb; ++b) maxF = std::max(maxF, (int)st[b].n_frames);
-    int Pneed = 1;
-    while (Pneed < maxF) Pneed <<= 1;
-    if (W.rope_P < Pneed) { float* dummy = nullptr; std::vector<int32_t> z((size_t)G, 0); // grow the shared RoPE tables up front
-        Q3_HIP_CHECK(hipMemcpy(codes_scratch_d, z.data(), z.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-        int32_t* tmp = nullptr; Q3_HIP_CHECK(hipMalloc((void**)&tmp, (size_t)maxF * G * sizeof(int32_t)));
-        Q3_HIP_CHECK(hipMemset(tmp, 0, (size_t)maxF * G * sizeof(int32_t)));
-        codec_run(tmp, maxF, &dummy, 0); sync(); (void)hipFree(tmp); }
-    hipEvent_t e0, e1;
-    Q3_HIP_CHECK(hipEventCreate(&e0)); Q3_HIP_CHECK(hipEventCreate(&e1));
-    Q3_HIP_CHECK(hipEventRecord(e0, stream));
-    for (int i = 1; i < W.nlane; ++i) Q3_HIP_CHECK(hipStreamWaitEvent(W.lane_stream[i], e0, 0));
-    std::vector<int> pending(W.nlane, -1);
-    std::vector<int64_t> pending_n(W.nlane, 0);
-    auto drain = [&](int lane) {
-        if (pending[lane] < 0) return;
-        Q3_HIP_CHECK(hipStreamSynchronize(W.lane_stream[lane]));
-        const int u = pending[lane];
-        const int64_t m = std::min(pending_n[lane], cap);
-        if (pcm_out && pcm_out[u] && m > 0) memcpy(pcm_out[u], W.pinned[lane], (size_t)m * sizeof(float));
-        pending[lane] = -1;
-    };
-    int64_t frames = 0;
-    for (int b = 0; b < nb; ++b) {
-        const int lane = b % W.nlane;
-        drain(lane);
-        const int nf = st[b].n_frames;
-        if (lens) lens[b] = 0;
-        if (nf <= 0) continue; // reference returns an empty vector when no frame was generated (tts_onnx.cpp:418)
-        float* pcm_d = nullptr;
-        const int64_t n = codec_run(codes_d + (size_t)b * max_frames_cap * G, nf, &pcm_d, lane);
-        frames += nf;
-        if (lens) lens[b] = n;
-        const int64_t m = std::min(n, cap);
-        if ((size_t)m > W.pinned_floats[lane]) {
-            if (W.pinned[lane]) (void)hipHostFree(W.pinned[lane]);
-            Q3_HIP_CHECK(hipHostMalloc((void**)&W.pinned[lane], (size_t)m * sizeof(float)));
-            W.pinned_floats[lane] = (size_t)m;
-        }
-        if (m > 0) Q3_HIP_CHECK(hipMemcpyAsync(W.pinned[lane], pcm_d, (size_t)m * sizeof(float), hipMemcpyDeviceToHost, W.lane_stream[lane]));
-        pending[lane] = b; pending_n[lane] = n;
+    int P = 1;
+    while (P < max_frames) P <<= 1;
+    if (W.rope_P < P) {   // grow the shared RoPE tables before any lane is in flight
+        int32_t* tmp = nullptr; float* dummy = nullptr;
+        Q3_HIP_CHECK(hipMalloc((void**)&tmp, (size_t)max_frames * c.n_groups * sizeof(int32_t)));
+        Q3_HIP_CHECK(hipMemset(tmp, 0, (size_t)max_frames * c.n_groups * sizeof(int32_t)));
+        codec_run(tmp, max_frames, &dummy, 0);
+        sync();
+        (void)hipFree(tmp);
     }
-    for (int i = 0; i < W.nlane; ++i) drain(i);
-    for (int i = 1; i < W.nlane; ++i) { Q3_HIP_CHECK(hipEventRecord(e1, W.lane_stream[i])); Q3_HIP_CHECK(hipStreamWaitEvent(stream, e1, 0)); }
-    Q3_HIP_CHECK(hipEventRecord(e1, stream));
+    const size_t need = (size_t)n_utt * max_frames * c.n_groups;
+    if (W.job_codes_n < need) {
+        sync();
+        if (W.job_codes) (void)hipFree(W.job_codes);
+        Q3_HIP_CHECK(hipMalloc((void**)&W.job_codes, need * sizeof(int32_t)));
+        W.job_codes_n = need;
+    }
+    W.rr = 0;   // a job's first utterances always land on the same lanes (their arenas are already sized)
+    if (!W.fork) { Q3_HIP_CHECK(hipEventCreateWithFlags(&W.fork, hipEventDisableTiming)); Q3_HIP_CHECK(hipEventCreate(&W.win0)); Q3_HIP_CHECK(hipEventCreate(&W.win1)); }
+}
+
+// slot's first nf frames -> row `utt` of the job buffer (stride = row_frames frames); ordered on the engine stream, so the slot may be re-armed next
+const int32_t* Engine::codec_stash(int slot, int nf, int utt, int row_frames) {
+    CodecW& W = *codec;
+    const int G = c.n_groups;
+    int32_t* dst = W.job_codes + (size_t)utt * row_frames * G;
+    if (nf > 0) Q3_HIP_CHECK(hipMemcpyAsync(dst, codes_d + (size_t)slot * max_frames_cap * G, (size_t)nf * G * sizeof(int32_t), hipMemcpyDeviceToDevice, stream));
+    return dst;
+}
+
+const int32_t* Engine::codec_job_codes(int utt, int row_frames) { return codec->job_codes + (size_t)utt * row_frames * c.n_groups; }
+
+void Engine::codec_async_drain_lane(int lane) {
+    CodecW& W = *codec;
+    CodecW::Pending& p = W.pend[lane];
+    if (!p.busy) return;
+    Q3_HIP_CHECK(hipStreamSynchronize(W.lane_stream[lane]));
+    const int64_t m = std::min(p.n, p.cap);
+    if (p.user && m > 0) memcpy(p.user, W.pinned[lane], (size_t)m * sizeof(float));
+    if (p.len) *p.len = p.n;
+    total_codec_frames += p.frames;
+    p.busy = false;
+}
+
+void Engine::codec_async_submit_dev(const int32_t* codes_dev, int nf, float* user_pcm, int64_t cap, int64_t* len_out) {
+    CodecW& W = *codec;
+    if (len_out) *len_out = 0;
+    if (nf <= 0) return;   // the reference returns an empty vector when no frame was generated (tts_onnx.cpp:418)
+    const int lane = W.nlane > 1 ? 1 + (W.rr++ % (W.nlane - 1)) : 0;
+    codec_async_drain_lane(lane);
+    if (!W.window_open) {   // the lanes start behind everything the engine stream has queued (the stashed codes among it)
+        Q3_HIP_CHECK(hipEventRecord(W.win0, stream));
+        Q3_HIP_CHECK(hipEventRecord(W.fork, stream));
+        for (int i = 1; i < W.nlane; ++i) Q3_HIP_CHECK(hipStreamWaitEvent(W.lane_stream[i], W.fork, 0));
+        W.window_open = true;
+    }
+    if (!W.lane_done[lane]) Q3_HIP_CHECK(hipEventCreateWithFlags(&W.lane_done[lane], hipEventDisableTiming));
+    hipStream_t ls = W.lane_stream[lane];
+    float* pcm_d = nullptr;
+    const int64_t n = codec_run(codes_dev, nf, &pcm_d, lane);
+    const int64_t m = std::min(n, cap);
+    if ((size_t)m > W.pinned_floats[lane]) {
+        if (W.pinned[lane]) (void)hipHostFree(W.pinned[lane]);
+        Q3_HIP_CHECK(hipHostMalloc((void**)&W.pinned[lane], (size_t)m * sizeof(float)));
+        W.pinned_floats[lane] = (size_t)m;
+    }
+    if (m > 0) Q3_HIP_CHECK(hipMemcpyAsync(W.pinned[lane], pcm_d, (size_t)m * sizeof(float), hipMemcpyDeviceToHost, ls));
+    Q3_HIP_CHECK(hipEventRecord(W.lane_done[lane], ls));
+    CodecW::Pending& p = W.pend[lane];
+    p.user = user_pcm; p.n = n; p.cap = cap; p.len = len_out; p.frames = nf; p.busy = true;
+}
+
+void Engine::codec_async_drain() {
+    if (!codec) return;
+    CodecW& W = *codec;
+    if (!W.window_open) return;
+    for (int i = 0; i < W.nlane; ++i)
+        if (W.pend[i].busy && i != 0) Q3_HIP_CHECK(hipStreamWaitEvent(stream, W.lane_done[i], 0));
+    Q3_HIP_CHECK(hipEventRecord(W.win1, stream));
+    for (int i = 0; i < W.nlane; ++i) codec_async_drain_lane(i);
     sync();
     float ms = 0.f;
-    Q3_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
-    total_codec_ms += ms; total_codec_frames += frames; last_codec_ms = ms;
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    Q3_HIP_CHECK(hipEventElapsedTime(&ms, W.win0, W.win1));
+    total_codec_ms += ms; last_codec_ms = ms;
+    W.window_open = false;
 }
 
 } // namespace q3

@@ -178,7 +178,11 @@ Engine::Engine(const q3tts_config& cfg, int device_, int max_batch, int max_ctx_
     if (const char* mr = getenv("Q3TTS_MFMA_MIN_ROWS")) mfma_min_rows = std::max(3, atoi(mr));   // A/B knob for the GEMV <-> GEMM crossover
     null_stream = getenv("Q3TTS_NULL_STREAM") && getenv("Q3TTS_NULL_STREAM")[0] == '1';
     if (null_stream) { stream = nullptr; flags |= Q3TTS_FLAG_NO_GRAPH; }
-    else Q3_HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    else {   // the decode chain is latency-bound: its launches go ahead of the vocoder lanes' (created at the lowest priority)
+        int lo = 0, hi = 0;
+        Q3_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        Q3_HIP_CHECK(hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, hi));
+    }
     Q3_HIP_CHECK(hipEventCreate(&ev0));
     Q3_HIP_CHECK(hipEventCreate(&ev1));
 
@@ -815,7 +819,8 @@ void Engine::slots_begin(const SlotInit* in, int n, const q3tts_sampling& p, uin
         if (q.n_trailing > 0)
             Q3_HIP_CHECK(hipMemcpyAsync(trailing_d + (size_t)q.slot * max_trailing * H, q.trailing, (size_t)q.n_trailing * H * sizeof(float), hipMemcpyHostToDevice, stream));
         SlotState& s = st_h[q.slot];
-        s.n_frames = 0; s.finished = 0; s.active = 1; s.prompt_len = q.S; s.trailing_len = q.n_trailing; s.max_frames = p.max_new_tokens;
+        s.n_frames = 0; s.finished = 0; s.active = 1; s.prompt_len = q.S; s.trailing_len = q.n_trailing;
+        s.max_frames = q.max_frames > 0 ? std::min(q.max_frames, p.max_new_tokens) : p.max_new_tokens;
         s.top_k = p.top_k; s.ignore_eos = ignore_eos; s.temperature = p.temperature; s.top_p = p.top_p; s.stream_id = q.stream_id; s.pad0 = 0; s.seed = seed;
         Q3_HIP_CHECK(hipMemcpyAsync(st_d + q.slot, &s, sizeof(SlotState), hipMemcpyHostToDevice, stream));
     }
@@ -852,6 +857,11 @@ int Engine::decode_steps(int n_steps) {
     last_decode_steps = n_steps;
     total_decode_ms += last_decode_ms; total_decode_steps += n_steps;
     return *active_h;
+}
+
+void Engine::slots_state(int nb, std::vector<SlotState>& out) {   // one copy for the whole batch (the scheduler polls it between step chunks)
+    out.resize((size_t)nb);
+    if (nb > 0) Q3_HIP_CHECK(hipMemcpy(out.data(), st_d, (size_t)nb * sizeof(SlotState), hipMemcpyDeviceToHost));
 }
 
 void Engine::slot_status(int slot, int* n_frames, int* finished) {

@@ -93,7 +93,8 @@ public:
     int64_t codec_decode_chunked_host(const int64_t* codes, int F, int chunk, int left_context, float* pcm, int64_t cap);
 
     // ---- fused generation ----
-    struct SlotInit { int slot = 0; const float* prompt = nullptr; int S = 0; const float* trailing = nullptr; int n_trailing = 0; uint32_t stream_id = 0; };
+    struct SlotInit { int slot = 0; const float* prompt = nullptr; int S = 0; const float* trailing = nullptr; int n_trailing = 0; uint32_t stream_id = 0;
+                      int max_frames = 0; /* 0: the call's max_new_tokens */ };
     void slots_begin(const SlotInit* in, int n, const q3tts_sampling& p, uint64_t seed, int ignore_eos); // batched prefill of equal-length prompts
     void slot_begin(int slot, const float* prompt, int S, const float* trailing, int n_trailing,
                     const q3tts_sampling& p, uint64_t seed, uint32_t stream_id, int ignore_eos);
@@ -116,7 +117,14 @@ public:
     CodecW* codec = nullptr;
     void codec_finalize();
     int64_t codec_run(const int32_t* codes_dev, int F, float** pcm_dev, int lane = 0); // returns sample count
-    void codec_decode_slots(int nb, float* const* pcm_out, int64_t cap, int64_t* lens);
+    // vocoder side of the scheduler: stash a finished slot's codes, vocode the job's utterances over the side lanes at the end
+    void codec_async_prepare(int max_frames, int n_utt);
+    const int32_t* codec_stash(int slot, int nf, int utt, int row_frames);
+    const int32_t* codec_job_codes(int utt, int row_frames);
+    void codec_async_submit_dev(const int32_t* codes_dev, int nf, float* user_pcm, int64_t cap, int64_t* len_out);
+    void codec_async_drain_lane(int lane);
+    void codec_async_drain();
+    void slots_state(int nb, std::vector<SlotState>& out);
     void codec_free();
 
     // ---- speaker encoder of the clone path (q3_speaker.cpp) ----

@@ -83,7 +83,7 @@ EXPORTS = [
     "q3tts_codec_decode_dev", "q3tts_stream", "q3tts_counters", "q3tts_stage_profile", "q3tts_config_num_tensors", "q3tts_config_tensor_info", "q3tts_read_weights_config", "q3tts_load_weights_file", "q3tts_save_weights_file",
     "q3tts_tokenizer_create", "q3tts_tokenizer_destroy", "q3tts_tokenizer_load_vocab", "q3tts_tokenizer_load_merges",
     "q3tts_tokenizer_ready", "q3tts_tokenize",
-    "q3tts_synthesize_clone_batch_host", "q3tts_read_wav_host", "q3tts_resample_host", "q3tts_mel_host",
+    "q3tts_synthesize_clone_batch_host", "q3tts_synthesize_schedule_host", "q3tts_read_wav_host", "q3tts_resample_host", "q3tts_mel_host",
     "q3tts_has_speaker_encoder", "q3tts_speaker_encoder_host", "q3tts_extract_speaker_embedding_host",
     "q3tts_codec_decode_chunked_host", "q3tts_slot_codec_decode_range_host",
 ]
@@ -142,6 +142,7 @@ def lib():
     L.q3tts_load_weights_file.argtypes = [vp, C.c_char_p]
     L.q3tts_save_weights_file.argtypes = [vp, C.c_char_p]
     L.q3tts_synthesize_clone_batch_host.argtypes = [vp, i32, vp, vp, i32, vp, C.POINTER(Sampling), C.c_uint64, i32, vp, i64, vp, vp, vp]
+    L.q3tts_synthesize_schedule_host.argtypes = [vp, i32, vp, vp, i32, vp, C.POINTER(Sampling), vp, C.c_uint64, i32, vp, i64, vp, vp, vp]
     L.q3tts_read_wav_host.argtypes = [C.c_char_p, vp, i64, C.POINTER(i64), C.POINTER(C.c_int32)]
     L.q3tts_resample_host.restype = i64
     L.q3tts_resample_host.argtypes = [vp, i64, i32, i32, vp, i64]
@@ -405,9 +406,10 @@ class Engine:
         self._ck(self.L.q3tts_extract_speaker_embedding_host(self.h, os.fsencode(wav_path), _p(out)))
         return out
 
-    def synthesize_batch(self, token_lists, sp, lang=0, seed=0, ignore_eos=False, want_codes=True, speakers=None):
+    def synthesize_batch(self, token_lists, sp, lang=0, seed=0, ignore_eos=False, want_codes=True, speakers=None, max_new_per_utt=None):
         """synthesize_tokens (reference src/tts_onnx.cpp:405-436) for a batch of utterances; `speakers` (one
-        [hidden] embedding or None per utterance) makes it synthesize_clone (:264-318)."""
+        [hidden] embedding or None per utterance) makes it synthesize_clone (:264-318).  More utterances than slots queue
+        (continuous batching); max_new_per_utt caps each utterance separately."""
         n = len(token_lists)
         flat = np.ascontiguousarray(np.concatenate([np.asarray(t, np.int64) for t in token_lists]))
         offs = np.zeros(n + 1, np.int32)
@@ -422,9 +424,12 @@ class Engine:
         if speakers is not None:
             spk_keep = [None if s_ is None else np.ascontiguousarray(s_, np.float32) for s_ in speakers]
             spk_ptrs = C.cast((C.c_void_p * n)(*[None if a is None else a.ctypes.data for a in spk_keep]), C.c_void_p)
-        self._ck(self.L.q3tts_synthesize_clone_batch_host(self.h, n, _p(flat), _p(offs), lang, spk_ptrs, C.byref(sp), seed, int(ignore_eos),
-                                                          C.cast(ptrs, C.c_void_p), cap, _p(pcm_len), _p(nfr),
-                                                          _p(codes) if want_codes else None))
+        caps = None if max_new_per_utt is None else np.ascontiguousarray(max_new_per_utt, np.int32)
+        if caps is not None and caps.shape != (n,):
+            raise ValueError("max_new_per_utt: one entry per utterance")
+        self._ck(self.L.q3tts_synthesize_schedule_host(self.h, n, _p(flat), _p(offs), lang, spk_ptrs, C.byref(sp), None if caps is None else _p(caps),
+                                                       seed, int(ignore_eos), C.cast(ptrs, C.c_void_p), cap, _p(pcm_len), _p(nfr),
+                                                       _p(codes) if want_codes else None))
         outs = [pcm[i][: pcm_len[i]] for i in range(n)]
         cl = [codes[i, : nfr[i]] for i in range(n)] if want_codes else None
         return outs, cl, nfr

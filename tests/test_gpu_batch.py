@@ -69,3 +69,54 @@ def test_batch16_full_size_greedy():
     assert not bad, bad
     eng.close()
     orc.close()
+
+
+def test_continuous_batching_is_schedule_independent():
+    """11 ragged utterances (EOS live) through 3 slots: a finished slot is re-armed with the next utterance while its codes go to an
+    asynchronous vocoder lane.  Every utterance equals the oracle's one-at-a-time result, and the 11-slot run, bit for bit."""
+    import q3tts
+    eng, orc, w = tiny_pair(seed=18, max_batch=3, max_ctx=96)
+    sp = q3tts.Sampling(temperature=0.9, top_p=0.95, top_k=40, max_new_tokens=40)
+    rng = np.random.default_rng(11)
+    toks = [frame_tokens(rng.integers(0, 151643, int(n))) for n in rng.integers(1, 20, 11)]
+    pcm, codes, nfr = eng.synthesize_batch(toks, sp, lang=0, seed=5, ignore_eos=False)
+    lens = set()
+    for u, t in enumerate(toks):
+        ref = orc.generate(orc.build_prompt(t, 0), to_osampling(sp), seed=5, stream=u, cp_cached=True, ignore_eos=False)
+        assert nfr[u] == len(ref) and np.array_equal(codes[u], ref), u
+        lens.add(len(ref))
+        if len(ref):
+            ref_pcm = orc.vocoder(ref)
+            assert pcm[u].shape == ref_pcm.shape and float(np.sqrt(np.mean((pcm[u] - ref_pcm) ** 2))) < 1e-4, u
+        else:
+            assert len(pcm[u]) == 0
+    assert len(lens) > 3                      # the lengths really are ragged
+    eng.close()
+    wide = q3tts.Engine(eng.cfg, device=0, max_batch=11, max_ctx=96)
+    wide.load(w)
+    pcm2, codes2, nfr2 = wide.synthesize_batch(toks, sp, lang=0, seed=5, ignore_eos=False)
+    for u in range(11):
+        assert np.array_equal(codes2[u], codes[u]) and np.array_equal(pcm2[u], pcm[u]), u
+    wide.close()
+    orc.close()
+
+
+def test_per_utterance_caps_fix_ragged_lengths():
+    """q3tts_synthesize_schedule_host: max_new_per_utt with EOS suppressed gives exactly those lengths, each utterance a prefix of its
+    uncapped generation (7 utterances through 2 slots)."""
+    import q3tts
+    eng, orc, _ = tiny_pair(seed=19, max_batch=2, max_ctx=96)
+    sp = q3tts.Sampling(temperature=0.8, top_p=0.95, top_k=50, max_new_tokens=30)
+    rng = np.random.default_rng(13)
+    toks = [frame_tokens(rng.integers(0, 151643, int(n))) for n in rng.integers(1, 12, 7)]
+    caps = np.array([5, 30, 1, 17, 9, 30, 12], np.int32)
+    pcm, codes, nfr = eng.synthesize_batch(toks, sp, lang=0, seed=2, ignore_eos=True, max_new_per_utt=caps)
+    assert np.array_equal(nfr, caps)
+    for u, t in enumerate(toks):
+        ref = orc.generate(orc.build_prompt(t, 0), to_osampling(sp), seed=2, stream=u, cp_cached=True, ignore_eos=True)
+        assert np.array_equal(codes[u], ref[: caps[u]]), u
+        assert len(pcm[u]) == eng.codec_decode_len(int(caps[u]))
+    with pytest.raises(ValueError):
+        eng.synthesize_batch(toks, sp, max_new_per_utt=caps[:3])
+    eng.close()
+    orc.close()
