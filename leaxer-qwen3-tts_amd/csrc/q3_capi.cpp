@@ -314,7 +314,11 @@ int q3tts_synthesize_schedule_host(q3tts_engine* h, int n_utt, const int64_t* id
                 rem = std::min(rem, cap_u - done_frames[(size_t)b]);
             }
             // (with EOS suppressed nothing can finish earlier than that, so the look-ahead only bounds how long the host is away)
-            e.decode_steps(std::max(1, std::min(rem, ignore_eos ? 64 : (live <= 16 ? 4 : 8))));
+            // While utterances wait in the queue a look is at least `quantum` steps away: a finished slot idles a few (masked, nearly free)
+            // steps, and the slots that finish within the quantum are re-armed together, sharing one prefill pass.
+            static const int quantum = getenv("Q3TTS_SCHED_QUANTUM") ? std::max(1, atoi(getenv("Q3TTS_SCHED_QUANTUM"))) : 4;
+            const int look = std::min(rem, ignore_eos ? 64 : (live <= 16 ? 4 : 8));
+            e.decode_steps(std::max(next < n_utt && live > 16 ? quantum : 1, look));
             e.slots_state(B, st);
             retired.clear();
             for (int b = 0; b < B; ++b) {

@@ -214,8 +214,11 @@ int64_t Engine::codec_run(const int32_t* codes_dev, int F, float** pcm_dev, int 
             off += bytes;
             return p;
         };
+        const size_t kslab_floats = (size_t)32 * 128 * 4096;   // split-K partial sums of the short pre-transformer / ConvNeXt GEMMs
+        float* kslab = take(kslab_floats);
         auto conv = [&](ConvArgs a) {
             if (plan) return;
+            a.slab = kslab; a.slab_floats = kslab_floats;
             const auto it = W.planes.find(a.W);
             if (it != W.planes.end()) { a.Wh = it->second.hi; a.Wl = it->second.lo; a.w_scale_inv = it->second.scale_inv; }
             launch_conv(a, stream);

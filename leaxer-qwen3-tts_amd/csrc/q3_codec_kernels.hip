@@ -57,6 +57,7 @@ struct ConvKArgs {
     float* out2; const float* s2_alpha; const float* s2_beta; // out2 = snake(out value)
     const bf16_t* Wh; const bf16_t* Wl; // optional (hi, lo) fp16 planes of W * 2^k for k_conv_split (16-bit storage)
     float acc_scale;                    // 2^-k (1 on the fp32 path)
+    int ksplit; float* slab;            // k_conv_split, 1-tap GEMMs: blockIdx.z = K slice, raw partial sums -> slab[z][T_out][C_out] (k_conv_finish)
 };
 
 // Epilogue of one 32x32 accumulator block: D[row][col], col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
@@ -275,10 +276,12 @@ void k_conv_split(ConvKArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
-    const int m0 = blockIdx.x * TM, co0 = blockIdx.y * TN, phase = blockIdx.z;
+    const bool ksp = KC == 128 && a.ksplit > 1;               // split-K (short pre-transformer GEMMs): blockIdx.z is the K slice, not a phase
+    const int m0 = blockIdx.x * TM, co0 = blockIdx.y * TN, phase = ksp ? 0 : blockIdx.z;
     const int NT = a.transposed ? a.taps / a.stride : a.taps;
     const int halo = a.transposed ? NT - 1 : (a.taps - 1) * a.dil;
-    const int n_chunks = a.C_in / KC, total = n_chunks * NT;
+    const int n_chunks = ksp ? a.C_in / KC / a.ksplit : a.C_in / KC, total = n_chunks * NT;
+    const int c_first = ksp ? (int)blockIdx.z * n_chunks : 0;
 
     f32x16 acc[MB][NB];
     const f32x16 zero16 = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
@@ -336,9 +339,9 @@ void k_conv_split(ConvKArgs a) {
     };
 
     CP_MARK(0);
-    loadA(0);
-    loadB(0, 0);
-    int chunk = 0, ti = 0;
+    loadA(c_first * KC);
+    loadB(c_first * KC, 0);
+    int chunk = c_first, ti = 0;
     for (int it = 0; it < total; ++it) {
         const int buf = NBUF == 2 ? (it & 1) : 0;
         CP_MARK(1 + it * 4);
@@ -387,9 +390,56 @@ void k_conv_split(ConvKArgs a) {
     __syncthreads();                                          // the staging slices below overlay the operand tiles
     float* stage = reinterpret_cast<float*>(smem) + wave * 32 * (NB * 32 + 8);
     // statically indexed row blocks (a rolled loop would give the accumulators a scratch home that the main loop keeps in sync)
+    if constexpr (KC == 128) {
+        if (ksp) {   // raw partial sums of this K slice; bias / activation / residual belong to k_conv_finish
+            ConvKArgs b = a;
+            b.out = a.slab + (size_t)blockIdx.z * a.T_out * a.C_out;
+            b.bias = nullptr; b.res = nullptr; b.res_scale = nullptr; b.mul = nullptr; b.out2 = nullptr; b.act = 0; b.acc_scale = 1.0f;
+            split_epilogue_block<NB>(b, acc[0], stage, m0 + wm * MB * 32, co0 + wn * NB * 32, lane, 0, NT);
+            if (MB > 1) split_epilogue_block<NB>(b, acc[MB - 1], stage, m0 + wm * MB * 32 + 32, co0 + wn * NB * 32, lane, 0, NT);
+            return;
+        }
+    }
     split_epilogue_block<NB>(a, acc[0], stage, m0 + wm * MB * 32, co0 + wn * NB * 32, lane, phase, NT);
     if (MB > 1) split_epilogue_block<NB>(a, acc[MB - 1], stage, m0 + wm * MB * 32 + 32, co0 + wn * NB * 32, lane, phase, NT);
     CP_MARK(63);
+}
+
+// Split-K tail: out = epilogue(sum of the K slices' partial sums, slice order).  One thread owns 4 consecutive channels of one row;
+// the arithmetic is split_epilogue_block's: x = acc * scale + bias, activation, x = res + res_scale * (x * mul), SnakeBeta second output.
+__global__ __launch_bounds__(256) void k_conv_finish(ConvKArgs a) {
+    const size_t n4 = (size_t)a.T_out * a.C_out / 4, i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const size_t o = i * 4, plane = (size_t)a.T_out * a.C_out;
+    const int co = (int)(o % a.C_out);
+    float4 s4 = *reinterpret_cast<const float4*>(a.slab + o);
+    for (int z = 1; z < a.ksplit; ++z) {
+        const float4 p = *reinterpret_cast<const float4*>(a.slab + z * plane + o);
+        s4.x += p.x; s4.y += p.y; s4.z += p.z; s4.w += p.w;
+    }
+    const float4 one4 = make_float4(1.f, 1.f, 1.f, 1.f), zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 b4 = a.bias ? *reinterpret_cast<const float4*>(a.bias + co) : zero4;
+    const float4 r4 = a.res_scale ? *reinterpret_cast<const float4*>(a.res_scale + co) : one4;
+    const float4 m4 = a.mul ? *reinterpret_cast<const float4*>(a.mul + o) : one4;
+    const float4 e4 = a.res ? *reinterpret_cast<const float4*>(a.res + o) : zero4;
+    const float v[4] = { s4.x, s4.y, s4.z, s4.w }, bs[4] = { b4.x, b4.y, b4.z, b4.w }, rs[4] = { r4.x, r4.y, r4.z, r4.w };
+    const float mv[4] = { m4.x, m4.y, m4.z, m4.w }, rv[4] = { e4.x, e4.y, e4.z, e4.w };
+    float x[4], s2[4] = { 0.f, 0.f, 0.f, 0.f };
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float t = v[e] * a.acc_scale + bs[e];
+        if (a.act == 1) t = gelu_f(t);
+        else if (a.act == 2) t = silu2_f(t);
+        x[e] = rv[e] + rs[e] * (t * mv[e]);
+    }
+    if (a.out2) {
+        const float4 al4 = *reinterpret_cast<const float4*>(a.s2_alpha + co), be4 = *reinterpret_cast<const float4*>(a.s2_beta + co);
+        const float al[4] = { al4.x, al4.y, al4.z, al4.w }, be[4] = { be4.x, be4.y, be4.z, be4.w };
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s2[e] = x[e] + (1.0f / (expf(be[e]) + 0.000000001f)) * sin_sq(x[e] * expf(al[e]));
+        *reinterpret_cast<float4*>(a.out2 + o) = make_float4(s2[0], s2[1], s2[2], s2[3]);
+    }
+    if (a.out) *reinterpret_cast<float4*>(a.out + o) = make_float4(x[0], x[1], x[2], x[3]);
 }
 
 // fp32 weights * scale -> (hi, lo) fp16 planes; absmax for choosing the power-of-two scale
@@ -461,6 +511,7 @@ void launch_conv(const ConvArgs& c, hipStream_t s) {
     a.out2 = c.out2; a.s2_alpha = c.snake_alpha; a.s2_beta = c.snake_beta;
     a.Wh = c.Wh; a.Wl = c.Wl;
     a.acc_scale = 1.0f;
+    a.ksplit = 0; a.slab = nullptr;
     if (c.transposed && c.taps % c.stride != 0) throw Error("conv: transposed kernel must be a multiple of the stride");
     const int rows = c.transposed ? c.T_in + c.taps / c.stride - 1 : c.T_out;
     dim3 grid((rows + CT_M - 1) / CT_M, (c.C_out + CT_N - 1) / CT_N, c.transposed ? c.stride : 1);
@@ -486,6 +537,23 @@ void launch_conv(const ConvArgs& c, hipStream_t s) {
         const bool deep = NTt * c.C_in > 512;
         if (n_thin < 512) {   // few workgroups, each walking K alone: 128-column chunks when the channel count allows
             const dim3 g((rows + 63) / 64, (c.C_out + 127) / 128, z);
+            // a short utterance's pre-transformer GEMM (<= 128 frames x 1024..3072 channels) has 8-48 of these workgroups, each streaming
+            // 0.5-1.5 MB of weights alone (47-75 us): cut K into 128-wide slices across workgroups, sum the slices in a tail kernel
+            int ks = 1;
+            if (c.taps == 1 && !c.transposed && c.C_in % 128 == 0 && c.C_in >= 512 && c.slab) {   // fewest slices that give >= 256 workgroups
+                const int nch = c.C_in / 128;
+                for (ks = 1; ks < nch; ++ks)
+                    if (nch % ks == 0 && (long)g.x * g.y * ks >= 256) break;
+                while (ks > 1 && (nch % ks != 0 || (size_t)ks * c.T_out * c.C_out > c.slab_floats)) --ks;
+            }
+            if (ks > 1) {
+                a.ksplit = ks; a.slab = c.slab;
+                hipLaunchKernelGGL((k_conv_split<2, 1, 1, 4, 2, 128, 1>), dim3(g.x, g.y, ks), dim3(256), 0, s, a);
+                const size_t n4 = (size_t)c.T_out * c.C_out / 4;
+                hipLaunchKernelGGL(k_conv_finish, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, a);
+                Q3_HIP_CHECK(hipGetLastError());
+                return;
+            }
             if (c.C_in % 128 == 0) {
                 if (extra == 0) hipLaunchKernelGGL((k_conv_split<2, 1, 1, 4, 2, 128, 1>), g, dim3(256), 0, s, a);
                 else if (extra == 1) hipLaunchKernelGGL((k_conv_split<2, 1, 1, 4, 3, 128, 1>), g, dim3(256), 0, s, a);

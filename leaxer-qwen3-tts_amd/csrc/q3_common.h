@@ -92,6 +92,7 @@ struct AttnArgs {
     const int* pos_dev = nullptr;    // per-slot position of new token 0 (device) or null -> pos_scalar
     int pos_scalar = 0;
     int slot_offset = 0, nb = 0, n_new = 0;
+    const int* slot_map = nullptr; // optional: batch row bi belongs to slot slot_map[bi] instead of slot_offset + bi (prefill of scattered slots)
     int nq = 0, nkv = 0, d = 0;
     float scale = 0.f;
     int window = 0;
@@ -210,6 +211,7 @@ struct ConvArgs { // out[t][co] = epi(bias[co] + sum_{tap,ci} W[tap][co][ci] * i
     float* out2 = nullptr;       // optional second output: SnakeBeta(value) for the NEXT layer
     const float* snake_alpha = nullptr;
     const float* snake_beta = nullptr;
+    float* slab = nullptr; size_t slab_floats = 0; // optional scratch for split-K partial sums of short 1-tap GEMMs ([slice][T_out][C_out])
 };
 void launch_conv(const ConvArgs& a, hipStream_t s);
 void launch_split_planes(const float* w, bf16_t* hi, bf16_t* lo, size_t n, float scale, hipStream_t s);

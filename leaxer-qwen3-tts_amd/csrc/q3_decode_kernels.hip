@@ -524,7 +524,7 @@ __global__ __launch_bounds__(256) void k_attn(const int* ppage_table, const int*
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); // provably wave-uniform: pointer selects stay scalar
     const int grp = a.nq / a.nkv;
-    const int slot = a.slot_offset + bi;
+    const int slot = a.slot_map ? a.slot_map[bi] : a.slot_offset + bi;
     const int row = bi * a.n_new + inew;
     const int pshift = a.page_shift, page_tokens = 1 << pshift;
 

@@ -250,6 +250,8 @@ Engine::Engine(const q3tts_config& cfg, int device_, int max_batch, int max_ctx_
     codes_d = (int32_t*)dmalloc((size_t)B * max_frames_cap * c.n_groups * sizeof(int32_t));
     codes_scratch_d = (int32_t*)dmalloc((size_t)max_frames_cap * c.n_groups * sizeof(int32_t));
     talker_pos_d = (int32_t*)dmalloc((size_t)B * sizeof(int32_t));
+    slot_map_d = (int*)dmalloc(128 * sizeof(int));
+    logits_g = fm((size_t)128 * c.vocab);
     Q3_HIP_CHECK(hipMemsetAsync(talker_pos_d, 0, (size_t)B * sizeof(int32_t), stream));
     st_d = (SlotState*)dmalloc((size_t)B * sizeof(SlotState));
     st_h.assign(B, SlotState{});
@@ -407,7 +409,7 @@ static int pick_ksplit(int K) { // K slices per GEMM: 256 (two LDS chunks) per w
 }
 
 bool Engine::run_layers(const DecStack& W, float* x, int ldx, int nb, int n_new, int slot_offset, const int* pos_dev, int pos_scalar,
-                        const float* final_gamma, float final_eps, float* final_xn, int final_ld_xn) {
+                        const float* final_gamma, float final_eps, float* final_xn, int final_ld_xn, const int* slot_map) {
     const int M = nb * n_new, QKV = (W.nq + 2 * W.nkv) * W.d, AO = W.nq * W.d;
     // M >= mfma_min_rows: bf16-MFMA skinny GEMM over (hi, lo) activation planes; below it the single-pass GEMV family
     const bool mfma = M >= mfma_min_rows && M <= 128 && W.H % 128 == 0 && AO % 128 == 0 && W.ffn % 128 == 0 && W.H <= 4096;
@@ -426,7 +428,7 @@ bool Engine::run_layers(const DecStack& W, float* x, int ldx, int nb, int n_new,
             g.M = M; g.N = QKV; g.K = W.H; g.epi = EPI_STORE; g.nt = W.nt;
             launch_gemv(g, stream);
         }
-        if (!mfma && nb == 1 && pos_dev == nullptr && W.n_splits == 1 && W.pages_per_slot == 1 && !(flags & Q3TTS_FLAG_NO_FUSED_CP)) {
+        if (!mfma && nb == 1 && pos_dev == nullptr && slot_map == nullptr && W.n_splits == 1 && W.pages_per_slot == 1 && !(flags & Q3TTS_FLAG_NO_FUSED_CP)) {
             // code predictor at b = 1: attention + o_proj + residual in one launch (identity page table: slot s owns page s)
             CpAttnOprojArgs f;
             const int ptok = 1 << W.page_shift;
@@ -453,7 +455,7 @@ bool Engine::run_layers(const DecStack& W, float* x, int ldx, int nb, int n_new,
         a.page_table = W.page_table; a.pages_per_slot = W.pages_per_slot; a.page_shift = W.page_shift;
         a.layer = l; a.n_layers = W.L; a.q_norm = w.q_norm; a.k_norm = w.k_norm; a.eps = W.eps;
         a.rope_cos = W.rope_cos; a.rope_sin = W.rope_sin; a.pos_dev = pos_dev; a.pos_scalar = pos_scalar;
-        a.slot_offset = slot_offset; a.nb = nb; a.n_new = n_new; a.nq = W.nq; a.nkv = W.nkv; a.d = W.d;
+        a.slot_offset = slot_offset; a.slot_map = slot_map; a.nb = nb; a.n_new = n_new; a.nq = W.nq; a.nkv = W.nkv; a.d = W.d;
         a.scale = 1.0f / sqrtf((float)W.d); a.window = 0; a.new_from_raw = 1;
         a.n_splits = W.n_splits; a.chunk = W.chunk; a.po = W.po; a.pm = W.pm; a.pl = W.pl;
         const bool direct_planes = mfma && W.n_splits == 1;     // one split: the attention kernel normalises and writes the planes itself
@@ -790,27 +792,46 @@ void Engine::slots_begin(const SlotInit* in, int n, const q3tts_sampling& p, uin
         if (p.max_new_tokens < 1 || in[i].S + p.max_new_tokens > max_ctx) throw Error("prompt + max_new_tokens exceeds max_ctx");
     }
     int i0 = 0;
+    std::vector<int32_t> pos_h, map_h;
     while (i0 < n) {
-        // a group: consecutive slots (slot ids increasing by one) with the same S, at most rows_max / S of them (and <= 128 rows)
+        // a group: entries with the same S, at most rows_max / S of them (and <= 128 rows); consecutive slot ids write their results in
+        // place, scattered ones (the scheduler re-arming whatever finished) go through a slot map and a scatter of the head's rows
         const bool mfma_ok = H % 128 == 0 && (c.n_heads * c.head_dim) % 128 == 0 && c.ffn % 128 == 0 && H <= 4096;   // run_layers' MFMA condition
-        const int S = in[i0].S, cap = mfma_ok ? std::max(1, std::min(rows_max, 128) / S) : 1;
+        const int S = in[i0].S, cap = mfma_ok ? std::max(1, std::min(std::min(rows_max, 128) / S, 128)) : 1;
         int g = 1;
-        while (i0 + g < n && g < cap && in[i0 + g].S == S && in[i0 + g].slot == in[i0].slot + g) ++g;
+        bool consecutive = true;
+        while (i0 + g < n && g < cap && in[i0 + g].S == S) { consecutive = consecutive && in[i0 + g].slot == in[i0].slot + g; ++g; }
+        for (int k = 1; k < g; ++k)   // a slot may appear once per group (its cache rows are written by one row group only)
+            for (int j = 0; j < k; ++j) if (in[i0 + k].slot == in[i0 + j].slot) throw Error("slots_begin: slot listed twice");
         if (g == 1 || g * S < mfma_min_rows) {
             for (int k = 0; k < g; ++k) talker_prefill(in[i0 + k].slot, in[i0 + k].prompt, S, nullptr, nullptr);
         } else {
-            const int slot0 = in[i0].slot, M = g * S;
+            const int slot0 = in[i0].slot;
             for (int k = 0; k < g; ++k)
                 Q3_HIP_CHECK(hipMemcpyAsync(xp + (size_t)k * S * H, in[i0 + k].prompt, (size_t)S * H * sizeof(float), hipMemcpyHostToDevice, stream));
-            const bool pr = run_layers(talker, xp, H, g, S, slot0, nullptr, 0, talker_norm, c.rms_eps, hn, H);
-            if (!pr) throw Error("batched prefill expects the MFMA path");   // M = g*S >= mfma_min_rows by construction
-            // codec head on the last row of every prompt straight into the fused path's logits; normalised last rows -> predictor input
-            head_proj(codec_head, xp, H, talker_norm, c.rms_eps, nullptr, 0, logits_t + (size_t)slot0 * V, V, g, V, H, true, true, S - 1, S);
-            launch_copy_rows(hn + (size_t)(S - 1) * H, S * H, x_cp + (size_t)slot0 * 2 * H, 2 * H, g, H, stream);
-            std::vector<int32_t> pos((size_t)g, S);
-            Q3_HIP_CHECK(hipMemcpyAsync(talker_pos_d + slot0, pos.data(), (size_t)g * sizeof(int32_t), hipMemcpyHostToDevice, stream));
-            sync();   // pos is a stack buffer
-            (void)M;
+            pos_h.assign((size_t)g, S);
+            if (consecutive) {
+                const bool pr = run_layers(talker, xp, H, g, S, slot0, nullptr, 0, talker_norm, c.rms_eps, hn, H);
+                if (!pr) throw Error("batched prefill expects the MFMA path");   // M = g*S >= mfma_min_rows by construction
+                // codec head on the last row of every prompt straight into the fused path's logits; normalised last rows -> predictor input
+                head_proj(codec_head, xp, H, talker_norm, c.rms_eps, nullptr, 0, logits_t + (size_t)slot0 * V, V, g, V, H, true, true, S - 1, S);
+                launch_copy_rows(hn + (size_t)(S - 1) * H, S * H, x_cp + (size_t)slot0 * 2 * H, 2 * H, g, H, stream);
+                Q3_HIP_CHECK(hipMemcpyAsync(talker_pos_d + slot0, pos_h.data(), (size_t)g * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+            } else {
+                map_h.resize((size_t)g);
+                for (int k = 0; k < g; ++k) map_h[(size_t)k] = in[i0 + k].slot;
+                Q3_HIP_CHECK(hipMemcpyAsync(slot_map_d, map_h.data(), (size_t)g * sizeof(int), hipMemcpyHostToDevice, stream));
+                const bool pr = run_layers(talker, xp, H, g, S, 0, nullptr, 0, talker_norm, c.rms_eps, hn, H, slot_map_d);
+                if (!pr) throw Error("batched prefill expects the MFMA path");
+                head_proj(codec_head, xp, H, talker_norm, c.rms_eps, nullptr, 0, logits_g, V, g, V, H, true, true, S - 1, S);
+                for (int k = 0; k < g; ++k) {
+                    const int sl = in[i0 + k].slot;
+                    launch_copy_rows(logits_g + (size_t)k * V, V, logits_t + (size_t)sl * V, V, 1, V, stream);
+                    launch_copy_rows(hn + (size_t)(k * S + S - 1) * H, H, x_cp + (size_t)sl * 2 * H, 2 * H, 1, H, stream);
+                    Q3_HIP_CHECK(hipMemcpyAsync(talker_pos_d + sl, pos_h.data(), sizeof(int32_t), hipMemcpyHostToDevice, stream));
+                }
+            }
+            sync();   // pos_h / map_h are reused by the next group
         }
         i0 += g;
     }

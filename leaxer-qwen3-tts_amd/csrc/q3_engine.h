@@ -163,6 +163,8 @@ public:
     int32_t* codes_d = nullptr;
     int32_t* codes_scratch_d = nullptr;
     int32_t* talker_pos_d = nullptr;
+    int* slot_map_d = nullptr;      // [128] slots of a batched prefill over scattered slots
+    float* logits_g = nullptr;      // [128][vocab] its head output before the scatter
     SlotState* st_d = nullptr;
     std::vector<SlotState> st_h;
     int32_t* active_d = nullptr;
@@ -175,7 +177,8 @@ public:
     // final_gamma != null (MFMA path only): the last layer's finish kernel also applies the stack's final RMSNorm,
     // leaving (hi, lo) planes of the normalised rows in pl0 (+ fp32 rows in final_xn); returns true in that case
     bool run_layers(const DecStack& W, float* x, int ldx, int nb, int n_new, int slot_offset, const int* pos_dev, int pos_scalar,
-                    const float* final_gamma = nullptr, float final_eps = 0.f, float* final_xn = nullptr, int final_ld_xn = 0);
+                    const float* final_gamma = nullptr, float final_eps = 0.f, float* final_xn = nullptr, int final_ld_xn = 0,
+                    const int* slot_map = nullptr);   // slot_map (device, nb ints): row group bi belongs to slot slot_map[bi]
     void record_step(int nb);
     void head_proj(const bf16_t* Wm, const float* x, int ldx, const float* gamma, float eps, float* xn_out, int ld_xn,
                    float* out, int ldo, int M, int N, int K, bool nt, bool planes_ready = false, int plane_row0 = 0, int plane_row_stride = 1);

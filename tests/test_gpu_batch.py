@@ -120,3 +120,21 @@ def test_per_utterance_caps_fix_ragged_lengths():
         eng.synthesize_batch(toks, sp, max_new_per_utt=caps[:3])
     eng.close()
     orc.close()
+
+
+def test_scattered_slots_share_one_prefill_pass():
+    """Slots 0, 2, 4, 6 finish at the same look (caps 6 / 20 alternate), so the scheduler re-arms four non-consecutive slots at once:
+    their prompts go through the talker stack as one row block addressed through a slot map.  Every utterance still equals the oracle."""
+    import q3tts
+    eng, orc, _ = tiny_pair(seed=23, max_batch=8, max_ctx=96, ocfg=qo.config_medium())
+    sp = q3tts.Sampling(temperature=0.8, top_p=0.95, top_k=50, max_new_tokens=20)
+    rng = np.random.default_rng(17)
+    toks = [frame_tokens(rng.integers(0, 151643, int(n))) for n in rng.integers(2, 14, 24)]
+    caps = np.array([6, 20] * 12, np.int32)
+    pcm, codes, nfr = eng.synthesize_batch(toks, sp, lang=1, seed=12, ignore_eos=True, max_new_per_utt=caps)
+    assert np.array_equal(nfr, caps)
+    for u, t in enumerate(toks):
+        ref = orc.generate(orc.build_prompt(t, 1), to_osampling(sp), seed=12, stream=u, cp_cached=True, ignore_eos=True)
+        assert np.array_equal(codes[u], ref[: caps[u]]), u
+    eng.close()
+    orc.close()
