@@ -535,7 +535,7 @@ void launch_conv(const ConvArgs& c, hipStream_t s) {
         // 256-row tiles when the grid still fills the chip a few times over and K is deep enough to be compute-bound; 128-row tiles
         // (2-3 workgroups per CU) for bandwidth-bound or mid-sized launches; 64-row tiles for the short pre-transformer GEMMs
         const bool deep = NTt * c.C_in > 512;
-        if (n_thin < 512) {   // few workgroups, each walking K alone: 128-column chunks when the channel count allows
+        if (n_thin < 256) {   // fewer 128-row tiles than CUs: 64-row tiles, 128-column chunks when the channel count allows (swept: 64 .. 512)
             const dim3 g((rows + 63) / 64, (c.C_out + 127) / 128, z);
             // a short utterance's pre-transformer GEMM (<= 128 frames x 1024..3072 channels) has 8-48 of these workgroups, each streaming
             // 0.5-1.5 MB of weights alone (47-75 us): cut K into 128-wide slices across workgroups, sum the slices in a tail kernel
