@@ -276,12 +276,11 @@ int q3tts_synthesize_schedule_host(q3tts_engine* h, int n_utt, const int64_t* id
             prow += 16; trow += (size_t)std::max(1, offsets[u + 1] - offsets[u] - 3);   // trailing rows: text tokens minus the first, plus tts_eos
         }
         prompts.resize(prow * H); trailing.resize(trow * H);
-        for (int u = 0; u < n_utt; ++u) {
-            Prep& q = prep[(size_t)u];
-            const int cap_rows = std::max(1, offsets[u + 1] - offsets[u] - 3);
-            e.build_prompt(ids + offsets[u], offsets[u + 1] - offsets[u], lang, speakers ? speakers[u] : nullptr, prompts.data() + q.poff * H, &q.S,
-                           trailing.data() + q.toff * H, std::min(cap_rows, e.max_trailing), &q.nt);
-        }
+        std::vector<size_t> toffs((size_t)n_utt);
+        std::vector<int> Ss((size_t)n_utt), nts((size_t)n_utt);
+        for (int u = 0; u < n_utt; ++u) toffs[(size_t)u] = prep[(size_t)u].toff;
+        e.build_prompts(ids, offsets, n_utt, lang, speakers, prompts.data(), Ss.data(), trailing.data(), toffs.data(), nts.data());
+        for (int u = 0; u < n_utt; ++u) { prep[(size_t)u].S = Ss[(size_t)u]; prep[(size_t)u].nt = nts[(size_t)u]; }
     }
     std::vector<Engine::SlotInit> init;
     std::vector<int> slot_utt((size_t)B, -1), done_frames((size_t)B, 0), fresh, retired;

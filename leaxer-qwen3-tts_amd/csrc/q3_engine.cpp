@@ -304,6 +304,8 @@ Engine::~Engine() {
     (void)hipSetDevice(device);
     if (stream) (void)hipStreamSynchronize(stream);
     for (auto& kv : graphs) (void)hipGraphExecDestroy(kv.second);
+    if (proj_ids_d) (void)hipFree(proj_ids_d);
+    if (proj_out_d) (void)hipFree(proj_out_d);
     codec_free();
     speaker_free();
     for (void* p : allocs) (void)hipFree(p);
@@ -535,23 +537,37 @@ void Engine::head_proj(const bf16_t* Wm, const float* x, int ldx, const float* g
 // ------------------------------------------------------------------------------------------------
 // session-shaped ops
 // ------------------------------------------------------------------------------------------------
+// All rows in one go: ids uploaded once, 16-row blocks (the last one padded with a repeat of the last id) through gather + fc1 + fc2
+// without a host round trip in between, one copy back.  Every block has the same shape, so a token's row does not depend on where in
+// the list — or in which job — it was projected.
 void Engine::text_project(const int64_t* ids, int n, float* out) {
     if (!finalized) throw Error("weights not finalized");
+    if (n <= 0) return;
     const int TH = c.text_hidden, H = c.hidden;
-    for (int i0 = 0; i0 < n; i0 += 16) {
-        const int m = std::min(16, n - i0);
-        for (int i = 0; i < m; ++i) if (ids[i0 + i] < 0 || ids[i0 + i] >= c.text_vocab) throw Error("text id out of range");
-        Q3_HIP_CHECK(hipMemcpyAsync(ids_d, ids + i0, (size_t)m * sizeof(int64_t), hipMemcpyHostToDevice, stream));
-        launch_gather_rows_bf16(text_embed, TH, ids_d, m, text_tmp, TH, stream);
+    for (int i = 0; i < n; ++i) if (ids[i] < 0 || ids[i] >= c.text_vocab) throw Error("text id out of range");
+    const int np = (n + 15) / 16 * 16;
+    if (proj_cap < (size_t)np) {
+        sync();
+        if (proj_ids_d) (void)hipFree(proj_ids_d);
+        if (proj_out_d) (void)hipFree(proj_out_d);
+        proj_cap = (size_t)std::max(np, 256);
+        Q3_HIP_CHECK(hipMalloc((void**)&proj_ids_d, proj_cap * sizeof(int64_t)));
+        Q3_HIP_CHECK(hipMalloc((void**)&proj_out_d, proj_cap * H * sizeof(float)));
+    }
+    std::vector<int64_t> padded((size_t)np, ids[n - 1]);
+    memcpy(padded.data(), ids, (size_t)n * sizeof(int64_t));
+    Q3_HIP_CHECK(hipMemcpyAsync(proj_ids_d, padded.data(), (size_t)np * sizeof(int64_t), hipMemcpyHostToDevice, stream));
+    for (int i0 = 0; i0 < np; i0 += 16) {
+        launch_gather_rows_bf16(text_embed, TH, proj_ids_d + i0, 16, text_tmp, TH, stream);
         GemvArgs a;
-        a.W = fc1_w; a.x = text_tmp; a.ldx = TH; a.bias = fc1_b; a.out = text_tmp2; a.ldo = TH; a.M = m; a.N = TH; a.K = TH; a.epi = EPI_BIAS_SILU;
+        a.W = fc1_w; a.x = text_tmp; a.ldx = TH; a.bias = fc1_b; a.out = text_tmp2; a.ldo = TH; a.M = 16; a.N = TH; a.K = TH; a.epi = EPI_BIAS_SILU;
         launch_gemv(a, stream);
         GemvArgs b;
-        b.W = fc2_w; b.x = text_tmp2; b.ldx = TH; b.bias = fc2_b; b.out = xp; b.ldo = H; b.M = m; b.N = H; b.K = TH; b.epi = EPI_BIAS;
+        b.W = fc2_w; b.x = text_tmp2; b.ldx = TH; b.bias = fc2_b; b.out = proj_out_d + (size_t)i0 * H; b.ldo = H; b.M = 16; b.N = H; b.K = TH; b.epi = EPI_BIAS;
         launch_gemv(b, stream);
-        Q3_HIP_CHECK(hipMemcpyAsync(out + (size_t)i0 * H, xp, (size_t)m * H * sizeof(float), hipMemcpyDeviceToHost, stream));
-        sync();
     }
+    Q3_HIP_CHECK(hipMemcpyAsync(out, proj_out_d, (size_t)n * H * sizeof(float), hipMemcpyDeviceToHost, stream));
+    sync();   // also keeps `padded` alive until the upload is done
 }
 
 void Engine::codec_embed(const int64_t* ids, int n, float* out) {
@@ -645,54 +661,79 @@ void Engine::sample(const float* logits, int n, const q3tts_sampling& p, float u
     sync();
 }
 
-// build_prompt_embeddings, reference src/tts_onnx.cpp:442-539 (row layout; fp32 adds on the host
-// exactly as the reference does them, network calls on the device)
+// build_prompt_embeddings, reference src/tts_onnx.cpp:442-539, for one utterance: the batch builder below with a batch of one
 void Engine::build_prompt(const int64_t* ids, int n_ids, int lang, const float* speaker, float* prompt, int* S,
                           float* trailing, int cap_rows, int* n_trailing) {
-    const int H = c.hidden;
     // the reference indexes input_ids[0..3] unguarded (:493, :518): 4 ids is the least it can take.  Empty text = the 5-token frame:
     // TTS_EOS lands in the "first text token" slot and the trailing block is just [tts_eos].
     if (n_ids < 4) throw Error("token sequence too short: need at least 4 ids (the reference indexes input_ids[3])");
-    std::vector<float> tts(3 * (size_t)H);
-    const int64_t tts_ids[3] = { TTS_BOS, TTS_EOS, TTS_PAD };
-    text_project(tts_ids, 3, tts.data());                       // :459-463
-    const float *tts_bos = tts.data(), *tts_eos = tts.data() + H, *tts_pad = tts.data() + 2 * H;
-    std::vector<int64_t> cpf;
-    if (lang == 0) cpf = { CODEC_NOTHINK, CODEC_THINK_BOS, CODEC_THINK_EOS };                      // :467-469
-    else cpf = { CODEC_THINK, CODEC_THINK_BOS, LANG_ENGLISH + (lang - 1), CODEC_THINK_EOS };       // :470-474
-    cpf.push_back(CODEC_PAD); cpf.push_back(CODEC_BOS);                                            // :475-476
-    const int ncp = (int)cpf.size();
-    std::vector<float> ce((size_t)(ncp + 1) * H);
-    codec_embed(cpf.data(), ncp, ce.data());                                                       // :478
-    if (speaker) { // speaker row inserted before the last (BOS) row, :481-490
-        memmove(ce.data() + (size_t)ncp * H, ce.data() + (size_t)(ncp - 1) * H, (size_t)H * sizeof(float));
-        memcpy(ce.data() + (size_t)(ncp - 1) * H, speaker, (size_t)H * sizeof(float));
-    }
-    int row = 0;
-    text_project(ids, 3, prompt);                                                                  // :493-494
-    row = 3;
-    const int pad_count = ncp - 2 + (speaker ? 1 : 0);                                             // :497-498
-    for (int i = 0; i <= pad_count; ++i, ++row) {                                                  // :506-512
-        const float* t = i < pad_count ? tts_pad : tts_bos;
-        for (int j = 0; j < H; ++j) prompt[(size_t)row * H + j] = t[j] + ce[(size_t)i * H + j];
-    }
-    const int text_start = 3, text_end = n_ids - 2;                                                // :515-516
-    std::vector<float> ft(H);
-    text_project(ids + text_start, 1, ft.data());                                                  // :518
-    for (int j = 0; j < H; ++j) prompt[(size_t)row * H + j] = ft[j] + ce[(size_t)(pad_count + 1) * H + j]; // :519-520
-    ++row;
-    *S = row;
-    int nt = text_end - (text_start + 1);
-    if (nt < 0) nt = 0;
-    if (nt + 1 > cap_rows) throw Error("text too long for the trailing buffer");
-    if (nt > 0) text_project(ids + text_start + 1, nt, trailing);                                  // :531-534 (row-wise identical to per-token calls)
-    memcpy(trailing + (size_t)nt * H, tts_eos, (size_t)H * sizeof(float));                         // :535
-    *n_trailing = nt + 1;                                                                          // :536
+    if (std::max(0, n_ids - 6) + 1 > cap_rows) throw Error("text too long for the trailing buffer");
+    const int32_t offsets[2] = { 0, n_ids };
+    const size_t toff = 0;
+    const float* spk[1] = { speaker };
+    build_prompts(ids, offsets, 1, lang, speaker ? spk : nullptr, prompt, S, trailing, &toff, n_trailing);
 }
 
 // ------------------------------------------------------------------------------------------------
 // fused generation: one frame = sampler + (n_groups-1) predictor passes + talker decode
 // ------------------------------------------------------------------------------------------------
+// build_prompt_embeddings for every utterance of a job: ONE projection pass over all the text ids the prompts need (the three tts
+// specials first) and one codec-embedding gather (the control rows depend on the language only), then the reference's fp32 row sums on
+// the host (tts_onnx.cpp:442-539, same order as build_prompt).  prompts: [n_utt][16][hidden]; trailing rows of utterance u start at row
+// toff[u] of `trailing`.
+void Engine::build_prompts(const int64_t* ids, const int32_t* offsets, int n_utt, int lang, const float* const* speakers,
+                           float* prompts, int* S_out, float* trailing, const size_t* toff, int* nt_out) {
+    const int H = c.hidden;
+    std::vector<int64_t> all = { TTS_BOS, TTS_EOS, TTS_PAD };
+    std::vector<size_t> first((size_t)n_utt);
+    for (int u = 0; u < n_utt; ++u) {
+        const int n_ids = offsets[u + 1] - offsets[u];
+        if (n_ids < 4) throw Error("token sequence too short: need at least 4 ids (the reference indexes input_ids[3])");
+        first[(size_t)u] = all.size();
+        const int used = std::max(4, n_ids - 2);                  // ids[0..2] role, ids[3] first text, ids[4 .. n-2) trailing
+        if (used - 4 + 1 > max_trailing) throw Error("text too long for the trailing buffer");
+        all.insert(all.end(), ids + offsets[u], ids + offsets[u] + used);
+    }
+    std::vector<float> proj(all.size() * (size_t)H);
+    text_project(all.data(), (int)all.size(), proj.data());
+    const float *tts_bos = proj.data(), *tts_eos = proj.data() + H, *tts_pad = proj.data() + 2 * (size_t)H;
+    std::vector<int64_t> cpf;
+    if (lang == 0) cpf = { CODEC_NOTHINK, CODEC_THINK_BOS, CODEC_THINK_EOS };                      // :467-469
+    else cpf = { CODEC_THINK, CODEC_THINK_BOS, LANG_ENGLISH + (lang - 1), CODEC_THINK_EOS };       // :470-474
+    cpf.push_back(CODEC_PAD); cpf.push_back(CODEC_BOS);                                            // :475-476
+    const int ncp = (int)cpf.size();
+    std::vector<float> ce0((size_t)ncp * H), ce((size_t)(ncp + 1) * H);
+    codec_embed(cpf.data(), ncp, ce0.data());                                                      // :478
+    for (int u = 0; u < n_utt; ++u) {
+        const int n_ids = offsets[u + 1] - offsets[u];
+        const float* speaker = speakers ? speakers[u] : nullptr;
+        const float* rows = proj.data() + first[(size_t)u] * H;   // projections of ids[0], ids[1], ...
+        float* prompt = prompts + (size_t)u * 16 * H;
+        memcpy(ce.data(), ce0.data(), ce0.size() * sizeof(float));
+        if (speaker) { // speaker row inserted before the last (BOS) row, :481-490
+            memmove(ce.data() + (size_t)ncp * H, ce.data() + (size_t)(ncp - 1) * H, (size_t)H * sizeof(float));
+            memcpy(ce.data() + (size_t)(ncp - 1) * H, speaker, (size_t)H * sizeof(float));
+        }
+        memcpy(prompt, rows, (size_t)3 * H * sizeof(float));                                        // :493-494
+        int row = 3;
+        const int pad_count = ncp - 2 + (speaker ? 1 : 0);                                         // :497-498
+        for (int i = 0; i <= pad_count; ++i, ++row) {                                              // :506-512
+            const float* t = i < pad_count ? tts_pad : tts_bos;
+            for (int j = 0; j < H; ++j) prompt[(size_t)row * H + j] = t[j] + ce[(size_t)i * H + j];
+        }
+        const float* ft = rows + (size_t)3 * H;                                                    // first text token, :518
+        for (int j = 0; j < H; ++j) prompt[(size_t)row * H + j] = ft[j] + ce[(size_t)(pad_count + 1) * H + j]; // :519-520
+        ++row;
+        S_out[u] = row;
+        int nt = (n_ids - 2) - 4;                                                                  // text_end - (text_start + 1), :531-534
+        if (nt < 0) nt = 0;
+        float* tr = trailing + toff[u] * H;
+        if (nt > 0) memcpy(tr, rows + (size_t)4 * H, (size_t)nt * H * sizeof(float));
+        memcpy(tr + (size_t)nt * H, tts_eos, (size_t)H * sizeof(float));                           // :535
+        nt_out[u] = nt + 1;                                                                        // :536
+    }
+}
+
 // predictor input rows: talker-width rows through cp.proj (bias) when the predictor is narrower, else the rows themselves
 float* Engine::cp_project(float* rows, int ld, int M) {
     if (!cp_projected()) return rows;

@@ -85,6 +85,9 @@ public:
     void sample(const float* logits, int n, const q3tts_sampling& p, float u, int suppress, int64_t* tok);
     void build_prompt(const int64_t* ids, int n_ids, int lang, const float* speaker, float* prompt, int* S,
                       float* trailing, int cap_rows, int* n_trailing);
+    void build_prompts(const int64_t* ids, const int32_t* offsets, int n_utt, int lang, const float* const* speakers,
+                       float* prompts, int* S_out, float* trailing, const size_t* toff, int* nt_out);
+    int64_t* proj_ids_d = nullptr; float* proj_out_d = nullptr; size_t proj_cap = 0;   // text_project staging (grow-only)
     int64_t codec_decode_host(const int64_t* codes, int F, float* pcm, int64_t cap);
     int64_t codec_decode_dev(const int32_t* codes_dev, int F, float* pcm_dev, int64_t cap);
     // exact chunked / streaming decode: samples owned by frames [a, b), decoded from the window [a - left_context, b)
