@@ -891,8 +891,11 @@ void Engine::slots_begin(const SlotInit* in, int n, const q3tts_sampling& p, uin
 
 int Engine::decode_steps(int n_steps) {
     if (!finalized) throw Error("weights not finalized");
-    const int nb = nb_in_use();
+    int nb = nb_in_use();
     if (nb == 0) return 0;
+    // One captured graph per batch width: past 16 rows widths are rounded up to a multiple of 8 (the extra slots are unarmed, their rows
+    // masked like any finished slot's), so a queue that drains from 64 slots to 17 replays 7 graphs instead of capturing 48.
+    if (nb > 16) nb = std::min(B, (nb + 7) / 8 * 8);
     hipGraphExec_t exec = nullptr;
     if (!(flags & Q3TTS_FLAG_NO_GRAPH)) {
         auto it = graphs.find(nb);
