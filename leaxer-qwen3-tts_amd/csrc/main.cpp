@@ -35,7 +35,7 @@ static int save_wav16(const char* path, const std::vector<float>& audio, uint32_
 
 static void usage(const char* prog) {
     printf("Usage: %s [options]\n\nQwen3-TTS synthesis on MI355X (HIP)\n\nOptions:\n", prog);
-    printf("  -m, --model DIR       model directory holding model.q3w, or synthetic:<seed> (required)\n");
+    printf("  -m, --model DIR       model directory holding model.q3w, or synthetic:<seed> / synthetic-1.7b:<seed> (required)\n");
     printf("  -p, --prompt TEXT     text to synthesize (needs vocab.json + merges.txt, see README)\n");
     printf("      --tokens IDS      comma-separated text token ids (framed as IM_START ASSISTANT TTS_BOS ids TTS_EOS IM_END)\n");
     printf("  -o, --output PATH     output WAV file (default: output.wav)\n");
@@ -84,7 +84,7 @@ int main(int argc, char** argv) {
         return 1;
     }
     struct stat stbuf;
-    if (model.rfind("synthetic:", 0) != 0 && stat(model.c_str(), &stbuf) != 0) {
+    if (model.rfind("synthetic:", 0) != 0 && model.rfind("synthetic-1.7b:", 0) != 0 && stat(model.c_str(), &stbuf) != 0) {
         fprintf(stderr, "Error: model directory not found: %s\n", model.c_str());
         return 1;
     }

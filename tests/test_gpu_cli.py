@@ -124,3 +124,13 @@ def test_cli_errors_like_the_reference(tmp_path):
     assert r.returncode == 1 and "model directory not found" in r.stderr
     r = subprocess.run([CLI, "-m", "synthetic:0", "-p", "hello", "--max-tokens", "4"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 1 and "Tokenizer not ready" in r.stderr and "synthesis failed" in r.stderr
+
+
+def test_cli_synthetic_1p7b_spec(tmp_path):
+    """-m synthetic-1.7b:<seed>: the 1.7B dims (talker 2048 wide, predictor behind cp.proj) through the reference-shaped CLI."""
+    out = str(tmp_path / "o.wav")
+    r = subprocess.run([CLI, "-m", "synthetic-1.7b:3", "--tokens", "1001,2002,3003", "-o", out, "--max-tokens", "6", "--seed", "1"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    pcm = read_wav16(out)
+    assert pcm.size > 6 * 1920 - 1920 and np.abs(pcm).max() > 0
