@@ -94,3 +94,22 @@ def test_sampling_parameter_extremes(pair):
         sp = q3tts.Sampling(max_new_tokens=1, **kw)
         for u in (0.0, 0.3, 0.999999):
             assert eng.sample(logits, sp, u) == orc.sample(logits, to_osampling(sp), u), (kw, u)
+
+
+def test_scheduler_error_leaves_the_engine_usable():
+    """A job with an invalid utterance (fewer than the 4 ids the reference indexes, or an id outside the text vocabulary) fails as a whole
+    with the reason; the next job on the same handle runs normally and matches the oracle."""
+    import q3tts
+    eng, orc, _ = tiny_pair(seed=27, max_batch=2, max_ctx=64)
+    sp = q3tts.Sampling(temperature=0.8, top_p=0.95, top_k=50, max_new_tokens=6)
+    good = frame_tokens([4, 5, 6])
+    with pytest.raises(RuntimeError, match="too short"):
+        eng.synthesize_batch([good, np.array([1, 2, 3], np.int64), good], sp)
+    with pytest.raises(RuntimeError, match="text id out of range"):
+        eng.synthesize_batch([good, frame_tokens([10 ** 7])], sp)
+    pcm, codes, nfr = eng.synthesize_batch([good, good, good], sp, seed=3, ignore_eos=True)
+    for u in range(3):
+        ref = orc.generate(orc.build_prompt(good, 0), to_osampling(sp), seed=3, stream=u, cp_cached=True, ignore_eos=True)
+        assert np.array_equal(codes[u], ref), u
+    eng.close()
+    orc.close()
