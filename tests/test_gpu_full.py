@@ -67,6 +67,23 @@ def test_greedy_generation_full_size(full):
     assert np.array_equal(codes, again)            # deterministic, slot-independent
 
 
+@pytest.mark.parametrize("sampled", [False, True])
+def test_forty_frames_full_size(full, sampled):
+    """0.6B dims, 40 frames = 640 codec decisions on one utterance (configs[1] sampling when `sampled`): ids bit-exact vs the oracle,
+    through the context growing across the first split boundary of the predictor-fused step."""
+    import q3tts
+    eng, orc = full
+    ids = frame_tokens(np.random.default_rng(4).integers(0, 151643, 16))
+    kw = dict(temperature=0.8, top_p=0.95, top_k=50) if sampled else dict(temperature=1.0, top_p=1.0, top_k=1)
+    sp = q3tts.Sampling(max_new_tokens=40, **kw)
+    p, t = eng.build_prompt(ids, 0)
+    codes = eng.generate(p, t, sp, seed=5, stream_id=2, ignore_eos=True)
+    ref = orc.generate(orc.build_prompt(ids, 0), to_osampling(sp), seed=5, stream=2, cp_cached=True, ignore_eos=True)
+    assert codes.shape == ref.shape == (40, 16)
+    bad = np.argwhere(codes != ref)
+    assert bad.size == 0, bad[:4]
+
+
 def test_fused_predictor_attention_matches_separate_launches(full):
     """b = 1 runs the code predictor's attention + o_proj as one launch (k_cp_attn_oproj); the separate-launch
     path (Q3TTS_FLAG_NO_FUSED_CP) and the oracle must give the same sampled frames."""
