@@ -156,3 +156,14 @@ def test_log_mel_matches_reference(ref):
         assert np.abs(got - want)[strong].max() < 1e-3, name
     assert q3tts.log_mel(np.zeros(0, np.float32)).shape == (128, 0)
     assert ref.ref_mel(None, 0, None, 0) == 0
+
+
+def test_host_parsers_survive_garbage_under_sanitizers():
+    """AddressSanitizer + UBSan build of the tokenizer-file readers, the WAV reader, the resampler and the mel extractor, driven with
+    seeded mutations of well-formed files (tools/host_sanitize.cpp): they parse what users supply, so no input may make them touch
+    memory they do not own.  CPU only (GPU sanitizers are not available on the pool)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run(["bash", os.path.join(root, "tools", "host_sanitize.sh"), "150"], capture_output=True, timeout=600)   # stderr echoes garbage bytes
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert b"no sanitizer report" in r.stdout
