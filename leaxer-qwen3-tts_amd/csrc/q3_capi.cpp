@@ -496,6 +496,9 @@ int q3tts_load_weights_file(q3tts_engine* h, const char* path) {
         rd(fl.f, &dtype, 1);
         uint64_t numel = 0;
         rd(fl.f, &numel, 8);
+        // the header is untrusted: size the buffers from the registry, not from the file
+        const q3::Tensor& want = h->e->T(name);
+        if ((uint64_t)want.numel != numel) throw q3::Error("weights file: tensor '" + name + "' has " + std::to_string(numel) + " elements, expected " + std::to_string(want.numel));
         f32.resize(numel);
         if (dtype == 0) rd(fl.f, f32.data(), numel * 4);
         else if (dtype == 1) {

@@ -113,3 +113,39 @@ def test_scheduler_error_leaves_the_engine_usable():
         assert np.array_equal(codes[u], ref), u
     eng.close()
     orc.close()
+
+
+def test_corrupt_weight_files_are_rejected(tmp_path):
+    """The weight file is user input: a wrong magic, a truncated file, an absurd element count or an unknown tensor name end in an error
+    message, never in a huge allocation or a partially loaded engine being used."""
+    import struct
+    import q3tts
+    eng, orc, _ = tiny_pair(seed=29, max_batch=1, max_ctx=64)
+    good = tmp_path / "good.q3w"
+    eng.save_weights(str(good))
+    raw = good.read_bytes()
+    cfg_bytes = struct.unpack("<I", raw[8:12])[0]
+    first = 8 + 4 + cfg_bytes + 4                       # offset of the first tensor record: u16 name length, name, u8 dtype, u64 numel
+    nl = struct.unpack("<H", raw[first:first + 2])[0]
+    numel_off = first + 2 + nl + 1
+    cases = {
+        "magic": b"XXXXXXXX" + raw[8:],
+        "truncated": raw[: len(raw) // 3],
+        "numel": raw[:numel_off] + struct.pack("<Q", 1 << 60) + raw[numel_off + 8:],
+        "name": raw[:first + 2] + b"Z" * nl + raw[first + 2 + nl:],
+        "cfg": raw[:8] + struct.pack("<I", 4096) + raw[12:],
+    }
+    for tag, blob in cases.items():
+        p = tmp_path / f"{tag}.q3w"
+        p.write_bytes(blob)
+        e2 = q3tts.Engine(eng.cfg, device=0, max_batch=1, max_ctx=64)
+        with pytest.raises(RuntimeError):
+            e2.load_weights(str(p))
+        e2.close()
+    e3 = q3tts.Engine(eng.cfg, device=0, max_batch=1, max_ctx=64)
+    e3.load_weights(str(good))
+    ids = frame_tokens([3, 4, 5])
+    assert np.array_equal(e3.build_prompt(ids, 0)[0], eng.build_prompt(ids, 0)[0])
+    e3.close()
+    eng.close()
+    orc.close()
