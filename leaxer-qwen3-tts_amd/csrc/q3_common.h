@@ -135,6 +135,7 @@ struct GemmArgs {
     float* out2 = nullptr;                    // EPI_SLAB2: slabs of the W2 product
     bf16_t* oh = nullptr; bf16_t* ol = nullptr; int ldp = 0; // optional plane outputs (input of the next GEMM)
     int M = 0, N = 0, K = 0, epi = EPI_STORE;
+    int slab_rows = 0;   // EPI_SLAB / EPI_SLAB2: rows per slab (0 = M); launch_gemm2 sets it when it cuts M into 128-row blocks
 };
 void launch_gemm2(const GemmArgs& a, int ksplit, int nw, hipStream_t s); // EPI_SLAB: out = slabs [ksplit][M][ldo]
 void launch_finish(float* x, int ldx, const float* slab, int nslab, size_t slab_stride, int ld_slab, const float* gamma, float eps,

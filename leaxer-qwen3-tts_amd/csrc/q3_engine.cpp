@@ -414,7 +414,7 @@ bool Engine::run_layers(const DecStack& W, float* x, int ldx, int nb, int n_new,
                         const float* final_gamma, float final_eps, float* final_xn, int final_ld_xn, const int* slot_map) {
     const int M = nb * n_new, QKV = (W.nq + 2 * W.nkv) * W.d, AO = W.nq * W.d;
     // M >= mfma_min_rows: bf16-MFMA skinny GEMM over (hi, lo) activation planes; below it the single-pass GEMV family
-    const bool mfma = M >= mfma_min_rows && M <= 128 && W.H % 128 == 0 && AO % 128 == 0 && W.ffn % 128 == 0 && W.H <= 4096;
+    const bool mfma = M >= mfma_min_rows && W.H % 128 == 0 && AO % 128 == 0 && W.ffn % 128 == 0 && W.H <= 4096;
     const int ks_q = mfma ? std::min(4, pick_ksplit(W.H)) : 1;
     if (mfma) // planes0 = RMSNorm(in_norm[0])(x)
         launch_finish(x, ldx, nullptr, 0, 0, 0, W.layers[0].in_norm, W.eps, M, W.H, pl0h, pl0l, ldp, nullptr, 0, stream);
@@ -517,7 +517,7 @@ bool Engine::run_layers(const DecStack& W, float* x, int ldx, int nb, int n_new,
 // final RMSNorm + output head (codec_head / cp.head.j); optionally keeps the normalised rows
 void Engine::head_proj(const bf16_t* Wm, const float* x, int ldx, const float* gamma, float eps, float* xn_out, int ld_xn,
                        float* out, int ldo, int M, int N, int K, bool nt, bool planes_ready, int plane_row0, int plane_row_stride) {
-    if (planes_ready || (M >= mfma_min_rows && M <= 128 && K % 128 == 0 && K <= 4096)) {
+    if (planes_ready || (M >= mfma_min_rows && K % 128 == 0 && K <= 4096)) {
         if (!planes_ready) {
             launch_finish(const_cast<float*>(x), ldx, nullptr, 0, 0, 0, gamma, eps, M, K, pl0h, pl0l, ldp, xn_out, ld_xn, stream);
             plane_row0 = 0; plane_row_stride = 1;

@@ -12,6 +12,8 @@
 //   k_gemm2  (17..128 rows): planes written by the producers (k_finish*, k_attn), activation slice staged through LDS and
 //                            shared by 64 columns, split-K slabs reduced in fixed order by k_finish / k_finish_swiglu
 // Summation order is fixed everywhere: results are bit-reproducible run to run.
+#include <algorithm>
+
 #include "q3_common.h"
 
 namespace q3 {
@@ -149,8 +151,8 @@ __global__ __launch_bounds__(NW * 64) void k_gemm2(const bf16_t* pW, const bf16_
             if (m >= M) continue;
             float o = acc[mt][r];
             if (EPI == EPI_SWIGLU) o = silu_g(o) * acc2[mt][r];
-            if (EPI == EPI_SLAB) { a.out[((size_t)blockIdx.y * M + m) * a.ldo + n] = o; continue; }
-            if (EPI == EPI_SLAB2) { a.out[((size_t)blockIdx.y * M + m) * a.ldo + n] = o; a.out2[((size_t)blockIdx.y * M + m) * a.ldo + n] = acc2[mt][r]; continue; }
+            if (EPI == EPI_SLAB) { a.out[((size_t)blockIdx.y * a.slab_rows + m) * a.ldo + n] = o; continue; }
+            if (EPI == EPI_SLAB2) { a.out[((size_t)blockIdx.y * a.slab_rows + m) * a.ldo + n] = o; a.out2[((size_t)blockIdx.y * a.slab_rows + m) * a.ldo + n] = acc2[mt][r]; continue; }
             if (a.out) a.out[(size_t)m * a.ldo + n] = o;
             if (a.oh) split_store(o, a.oh + (size_t)m * a.ldp + n, a.ol + (size_t)m * a.ldp + n);
         }
@@ -174,13 +176,25 @@ static void gemm2_nw(const GemmArgs& a, int ksplit, int nw, hipStream_t s) {
     if (nw == 2) gemm2_epi<MTILES, 2>(a, ksplit, s); else gemm2_epi<MTILES, 4>(a, ksplit, s);
 }
 // ksplit: number of K slices (1 = complete sums, direct epilogue; >1 requires EPI_SLAB); nw: waves (= 16-column tiles) per workgroup
-void launch_gemm2(const GemmArgs& a, int ksplit, int nw, hipStream_t s) {
-    if (a.M < 1 || a.M > 128 || a.K % (G2_KC * ksplit) != 0 || a.ldx % 8 != 0) throw Error("gemm2: unsupported shape");
-    if (ksplit > 1 && a.epi != EPI_SLAB && a.epi != EPI_SLAB2) throw Error("gemm2: split-K needs a slab epilogue");
-    if (a.M <= 16) gemm2_nw<1>(a, ksplit, nw, s);
-    else if (a.M <= 32) gemm2_nw<2>(a, ksplit, nw, s);
-    else if (a.M <= 64) gemm2_nw<4>(a, ksplit, nw, s);
-    else gemm2_nw<8>(a, ksplit, nw, s);
+void launch_gemm2(const GemmArgs& a0, int ksplit, int nw, hipStream_t s) {
+    if (a0.M < 1 || a0.K % (G2_KC * ksplit) != 0 || a0.ldx % 8 != 0) throw Error("gemm2: unsupported shape");
+    if (ksplit > 1 && a0.epi != EPI_SLAB && a0.epi != EPI_SLAB2) throw Error("gemm2: split-K needs a slab epilogue");
+    // more than 128 rows: 128-row blocks, each streaming the weights again (L2 / MALL resident after the first); slabs keep their
+    // [slice][all rows][N] shape, a block writes its rows of every slice
+    for (int m0 = 0; m0 < a0.M; m0 += 128) {
+        GemmArgs a = a0;
+        a.M = std::min(128, a0.M - m0);
+        a.slab_rows = a0.slab_rows > 0 ? a0.slab_rows : a0.M;
+        a.xh = a0.xh + (size_t)m0 * a0.ldx; a.xl = a0.xl + (size_t)m0 * a0.ldx;
+        if (a0.out) a.out = a0.out + (size_t)m0 * a0.ldo;
+        if (a0.out2) a.out2 = a0.out2 + (size_t)m0 * a0.ldo;
+        if (a0.oh) { a.oh = a0.oh + (size_t)m0 * a0.ldp; a.ol = a0.ol + (size_t)m0 * a0.ldp; }
+        if (a0.res) a.res = a0.res + (size_t)m0 * a0.ldres;
+        if (a.M <= 16) gemm2_nw<1>(a, ksplit, nw, s);
+        else if (a.M <= 32) gemm2_nw<2>(a, ksplit, nw, s);
+        else if (a.M <= 64) gemm2_nw<4>(a, ksplit, nw, s);
+        else gemm2_nw<8>(a, ksplit, nw, s);
+    }
 }
 
 // ================================================================================================

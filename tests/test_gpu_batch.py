@@ -138,3 +138,19 @@ def test_scattered_slots_share_one_prefill_pass():
         assert np.array_equal(codes[u], ref[: caps[u]]), u
     eng.close()
     orc.close()
+
+
+def test_more_than_128_rows_per_projection():
+    """70 utterances in one batch: predictor pass 0 has 140 rows, which the matrix-core GEMM walks as 128-row blocks (the slabs keep
+    their [slice][all rows] shape).  Codes of utterances on both sides of the block boundary bit-exact vs the oracle."""
+    import q3tts
+    eng, orc, _ = tiny_pair(seed=31, max_batch=70, max_ctx=64, ocfg=qo.config_medium())
+    sp = q3tts.Sampling(temperature=0.8, top_p=0.95, top_k=50, max_new_tokens=10)
+    rng = np.random.default_rng(19)
+    toks = [frame_tokens(rng.integers(0, 151643, int(n))) for n in rng.integers(1, 10, 70)]
+    pcm, codes, nfr = eng.synthesize_batch(toks, sp, lang=0, seed=44, ignore_eos=True)
+    for u in (0, 31, 62, 63, 64, 65, 69):
+        ref = orc.generate(orc.build_prompt(toks[u], 0), to_osampling(sp), seed=44, stream=u, cp_cached=True, ignore_eos=True)
+        assert nfr[u] == 10 and np.array_equal(codes[u], ref), u
+    eng.close()
+    orc.close()
