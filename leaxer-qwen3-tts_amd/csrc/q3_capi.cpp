@@ -344,9 +344,18 @@ int q3tts_synthesize_schedule_host(q3tts_engine* h, int n_utt, const int64_t* id
         for (int b = 0; b < B; ++b) { try { e.slot_release(b); } catch (...) { } }
         throw;
     }
-    for (int u = 0; u < n_utt; ++u) {   // vocoder: every utterance of the job over the side lanes, once the decode queue is empty
+    // vocoder, once the decode queue is empty: the pre-transformer of all utterances in one batched pass (when padding them to the
+    // longest costs less than half as many rows again), then every utterance's conv stack over the side lanes
+    int64_t sum_f = 0;
+    int Fp = 0;
+    for (int u = 0; u < n_utt; ++u) { sum_f += got_frames[(size_t)u]; Fp = std::max(Fp, (int)got_frames[(size_t)u]); }
+    const float* hb = nullptr;
+    if (n_utt >= 2 && Fp > 0 && (int64_t)n_utt * Fp <= sum_f + sum_f / 2 && (int64_t)n_utt * Fp <= (int64_t)1 << 18)   // 49 KB of workspace per row
+        hb = e.codec_pre_batch(e.codec_job_codes(0, row_frames), row_frames, n_utt, Fp);
+    for (int u = 0; u < n_utt; ++u) {
         if (pcm_len) pcm_len[u] = 0;
-        e.codec_async_submit_dev(e.codec_job_codes(u, row_frames), got_frames[(size_t)u], pcm_out ? pcm_out[u] : nullptr, pcm_cap, pcm_len ? pcm_len + u : nullptr);
+        e.codec_async_submit_dev(e.codec_job_codes(u, row_frames), got_frames[(size_t)u], pcm_out ? pcm_out[u] : nullptr, pcm_cap, pcm_len ? pcm_len + u : nullptr,
+                                 hb ? hb + (size_t)u * Fp * e.c.cd_hidden : nullptr);
     }
     e.codec_async_drain();
     return 0;

@@ -43,10 +43,12 @@ struct CodecW {
     // asynchronous per-utterance decodes over the side lanes: result parked in the lane's pinned buffer until the lane is drained
     struct Pending { float* user = nullptr; int64_t n = 0, cap = 0; int64_t* len = nullptr; int frames = 0; bool busy = false; };
     Pending pend[NLANE];
-    int32_t* job_codes = nullptr; size_t job_codes_n = 0;   // codes of a scheduler job's finished utterances, [utterance][max_new][groups]
+    int32_t* job_codes = nullptr; size_t job_codes_n = 0;
+    char* batch_arena = nullptr; size_t batch_arena_bytes = 0;   // batched pre-transformer of a job (codec_pre_batch)
+    int* batch_pages = nullptr; int batch_pages_n = 0;           // identity page table, one cache block per utterance   // codes of a scheduler job's finished utterances, [utterance][max_new][groups]
     hipEvent_t lane_done[NLANE] = {};
     hipEvent_t fork = nullptr, win0 = nullptr, win1 = nullptr;
-    bool window_open = false;
+    bool window_open = false, win0_recorded = false;
     int rr = 0;
 };
 
@@ -62,6 +64,8 @@ void Engine::codec_free() {
     }
     for (hipEvent_t ev : { codec->fork, codec->win0, codec->win1 }) if (ev) (void)hipEventDestroy(ev);
     if (codec->job_codes) (void)hipFree(codec->job_codes);
+    if (codec->batch_arena) (void)hipFree(codec->batch_arena);
+    if (codec->batch_pages) (void)hipFree(codec->batch_pages);
     if (codec->rope_cos) (void)hipFree(codec->rope_cos);
     if (codec->rope_sin) (void)hipFree(codec->rope_sin);
     if (codec->page_table) (void)hipFree(codec->page_table);
@@ -175,7 +179,7 @@ static int tconv_out_len(const q3tts_config& c, int T, int k, int s, int* left_o
     return (T - 1) * s + k - left - pad;
 }
 
-int64_t Engine::codec_run(const int32_t* codes_dev, int F, float** pcm_dev, int lane) {
+int64_t Engine::codec_run(const int32_t* codes_dev, int F, float** pcm_dev, int lane, const float* h_in) {
     if (!codec) throw Error("codec decoder not finalized");
     CodecW& W = *codec;
     if (lane < 0 || lane >= W.nlane) throw Error("codec: bad lane");
@@ -236,8 +240,8 @@ int64_t Engine::codec_run(const int32_t* codes_dev, int F, float** pcm_dev, int 
         float* gb = take((size_t)F * FF);
         float* kc = take((size_t)NH * P * HD);
         float* vc = take((size_t)NH * P * HD);
-        if (!plan) launch_code_embed_mean(W.code_embed, codes_dev, F, c.n_groups, c.cd_codebook, CH, h, stream);
-        for (int l = 0; l < c.cd_layers; ++l) {
+        if (!plan && !h_in) launch_code_embed_mean(W.code_embed, codes_dev, F, c.n_groups, c.cd_codebook, CH, h, stream);
+        for (int l = 0; l < (h_in ? 0 : c.cd_layers); ++l) {   // h_in: the pre-transformer of this utterance already ran in codec_pre_batch
             const CodecW::Layer& L = W.layers[l];
             if (!plan) launch_rmsnorm_rows(h, L.in_norm, c.cd_rms_eps, F, CH, hn, stream);
             conv(gemm(hn, F, CH, L.qkv, nullptr, 3 * CH, qkvb));
@@ -256,9 +260,9 @@ int64_t Engine::codec_run(const int32_t* codes_dev, int F, float** pcm_dev, int 
             { ConvArgs a = gemm(hn, F, CH, L.gate, nullptr, FF, gb); a.act = 2; a.mul = ub; conv(a); }
             { ConvArgs a = gemm(gb, F, FF, L.down, nullptr, CH, h); a.res_scale = L.mlp_scale; a.res = h; conv(a); }
         }
-        if (!plan) launch_rmsnorm_rows(h, W.norm, c.cd_rms_eps, F, CH, h, stream);
+        if (!plan && !h_in) launch_rmsnorm_rows(h, W.norm, c.cd_rms_eps, F, CH, h, stream);
         // ---- ConvNeXt upsampling stages ----
-        float* cur = h;
+        float* cur = h_in ? const_cast<float*>(h_in) : h;
         int Tc = F;
         for (int s = 0; s < c.cd_n_up; ++s) {
             const CodecW::Up& U = W.up[s];
@@ -321,6 +325,84 @@ int64_t Engine::codec_run(const int32_t* codes_dev, int F, float** pcm_dev, int 
 
 
 // ------------------------------------------------------------------------------------------------
+// Pre-transformer of a whole job in one pass: the utterances' frames are laid out as [utterance][Fp] rows (Fp = the longest, shorter
+// ones padded: attention is causal, so padding rows never reach a real one), every linear layer is ONE matrix-core GEMM over all rows
+// (weights streamed once, full grids) instead of one short GEMM per utterance, attention runs with the utterance as its batch
+// dimension.  Returns the normalised hidden rows [n][Fp][cd_hidden] (valid until the next call); codes: [n][codes_stride_frames][groups].
+// ------------------------------------------------------------------------------------------------
+const float* Engine::codec_pre_batch(const int32_t* codes_dev, int codes_stride_frames, int n, int Fp) {
+    if (!codec) throw Error("codec decoder not finalized");
+    CodecW& W = *codec;
+    const int CH = c.cd_hidden, NH = c.cd_heads, HD = c.cd_head_dim, FF = c.cd_ffn;
+    int P = 1, pshift = 0;
+    while (P < Fp) { P <<= 1; ++pshift; }
+    if (W.rope_P < P) throw Error("codec_pre_batch: RoPE tables not prepared");
+    const size_t rows = (size_t)n * Fp;
+    auto bytes_of = [](size_t nfloat) { return (nfloat * sizeof(float) + 255) & ~(size_t)255; };
+    const size_t kslab_floats = (size_t)32 * 128 * 4096;
+    const size_t need = bytes_of(rows * CH) * 3 + bytes_of(rows * 3 * CH) + bytes_of(rows * FF) * 2 + bytes_of((size_t)n * NH * P * HD) * 2 + bytes_of(kslab_floats);
+    if (W.batch_arena_bytes < need) {
+        sync();
+        if (W.batch_arena) (void)hipFree(W.batch_arena);
+        W.batch_arena = nullptr;
+        Q3_HIP_CHECK(hipMalloc((void**)&W.batch_arena, need));
+        W.batch_arena_bytes = need;
+    }
+    if (W.batch_pages_n < n) {
+        sync();
+        if (W.batch_pages) (void)hipFree(W.batch_pages);
+        std::vector<int> idt((size_t)n);
+        for (int i = 0; i < n; ++i) idt[(size_t)i] = i;
+        Q3_HIP_CHECK(hipMalloc((void**)&W.batch_pages, (size_t)n * sizeof(int)));
+        Q3_HIP_CHECK(hipMemcpy(W.batch_pages, idt.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice));
+        W.batch_pages_n = n;
+    }
+    size_t off = 0;
+    auto take = [&](size_t nfloat) { float* p = (float*)(W.batch_arena + off); off += bytes_of(nfloat); return p; };
+    float* h = take(rows * CH);
+    float* hn = take(rows * CH);
+    float* att = take(rows * CH);
+    float* qkvb = take(rows * 3 * CH);
+    float* ub = take(rows * FF);
+    float* gb = take(rows * FF);
+    float* kc = take((size_t)n * NH * P * HD);
+    float* vc = take((size_t)n * NH * P * HD);
+    float* kslab = take(kslab_floats);
+    const int T = (int)rows;
+    if (!W.win0_recorded) { Q3_HIP_CHECK(hipEventRecord(W.win0, stream)); W.win0_recorded = true; }   // the vocoder window starts here
+    auto conv = [&](ConvArgs a) {
+        a.slab = kslab; a.slab_floats = kslab_floats;
+        const auto it = W.planes.find(a.W);
+        if (it != W.planes.end()) { a.Wh = it->second.hi; a.Wl = it->second.lo; a.w_scale_inv = it->second.scale_inv; }
+        launch_conv(a, stream);
+    };
+    auto gemm = [&](const float* in, int Cin, const float* Wm, int Cout, float* out) {
+        ConvArgs a; a.in = in; a.T_in = T; a.C_in = Cin; a.out = out; a.T_out = T; a.C_out = Cout; a.W = Wm;
+        return a;
+    };
+    launch_code_embed_mean(W.code_embed, codes_dev, Fp, c.n_groups, c.cd_codebook, CH, h, stream, n, (size_t)codes_stride_frames * c.n_groups);
+    for (int l = 0; l < c.cd_layers; ++l) {
+        const CodecW::Layer& L = W.layers[l];
+        launch_rmsnorm_rows(h, L.in_norm, c.cd_rms_eps, T, CH, hn, stream);
+        conv(gemm(hn, CH, L.qkv, 3 * CH, qkvb));
+        launch_rope_store(qkvb, 3 * CH, Fp, NH, NH, HD, W.rope_cos, W.rope_sin, kc, vc, P, stream, n);
+        AttnArgs a;
+        a.qkv = qkvb; a.ld_qkv = 3 * CH; a.out = att; a.ld_out = CH; a.kcache = kc; a.vcache = vc;
+        a.page_table = W.batch_pages; a.pages_per_slot = 1; a.page_shift = pshift; a.layer = 0; a.n_layers = 1;
+        a.pos_scalar = 0; a.slot_offset = 0; a.nb = n; a.n_new = Fp; a.nq = NH; a.nkv = NH; a.d = HD;
+        a.scale = 1.0f / sqrtf((float)HD); a.window = c.cd_window; a.new_from_raw = 0;
+        launch_attn(a, stream);
+        { ConvArgs g = gemm(att, CH, L.o, CH, h); g.res_scale = L.attn_scale; g.res = h; conv(g); }
+        launch_rmsnorm_rows(h, L.post_norm, c.cd_rms_eps, T, CH, hn, stream);
+        conv(gemm(hn, CH, L.up, FF, ub));
+        { ConvArgs g = gemm(hn, CH, L.gate, FF, gb); g.act = 2; g.mul = ub; conv(g); }
+        { ConvArgs g = gemm(gb, FF, L.down, CH, h); g.res_scale = L.mlp_scale; g.res = h; conv(g); }
+    }
+    launch_rmsnorm_rows(h, W.norm, c.cd_rms_eps, T, CH, h, stream);
+    return h;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Vocoder side of the scheduler (q3tts_synthesize_schedule_host).  A slot that finishes copies its codes into the job's buffer on the
 // engine stream (codec_stash) and is free at once; when the decode queue has run dry the utterances are vocoded over the side lanes
 // (codec_async_submit_dev / codec_async_drain), their small-grid kernels overlapping each other.  Vocoding while other slots still
@@ -348,6 +430,7 @@ void Engine::codec_async_prepare(int max_frames, int n_utt) {
         W.job_codes_n = need;
     }
     W.rr = 0;   // a job's first utterances always land on the same lanes (their arenas are already sized)
+    W.win0_recorded = false;
     if (!W.fork) { Q3_HIP_CHECK(hipEventCreateWithFlags(&W.fork, hipEventDisableTiming)); Q3_HIP_CHECK(hipEventCreate(&W.win0)); Q3_HIP_CHECK(hipEventCreate(&W.win1)); }
 }
 
@@ -374,14 +457,14 @@ void Engine::codec_async_drain_lane(int lane) {
     p.busy = false;
 }
 
-void Engine::codec_async_submit_dev(const int32_t* codes_dev, int nf, float* user_pcm, int64_t cap, int64_t* len_out) {
+void Engine::codec_async_submit_dev(const int32_t* codes_dev, int nf, float* user_pcm, int64_t cap, int64_t* len_out, const float* h_in) {
     CodecW& W = *codec;
     if (len_out) *len_out = 0;
     if (nf <= 0) return;   // the reference returns an empty vector when no frame was generated (tts_onnx.cpp:418)
     const int lane = W.nlane > 1 ? 1 + (W.rr++ % (W.nlane - 1)) : 0;
     codec_async_drain_lane(lane);
     if (!W.window_open) {   // the lanes start behind everything the engine stream has queued (the stashed codes among it)
-        Q3_HIP_CHECK(hipEventRecord(W.win0, stream));
+        if (!W.win0_recorded) { Q3_HIP_CHECK(hipEventRecord(W.win0, stream)); W.win0_recorded = true; }
         Q3_HIP_CHECK(hipEventRecord(W.fork, stream));
         for (int i = 1; i < W.nlane; ++i) Q3_HIP_CHECK(hipStreamWaitEvent(W.lane_stream[i], W.fork, 0));
         W.window_open = true;
@@ -389,7 +472,7 @@ void Engine::codec_async_submit_dev(const int32_t* codes_dev, int nf, float* use
     if (!W.lane_done[lane]) Q3_HIP_CHECK(hipEventCreateWithFlags(&W.lane_done[lane], hipEventDisableTiming));
     hipStream_t ls = W.lane_stream[lane];
     float* pcm_d = nullptr;
-    const int64_t n = codec_run(codes_dev, nf, &pcm_d, lane);
+    const int64_t n = codec_run(codes_dev, nf, &pcm_d, lane, h_in);
     const int64_t m = std::min(n, cap);
     if ((size_t)m > W.pinned_floats[lane]) {
         if (W.pinned[lane]) (void)hipHostFree(W.pinned[lane]);
@@ -414,7 +497,7 @@ void Engine::codec_async_drain() {
     float ms = 0.f;
     Q3_HIP_CHECK(hipEventElapsedTime(&ms, W.win0, W.win1));
     total_codec_ms += ms; last_codec_ms = ms;
-    W.window_open = false;
+    W.window_open = false; W.win0_recorded = false;
 }
 
 } // namespace q3

@@ -589,8 +589,11 @@ void launch_repack_conv(const float* w, float* out, int cin, int cout, int k, in
 }
 
 // ---- code_embedding(codes + g*codebook).mean over the G quantizers (Code2Wav.forward) ----
-__global__ void k_code_embed_mean(const float* table, const int32_t* codes, int G, int codebook, int C, float* out) {
+// grid (rows per utterance, utterances): utterance u reads codes + u * codes_stride (ints) and writes rows u * gridDim.x + t
+__global__ void k_code_embed_mean(const float* table, const int32_t* codes0, int G, int codebook, int C, float* out0, size_t codes_stride) {
     const int t = blockIdx.x;
+    const int32_t* codes = codes0 + (size_t)blockIdx.y * codes_stride;
+    float* out = out0 + (size_t)blockIdx.y * gridDim.x * C;
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
         float s = 0.f;
         for (int g = 0; g < G; ++g) {
@@ -601,8 +604,9 @@ __global__ void k_code_embed_mean(const float* table, const int32_t* codes, int 
         out[(size_t)t * C + c] = s / (float)G;
     }
 }
-void launch_code_embed_mean(const float* table, const int32_t* codes, int F, int G, int codebook, int C, float* out, hipStream_t s) {
-    hipLaunchKernelGGL(k_code_embed_mean, dim3(F), dim3(256), 0, s, table, codes, G, codebook, C, out);
+void launch_code_embed_mean(const float* table, const int32_t* codes, int F, int G, int codebook, int C, float* out, hipStream_t s,
+                            int n_utt, size_t codes_stride) {
+    if (F > 0 && n_utt > 0) hipLaunchKernelGGL(k_code_embed_mean, dim3(F, n_utt), dim3(256), 0, s, table, codes, G, codebook, C, out, codes_stride);
 }
 
 static __device__ float block_sum256(float v, float* red) {
@@ -629,10 +633,13 @@ void launch_rmsnorm_rows(const float* x, const float* w, float eps, int rows, in
 }
 
 // RoPE on q (in place) and k, K/V copied into the attention cache layout [kvh][P][d] (one layer at a time)
+// grid (positions, utterances): utterance u owns rows [u * gridDim.x, (u + 1) * gridDim.x) of qkv and cache block u ([kvh][P][d])
 __global__ void k_rope_store(float* qkv, int ld, int nq, int nkv, int d, const float* cs, const float* sn,
-                             float* kc, float* vc, int P) {
+                             float* kc0, float* vc0, int P) {
     const int t = blockIdx.x, half = d / 2;
-    float* row = qkv + (size_t)t * ld;
+    float* row = qkv + ((size_t)blockIdx.y * gridDim.x + t) * ld;
+    float* kc = kc0 + (size_t)blockIdx.y * nkv * P * d;
+    float* vc = vc0 + (size_t)blockIdx.y * nkv * P * d;
     for (int i = threadIdx.x; i < (nq + nkv) * half; i += blockDim.x) {
         const int h = i / half, e = i % half;
         float* v = row + (size_t)h * d;
@@ -652,8 +659,8 @@ __global__ void k_rope_store(float* qkv, int ld, int nq, int nkv, int d, const f
     }
 }
 void launch_rope_store(float* qkv, int ld, int T, int nq, int nkv, int d, const float* cs, const float* sn,
-                       float* kc, float* vc, int P, hipStream_t s) {
-    if (T > 0) hipLaunchKernelGGL(k_rope_store, dim3(T), dim3(256), 0, s, qkv, ld, nq, nkv, d, cs, sn, kc, vc, P);
+                       float* kc, float* vc, int P, hipStream_t s, int n_utt) {
+    if (T > 0 && n_utt > 0) hipLaunchKernelGGL(k_rope_store, dim3(T, n_utt), dim3(256), 0, s, qkv, ld, nq, nkv, d, cs, sn, kc, vc, P);
 }
 
 // ConvNeXt front half: depthwise causal k7 conv + LayerNorm(eps 1e-6) over channels, one row per block

@@ -218,10 +218,11 @@ void launch_conv(const ConvArgs& a, hipStream_t s);
 void launch_split_planes(const float* w, bf16_t* hi, bf16_t* lo, size_t n, float scale, hipStream_t s);
 void launch_absmax(const float* w, size_t n, unsigned* out, hipStream_t s);
 void launch_repack_conv(const float* w, float* out, int cin, int cout, int k, int transposed, hipStream_t s);
-void launch_code_embed_mean(const float* table, const int32_t* codes, int F, int G, int codebook, int C, float* out, hipStream_t s);
+void launch_code_embed_mean(const float* table, const int32_t* codes, int F, int G, int codebook, int C, float* out, hipStream_t s,
+                            int n_utt = 1, size_t codes_stride = 0);
 void launch_rmsnorm_rows(const float* x, const float* w, float eps, int rows, int C, float* out, hipStream_t s);
 void launch_rope_store(float* qkv, int ld, int T, int nq, int nkv, int d, const float* cs, const float* sn,
-                       float* kc, float* vc, int P, hipStream_t s);
+                       float* kc, float* vc, int P, hipStream_t s, int n_utt = 1);
 void launch_dwconv_ln(const float* x, int T, int C, const float* dw_w, const float* dw_b, const float* ln_w,
                       const float* ln_b, float* out, hipStream_t s);
 
