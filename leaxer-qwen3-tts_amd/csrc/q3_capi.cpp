@@ -350,12 +350,16 @@ int q3tts_synthesize_schedule_host(q3tts_engine* h, int n_utt, const int64_t* id
     int Fp = 0;
     for (int u = 0; u < n_utt; ++u) { sum_f += got_frames[(size_t)u]; Fp = std::max(Fp, (int)got_frames[(size_t)u]); }
     const float* hb = nullptr;
-    if (n_utt >= 2 && Fp > 0 && (int64_t)n_utt * Fp <= sum_f + sum_f / 2 && (int64_t)n_utt * Fp <= (int64_t)1 << 18)   // 49 KB of workspace per row
-        hb = e.codec_pre_batch(e.codec_job_codes(0, row_frames), row_frames, n_utt, Fp);
+    int hb_rows = 0, hb_stage = 1;
+    if (n_utt >= 2 && Fp > 0 && (int64_t)n_utt * Fp <= sum_f + sum_f / 2 && (int64_t)n_utt * Fp <= (int64_t)1 << 18) {   // 49 KB of workspace per row
+        const bool up = (int64_t)n_utt * Fp <= (int64_t)1 << 16;        // + 98 KB per row with the upsampling stages
+        hb = e.codec_pre_batch(e.codec_job_codes(0, row_frames), row_frames, n_utt, Fp, up, &hb_rows);
+        hb_stage = up ? 2 : 1;
+    }
     for (int u = 0; u < n_utt; ++u) {
         if (pcm_len) pcm_len[u] = 0;
         e.codec_async_submit_dev(e.codec_job_codes(u, row_frames), got_frames[(size_t)u], pcm_out ? pcm_out[u] : nullptr, pcm_cap, pcm_len ? pcm_len + u : nullptr,
-                                 hb ? hb + (size_t)u * Fp * e.c.cd_hidden : nullptr);
+                                 hb ? hb + (size_t)u * hb_rows * e.c.cd_hidden : nullptr, hb_stage);
     }
     e.codec_async_drain();
     return 0;

@@ -179,7 +179,7 @@ static int tconv_out_len(const q3tts_config& c, int T, int k, int s, int* left_o
     return (T - 1) * s + k - left - pad;
 }
 
-int64_t Engine::codec_run(const int32_t* codes_dev, int F, float** pcm_dev, int lane, const float* h_in) {
+int64_t Engine::codec_run(const int32_t* codes_dev, int F, float** pcm_dev, int lane, const float* h_in, int h_stage) {
     if (!codec) throw Error("codec decoder not finalized");
     CodecW& W = *codec;
     if (lane < 0 || lane >= W.nlane) throw Error("codec: bad lane");
@@ -264,7 +264,9 @@ int64_t Engine::codec_run(const int32_t* codes_dev, int F, float** pcm_dev, int 
         // ---- ConvNeXt upsampling stages ----
         float* cur = h_in ? const_cast<float*>(h_in) : h;
         int Tc = F;
-        for (int s = 0; s < c.cd_n_up; ++s) {
+        if (h_in && h_stage == 2)   // the ConvNeXt upsampling stages ran in codec_pre_batch too
+            for (int s = 0; s < c.cd_n_up; ++s) Tc = tconv_out_len(c, Tc, c.cd_up_ratios[s], c.cd_up_ratios[s], nullptr);
+        for (int s = 0; s < (h_in && h_stage == 2 ? 0 : c.cd_n_up); ++s) {
             const CodecW::Up& U = W.up[s];
             const int f = c.cd_up_ratios[s];
             int left = 0;
@@ -330,7 +332,7 @@ int64_t Engine::codec_run(const int32_t* codes_dev, int F, float** pcm_dev, int 
 // (weights streamed once, full grids) instead of one short GEMM per utterance, attention runs with the utterance as its batch
 // dimension.  Returns the normalised hidden rows [n][Fp][cd_hidden] (valid until the next call); codes: [n][codes_stride_frames][groups].
 // ------------------------------------------------------------------------------------------------
-const float* Engine::codec_pre_batch(const int32_t* codes_dev, int codes_stride_frames, int n, int Fp) {
+const float* Engine::codec_pre_batch(const int32_t* codes_dev, int codes_stride_frames, int n, int Fp, bool with_upsampling, int* rows_per_utt_out) {
     if (!codec) throw Error("codec decoder not finalized");
     CodecW& W = *codec;
     const int CH = c.cd_hidden, NH = c.cd_heads, HD = c.cd_head_dim, FF = c.cd_ffn;
@@ -340,7 +342,11 @@ const float* Engine::codec_pre_batch(const int32_t* codes_dev, int codes_stride_
     const size_t rows = (size_t)n * Fp;
     auto bytes_of = [](size_t nfloat) { return (nfloat * sizeof(float) + 255) & ~(size_t)255; };
     const size_t kslab_floats = (size_t)32 * 128 * 4096;
-    const size_t need = bytes_of(rows * CH) * 3 + bytes_of(rows * 3 * CH) + bytes_of(rows * FF) * 2 + bytes_of((size_t)n * NH * P * HD) * 2 + bytes_of(kslab_floats);
+    size_t need = bytes_of(rows * CH) * 3 + bytes_of(rows * 3 * CH) + bytes_of(rows * FF) * 2 + bytes_of((size_t)n * NH * P * HD) * 2 + bytes_of(kslab_floats);
+    if (with_upsampling) {   // per stage: y, ln (CH each) and the 4x wide hidden, at the stage's output rate
+        size_t r = rows;
+        for (int s2 = 0; s2 < c.cd_n_up; ++s2) { r *= (size_t)c.cd_up_ratios[s2]; need += bytes_of(r * CH) * 2 + bytes_of(r * 4 * CH); }
+    }
     if (W.batch_arena_bytes < need) {
         sync();
         if (W.batch_arena) (void)hipFree(W.batch_arena);
@@ -399,7 +405,30 @@ const float* Engine::codec_pre_batch(const int32_t* codes_dev, int codes_stride_
         { ConvArgs g = gemm(gb, FF, L.down, CH, h); g.res_scale = L.mlp_scale; g.res = h; conv(g); }
     }
     launch_rmsnorm_rows(h, W.norm, c.cd_rms_eps, T, CH, h, stream);
-    return h;
+    if (rows_per_utt_out) *rows_per_utt_out = Fp;
+    if (!with_upsampling) return h;
+    // ---- ConvNeXt upsampling stages over all utterances: the transposed convs have kernel == stride (every input row expands on its
+    // own), the depthwise causal conv stops at each utterance's first row, the pointwise layers are plain GEMMs ----
+    float* cur = h;
+    int Tc = T, per = Fp;
+    for (int s2 = 0; s2 < c.cd_n_up; ++s2) {
+        const CodecW::Up& U = W.up[s2];
+        const int f = c.cd_up_ratios[s2];
+        if (U.tconv.k != f) throw Error("codec_pre_batch: upsampling kernel != stride");
+        const int To = Tc * f;
+        float* y = take((size_t)To * CH);
+        float* ln = take((size_t)To * CH);
+        float* a4 = take((size_t)To * 4 * CH);
+        { ConvArgs a; a.in = cur; a.T_in = Tc; a.C_in = CH; a.out = y; a.T_out = To; a.C_out = CH; a.W = U.tconv.w; a.bias = U.tconv.b;
+          a.taps = f; a.transposed = 1; a.stride = f; a.left = 0; conv(a); }
+        per *= f;
+        launch_dwconv_ln(y, To, CH, U.dw_w, U.dw_b, U.ln_w, U.ln_b, ln, stream, per);
+        { ConvArgs a; a.in = ln; a.T_in = To; a.C_in = CH; a.out = a4; a.T_out = To; a.C_out = 4 * CH; a.W = U.pw1_w; a.bias = U.pw1_b; a.act = 1; conv(a); }
+        { ConvArgs a; a.in = a4; a.T_in = To; a.C_in = 4 * CH; a.out = y; a.T_out = To; a.C_out = CH; a.W = U.pw2_w; a.bias = U.pw2_b; a.res_scale = U.gamma; a.res = y; conv(a); }
+        cur = y; Tc = To;
+    }
+    if (rows_per_utt_out) *rows_per_utt_out = per;
+    return cur;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -457,7 +486,7 @@ void Engine::codec_async_drain_lane(int lane) {
     p.busy = false;
 }
 
-void Engine::codec_async_submit_dev(const int32_t* codes_dev, int nf, float* user_pcm, int64_t cap, int64_t* len_out, const float* h_in) {
+void Engine::codec_async_submit_dev(const int32_t* codes_dev, int nf, float* user_pcm, int64_t cap, int64_t* len_out, const float* h_in, int h_stage) {
     CodecW& W = *codec;
     if (len_out) *len_out = 0;
     if (nf <= 0) return;   // the reference returns an empty vector when no frame was generated (tts_onnx.cpp:418)
@@ -472,7 +501,7 @@ void Engine::codec_async_submit_dev(const int32_t* codes_dev, int nf, float* use
     if (!W.lane_done[lane]) Q3_HIP_CHECK(hipEventCreateWithFlags(&W.lane_done[lane], hipEventDisableTiming));
     hipStream_t ls = W.lane_stream[lane];
     float* pcm_d = nullptr;
-    const int64_t n = codec_run(codes_dev, nf, &pcm_d, lane, h_in);
+    const int64_t n = codec_run(codes_dev, nf, &pcm_d, lane, h_in, h_stage);
     const int64_t m = std::min(n, cap);
     if ((size_t)m > W.pinned_floats[lane]) {
         if (W.pinned[lane]) (void)hipHostFree(W.pinned[lane]);

@@ -664,17 +664,19 @@ void launch_rope_store(float* qkv, int ld, int T, int nq, int nkv, int d, const 
 }
 
 // ConvNeXt front half: depthwise causal k7 conv + LayerNorm(eps 1e-6) over channels, one row per block
+// rows_per_utt > 0: the T rows are [utterance][rows_per_utt] blocks, the causal taps stop at the utterance's first row
 __global__ __launch_bounds__(256) void k_dwconv_ln(const float* x, int T, int C, const float* dw_w, const float* dw_b,
-                                                   const float* ln_w, const float* ln_b, float* out) {
+                                                   const float* ln_w, const float* ln_b, float* out, int rows_per_utt) {
     __shared__ float red[4];
     extern __shared__ float hbuf[];
     const int t = blockIdx.x;
+    const int t_first = rows_per_utt > 0 ? t - t % rows_per_utt : 0;
     float s1 = 0.f;
     for (int c = threadIdx.x; c < C; c += 256) {
         float acc = dw_b[c];
         for (int tap = 0; tap < 7; ++tap) {
             const int ts = t - (6 - tap);
-            if (ts >= 0) acc += dw_w[c * 7 + tap] * x[(size_t)ts * C + c];
+            if (ts >= t_first) acc += dw_w[c * 7 + tap] * x[(size_t)ts * C + c];
         }
         hbuf[c] = acc;
         s1 += acc;
@@ -687,8 +689,8 @@ __global__ __launch_bounds__(256) void k_dwconv_ln(const float* x, int T, int C,
     for (int c = threadIdx.x; c < C; c += 256) out[(size_t)t * C + c] = (hbuf[c] - mean) * r * ln_w[c] + ln_b[c];
 }
 void launch_dwconv_ln(const float* x, int T, int C, const float* dw_w, const float* dw_b, const float* ln_w,
-                      const float* ln_b, float* out, hipStream_t s) {
-    if (T > 0) hipLaunchKernelGGL(k_dwconv_ln, dim3(T), dim3(256), (size_t)C * sizeof(float), s, x, T, C, dw_w, dw_b, ln_w, ln_b, out);
+                      const float* ln_b, float* out, hipStream_t s, int rows_per_utt) {
+    if (T > 0) hipLaunchKernelGGL(k_dwconv_ln, dim3(T), dim3(256), (size_t)C * sizeof(float), s, x, T, C, dw_w, dw_b, ln_w, ln_b, out, rows_per_utt);
 }
 
 } // namespace q3

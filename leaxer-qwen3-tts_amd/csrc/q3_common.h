@@ -224,7 +224,7 @@ void launch_rmsnorm_rows(const float* x, const float* w, float eps, int rows, in
 void launch_rope_store(float* qkv, int ld, int T, int nq, int nkv, int d, const float* cs, const float* sn,
                        float* kc, float* vc, int P, hipStream_t s, int n_utt = 1);
 void launch_dwconv_ln(const float* x, int T, int C, const float* dw_w, const float* dw_b, const float* ln_w,
-                      const float* ln_b, float* out, hipStream_t s);
+                      const float* ln_b, float* out, hipStream_t s, int rows_per_utt = 0);
 
 
 // ---- speaker encoder (q3_speaker_kernels.hip) ----

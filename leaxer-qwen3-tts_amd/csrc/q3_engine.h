@@ -119,13 +119,14 @@ public:
     // ---- codec decoder (q3_codec.cpp) ----
     CodecW* codec = nullptr;
     void codec_finalize();
-    int64_t codec_run(const int32_t* codes_dev, int F, float** pcm_dev, int lane = 0, const float* h_in = nullptr); // returns sample count; h_in: rows from codec_pre_batch
-    const float* codec_pre_batch(const int32_t* codes_dev, int codes_stride_frames, int n, int Fp);
+    // returns the sample count; h_in: this utterance's rows from codec_pre_batch (h_stage 1: after the pre-transformer, 2: after the upsampling stages too)
+    int64_t codec_run(const int32_t* codes_dev, int F, float** pcm_dev, int lane = 0, const float* h_in = nullptr, int h_stage = 1);
+    const float* codec_pre_batch(const int32_t* codes_dev, int codes_stride_frames, int n, int Fp, bool with_upsampling, int* rows_per_utt_out);
     // vocoder side of the scheduler: stash a finished slot's codes, vocode the job's utterances over the side lanes at the end
     void codec_async_prepare(int max_frames, int n_utt);
     const int32_t* codec_stash(int slot, int nf, int utt, int row_frames);
     const int32_t* codec_job_codes(int utt, int row_frames);
-    void codec_async_submit_dev(const int32_t* codes_dev, int nf, float* user_pcm, int64_t cap, int64_t* len_out, const float* h_in = nullptr);
+    void codec_async_submit_dev(const int32_t* codes_dev, int nf, float* user_pcm, int64_t cap, int64_t* len_out, const float* h_in = nullptr, int h_stage = 1);
     void codec_async_drain_lane(int lane);
     void codec_async_drain();
     void slots_state(int nb, std::vector<SlotState>& out);
