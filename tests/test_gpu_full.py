@@ -200,3 +200,22 @@ def test_talker_decode_across_split_boundary_full_size(full):
         worst = max(worst, float(np.abs(lg - lo).max()), float(np.abs(lh - ho).max()))
     big.close()
     assert worst < 3e-4, worst
+
+
+def test_batched_vocoder_front_matches_single_decodes_full_size(full):
+    """0.6B dims: a job's utterances share one padded pass through the pre-transformer and the upsampling stages (rows [utterance][longest]);
+    each PCM equals the one-utterance decode of its own codes (different GEMM tilings: fp32 summation noise only) and has its own length."""
+    import q3tts
+    eng, orc = full
+    sp = q3tts.Sampling(temperature=0.8, top_p=0.95, top_k=50, max_new_tokens=30)
+    rng = np.random.default_rng(23)
+    toks = [frame_tokens(rng.integers(0, 151643, int(n))) for n in (5, 16, 9)]
+    caps = np.array([22, 30, 21], np.int32)          # 3 x 30 padded rows <= 1.5 x 73 real rows: the batched front is taken
+    pcm, codes, nfr = eng.synthesize_batch(toks, sp, lang=0, seed=4, ignore_eos=True, max_new_per_utt=caps)
+    assert np.array_equal(nfr, caps)
+    for u in range(3):
+        single = eng.codec_decode(codes[u])
+        assert pcm[u].shape == single.shape == (eng.codec_decode_len(int(caps[u])),)
+        assert float(np.sqrt(np.mean((pcm[u] - single) ** 2))) < 1e-5 and np.abs(pcm[u] - single).max() < 1e-4, u
+    ref = orc.vocoder(codes[2])
+    assert float(np.sqrt(np.mean((pcm[2] - ref) ** 2))) < 1e-4
