@@ -41,7 +41,8 @@ struct CodecW {
     float *rope_cos = nullptr, *rope_sin = nullptr; int rope_P = 0;
     int* page_table = nullptr;
     // asynchronous per-utterance decodes over the side lanes: result parked in the lane's pinned buffer until the lane is drained
-    struct Pending { float* user = nullptr; int64_t n = 0, cap = 0; int64_t* len = nullptr; int frames = 0; bool busy = false; };
+    struct Item { float* user; int64_t n, cap, off; int64_t* len; };   // off: float offset of the utterance's samples in the lane's pinned buffer
+    struct Pending { std::vector<Item> items; int frames = 0; bool busy = false; };
     Pending pend[NLANE];
     int32_t* job_codes = nullptr; size_t job_codes_n = 0;
     char* batch_arena = nullptr; size_t batch_arena_bytes = 0;   // batched pre-transformer of a job (codec_pre_batch)
@@ -179,11 +180,13 @@ static int tconv_out_len(const q3tts_config& c, int T, int k, int s, int* left_o
     return (T - 1) * s + k - left - pad;
 }
 
-int64_t Engine::codec_run(const int32_t* codes_dev, int F, float** pcm_dev, int lane, const float* h_in, int h_stage) {
+int64_t Engine::codec_run(const int32_t* codes_dev, int F, float** pcm_dev, int lane, const float* h_in, int h_stage, int nbatch, size_t h_ustride) {
     if (!codec) throw Error("codec decoder not finalized");
     CodecW& W = *codec;
     if (lane < 0 || lane >= W.nlane) throw Error("codec: bad lane");
     hipStream_t stream = W.lane_stream[lane]; // shadows the engine stream for every launch below
+    if (nbatch < 1 || (nbatch > 1 && !(h_in && h_stage == 2))) throw Error("codec: a batched decode starts from codec_pre_batch's upsampled rows");
+    const size_t nbz = (size_t)nbatch;   // sequences per launch of the conv decoder (rows [sequence][T] everywhere)
     const int CH = c.cd_hidden, NH = c.cd_heads, HD = c.cd_head_dim, FF = c.cd_ffn, D = c.cd_decoder_dim;
     if (NH * HD != CH) throw Error("codec: heads*head_dim must equal hidden");
     int P = 1, pshift = 0;
@@ -222,7 +225,7 @@ int64_t Engine::codec_run(const int32_t* codes_dev, int F, float** pcm_dev, int 
         float* kslab = take(kslab_floats);
         auto conv = [&](ConvArgs a) {
             if (plan) return;
-            a.slab = kslab; a.slab_floats = kslab_floats;
+            a.slab = kslab; a.slab_floats = kslab_floats; a.batch = nbatch;
             const auto it = W.planes.find(a.W);
             if (it != W.planes.end()) { a.Wh = it->second.hi; a.Wl = it->second.lo; a.w_scale_inv = it->second.scale_inv; }
             launch_conv(a, stream);
@@ -282,9 +285,10 @@ int64_t Engine::codec_run(const int32_t* codes_dev, int F, float** pcm_dev, int 
             cur = y; Tc = To;
         }
         // ---- SnakeBeta decoder: conv_in, 4 x (snake, transposed conv, 3 residual units), snake, conv_out ----
-        float* x = take((size_t)Tc * D);
-        float* sx = take((size_t)Tc * D);
+        float* x = take(nbz * Tc * D);
+        float* sx = take(nbz * Tc * D);
         { ConvArgs a; a.in = cur; a.T_in = Tc; a.C_in = CH; a.out = x; a.T_out = Tc; a.C_out = D; a.W = W.conv_in.w; a.bias = W.conv_in.b; a.taps = 7;
+          a.in_ustride = nbatch > 1 ? h_ustride : 0;   // the batched front pads every utterance to the job's longest; a group runs at its own longest
           a.out2 = sx; a.snake_alpha = W.blocks[0].act.alpha; a.snake_beta = W.blocks[0].act.beta; conv(a); }
         int C = D;
         static const int dil[3] = { 1, 3, 9 };
@@ -293,9 +297,9 @@ int64_t Engine::codec_run(const int32_t* codes_dev, int F, float** pcm_dev, int 
             const int r = c.cd_up_rates[i], Co = C / 2;
             int left = 0;
             const int To = tconv_out_len(c, Tc, 2 * r, r, &left);
-            float* nx = take((size_t)To * Co);
-            float* ns = take((size_t)To * Co);
-            float* nt = take((size_t)To * Co);
+            float* nx = take(nbz * To * Co);
+            float* ns = take(nbz * To * Co);
+            float* nt = take(nbz * To * Co);
             { ConvArgs a; a.in = sx; a.T_in = Tc; a.C_in = C; a.out = nx; a.T_out = To; a.C_out = Co; a.W = B.tconv.w; a.bias = B.tconv.b;
               a.taps = 2 * r; a.transposed = 1; a.stride = r; a.left = left;
               a.out2 = ns; a.snake_alpha = B.res[0].a1.alpha; a.snake_beta = B.res[0].a1.beta; conv(a); }
@@ -309,7 +313,7 @@ int64_t Engine::codec_run(const int32_t* codes_dev, int F, float** pcm_dev, int 
             }
             x = nx; sx = ns; Tc = To; C = Co;
         }
-        pcm = take((size_t)Tc);
+        pcm = take(nbz * Tc);
         { ConvArgs a; a.in = sx; a.T_in = Tc; a.C_in = C; a.out = pcm; a.T_out = Tc; a.C_out = 1; a.W = W.conv_out.w; a.bias = W.conv_out.b;
           a.taps = 7; a.clamp = 1; conv(a); }
         n_pcm = Tc;
@@ -332,7 +336,8 @@ int64_t Engine::codec_run(const int32_t* codes_dev, int F, float** pcm_dev, int 
 // (weights streamed once, full grids) instead of one short GEMM per utterance, attention runs with the utterance as its batch
 // dimension.  Returns the normalised hidden rows [n][Fp][cd_hidden] (valid until the next call); codes: [n][codes_stride_frames][groups].
 // ------------------------------------------------------------------------------------------------
-const float* Engine::codec_pre_batch(const int32_t* codes_dev, int codes_stride_frames, int n, int Fp, bool with_upsampling, int* rows_per_utt_out) {
+const float* Engine::codec_pre_batch(const int32_t* codes_dev, int codes_stride_frames, int n, int Fp, bool with_upsampling, int* rows_per_utt_out,
+                                     const int* perm_host) {
     if (!codec) throw Error("codec decoder not finalized");
     CodecW& W = *codec;
     const int CH = c.cd_hidden, NH = c.cd_heads, HD = c.cd_head_dim, FF = c.cd_ffn;
@@ -354,14 +359,19 @@ const float* Engine::codec_pre_batch(const int32_t* codes_dev, int codes_stride_
         Q3_HIP_CHECK(hipMalloc((void**)&W.batch_arena, need));
         W.batch_arena_bytes = need;
     }
-    if (W.batch_pages_n < n) {
+    if (W.batch_pages_n < n) {   // [0, n): identity page table; [n_cap, 2 n_cap): the job's utterance order (perm)
         sync();
         if (W.batch_pages) (void)hipFree(W.batch_pages);
         std::vector<int> idt((size_t)n);
         for (int i = 0; i < n; ++i) idt[(size_t)i] = i;
-        Q3_HIP_CHECK(hipMalloc((void**)&W.batch_pages, (size_t)n * sizeof(int)));
+        Q3_HIP_CHECK(hipMalloc((void**)&W.batch_pages, (size_t)2 * n * sizeof(int)));
         Q3_HIP_CHECK(hipMemcpy(W.batch_pages, idt.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice));
         W.batch_pages_n = n;
+    }
+    const int* perm_d = nullptr;
+    if (perm_host) {   // row block y of every buffer holds utterance perm[y] (the scheduler sorts by length so that decoder groups pad little)
+        Q3_HIP_CHECK(hipMemcpyAsync(W.batch_pages + W.batch_pages_n, perm_host, (size_t)n * sizeof(int), hipMemcpyHostToDevice, stream));
+        perm_d = W.batch_pages + W.batch_pages_n;
     }
     size_t off = 0;
     auto take = [&](size_t nfloat) { float* p = (float*)(W.batch_arena + off); off += bytes_of(nfloat); return p; };
@@ -386,7 +396,7 @@ const float* Engine::codec_pre_batch(const int32_t* codes_dev, int codes_stride_
         ConvArgs a; a.in = in; a.T_in = T; a.C_in = Cin; a.out = out; a.T_out = T; a.C_out = Cout; a.W = Wm;
         return a;
     };
-    launch_code_embed_mean(W.code_embed, codes_dev, Fp, c.n_groups, c.cd_codebook, CH, h, stream, n, (size_t)codes_stride_frames * c.n_groups);
+    launch_code_embed_mean(W.code_embed, codes_dev, Fp, c.n_groups, c.cd_codebook, CH, h, stream, n, (size_t)codes_stride_frames * c.n_groups, perm_d);
     for (int l = 0; l < c.cd_layers; ++l) {
         const CodecW::Layer& L = W.layers[l];
         launch_rmsnorm_rows(h, L.in_norm, c.cd_rms_eps, T, CH, hn, stream);
@@ -479,10 +489,13 @@ void Engine::codec_async_drain_lane(int lane) {
     CodecW::Pending& p = W.pend[lane];
     if (!p.busy) return;
     Q3_HIP_CHECK(hipStreamSynchronize(W.lane_stream[lane]));
-    const int64_t m = std::min(p.n, p.cap);
-    if (p.user && m > 0) memcpy(p.user, W.pinned[lane], (size_t)m * sizeof(float));
-    if (p.len) *p.len = p.n;
+    for (const CodecW::Item& it : p.items) {
+        const int64_t m = std::min(it.n, it.cap);
+        if (it.user && m > 0) memcpy(it.user, W.pinned[lane] + it.off, (size_t)m * sizeof(float));
+        if (it.len) *it.len = it.n;
+    }
     total_codec_frames += p.frames;
+    p.items.clear();
     p.busy = false;
 }
 
@@ -511,7 +524,60 @@ void Engine::codec_async_submit_dev(const int32_t* codes_dev, int nf, float* use
     if (m > 0) Q3_HIP_CHECK(hipMemcpyAsync(W.pinned[lane], pcm_d, (size_t)m * sizeof(float), hipMemcpyDeviceToHost, ls));
     Q3_HIP_CHECK(hipEventRecord(W.lane_done[lane], ls));
     CodecW::Pending& p = W.pend[lane];
-    p.user = user_pcm; p.n = n; p.cap = cap; p.len = len_out; p.frames = nf; p.busy = true;
+    p.items.assign(1, CodecW::Item{ user_pcm, n, cap, 0, len_out });
+    p.frames = nf; p.busy = true;
+}
+
+bool Engine::codec_batchable() const {
+    if (!codec || codec->planes.empty()) return false;                     // exact-fp32 codec: no split-precision planes
+    const int D = c.cd_decoder_dim, OD = D >> c.cd_n_blocks;
+    if (c.cd_hidden % 32 || OD % 32 || OD < 32) return false;             // every channel count of the decoder is then a multiple of 32
+    if ((size_t)(128 + 6) * (OD + 1) * sizeof(float) > 60 * 1024) return false;   // last conv (C_out = 1) in LDS
+    for (int i = 0; i < c.cd_n_blocks; ++i) if (c.cd_up_rates[i] < 1) return false;
+    return true;
+}
+
+// The conv decoder of g consecutive utterances of codec_pre_batch's output in ONE set of launches (rows [utterance][Tp] in every layer; the
+// kernels' row tiles never straddle utterances, and causality keeps the padding out of the real samples): h_group = the group's upsampled
+// rows (h_ustride floats apart), Fg = frames of the group's longest utterance.  Each utterance's sample count comes from its own frame count.
+void Engine::codec_async_submit_group(const float* h_group, size_t h_ustride, int Fg, int g, const int* nf, float* const* user_pcm, int64_t cap, int64_t* const* len_out) {
+    CodecW& W = *codec;
+    // a group's launches fill the chip on their own: two lanes are enough to overlap one group's tail with the next one's start (and each
+    // lane owns a group-sized arena)
+    const int lane = W.nlane > 1 ? 1 + (W.rr++ % std::min(W.nlane - 1, 2)) : 0;
+    codec_async_drain_lane(lane);
+    if (!W.window_open) {
+        if (!W.win0_recorded) { Q3_HIP_CHECK(hipEventRecord(W.win0, stream)); W.win0_recorded = true; }
+        Q3_HIP_CHECK(hipEventRecord(W.fork, stream));
+        for (int i = 1; i < W.nlane; ++i) Q3_HIP_CHECK(hipStreamWaitEvent(W.lane_stream[i], W.fork, 0));
+        W.window_open = true;
+    }
+    if (!W.lane_done[lane]) Q3_HIP_CHECK(hipEventCreateWithFlags(&W.lane_done[lane], hipEventDisableTiming));
+    hipStream_t ls = W.lane_stream[lane];
+    float* pcm_d = nullptr;
+    const int64_t Tp = codec_run(nullptr, Fg, &pcm_d, lane, h_group, 2, g, h_ustride);   // padded samples per utterance (Fg = the group's longest)
+    CodecW::Pending& p = W.pend[lane];
+    p.items.clear();
+    int64_t total = 0;
+    int frames = 0;
+    for (int u = 0; u < g; ++u) {
+        const int64_t n = nf[u] > 0 ? q3tts_codec_decode_len(&c, nf[u]) : 0;
+        p.items.push_back(CodecW::Item{ user_pcm ? user_pcm[u] : nullptr, n, cap, total, len_out ? len_out[u] : nullptr });
+        total += std::min(n, cap);
+        frames += std::max(nf[u], 0);
+    }
+    if ((size_t)total > W.pinned_floats[lane]) {
+        if (W.pinned[lane]) (void)hipHostFree(W.pinned[lane]);
+        Q3_HIP_CHECK(hipHostMalloc((void**)&W.pinned[lane], (size_t)total * sizeof(float)));
+        W.pinned_floats[lane] = (size_t)total;
+    }
+    for (int u = 0; u < g; ++u) {
+        const CodecW::Item& it = p.items[(size_t)u];
+        const int64_t m = std::min(it.n, it.cap);
+        if (m > 0) Q3_HIP_CHECK(hipMemcpyAsync(W.pinned[lane] + it.off, pcm_d + (size_t)u * Tp, (size_t)m * sizeof(float), hipMemcpyDeviceToHost, ls));
+    }
+    Q3_HIP_CHECK(hipEventRecord(W.lane_done[lane], ls));
+    p.frames = frames; p.busy = true;
 }
 
 void Engine::codec_async_drain() {

@@ -58,7 +58,25 @@ struct ConvKArgs {
     const bf16_t* Wh; const bf16_t* Wl; // optional (hi, lo) fp16 planes of W * 2^k for k_conv_split (16-bit storage)
     float acc_scale;                    // 2^-k (1 on the fp32 path)
     int ksplit; float* slab;            // k_conv_split, 1-tap GEMMs: blockIdx.z = K slice, raw partial sums -> slab[z][T_out][C_out] (k_conv_finish)
+    int batch_tiles;                    // > 0: blockIdx.x = sequence * batch_tiles + row tile; sequences are in_ustride / T_out * C_out floats apart
+    size_t in_ustride;
 };
+
+// batched launch: rebase the sequence-shaped pointers to this workgroup's sequence and return its row-tile index
+static __device__ __forceinline__ int conv_batch_rebase(ConvKArgs& a) {
+    int bx = blockIdx.x;
+    if (a.batch_tiles > 0) {
+        const int u = bx / a.batch_tiles;
+        bx -= u * a.batch_tiles;
+        const size_t io = (size_t)u * a.in_ustride, oo = (size_t)u * a.T_out * a.C_out;
+        a.in += io;
+        if (a.out) a.out += oo;
+        if (a.out2) a.out2 += oo;
+        if (a.res) a.res += oo;
+        if (a.mul) a.mul += oo;
+    }
+    return bx;
+}
 
 // Epilogue of one 32x32 accumulator block: D[row][col], col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
 static __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, const f32x16 acc, int mrow0, int co, int lane, int phase, int NT) {
@@ -263,7 +281,9 @@ template <int MB, int NB, int WM, int WN, int PA, int KC = 32, int NBUF = 2>
 // <= 96 accumulator registers and 32-column chunks: two workgroups per CU (256 registers each); otherwise ONE wave per SIMD with the
 // whole 512-register file — said explicitly, or hipcc still budgets 256 and spills the prefetch registers right behind their loads
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MB * NB <= 6 && KC == 32 ? 2 : 1), (MB * NB <= 6 && KC == 32 ? 2 : 1))))
-void k_conv_split(ConvKArgs a) {
+void k_conv_split(ConvKArgs a0) {
+    ConvKArgs a = a0;
+    const int bx = conv_batch_rebase(a);
     constexpr int TM = WM * MB * 32, TN = WN * NB * 32, AROWS = PA * 32;
     constexpr int CB = KC / 32, SEG = KC / 8, LD = KC + 8;       // 32-column blocks, 16-byte segments and padded halves per staged row
     constexpr int PB = TN * SEG * 2 / 256;                       // 16-B segments per thread of one weight tile (2 planes x TN rows x SEG)
@@ -277,7 +297,7 @@ void k_conv_split(ConvKArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const bool ksp = KC == 128 && a.ksplit > 1;               // split-K (short pre-transformer GEMMs): blockIdx.z is the K slice, not a phase
-    const int m0 = blockIdx.x * TM, co0 = blockIdx.y * TN, phase = ksp ? 0 : blockIdx.z;
+    const int m0 = bx * TM, co0 = blockIdx.y * TN, phase = ksp ? 0 : blockIdx.z;
     const int NT = a.transposed ? a.taps / a.stride : a.taps;
     const int halo = a.transposed ? NT - 1 : (a.taps - 1) * a.dil;
     const int n_chunks = ksp ? a.C_in / KC / a.ksplit : a.C_in / KC, total = n_chunks * NT;
@@ -477,9 +497,11 @@ static void launch_split_pa(const ConvKArgs& a, dim3 grid, int extra, hipStream_
 // C_out == 1 (the decoder's last conv): one output sample per thread, the input rows of a 128-sample tile (+ tap halo) staged in
 // LDS with an odd row stride; a matrix-core tile would be 1/64 full.  Causal taps, optional clamp.
 #define CO1_T 128
-__global__ __launch_bounds__(CO1_T) void k_conv_cout1(ConvKArgs a) {
+__global__ __launch_bounds__(CO1_T) void k_conv_cout1(ConvKArgs a0) {
     extern __shared__ float xs[];                    // [(CO1_T + halo)][C_in + 1]
-    const int ld = a.C_in + 1, halo = (a.taps - 1) * a.dil, t0 = blockIdx.x * CO1_T, rows = CO1_T + halo;
+    ConvKArgs a = a0;
+    const int bx = conv_batch_rebase(a);
+    const int ld = a.C_in + 1, halo = (a.taps - 1) * a.dil, t0 = bx * CO1_T, rows = CO1_T + halo;
     for (int i = threadIdx.x; i < rows * (a.C_in / 4); i += CO1_T) {
         const int r = i / (a.C_in / 4), c4 = (i % (a.C_in / 4)) * 4, src = t0 - halo + r;
         const int sc = src < 0 ? 0 : (src < a.T_in ? src : a.T_in - 1);
@@ -511,7 +533,9 @@ void launch_conv(const ConvArgs& c, hipStream_t s) {
     a.out2 = c.out2; a.s2_alpha = c.snake_alpha; a.s2_beta = c.snake_beta;
     a.Wh = c.Wh; a.Wl = c.Wl;
     a.acc_scale = 1.0f;
-    a.ksplit = 0; a.slab = nullptr;
+    a.ksplit = 0; a.slab = nullptr; a.batch_tiles = 0;
+    a.in_ustride = c.in_ustride ? c.in_ustride : (size_t)c.T_in * c.C_in;
+    const int nb = c.batch > 1 ? c.batch : 1;
     if (c.transposed && c.taps % c.stride != 0) throw Error("conv: transposed kernel must be a multiple of the stride");
     const int rows = c.transposed ? c.T_in + c.taps / c.stride - 1 : c.T_out;
     dim3 grid((rows + CT_M - 1) / CT_M, (c.C_out + CT_N - 1) / CT_N, c.transposed ? c.stride : 1);
@@ -519,7 +543,9 @@ void launch_conv(const ConvArgs& c, hipStream_t s) {
     if (c.C_out == 1 && !c.transposed && c.C_in % 4 == 0 && c.out && !c.out2 && !c.res && !c.mul && !c.res_scale && c.act == 0) {
         const size_t lds = (size_t)(CO1_T + (c.taps - 1) * c.dil) * (c.C_in + 1) * sizeof(float);
         if (lds <= 60 * 1024) {
-            hipLaunchKernelGGL(k_conv_cout1, dim3((c.T_out + CO1_T - 1) / CO1_T), dim3(CO1_T), lds, s, a);
+            const int tiles = (c.T_out + CO1_T - 1) / CO1_T;
+            if (nb > 1) a.batch_tiles = tiles;
+            hipLaunchKernelGGL(k_conv_cout1, dim3(tiles * nb), dim3(CO1_T), lds, s, a);
             Q3_HIP_CHECK(hipGetLastError());
             return;
         }
@@ -531,16 +557,17 @@ void launch_conv(const ConvArgs& c, hipStream_t s) {
         const int extra = (halo + 31) / 32, z = c.transposed ? c.stride : 1;
         const bool n96 = c.C_out % 96 == 0;   // every decoder width (1536 .. 96) and the FFN; 96-wide tiles fit two workgroups per CU
         const int ntile = n96 ? c.C_out / 96 : (c.C_out + 127) / 128;
-        const long n_big = (long)((rows + 255) / 256) * ntile * z, n_thin = (long)((rows + 127) / 128) * ntile * z;
+        const long n_big = (long)((rows + 255) / 256) * ntile * z * nb, n_thin = (long)((rows + 127) / 128) * ntile * z * nb;
+        auto bgrid = [&](int tiles, int gy, int gz) { if (nb > 1) a.batch_tiles = tiles; return dim3((unsigned)(tiles * nb), (unsigned)gy, (unsigned)gz); };
         // 256-row tiles when the grid still fills the chip a few times over and K is deep enough to be compute-bound; 128-row tiles
         // (2-3 workgroups per CU) for bandwidth-bound or mid-sized launches; 64-row tiles for the short pre-transformer GEMMs
         const bool deep = NTt * c.C_in > 512;
         if (n_thin < 256) {   // fewer 128-row tiles than CUs: 64-row tiles, 128-column chunks when the channel count allows (swept: 64 .. 512)
-            const dim3 g((rows + 63) / 64, (c.C_out + 127) / 128, z);
+            const dim3 g = bgrid((rows + 63) / 64, (c.C_out + 127) / 128, z);
             // a short utterance's pre-transformer GEMM (<= 128 frames x 1024..3072 channels) has 8-48 of these workgroups, each streaming
             // 0.5-1.5 MB of weights alone (47-75 us): cut K into 128-wide slices across workgroups, sum the slices in a tail kernel
             int ks = 1;
-            if (c.taps == 1 && !c.transposed && c.C_in % 128 == 0 && c.C_in >= 512 && c.slab) {   // fewest slices that give >= 256 workgroups
+            if (nb == 1 && c.taps == 1 && !c.transposed && c.C_in % 128 == 0 && c.C_in >= 512 && c.slab) {   // fewest slices that give >= 256 workgroups
                 const int nch = c.C_in / 128;
                 for (ks = 1; ks < nch; ++ks)
                     if (nch % ks == 0 && (long)g.x * g.y * ks >= 256) break;
@@ -561,16 +588,19 @@ void launch_conv(const ConvArgs& c, hipStream_t s) {
             } else launch_split_pa<2, 1, 1, 4>(a, g, extra, s);
         }
         else if (!deep || n_big < 1024) {
-            if (n96) launch_split_pa<1, 3, 4, 1>(a, dim3((rows + 127) / 128, ntile, z), extra, s);
-            else launch_split_pa<1, 4, 4, 1>(a, dim3((rows + 127) / 128, ntile, z), extra, s);
+            const dim3 g2 = bgrid((rows + 127) / 128, ntile, z);
+            if (n96) launch_split_pa<1, 3, 4, 1>(a, g2, extra, s);
+            else launch_split_pa<1, 4, 4, 1>(a, g2, extra, s);
         } else {
-            if (n96) launch_split_pa<2, 3, 4, 1>(a, dim3((rows + 255) / 256, ntile, z), extra, s);
-            else launch_split_pa<2, 4, 4, 1>(a, dim3((rows + 255) / 256, ntile, z), extra, s);
+            const dim3 g2 = bgrid((rows + 255) / 256, ntile, z);
+            if (n96) launch_split_pa<2, 3, 4, 1>(a, g2, extra, s);
+            else launch_split_pa<2, 4, 4, 1>(a, g2, extra, s);
         }
         (void)n_thin;
         Q3_HIP_CHECK(hipGetLastError());
         return;
     }
+    if (nb > 1) throw Error("conv: a batched launch needs the split-precision path (or C_out == 1)");
     hipLaunchKernelGGL(k_conv_mfma, grid, dim3(256), 0, s, a);
 }
 
@@ -590,9 +620,9 @@ void launch_repack_conv(const float* w, float* out, int cin, int cout, int k, in
 
 // ---- code_embedding(codes + g*codebook).mean over the G quantizers (Code2Wav.forward) ----
 // grid (rows per utterance, utterances): utterance u reads codes + u * codes_stride (ints) and writes rows u * gridDim.x + t
-__global__ void k_code_embed_mean(const float* table, const int32_t* codes0, int G, int codebook, int C, float* out0, size_t codes_stride) {
+__global__ void k_code_embed_mean(const float* table, const int32_t* codes0, int G, int codebook, int C, float* out0, size_t codes_stride, const int* perm) {
     const int t = blockIdx.x;
-    const int32_t* codes = codes0 + (size_t)blockIdx.y * codes_stride;
+    const int32_t* codes = codes0 + (size_t)(perm ? perm[blockIdx.y] : (int)blockIdx.y) * codes_stride;   // perm: row block y holds utterance perm[y]
     float* out = out0 + (size_t)blockIdx.y * gridDim.x * C;
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
         float s = 0.f;
@@ -605,8 +635,8 @@ __global__ void k_code_embed_mean(const float* table, const int32_t* codes0, int
     }
 }
 void launch_code_embed_mean(const float* table, const int32_t* codes, int F, int G, int codebook, int C, float* out, hipStream_t s,
-                            int n_utt, size_t codes_stride) {
-    if (F > 0 && n_utt > 0) hipLaunchKernelGGL(k_code_embed_mean, dim3(F, n_utt), dim3(256), 0, s, table, codes, G, codebook, C, out, codes_stride);
+                            int n_utt, size_t codes_stride, const int* perm) {
+    if (F > 0 && n_utt > 0) hipLaunchKernelGGL(k_code_embed_mean, dim3(F, n_utt), dim3(256), 0, s, table, codes, G, codebook, C, out, codes_stride, perm);
 }
 
 static __device__ float block_sum256(float v, float* red) {

@@ -213,13 +213,15 @@ struct ConvArgs { // out[t][co] = epi(bias[co] + sum_{tap,ci} W[tap][co][ci] * i
     const float* snake_alpha = nullptr;
     const float* snake_beta = nullptr;
     float* slab = nullptr; size_t slab_floats = 0; // optional scratch for split-K partial sums of short 1-tap GEMMs ([slice][T_out][C_out])
+    int batch = 1;               // independent sequences of the same shape: sequence u at in + u * in_ustride, out / out2 / res / mul at + u * T_out * C_out
+    size_t in_ustride = 0;       // floats between the sequences' inputs (0: T_in * C_in, i.e. densely packed)
 };
 void launch_conv(const ConvArgs& a, hipStream_t s);
 void launch_split_planes(const float* w, bf16_t* hi, bf16_t* lo, size_t n, float scale, hipStream_t s);
 void launch_absmax(const float* w, size_t n, unsigned* out, hipStream_t s);
 void launch_repack_conv(const float* w, float* out, int cin, int cout, int k, int transposed, hipStream_t s);
 void launch_code_embed_mean(const float* table, const int32_t* codes, int F, int G, int codebook, int C, float* out, hipStream_t s,
-                            int n_utt = 1, size_t codes_stride = 0);
+                            int n_utt = 1, size_t codes_stride = 0, const int* perm = nullptr);
 void launch_rmsnorm_rows(const float* x, const float* w, float eps, int rows, int C, float* out, hipStream_t s);
 void launch_rope_store(float* qkv, int ld, int T, int nq, int nkv, int d, const float* cs, const float* sn,
                        float* kc, float* vc, int P, hipStream_t s, int n_utt = 1);

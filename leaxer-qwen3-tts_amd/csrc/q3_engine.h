@@ -120,8 +120,11 @@ public:
     CodecW* codec = nullptr;
     void codec_finalize();
     // returns the sample count; h_in: this utterance's rows from codec_pre_batch (h_stage 1: after the pre-transformer, 2: after the upsampling stages too)
-    int64_t codec_run(const int32_t* codes_dev, int F, float** pcm_dev, int lane = 0, const float* h_in = nullptr, int h_stage = 1);
-    const float* codec_pre_batch(const int32_t* codes_dev, int codes_stride_frames, int n, int Fp, bool with_upsampling, int* rows_per_utt_out);
+    int64_t codec_run(const int32_t* codes_dev, int F, float** pcm_dev, int lane = 0, const float* h_in = nullptr, int h_stage = 1, int nbatch = 1, size_t h_ustride = 0);
+    void codec_async_submit_group(const float* h_group, size_t h_ustride, int Fg, int g, const int* nf, float* const* user_pcm, int64_t cap, int64_t* const* len_out);
+    bool codec_batchable() const;   // every conv of the decoder takes the split-precision path (the batched kernels)
+    const float* codec_pre_batch(const int32_t* codes_dev, int codes_stride_frames, int n, int Fp, bool with_upsampling, int* rows_per_utt_out,
+                                 const int* perm_host = nullptr);
     // vocoder side of the scheduler: stash a finished slot's codes, vocode the job's utterances over the side lanes at the end
     void codec_async_prepare(int max_frames, int n_utt);
     const int32_t* codec_stash(int slot, int nf, int utt, int row_frames);
