@@ -344,51 +344,48 @@ int q3tts_synthesize_schedule_host(q3tts_engine* h, int n_utt, const int64_t* id
         for (int b = 0; b < B; ++b) { try { e.slot_release(b); } catch (...) { } }
         throw;
     }
-    // vocoder, once the decode queue is empty: the pre-transformer of all utterances in one batched pass (when padding them to the
-    // longest costs less than half as many rows again), then every utterance's conv stack over the side lanes
-    int64_t sum_f = 0;
-    int Fp = 0;
-    for (int u = 0; u < n_utt; ++u) { sum_f += got_frames[(size_t)u]; Fp = std::max(Fp, (int)got_frames[(size_t)u]); }
-    // row block y of the batched buffers holds utterance order[y]: longest first, so that a decoder group's members have similar lengths
+    // Vocoder, once the decode queue is empty.  Utterances are taken longest first, in blocks of similar length (the shortest at least half
+    // the longest, at most 2^16 padded frames): a block's pre-transformer and upsampling stages run as one batched pass, its conv decoder in
+    // groups of up to 32 utterances per set of launches (about 4.7 MB of workspace per frame: groups sized to ~8 GB), each group padded to its
+    // own longest member.  Padding is exact: every layer is causal.  Single utterances, the exact-fp32 codec and configs whose decoder the
+    // batched kernels do not cover go one utterance at a time over the side lanes.
     std::vector<int> order((size_t)n_utt);
-    for (int u = 0; u < n_utt; ++u) order[(size_t)u] = u;
+    for (int u = 0; u < n_utt; ++u) { order[(size_t)u] = u; if (pcm_len) pcm_len[u] = 0; }
     std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return got_frames[(size_t)x] > got_frames[(size_t)y]; });
-    const float* hb = nullptr;
-    int hb_rows = 0, hb_stage = 1;
-    if (n_utt >= 2 && Fp > 0 && (int64_t)n_utt * Fp <= sum_f + sum_f / 2 && (int64_t)n_utt * Fp <= (int64_t)1 << 18) {   // 49 KB of workspace per row
-        const bool up = (int64_t)n_utt * Fp <= (int64_t)1 << 16;        // + 98 KB per row with the upsampling stages
-        hb = e.codec_pre_batch(e.codec_job_codes(0, row_frames), row_frames, n_utt, Fp, up, &hb_rows, order.data());
-        hb_stage = up ? 2 : 1;
-    }
-    // the conv decoder: groups of consecutive (similar-length) utterances in one set of launches when the batched front produced their
-    // upsampled rows (about 4.7 MB of workspace per frame: groups sized to ~8 GB), else one utterance at a time over the side lanes
-    int group = 1;
-    if (hb && hb_stage == 2 && e.codec_batchable()) group = (int)std::max<int64_t>(1, std::min<int64_t>(32, ((int64_t)8 << 30) / ((int64_t)4700000 * Fp)));
-    const size_t ustride = (size_t)hb_rows * e.c.cd_hidden;
-    if (group >= 2) {
-        std::vector<int> nf;
-        std::vector<float*> up;
-        std::vector<int64_t*> lp;
-        for (int y0 = 0; y0 < n_utt; y0 += group) {
-            const int g = std::min(group, n_utt - y0);
-            nf.assign((size_t)g, 0); up.assign((size_t)g, nullptr); lp.assign((size_t)g, nullptr);
-            for (int k = 0; k < g; ++k) {
-                const int u = order[(size_t)(y0 + k)];
-                nf[(size_t)k] = got_frames[(size_t)u];
-                if (pcm_len) { pcm_len[u] = 0; lp[(size_t)k] = pcm_len + u; }
-                if (pcm_out) up[(size_t)k] = pcm_out[u];
+    const bool batchable = e.codec_batchable();
+    std::vector<int> nf;
+    std::vector<float*> up;
+    std::vector<int64_t*> lp;
+    for (int y0 = 0; y0 < n_utt;) {
+        const int F0 = got_frames[(size_t)order[(size_t)y0]];
+        if (F0 <= 0) break;                                            // sorted: the rest of the job produced no frame
+        int y1 = y0 + 1;
+        while (y1 < n_utt && (int64_t)(y1 - y0 + 1) * F0 <= (int64_t)1 << 16 && got_frames[(size_t)order[(size_t)y1]] * 2 >= F0) ++y1;
+        const int nblk = y1 - y0;
+        if (nblk >= 2 && batchable && F0 <= ((int64_t)1 << 16) / 2) {
+            int rows = 0;
+            e.codec_lanes_join();                                      // the previous block's groups still read the batched buffers
+            const float* hb = e.codec_pre_batch(e.codec_job_codes(0, row_frames), row_frames, nblk, F0, true, &rows, order.data() + y0);
+            const size_t ustride = (size_t)rows * e.c.cd_hidden;
+            const int group = (int)std::max<int64_t>(1, std::min<int64_t>(32, ((int64_t)8 << 30) / ((int64_t)4700000 * F0)));
+            for (int g0 = 0; g0 < nblk; g0 += group) {
+                const int g = std::min(group, nblk - g0);
+                nf.assign((size_t)g, 0); up.assign((size_t)g, nullptr); lp.assign((size_t)g, nullptr);
+                for (int k = 0; k < g; ++k) {
+                    const int u = order[(size_t)(y0 + g0 + k)];
+                    nf[(size_t)k] = got_frames[(size_t)u];
+                    if (pcm_len) lp[(size_t)k] = pcm_len + u;
+                    if (pcm_out) up[(size_t)k] = pcm_out[u];
+                }
+                e.codec_async_submit_group(hb + (size_t)g0 * ustride, ustride, nf[0], g, nf.data(), up.data(), pcm_cap, lp.data());
             }
-            if (nf[0] <= 0) break;                                       // sorted: the rest of the job produced no frame
-            e.codec_async_submit_group(hb + (size_t)y0 * ustride, ustride, nf[0], g, nf.data(), up.data(), pcm_cap, lp.data());
+        } else {
+            for (int y = y0; y < y1; ++y) {
+                const int u = order[(size_t)y];
+                e.codec_async_submit_dev(e.codec_job_codes(u, row_frames), got_frames[(size_t)u], pcm_out ? pcm_out[u] : nullptr, pcm_cap, pcm_len ? pcm_len + u : nullptr);
+            }
         }
-        if (pcm_len) for (int u = 0; u < n_utt; ++u) if (got_frames[(size_t)u] <= 0) pcm_len[u] = 0;
-    } else {
-        for (int y = 0; y < n_utt; ++y) {
-            const int u = order[(size_t)y];
-            if (pcm_len) pcm_len[u] = 0;
-            e.codec_async_submit_dev(e.codec_job_codes(u, row_frames), got_frames[(size_t)u], pcm_out ? pcm_out[u] : nullptr, pcm_cap, pcm_len ? pcm_len + u : nullptr,
-                                     hb ? hb + (size_t)y * ustride : nullptr, hb_stage);
-        }
+        y0 = y1;
     }
     e.codec_async_drain();
     return 0;

@@ -554,6 +554,10 @@ void Engine::codec_async_submit_group(const float* h_group, size_t h_ustride, in
     }
     if (!W.lane_done[lane]) Q3_HIP_CHECK(hipEventCreateWithFlags(&W.lane_done[lane], hipEventDisableTiming));
     hipStream_t ls = W.lane_stream[lane];
+    if (lane != 0) {   // this group's rows come from the batched pass just queued on the engine stream (a later block than the window's first)
+        Q3_HIP_CHECK(hipEventRecord(W.fork, stream));
+        Q3_HIP_CHECK(hipStreamWaitEvent(ls, W.fork, 0));
+    }
     float* pcm_d = nullptr;
     const int64_t Tp = codec_run(nullptr, Fg, &pcm_d, lane, h_group, 2, g, h_ustride);   // padded samples per utterance (Fg = the group's longest)
     CodecW::Pending& p = W.pend[lane];
@@ -578,6 +582,14 @@ void Engine::codec_async_submit_group(const float* h_group, size_t h_ustride, in
     }
     Q3_HIP_CHECK(hipEventRecord(W.lane_done[lane], ls));
     p.frames = frames; p.busy = true;
+}
+
+// the engine stream waits for every lane's queued work (no host synchronisation): what it launches next may overwrite what the lanes read
+void Engine::codec_lanes_join() {
+    if (!codec) return;
+    CodecW& W = *codec;
+    for (int i = 1; i < W.nlane; ++i)
+        if (W.pend[i].busy && W.lane_done[i]) Q3_HIP_CHECK(hipStreamWaitEvent(stream, W.lane_done[i], 0));
 }
 
 void Engine::codec_async_drain() {

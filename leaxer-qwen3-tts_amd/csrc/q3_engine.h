@@ -132,6 +132,7 @@ public:
     void codec_async_submit_dev(const int32_t* codes_dev, int nf, float* user_pcm, int64_t cap, int64_t* len_out, const float* h_in = nullptr, int h_stage = 1);
     void codec_async_drain_lane(int lane);
     void codec_async_drain();
+    void codec_lanes_join();
     void slots_state(int nb, std::vector<SlotState>& out);
     void codec_free();
 

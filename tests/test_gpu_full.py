@@ -219,3 +219,19 @@ def test_batched_vocoder_front_matches_single_decodes_full_size(full):
         assert float(np.sqrt(np.mean((pcm[u] - single) ** 2))) < 1e-5 and np.abs(pcm[u] - single).max() < 1e-4, u
     ref = orc.vocoder(codes[2])
     assert float(np.sqrt(np.mean((pcm[2] - ref) ** 2))) < 1e-4
+
+
+def test_vocoder_blocks_of_mixed_lengths_full_size(full):
+    """Lengths 40, 38, 12, 11, 10 and 3 frames: the vocoder phase takes them longest first in blocks whose shortest member is at least half
+    the longest ({40, 38}, {12, 11, 10}, {3} alone), each block through the batched passes; every PCM equals its single-utterance decode."""
+    import q3tts
+    eng, orc = full
+    sp = q3tts.Sampling(temperature=0.8, top_p=0.95, top_k=50, max_new_tokens=40)
+    rng = np.random.default_rng(29)
+    toks = [frame_tokens(rng.integers(0, 151643, int(n))) for n in (4, 9, 16, 3, 7, 12)]
+    caps = np.array([11, 40, 3, 38, 12, 10], np.int32)
+    pcm, codes, nfr = eng.synthesize_batch(toks[:2] + toks[2:], sp, lang=0, seed=6, ignore_eos=True, max_new_per_utt=caps)
+    assert np.array_equal(nfr, caps)
+    for u in range(6):
+        single = eng.codec_decode(codes[u])
+        assert pcm[u].shape == single.shape and float(np.sqrt(np.mean((pcm[u] - single) ** 2))) < 1e-5, u
