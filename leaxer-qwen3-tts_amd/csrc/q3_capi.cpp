@@ -264,8 +264,8 @@ int q3tts_synthesize_schedule_host(q3tts_engine* h, int n_utt, const int64_t* id
     const int row_frames = std::max(1, std::min(p->max_new_tokens, e.max_frames_cap));
     e.codec_async_prepare(row_frames, n_utt);
     std::vector<int32_t> got_frames((size_t)n_utt, 0);
-    // Prompt rows of every utterance are assembled before the first step: prompt assembly is a handful of small synchronous device
-    // round trips per utterance, cheap on an idle GPU and slow once vocoder lanes keep it busy.
+    // Prompt rows of every utterance are assembled before the first step, all in one projection pass (Engine::build_prompts): one
+    // utterance at a time it is a handful of small synchronous device round trips each.
     struct Prep { int S = 0, nt = 0; size_t poff = 0, toff = 0; };
     std::vector<Prep> prep((size_t)n_utt);
     std::vector<float> prompts, trailing;
