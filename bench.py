@@ -1,5 +1,5 @@
 """bench.py — headline metric of BASELINE.json: real-time factor (24 kHz audio seconds / wall seconds)
-and codec-frames/sec of Qwen3-TTS-0.6B synthesis on MI355X.
+and codec-frames/sec of Qwen3-TTS-0.6B synthesis on MI355X, "0.6B @ b1/b64".
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--frames F]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -9,16 +9,26 @@ talker prefill, F frames of [sampler + 15 code-predictor passes + talker decode]
 hipGraph, then the 12 Hz codec decode to 24 kHz PCM.  Default workload = BASELINE.json configs[1]:
 0.6B, batch 1, sampled (temp 0.8 / top-k 50 / top-p 0.95), max-tokens 2048, 16-token prompt; weights
 are seeded synthetic (no checkpoint in the image), EOS is suppressed so every utterance runs the full
-2048 frames (random weights never learnt to stop).  Multi-GPU: utterances are independent, each rank
-runs its own batch on its own GPU (weak scaling); RCCL carries only the final gather of codes.
+2048 frames (random weights never learnt to stop).  The default line also carries the other half of
+the metric as the sub-record "b64": configs[2] (64 utterances in one batch, 256 frames each), run in
+the same process after the timed region of `value`.
+
+Multi-GPU (configs[3]): utterances are independent, each rank runs its own batch on its own GPU
+(weak scaling); RCCL carries only the final gather of codes + PCM lengths.  `--gpus N` with
+WORLD_SIZE unset starts the N ranks itself: N child processes (rank i on GPU i, rendezvous on
+127.0.0.1), spawned before the parent touches the GPU; under torch.distributed.run the ranks are
+already there.  Either way world_size must equal --gpus.
 
 Rank 0 prints ONE JSON line.  `roofline` is for the decode step (the hipGraph replayed per frame):
 algorithmic bytes / device time measured with HIP events on the engine's stream.
-`cpu_baseline` times the CPU oracle (a port of the reference's call pattern, fp32) on a bounded sample.
+`cpu_baseline` is the reference CLI on ONNX Runtime's CPU EP when an operator supplies it (probe below),
+else the CPU oracle (a port of the reference's call pattern, fp32) timed on a bounded sample.
 """
 import argparse
 import json
 import os
+import shutil
+import subprocess
 import sys
 import time
 
@@ -30,35 +40,73 @@ import numpy as np  # noqa: E402
 
 FRAME_SECONDS = 0.08  # 12.5 Hz codec frames
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+IM_START, ASSISTANT, TTS_BOS, TTS_EOS, IM_END = 151644, 77091, 151672, 151673, 151645
+
+
+def layer_bytes(Hw, nq, nkv, d, ffn):
+    return 2.0 * (Hw * (nq + 2 * nkv) * d + Hw * nq * d + 3 * Hw * ffn)
+
+
+def weight_step_bytes(cfg):
+    """talker weights once + predictor weights once per pass (bf16)."""
+    H = cfg.hidden
+    Hc = cfg.cp_hidden or H        # 1.7B: narrower predictor behind cp.proj
+    w = cfg.n_layers * layer_bytes(H, cfg.n_heads, cfg.n_kv_heads, cfg.head_dim, cfg.ffn) + 2.0 * H * cfg.vocab
+    w += (cfg.n_groups - 1) * (cfg.cp_layers * layer_bytes(Hc, cfg.cp_heads, cfg.cp_kv_heads, cfg.cp_head_dim, cfg.cp_ffn)
+                               + 2.0 * Hc * cfg.sub_vocab + (2.0 * H * Hc if Hc != H else 0.0))
+    return w
+
+
+def kv_step_bytes(cfg, batch, avg_ctx, bytes_per_elem):
+    return batch * avg_ctx * cfg.n_layers * 2.0 * cfg.n_kv_heads * cfg.head_dim * bytes_per_elem
 
 
 def algorithmic_step_bytes(cfg, batch, avg_ctx):
-    """talker weights once + predictor weights once per pass (bf16) + bf16-equivalent
-    KV bytes the attention must read (B x T x 2 x L x n_kv x d x 2 B)."""
-    H = cfg.hidden
-    Hc = cfg.cp_hidden or H        # 1.7B: narrower predictor behind cp.proj
-
-    def layer(Hw, nq, nkv, d, ffn):
-        return 2.0 * (Hw * (nq + 2 * nkv) * d + Hw * nq * d + 3 * Hw * ffn)
-    w = cfg.n_layers * layer(H, cfg.n_heads, cfg.n_kv_heads, cfg.head_dim, cfg.ffn) + 2.0 * H * cfg.vocab
-    w += (cfg.n_groups - 1) * (cfg.cp_layers * layer(Hc, cfg.cp_heads, cfg.cp_kv_heads, cfg.cp_head_dim, cfg.cp_ffn)
-                               + 2.0 * Hc * cfg.sub_vocab + (2.0 * H * Hc if Hc != H else 0.0))
-    kv = batch * avg_ctx * cfg.n_layers * 2.0 * cfg.n_kv_heads * cfg.head_dim * 2.0
-    return w + kv
+    """weights + the bf16-equivalent KV bytes the attention must read (B x T x 2 x L x n_kv x d x 2 B): the roofline numerator"""
+    return weight_step_bytes(cfg) + kv_step_bytes(cfg, batch, avg_ctx, 2.0)
 
 
 CODEC_GFLOP_PER_FRAME = 5.0     # SURVEY.md section 8d / DESIGN.md section 4
 MFMA_16BIT_DENSE_TFLOPS = 2500.0
 
 
-def stage_report(eng, q3tts, cfg, toks, sp, B, F, ctr):
+def kernel_sources_digest():
+    """sha1 over the HIP sources: a PMC traffic figure under profiles/ is only quoted for the build it was measured on"""
+    import hashlib
+    h = hashlib.sha1()
+    d = os.path.join(ROOT, "leaxer-qwen3-tts_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h", ".cpp")):
+            with open(os.path.join(d, f), "rb") as fh:
+                h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def measured_traffic(batch, model):
+    """HBM bytes per decode step from the rocprofv3 --pmc passes (tools/pmc_traffic.py writes profiles/decode_step_traffic.json with the
+    digest of the kernel sources it ran): quoted only when it was measured on THIS build at THIS batch, else null with the reason."""
+    tf = os.path.join(ROOT, "profiles", "decode_step_traffic.json")
+    if model != "0.6b":
+        return None, "no PMC pass for this model size"
+    if not os.path.exists(tf):
+        return None, "profiles/decode_step_traffic.json absent (run tools/pmc_traffic.py under gpurun)"
+    try:
+        j = json.load(open(tf))
+    except Exception as ex:
+        return None, f"unreadable traffic file: {ex}"
+    rec = j.get(f"b{batch}")
+    if rec is None:
+        return None, f"no PMC pass at batch {batch} (rocprofv3 --pmc runs separately from the bench: counters cannot be read inside the timed process)"
+    if j.get("src_digest") != kernel_sources_digest():
+        return None, "PMC passes under profiles/ were taken on a different build of the kernels (src_digest mismatch); re-run tools/pmc_traffic.py"
+    return rec, "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over eager decode steps of this build (tools/pmc_traffic.py); FETCH_SIZE x2 (gfx950)"
+
+
+def stage_report(eng, cfg, toks, sp, B, F, ctr):
     """north_star: achieved fraction of the HBM / MFMA roofline per stage.  Arms the B slots again, advances them to mid-utterance with
     graph replays, then runs 16 EAGER steps with HIP events at the stage boundaries (q3tts_stage_profile); eager launches carry a
     little more launch gap than the graph replay the headline times.  Codec numbers come from the timed region's counters."""
     H, Hc = cfg.hidden, cfg.cp_hidden or cfg.hidden
-
-    def layer(Hw, nq, nkv, d, ffn):
-        return 2.0 * (Hw * (nq + 2 * nkv) * d + Hw * nq * d + 3 * Hw * ffn)
     for b in range(B):
         eng.slot_release(b)
     t0 = time.perf_counter()
@@ -70,9 +118,9 @@ def stage_report(eng, q3tts, cfg, toks, sp, B, F, ctr):
     eng.decode_steps(mid)
     st = eng.stage_profile(16)
     ctx = 9 + mid + 8
-    talker_bytes = cfg.n_layers * layer(H, cfg.n_heads, cfg.n_kv_heads, cfg.head_dim, cfg.ffn) + 2.0 * H * cfg.vocab \
-        + B * ctx * cfg.n_layers * 2.0 * cfg.n_kv_heads * cfg.head_dim * 2.0
-    pred_bytes = (cfg.n_groups - 1) * (cfg.cp_layers * layer(Hc, cfg.cp_heads, cfg.cp_kv_heads, cfg.cp_head_dim, cfg.cp_ffn)
+    talker_w = cfg.n_layers * layer_bytes(H, cfg.n_heads, cfg.n_kv_heads, cfg.head_dim, cfg.ffn) + 2.0 * H * cfg.vocab
+    talker_bytes = talker_w + kv_step_bytes(cfg, B, ctx, 2.0)
+    pred_bytes = (cfg.n_groups - 1) * (cfg.cp_layers * layer_bytes(Hc, cfg.cp_heads, cfg.cp_kv_heads, cfg.cp_head_dim, cfg.cp_ffn)
                                        + 2.0 * Hc * cfg.sub_vocab + (2.0 * H * Hc if Hc != H else 0.0))
     for b in range(B):
         eng.slot_release(b)
@@ -83,7 +131,8 @@ def stage_report(eng, q3tts, cfg, toks, sp, B, F, ctr):
     codec_ms = ctr["codec_ms"] / max(ctr["codec_frames"], 1)
     tf = CODEC_GFLOP_PER_FRAME * 1e9 / (codec_ms * 1e-3) / 1e12 if codec_ms > 0 else 0.0
     return {
-        "talker_decode": dict(hbm(st["talker_decode_ms"], talker_bytes), context=ctx),
+        "talker_decode": dict(hbm(st["talker_decode_ms"], talker_bytes), context=ctx,
+                              kv_bytes_actual_fp32=int(kv_step_bytes(cfg, B, ctx, 4.0))),
         "code_predictor": hbm(st["code_predictor_ms"], pred_bytes),
         "sampler": {"ms_per_step": round(st["sampler_ms"], 4), "launches_per_step": cfg.n_groups, "bound": "latency"},
         "codec_decode": {"ms_per_frame": round(codec_ms, 5), "GFLOP_per_frame": CODEC_GFLOP_PER_FRAME, "TFLOP/s": round(tf, 1),
@@ -94,11 +143,84 @@ def stage_report(eng, q3tts, cfg, toks, sp, B, F, ctr):
     }
 
 
+def roofline_record(cfg, B, F, step_ms, model):
+    abytes = algorithmic_step_bytes(cfg, B, 8 + F / 2.0)
+    achieved = abytes / (step_ms * 1e-3) / 1e9 if step_ms > 0 else 0.0
+    traffic, note = measured_traffic(B, model)
+    return {"bound": "hbm", "kernel": "decode step = one hipGraph replay per frame ("
+            + ("q3::k_gemv1 (QKV / o_proj / gate-up / down / heads), k_cp_attn_oproj x75, k_attn x28, k_sample x16" if B <= 2 else
+               ("q3::k_gemv16 family" if B <= 16 else "q3::k_gemm2 (+ split-K finish) + k_attn + k_sample")) + ")",
+            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_note": note,
+            "algorithmic_bytes_per_launch": int(abytes), "launch_ms": round(step_ms, 4),
+            "kv_bytes_bf16_equivalent": int(kv_step_bytes(cfg, B, 8 + F / 2.0, 2.0)),
+            "kv_bytes_actual": int(kv_step_bytes(cfg, B, 8 + F / 2.0, 4.0)),
+            "kv_note": "the KV cache is fp32 (bit-exact code parity with the fp32 oracle): the hardware moves kv_bytes_actual per step, "
+                       "the numerator counts the bf16-equivalent SURVEY.md 8d budgets, so frac under-reports the bytes moved"}
+
+
+# ------------------------------------------------------------------------------------------------
+# CPU baseline: the unmodified reference on ONNX Runtime's CPU EP when an operator supplies it, else the oracle port
+# ------------------------------------------------------------------------------------------------
+def probe_reference_ort():
+    """the intended baseline is the reference CLI on ONNX Runtime CPU EP (4 intra-op threads, hard-coded at
+    /root/reference/src/tts_onnx.cpp:140-141).  Neither ORT nor the .onnx graphs exist in the image, so this looks for operator-supplied
+    pieces: Q3TTS_REF_CLI (or `leaxer-qwen3-tts` on PATH), Q3TTS_REF_MODEL_DIR holding talker_decode.onnx, and a loadable
+    libonnxruntime (ONNXRUNTIME_DIR/lib or the loader path).  Returns (dict of found paths | None, reason)."""
+    import ctypes.util
+    cli = os.environ.get("Q3TTS_REF_CLI") or shutil.which("leaxer-qwen3-tts") or shutil.which("leaxer-tts-onnx")
+    mdir = os.environ.get("Q3TTS_REF_MODEL_DIR")
+    ort = None
+    for cand in ([os.path.join(os.environ["ONNXRUNTIME_DIR"], "lib", "libonnxruntime.so")] if os.environ.get("ONNXRUNTIME_DIR") else []):
+        if os.path.exists(cand):
+            ort = cand
+    if ort is None:
+        ort = ctypes.util.find_library("onnxruntime")
+    missing = []
+    if not cli or not os.path.exists(cli):
+        missing.append("reference CLI (Q3TTS_REF_CLI)")
+    if not mdir or not os.path.exists(os.path.join(mdir, "talker_decode.onnx")):
+        missing.append("talker_decode.onnx (Q3TTS_REF_MODEL_DIR)")
+    if not ort:
+        missing.append("libonnxruntime (ONNXRUNTIME_DIR)")
+    if missing:
+        return None, "reference ORT-CPU baseline unavailable: missing " + ", ".join(missing)
+    return {"cli": cli, "model_dir": mdir, "ort": ort}, "found"
+
+
+def reference_ort_baseline(found, frames):
+    """Run the reference CLI once (greedy = --top-k 1; the prompt is its own tokenizer's business) and time it."""
+    import tempfile
+    import wave
+    out = os.path.join(tempfile.mkdtemp(prefix="q3ref_"), "ref.wav")
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = os.path.dirname(found["ort"]) + ":" + env.get("LD_LIBRARY_PATH", "")
+    text = "The quick brown fox jumps over the lazy dog near the quiet river bank today."
+    cmd = [found["cli"], "-m", found["model_dir"], "-p", text, "-o", out, "--top-k", "1", "--max-tokens", str(frames)]
+    t0 = time.perf_counter()
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1800)
+    dt = time.perf_counter() - t0
+    if r.returncode != 0 or not os.path.exists(out):
+        raise RuntimeError("reference CLI failed: " + (r.stderr or r.stdout)[-300:])
+    with wave.open(out, "rb") as w:
+        seconds = w.getnframes() / float(w.getframerate())
+    return {"value": round(seconds / dt, 5), "unit": "x real-time (audio s / wall s)", "cores": 4, "threads": 4, "nproc": os.cpu_count(),
+            "kind": "reference", "frames_per_s": round(seconds / FRAME_SECONDS / dt, 3),
+            "sample": f"unmodified reference CLI on ONNX Runtime CPU EP (4 intra-op threads, tts_onnx.cpp:140), --top-k 1, --max-tokens {frames}: "
+                      f"{seconds:.2f} s of audio in {dt:.1f} s wall (includes model load)"}
+
+
 def cpu_baseline(eng, cfg, ids, sp_kwargs, frames):
     """Times the CPU oracle (oracle/, fp32, OpenMP) on a bounded sample of the same workload: prompt
     assembly + prefill + `frames` frames in the REFERENCE's call pattern (predictor re-run without a
     KV cache, tts_onnx.cpp:862-868) + vocoder of those frames.  The oracle is only the checker /
     baseline here; nothing measured as `value` touches it."""
+    found, why = probe_reference_ort()
+    if found is not None:
+        try:
+            return reference_ort_baseline(found, frames)
+        except Exception as ex:
+            why = f"reference ORT-CPU baseline found but failed ({ex}); falling back to the port"
     import q3_oracle as qo
     ocfg = qo.Config.from_dict(cfg.to_dict())
     orc = qo.Oracle(ocfg, max_ctx=frames + 32)
@@ -112,11 +234,111 @@ def cpu_baseline(eng, cfg, ids, sp_kwargs, frames):
     pcm = orc.vocoder(codes)
     dt = time.perf_counter() - t0
     orc.close()
+    try:
+        affinity = len(os.sched_getaffinity(0))
+    except AttributeError:
+        affinity = os.cpu_count()
     return {"value": round(len(codes) * FRAME_SECONDS / dt, 5), "unit": "x real-time (audio s / wall s)", "cores": threads,
+            "threads": threads, "nproc": os.cpu_count(), "cpus_allowed": affinity,
             "kind": "port", "frames_per_s": round(len(codes) / dt, 3),
             "sample": f"1 utterance, 16-token prompt, prefill + {len(codes)} frames (reference call pattern, no predictor KV cache) "
-                      f"+ vocoder of {len(codes)} frames ({len(pcm)} samples), fp32 oracle, {dt:.1f} s wall; "
-                      "reference ORT-CPU baseline unavailable (no onnxruntime / models in image)"}
+                      f"+ vocoder of {len(codes)} frames ({len(pcm)} samples), fp32 oracle on {threads} OpenMP threads "
+                      f"(the box reports {os.cpu_count()} logical CPUs, {affinity} allowed), {dt:.1f} s wall; {why}"}
+
+
+# ------------------------------------------------------------------------------------------------
+# self-launch: `python bench.py --gpus N` starts its own N ranks
+# ------------------------------------------------------------------------------------------------
+def self_launch(args, argv):
+    """Spawn N ranks of this script (rank i -> GPU i) BEFORE this process touches the GPU (it never does: no exec, no HIP call here),
+    wait for all of them, pass rank 0's JSON line through, exit non-zero if any rank failed."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   Q3TTS_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    if out0:
+        sys.stdout.write(out0)
+        sys.stdout.flush()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        sys.stderr.write("bench.py: ranks failed (rank, exit code): %s\n" % bad)
+        sys.exit(1)
+    sys.exit(0)
+
+
+def run_workload(q3tts, cfg, local_rank, B, F, sp_kwargs, steps, warmup, rank, no_graph, dist=None, torch=None, world=1, backend=None):
+    """W untimed warmup steps, then exactly K timed steps bracketed by barrier + synchronize; returns the engine and the raw measurements."""
+    eng = q3tts.Engine(cfg, device=local_rank, max_batch=B, max_ctx=F + 32, flags=q3tts.FLAG_NO_GRAPH if no_graph else 0)
+    eng.fill_synthetic(seed=0)
+    sp = q3tts.Sampling(max_new_tokens=F, **sp_kwargs)
+    rng = np.random.default_rng(1 + rank)
+    toks = [np.array([IM_START, ASSISTANT, TTS_BOS] + list(rng.integers(0, 151643, 16)) + [TTS_EOS, IM_END], np.int64) for _ in range(B)]
+    gathered = {"utterances": 0, "pcm_samples": 0}
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+            if torch is not None and backend == "nccl":
+                torch.cuda.synchronize()
+
+    def step(i):
+        pcm, codes, nfr = eng.synthesize_batch(toks, sp, lang=0, seed=100 + i, ignore_eos=True, want_codes=True)
+        if dist is not None:  # the only exchange on the path: gather of the generated codes + PCM lengths (RCCL over xGMI)
+            import q3dist
+            dev = torch.device("cuda", local_rank) if backend == "nccl" else None
+            allc, alln = q3dist.gather_codes(dist, codes, [rank * B + u for u in range(B)], world * B, F, cfg.n_groups, device=dev,
+                                             pcm_lens=[len(p) for p in pcm])
+            gathered["utterances"] = sum(c is not None for c in allc)
+            gathered["pcm_samples"] = int(sum(alln))
+        return int(nfr.sum()), sum(len(p) for p in pcm)
+
+    for i in range(warmup):
+        step(-1 - i)
+    eng.counters(reset=True)
+    barrier()
+    t0 = time.perf_counter()
+    frames = samples = 0
+    for i in range(steps):
+        f, s = step(i)
+        frames += f
+        samples += s
+    barrier()
+    dt = time.perf_counter() - t0
+    return eng, toks, sp, dt, frames, samples, eng.counters(), gathered
+
+
+def dry_launch(args, rank, world):
+    """--dry-launch: the launch / rendezvous / gather plumbing of the N-rank bench on CPU (gloo), no GPU and no synthesis: every rank
+    contributes fabricated codes for its shard and checks what the gather returns.  tests/test_dist_cpu.py runs it with --gpus 2."""
+    import torch.distributed as dist
+    import q3dist
+    assert world == args.gpus, f"world_size {world} != --gpus {args.gpus}"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    B, F, G = args.batch, min(args.frames, 12), 16
+    codes = [np.full((3 + (rank * B + u) % 5, G), rank * B + u, np.int64) for u in range(B)]
+    lens = [1920 * len(c) - 555 for c in codes]
+    dist.barrier()
+    t0 = time.perf_counter()
+    allc, alln = q3dist.gather_codes(dist, codes, [rank * B + u for u in range(B)], world * B, F, G, pcm_lens=lens)
+    dist.barrier()
+    dt = time.perf_counter() - t0
+    ok = all(c is not None and len(c) == 3 + g % 5 and (c == g).all() and alln[g] == 1920 * len(c) - 555 for g, c in enumerate(allc))
+    if rank == 0:
+        print(json.dumps({"metric": "dry launch (no GPU work)", "dry_launch": True, "n_gpus": world, "ranks_ok": bool(ok),
+                          "gathered_utterances": len(allc), "gather_ms": round(dt * 1e3, 3), "backend": "gloo"}), flush=True)
+    dist.destroy_process_group()
+    sys.exit(0 if ok else 1)
 
 
 def main():
@@ -129,61 +351,45 @@ def main():
     ap.add_argument("--greedy", action="store_true", help="top_k=1 instead of the sampled default")
     ap.add_argument("--model", default="0.6b", choices=["0.6b", "1.7b"], help="model dims (the headline is 0.6b; 1.7b = configs[4] dims)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-b64", action="store_true", help="skip the configs[2] sub-record (64 utterances x 256 frames) of the default line")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay (rocprofv3 kernel tracing "
                                                              "crashes inside hipGraphLaunch on this ROCm; same kernels either way)")
     ap.add_argument("--cpu-frames", type=int, default=160)
+    ap.add_argument("--dry-launch", action="store_true", help="only the N-rank launch + gloo rendezvous + gather plumbing, on CPU")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args, sys.argv[1:])          # never returns
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.stderr.write(f"bench.py: WORLD_SIZE={world} but --gpus {args.gpus}: launch one rank per GPU (or let --gpus N start them)\n")
+        sys.exit(2)
+    if args.dry_launch:
+        dry_launch(args, rank, world)
+
     dist = None
     torch = None
+    backend = None
     if world > 1 or os.environ.get("Q3TTS_BENCH_FORCE_DIST") == "1":   # the env var rehearses the RCCL path with one rank
         import torch
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        backend = "nccl"
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))  # RCCL on ROCm
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))  # RCCL on ROCm
 
     import q3tts
     cfg = q3tts.default_config(args.model)
     MODEL = "Qwen3-TTS-" + args.model.upper()
     B, F = args.batch, args.frames
-    eng = q3tts.Engine(cfg, device=local_rank, max_batch=B, max_ctx=F + 32, flags=q3tts.FLAG_NO_GRAPH if args.no_graph else 0)
-    eng.fill_synthetic(seed=0)
     sp_kwargs = dict(temperature=1.0, top_p=1.0, top_k=1) if args.greedy else dict(temperature=0.8, top_p=0.95, top_k=50)
-    sp = q3tts.Sampling(max_new_tokens=F, **sp_kwargs)
-    rng = np.random.default_rng(1 + rank)
-    IM_START, ASSISTANT, TTS_BOS, TTS_EOS, IM_END = 151644, 77091, 151672, 151673, 151645
-    toks = [np.array([IM_START, ASSISTANT, TTS_BOS] + list(rng.integers(0, 151643, 16)) + [TTS_EOS, IM_END], np.int64)
-            for _ in range(B)]
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    def step(i):
-        pcm, codes, nfr = eng.synthesize_batch(toks, sp, lang=0, seed=100 + i, ignore_eos=True, want_codes=True)
-        if dist is not None:  # the only exchange on the path: gather of the generated codes (RCCL over xGMI)
-            import q3dist
-            q3dist.gather_codes(dist, codes, [rank * B + u for u in range(B)], world * B, F, cfg.n_groups,
-                                device=torch.device("cuda", local_rank))
-        return int(nfr.sum()), sum(len(p) for p in pcm)
-
-    for i in range(args.warmup):
-        step(-1 - i)
-    eng.counters(reset=True)
-    barrier()
-    t0 = time.perf_counter()
-    frames = samples = 0
-    for i in range(args.steps):
-        f, s = step(i)
-        frames += f
-        samples += s
-    barrier()
-    dt = time.perf_counter() - t0
-    ctr = eng.counters()
+    sampling_txt = "greedy top_k=1" if args.greedy else "sampled temp=0.8 top-k=50 top-p=0.95"
+    eng, toks, sp, dt, frames, samples, ctr, gathered = run_workload(q3tts, cfg, local_rank, B, F, sp_kwargs, args.steps, args.warmup, rank,
+                                                                     args.no_graph, dist, torch, world, backend)
 
     if dist is not None:
         v = torch.tensor([dt, float(frames), float(samples)], dtype=torch.float64, device="cuda")
@@ -211,21 +417,12 @@ def main():
     stages = None
     if world == 1 and dist is None and not args.no_graph:
         try:
-            stages = stage_report(eng, q3tts, cfg, toks, sp, B, F, ctr)
+            stages = stage_report(eng, cfg, toks, sp, B, F, ctr)
         except Exception as ex:   # a reported extra, never the measurement
             stages = {"error": str(ex)}
 
     if rank == 0:
         step_ms = ctr["decode_ms"] / max(ctr["decode_steps"], 1)
-        abytes = algorithmic_step_bytes(cfg, B, 8 + F / 2.0)
-        achieved = abytes / (step_ms * 1e-3) / 1e9 if step_ms > 0 else 0.0
-        traffic = None
-        tf = os.path.join(ROOT, "profiles", "decode_step_traffic.json")
-        if os.path.exists(tf):
-            try:
-                traffic = json.load(open(tf)).get(f"b{B}") if args.model == "0.6b" else None
-            except Exception:
-                traffic = None
         out = {
             "metric": f"real-time factor (24 kHz audio sec / wall sec), {MODEL}",
             "value": round(frames * FRAME_SECONDS / dt, 3),
@@ -234,8 +431,7 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16 weights, fp32 activations/accumulate (codec decoder: fp16 hi/lo split operands, fp32 accumulate)", "data": "synthetic",
-            "config": {"workload": f"{MODEL}, batch={B}/GPU, 16-token prompt, "
-                                   + ("greedy top_k=1" if args.greedy else "sampled temp=0.8 top-k=50 top-p=0.95")
+            "config": {"workload": f"{MODEL}, batch={B}/GPU, 16-token prompt, {sampling_txt}"
                                    + f", max-tokens={F} (EOS suppressed), synthetic seeded weights",
                        "batch_per_gpu": B, "frames_per_utterance": F, "parallelism": f"dp{world} (independent utterances)"},
             "codec_frames_per_s": round(frames / dt, 2),
@@ -243,23 +439,50 @@ def main():
             "decode_ms_per_frame_step": round(step_ms, 4),
             "codec_decode_ms_per_frame": round(ctr["codec_ms"] / max(ctr["codec_frames"], 1), 5),
             "first_2s_audio_latency_ms": first_audio,
-            "roofline": {"bound": "hbm", "kernel": "decode step = one hipGraph replay per frame ("
-                                   + ("q3::k_gemv1 (QKV / o_proj / gate-up / down / heads), k_cp_attn_oproj x75, k_attn x28, k_sample x16" if B <= 4 else
-                                      "q3::k_gemm2 + k_finish + k_attn + k_attn_combine + k_sample") + ")",
-                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "algorithmic_bytes_per_launch": int(abytes), "launch_ms": round(step_ms, 4)},
+            "roofline": roofline_record(cfg, B, F, step_ms, args.model),
         }
+        if dist is not None:
+            out["multi_gpu"] = {"backend": "nccl (RCCL)", "world_size": world, "gathered_utterances": gathered["utterances"],
+                                "gathered_pcm_samples": gathered["pcm_samples"],
+                                "scaling_note": "weak scaling over independent utterances; efficiency is the driver's to compute"
+                                if world > 1 else "unmeasured: one rank rehearsing the RCCL path (Q3TTS_BENCH_FORCE_DIST=1)"}
         if stages is not None:
             out["stages"] = stages
-        if world == 1 and not args.no_cpu_baseline:
+        eng.close()
+        eng = None
+        if world == 1 and dist is None and B == 1 and args.model == "0.6b" and not args.no_b64 and not args.no_graph:
+            # the other half of BASELINE.json's metric ("0.6B @ b1/b64"): configs[2], 64 utterances in one batch x 256 frames, same process
             try:
-                out["cpu_baseline"] = cpu_baseline(eng, cfg, toks[0], sp_kwargs, args.cpu_frames)
+                B2, F2 = 64, 256
+                e2, toks2, sp2, dt2, fr2, smp2, ctr2, _ = run_workload(q3tts, cfg, local_rank, B2, F2, sp_kwargs, 2, 1, rank, False)
+                sm2 = ctr2["decode_ms"] / max(ctr2["decode_steps"], 1)
+                rec = {"config": {"workload": f"{MODEL}, batch={B2}/GPU, 16-token prompt, {sampling_txt}, max-tokens={F2} (EOS suppressed), "
+                                              "hipGraph decode loop, synthetic seeded weights", "batch_per_gpu": B2, "frames_per_utterance": F2},
+                       "value": round(fr2 * FRAME_SECONDS / dt2, 3), "unit": "x real-time (audio s / wall s)", "steps": 2, "warmup": 1,
+                       "ms_per_step": round(dt2 / 2 * 1e3, 3), "codec_frames_per_s": round(fr2 / dt2, 2),
+                       "decode_ms_per_frame_step": round(sm2, 4),
+                       "codec_decode_ms_per_frame": round(ctr2["codec_ms"] / max(ctr2["codec_frames"], 1), 5),
+                       "roofline": roofline_record(cfg, B2, F2, sm2, args.model)}
+                try:
+                    rec["stages"] = stage_report(e2, cfg, toks2, sp2, B2, F2, ctr2)
+                except Exception as ex:
+                    rec["stages"] = {"error": str(ex)}
+                e2.close()
+                out["b64"] = rec
+            except Exception as ex:
+                out["b64"] = {"error": str(ex)}
+        if world == 1 and dist is None and not args.no_cpu_baseline:
+            try:
+                e3 = q3tts.Engine(cfg, device=local_rank, max_batch=1, max_ctx=64)   # weights only: the oracle copies the same seeded tensors
+                e3.fill_synthetic(seed=0)
+                out["cpu_baseline"] = cpu_baseline(e3, cfg, toks[0], sp_kwargs, args.cpu_frames)
+                e3.close()
             except Exception as ex:  # the baseline is a reported extra, never the measurement
                 out["cpu_baseline"] = {"value": None, "unit": "x real-time (audio s / wall s)", "cores": os.cpu_count(), "kind": "port",
                                        "sample": f"failed: {ex}"}
         print(json.dumps(out), flush=True)
-    eng.close()
+    if eng is not None:
+        eng.close()
     if dist is not None:
         dist.destroy_process_group()
 

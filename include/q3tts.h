@@ -144,6 +144,10 @@ int q3tts_decode_steps(q3tts_engine* e, int n_steps);
 int q3tts_slot_status(q3tts_engine* e, int slot, int* n_frames, int* finished);
 /* codes[cap_frames][n_groups], int64 like the reference (tts_onnx.cpp:421-427) */
 int q3tts_slot_codes_host(q3tts_engine* e, int slot, int64_t* codes, int cap_frames);
+/* run_decode's outputs (tts_onnx.cpp:714-719) as the fused path holds them for the slot: logits[vocab] the slot's next code0 will be
+ * sampled from and last_hidden[hidden] the code predictor's first input row (either may be NULL).  For teacher-forced parity checks
+ * of the batched step; the data never leaves HBM in normal operation. */
+int q3tts_slot_logits_host(q3tts_engine* e, int slot, float* logits, float* last_hidden);
 /* vocoder over the slot's device-resident codes */
 int q3tts_slot_codec_decode_host(q3tts_engine* e, int slot, float* pcm, int64_t cap, int64_t* out_len);
 int q3tts_slot_release(q3tts_engine* e, int slot);

@@ -40,7 +40,7 @@ static void usage(const char* prog) {
     printf("      --tokens IDS      comma-separated text token ids (framed as IM_START ASSISTANT TTS_BOS ids TTS_EOS IM_END)\n");
     printf("  -o, --output PATH     output WAV file (default: output.wav)\n");
     printf("  --lang LANG           auto, en, zh, ja, ko (default: auto)\n");
-    printf("  --ref PATH            reference audio for voice clone (speaker encoder not built yet)\n");
+    printf("  --ref PATH            reference audio for voice clone (WAV; resampled to 24 kHz, ECAPA speaker encoder on the GPU)\n");
     printf("  --temp FLOAT          temperature (default: 0.8; 0 samples at T=1 like the reference, use --top-k 1 for greedy)\n");
     printf("  --top-k N             top-k (default: 50)\n  --top-p FLOAT         top-p (default: 0.95)\n");
     printf("  --max-tokens N        max codec frames (default: 2048)\n  --seed N              sampling seed (default: 0)\n");

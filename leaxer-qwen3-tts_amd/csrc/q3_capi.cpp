@@ -220,6 +220,9 @@ int q3tts_slot_status(q3tts_engine* h, int slot, int* n_frames, int* finished) {
 int q3tts_slot_codes_host(q3tts_engine* h, int slot, int64_t* codes, int cap_frames) {
     Q3_API_BEGIN(h) h->e->slot_codes(slot, codes, cap_frames); return 0; Q3_API_END(h)
 }
+int q3tts_slot_logits_host(q3tts_engine* h, int slot, float* logits, float* last_hidden) {
+    Q3_API_BEGIN(h) h->e->slot_logits(slot, logits, last_hidden); return 0; Q3_API_END(h)
+}
 int q3tts_slot_codec_decode_host(q3tts_engine* h, int slot, float* pcm, int64_t cap, int64_t* out_len) {
     Q3_API_BEGIN(h)
     const int64_t n = h->e->slot_codec_decode(slot, pcm, cap);
@@ -260,6 +263,7 @@ int q3tts_synthesize_schedule_host(q3tts_engine* h, int n_utt, const int64_t* id
     const int H = e.c.hidden, G = e.c.n_groups, B = e.B;
     if (n_utt <= 0) return 0;
     if (!ids || !offsets || !p) throw q3::Error("synthesize: null argument");
+    if (pcm_cap < 0) throw q3::Error("synthesize: negative pcm_cap");
     for (int b = 0; b < B; ++b) e.slot_release(b);
     const int row_frames = std::max(1, std::min(p->max_new_tokens, e.max_frames_cap));
     e.codec_async_prepare(row_frames, n_utt);
@@ -349,6 +353,9 @@ int q3tts_synthesize_schedule_host(q3tts_engine* h, int n_utt, const int64_t* id
     // groups of up to 32 utterances per set of launches (about 4.7 MB of workspace per frame: groups sized to ~8 GB), each group padded to its
     // own longest member.  Padding is exact: every layer is causal.  Single utterances, the exact-fp32 codec and configs whose decoder the
     // batched kernels do not cover go one utterance at a time over the side lanes.
+    // A failure in here (arena / pinned-buffer allocation, a launch error) must not leave lanes holding this job's pcm_out / pcm_len
+    // pointers: the next job's drain would write through them.  codec_async_abort() waits for the lanes and forgets their items.
+    try {
     std::vector<int> order((size_t)n_utt);
     for (int u = 0; u < n_utt; ++u) { order[(size_t)u] = u; if (pcm_len) pcm_len[u] = 0; }
     std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return got_frames[(size_t)x] > got_frames[(size_t)y]; });
@@ -360,7 +367,8 @@ int q3tts_synthesize_schedule_host(q3tts_engine* h, int n_utt, const int64_t* id
         const int F0 = got_frames[(size_t)order[(size_t)y0]];
         if (F0 <= 0) break;                                            // sorted: the rest of the job produced no frame
         int y1 = y0 + 1;
-        while (y1 < n_utt && (int64_t)(y1 - y0 + 1) * F0 <= (int64_t)1 << 16 && got_frames[(size_t)order[(size_t)y1]] * 2 >= F0) ++y1;
+        // a block is a batch dimension of the batched kernels (gridDim.y / .z <= 65535): at most 4096 sequences and 2^16 padded frames
+        while (y1 < n_utt && y1 - y0 < 4096 && (int64_t)(y1 - y0 + 1) * F0 <= (int64_t)1 << 16 && got_frames[(size_t)order[(size_t)y1]] * 2 >= F0) ++y1;
         const int nblk = y1 - y0;
         if (nblk >= 2 && batchable && F0 <= ((int64_t)1 << 16) / 2) {
             int rows = 0;
@@ -388,6 +396,11 @@ int q3tts_synthesize_schedule_host(q3tts_engine* h, int n_utt, const int64_t* id
         y0 = y1;
     }
     e.codec_async_drain();
+    } catch (...) {
+        e.codec_async_abort();
+        for (int u = 0; u < n_utt; ++u) if (pcm_len) pcm_len[u] = 0;
+        throw;
+    }
     return 0;
     Q3_API_END(h)
 }
@@ -437,6 +450,8 @@ int q3tts_extract_speaker_embedding_host(q3tts_engine* h, const char* wav_path, 
     int sr = 0;
     std::vector<float> a = q3::read_wav(wav_path, &sr);
     if (a.empty()) throw q3::Error(std::string("Failed to read audio: ") + wav_path);
+    // the header's 32-bit rate is untrusted: >= 2^31 reads as a negative int (a negative resampling ratio is undefined behaviour)
+    if (sr <= 0 || sr > 768000) throw q3::Error(std::string("Failed to read audio: ") + wav_path + " (sample rate " + std::to_string((unsigned)sr) + " out of range)");
     if (sr != 24000) a = q3::resample_linear(a, sr, 24000);
     int frames = 0;
     const std::vector<float> m = q3::log_mel(a, q3::MelSpec(), &frames);
@@ -526,6 +541,9 @@ int q3tts_load_weights_file(q3tts_engine* h, const char* path) {
     if (memcmp(&cfg, &h->e->c, sizeof cfg) != 0) throw q3::Error("weights file was written for a different model config");
     std::vector<float> f32;
     std::vector<uint16_t> b16;
+    // every registry tensor exactly once: storage is a bare hipMalloc, so a tensor the file does not carry would be synthesized from
+    // uninitialised HBM (the reference refuses to start when a model file is missing, tts_onnx.cpp:91-107)
+    std::vector<char> seen(h->e->tensors.size(), 0);
     for (uint32_t t = 0; t < n; ++t) {
         uint16_t nl = 0;
         rd(fl.f, &nl, 2);
@@ -537,6 +555,9 @@ int q3tts_load_weights_file(q3tts_engine* h, const char* path) {
         rd(fl.f, &numel, 8);
         // the header is untrusted: size the buffers from the registry, not from the file
         const q3::Tensor& want = h->e->T(name);
+        char& mark = seen[(size_t)h->e->tindex.at(name)];
+        if (mark) throw q3::Error("weights file: tensor '" + name + "' appears twice");
+        mark = 1;
         if ((uint64_t)want.numel != numel) throw q3::Error("weights file: tensor '" + name + "' has " + std::to_string(numel) + " elements, expected " + std::to_string(want.numel));
         f32.resize(numel);
         if (dtype == 0) rd(fl.f, f32.data(), numel * 4);
@@ -546,6 +567,13 @@ int q3tts_load_weights_file(q3tts_engine* h, const char* path) {
             for (uint64_t i = 0; i < numel; ++i) f32[i] = q3::bf16_to_f32(b16[i]);
         } else throw q3::Error("weights file: unknown dtype for " + name);
         h->e->set_tensor(name, f32.data(), (int64_t)numel);
+    }
+    {   // name every missing tensor at once (an importer with a wrong key prefix drops whole components)
+        std::string missing;
+        size_t n_missing = 0;
+        for (size_t i = 0; i < seen.size(); ++i)
+            if (!seen[i]) { if (n_missing++ < 24) missing += (missing.empty() ? "" : ", ") + h->e->tensors[i].name; }
+        if (n_missing) throw q3::Error("weights file: " + std::to_string(n_missing) + " of " + std::to_string(seen.size()) + " tensors missing: " + missing + (n_missing > 24 ? ", ..." : ""));
     }
     h->e->finalize();
     return 0;

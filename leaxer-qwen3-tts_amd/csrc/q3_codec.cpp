@@ -6,6 +6,7 @@
 // chunking.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <unordered_map>
 #include <vector>
@@ -51,6 +52,7 @@ struct CodecW {
     hipEvent_t fork = nullptr, win0 = nullptr, win1 = nullptr;
     bool window_open = false, win0_recorded = false;
     int rr = 0;
+    int submits = 0, fail_at_submit = 0;   // fault injection for the tests: the fail_at_submit-th submit of a job throws
 };
 
 void Engine::codec_free() {
@@ -448,9 +450,27 @@ const float* Engine::codec_pre_batch(const int32_t* codes_dev, int codes_stride_
 // decode was measured and dropped: the conv kernels own whole CUs and stream gigabytes through L2 / MALL, so every decode step of the
 // latency-bound chain got 12 % longer and the job 10 % slower than with the two phases back to back (profiles/r01_negative_results.txt).
 // ------------------------------------------------------------------------------------------------
+// Forget every queued vocoder result without delivering it: after a failure inside the vocoder phase the pending items still hold the
+// failed job's host pointers (pcm_out rows, pcm_len entries), which a later job's drain must never write through.
+void Engine::codec_async_abort() {
+    if (!codec) return;
+    CodecW& W = *codec;
+    for (int i = 0; i < W.nlane; ++i) {
+        if (i > 0 && W.lane_stream[i]) (void)hipStreamSynchronize(W.lane_stream[i]);
+        W.pend[i].items.clear();
+        W.pend[i].frames = 0;
+        W.pend[i].busy = false;
+    }
+    if (stream || null_stream) (void)hipStreamSynchronize(stream);
+    W.window_open = false; W.win0_recorded = false;
+    W.submits = 0;
+}
+
 void Engine::codec_async_prepare(int max_frames, int n_utt) {
     if (!codec) throw Error("codec decoder not finalized");
     CodecW& W = *codec;
+    codec_async_abort();   // a previous job that failed mid-way must not leak its pending items into this one
+    if (const char* fv = getenv("Q3TTS_TEST_FAIL_VOCODER_SUBMIT")) W.fail_at_submit = atoi(fv); else W.fail_at_submit = 0;   // test hook (tests/test_gpu_edges.py)
     int P = 1;
     while (P < max_frames) P <<= 1;
     if (W.rope_P < P) {   // grow the shared RoPE tables before any lane is in flight
@@ -505,6 +525,7 @@ void Engine::codec_async_submit_dev(const int32_t* codes_dev, int nf, float* use
     if (nf <= 0) return;   // the reference returns an empty vector when no frame was generated (tts_onnx.cpp:418)
     const int lane = W.nlane > 1 ? 1 + (W.rr++ % (W.nlane - 1)) : 0;
     codec_async_drain_lane(lane);
+    if (W.fail_at_submit > 0 && ++W.submits == W.fail_at_submit) throw Error("vocoder submit failed (injected by Q3TTS_TEST_FAIL_VOCODER_SUBMIT)");
     if (!W.window_open) {   // the lanes start behind everything the engine stream has queued (the stashed codes among it)
         if (!W.win0_recorded) { Q3_HIP_CHECK(hipEventRecord(W.win0, stream)); W.win0_recorded = true; }
         Q3_HIP_CHECK(hipEventRecord(W.fork, stream));
@@ -546,6 +567,7 @@ void Engine::codec_async_submit_group(const float* h_group, size_t h_ustride, in
     // lane owns a group-sized arena)
     const int lane = W.nlane > 1 ? 1 + (W.rr++ % std::min(W.nlane - 1, 2)) : 0;
     codec_async_drain_lane(lane);
+    if (W.fail_at_submit > 0 && ++W.submits == W.fail_at_submit) throw Error("vocoder submit failed (injected by Q3TTS_TEST_FAIL_VOCODER_SUBMIT)");
     if (!W.window_open) {
         if (!W.win0_recorded) { Q3_HIP_CHECK(hipEventRecord(W.win0, stream)); W.win0_recorded = true; }
         Q3_HIP_CHECK(hipEventRecord(W.fork, stream));

@@ -188,6 +188,8 @@ Engine::Engine(const q3tts_config& cfg, int device_, int max_batch, int max_ctx_
 
     if (c.spk_enc_dim > 0 && (c.spk_scale < 2 || c.spk_scale > 16 || c.spk_channels % c.spk_scale || c.spk_mel < 1 || c.spk_se < 1 || c.spk_att < 1))
         throw Error("speaker encoder dims out of range");
+    // the encoder's output is spliced into the prompt as ONE talker-width row (build_prompts copies `hidden` floats from it)
+    if (c.spk_enc_dim > 0 && c.spk_enc_dim != c.hidden) throw Error("speaker encoder output width must equal the talker width (spk_enc_dim == hidden)");
     {   // allocate the registry (q | k | v of a layer share one block so that their rows are contiguous)
         char* fused = nullptr; size_t fused_off = 0;
         const std::vector<TensorSpec> specs = tensor_specs(c);
@@ -944,6 +946,13 @@ void Engine::slot_codes(int slot, int64_t* codes, int cap_frames) {
     std::vector<int32_t> tmp((size_t)n * G);
     if (n > 0) Q3_HIP_CHECK(hipMemcpy(tmp.data(), codes_d + (size_t)slot * max_frames_cap * G, tmp.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
     for (size_t i = 0; i < tmp.size(); ++i) codes[i] = tmp[i];
+}
+
+void Engine::slot_logits(int slot, float* logits, float* last_hidden) {
+    if (slot < 0 || slot >= B) throw Error("slot out of range");
+    sync();
+    if (logits) Q3_HIP_CHECK(hipMemcpy(logits, logits_t + (size_t)slot * c.vocab, (size_t)c.vocab * sizeof(float), hipMemcpyDeviceToHost));
+    if (last_hidden) Q3_HIP_CHECK(hipMemcpy(last_hidden, x_cp + (size_t)slot * 2 * c.hidden, (size_t)c.hidden * sizeof(float), hipMemcpyDeviceToHost));
 }
 
 void Engine::slot_release(int slot) {

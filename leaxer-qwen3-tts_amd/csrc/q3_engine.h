@@ -104,6 +104,7 @@ public:
     int decode_steps(int n_steps);
     void slot_status(int slot, int* n_frames, int* finished);
     void slot_codes(int slot, int64_t* codes, int cap_frames);
+    void slot_logits(int slot, float* logits, float* last_hidden);
     int64_t slot_codec_decode(int slot, float* pcm, int64_t cap);
     void slot_release(int slot);
     void step_bytes(double* wbytes, double* kvbytes);
@@ -132,6 +133,7 @@ public:
     void codec_async_submit_dev(const int32_t* codes_dev, int nf, float* user_pcm, int64_t cap, int64_t* len_out, const float* h_in = nullptr, int h_stage = 1);
     void codec_async_drain_lane(int lane);
     void codec_async_drain();
+    void codec_async_abort();   // drop every pending vocoder result (error path: their host pointers belong to a failed job)
     void codec_lanes_join();
     void slots_state(int nb, std::vector<SlotState>& out);
     void codec_free();

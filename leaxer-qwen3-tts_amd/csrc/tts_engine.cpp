@@ -137,6 +137,10 @@ std::vector<float> TTSEngine::synthesize_clone(const std::string& text, const st
 std::vector<float> TTSEngine::synthesize_tokens_clone(const std::vector<int64_t>& token_ids, const std::vector<float>& speaker_embed,
                                                       Language lang, const SamplingParams& params) {
     if (!ready_) return {};
+    if (!speaker_embed.empty() && (int)speaker_embed.size() != cfg_hidden_) {   // the row is spliced into the prompt as one talker-width embedding
+        std::cerr << "[TTSEngine] Synthesis error: speaker embedding has " << speaker_embed.size() << " values, the model needs " << cfg_hidden_ << std::endl;
+        return {};
+    }
     q3tts_sampling sp{ params.temperature, params.top_p, params.top_k, params.repetition_penalty, params.max_new_tokens };
     const int32_t offs[2] = { 0, (int32_t)token_ids.size() };
     const int64_t cap = (int64_t)params.max_new_tokens * 1920 + 1920;

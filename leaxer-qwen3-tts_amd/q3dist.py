@@ -16,18 +16,22 @@ def shard_utterances(lengths, world, rank):
     return sorted(order[rank::world])
 
 
-def gather_codes(dist, codes_list, index_list, n_total, max_frames, n_groups, device=None):
-    """All-gather per-utterance code arrays.  codes_list[i] is [F_i, n_groups] for global utterance
-    index_list[i].  Returns a list of n_total arrays on every rank."""
+def gather_codes(dist, codes_list, index_list, n_total, max_frames, n_groups, device=None, pcm_lens=None):
+    """All-gather per-utterance code arrays (and, with pcm_lens, each utterance's PCM sample count: the PCM itself stays on the rank
+    that produced it).  codes_list[i] is [F_i, n_groups] for global utterance index_list[i].  Returns a list of n_total arrays on
+    every rank — plus the list of n_total sample counts when pcm_lens is given."""
     import torch
     world = dist.get_world_size()
     per = max(1, -(-n_total // world))
+    if len(codes_list) > per:
+        raise ValueError("gather_codes: a rank holds more utterances than ceil(n_total / world)")
     buf = np.full((per, max_frames, n_groups), -1, np.int32)
-    meta = np.full((per, 2), -1, np.int32)  # (global index, n_frames)
+    meta = np.full((per, 4), -1, np.int32)  # (global index, n_frames, pcm samples low 31 bits, pcm samples high bits)
     for slot, (c, gi) in enumerate(zip(codes_list, index_list)):
         f = min(len(c), max_frames)
         buf[slot, :f] = c[:f]
-        meta[slot] = (gi, f)
+        n = int(pcm_lens[slot]) if pcm_lens is not None else 0
+        meta[slot] = (gi, f, n & 0x7FFFFFFF, n >> 31)
     tb, tm = torch.from_numpy(buf), torch.from_numpy(meta)
     if device is not None:
         tb, tm = tb.to(device), tm.to(device)
@@ -36,10 +40,12 @@ def gather_codes(dist, codes_list, index_list, n_total, max_frames, n_groups, de
     dist.all_gather(ob, tb)
     dist.all_gather(om, tm)
     out = [None] * n_total
+    lens = [0] * n_total
     for r in range(world):
         b, m = ob[r].cpu().numpy(), om[r].cpu().numpy()
         for slot in range(per):
             gi, f = int(m[slot, 0]), int(m[slot, 1])
             if gi >= 0:
                 out[gi] = b[slot, :f].astype(np.int64)
-    return out
+                lens[gi] = int(m[slot, 2]) | (int(m[slot, 3]) << 31)
+    return (out, lens) if pcm_lens is not None else out

@@ -85,7 +85,7 @@ EXPORTS = [
     "q3tts_tokenizer_ready", "q3tts_tokenize",
     "q3tts_synthesize_clone_batch_host", "q3tts_synthesize_schedule_host", "q3tts_read_wav_host", "q3tts_resample_host", "q3tts_mel_host",
     "q3tts_has_speaker_encoder", "q3tts_speaker_encoder_host", "q3tts_extract_speaker_embedding_host",
-    "q3tts_codec_decode_chunked_host", "q3tts_slot_codec_decode_range_host",
+    "q3tts_codec_decode_chunked_host", "q3tts_slot_codec_decode_range_host", "q3tts_slot_logits_host",
 ]
 
 _lib = None
@@ -131,6 +131,7 @@ def lib():
     L.q3tts_slot_codes_host.argtypes = [vp, i32, vp, i32]
     L.q3tts_slot_codec_decode_host.argtypes = [vp, i32, vp, i64, C.POINTER(i64)]
     L.q3tts_slot_release.argtypes = [vp, i32]
+    L.q3tts_slot_logits_host.argtypes = [vp, i32, vp, vp]
     L.q3tts_synthesize_batch_host.argtypes = [vp, i32, vp, vp, i32, C.POINTER(Sampling), C.c_uint64, i32,
                                               vp, i64, vp, vp, vp]
     L.q3tts_last_decode_ms.argtypes = [vp, C.POINTER(f32), C.POINTER(i32)]
@@ -340,6 +341,8 @@ class Engine:
         trailing = np.zeros((cap_rows, self.cfg.hidden), np.float32)
         S, nt = C.c_int(0), C.c_int(0)
         sp = np.ascontiguousarray(speaker, dtype=np.float32) if speaker is not None else None
+        if sp is not None and sp.size != self.cfg.hidden:
+            raise ValueError("speaker embedding has %d values, the model needs %d" % (sp.size, self.cfg.hidden))
         self._ck(self.L.q3tts_build_prompt_host(self.h, _p(ids), ids.size, lang, _p(sp) if sp is not None else None,
                                                 _p(prompt), C.byref(S), _p(trailing), cap_rows, C.byref(nt)))
         return prompt[: S.value].copy(), trailing[: nt.value].copy()
@@ -364,6 +367,13 @@ class Engine:
         codes = np.zeros((max(nf, 1), self.cfg.n_groups), np.int64)
         self._ck(self.L.q3tts_slot_codes_host(self.h, slot, _p(codes), nf))
         return codes[:nf]
+
+    def slot_logits(self, slot):
+        """(logits[vocab], last_hidden[hidden]) the fused path holds for the slot's next frame (run_decode's outputs)"""
+        lg = np.empty(self.cfg.vocab, np.float32)
+        lh = np.empty(self.cfg.hidden, np.float32)
+        self._ck(self.L.q3tts_slot_logits_host(self.h, slot, _p(lg), _p(lh)))
+        return lg, lh
 
     def slot_codec_decode(self, slot):
         nf, _ = self.slot_status(slot)
@@ -422,7 +432,12 @@ class Engine:
         codes = np.zeros((n, sp.max_new_tokens, self.cfg.n_groups), np.int64) if want_codes else None
         spk_keep, spk_ptrs = [], None
         if speakers is not None:
+            if len(speakers) != n:
+                raise ValueError("speakers: one entry (embedding or None) per utterance")
             spk_keep = [None if s_ is None else np.ascontiguousarray(s_, np.float32) for s_ in speakers]
+            for a in spk_keep:   # the library copies `hidden` floats from each row (the speaker row of the prompt is one talker-width embedding)
+                if a is not None and a.size != self.cfg.hidden:
+                    raise ValueError("speaker embedding has %d values, the model needs %d" % (a.size, self.cfg.hidden))
             spk_ptrs = C.cast((C.c_void_p * n)(*[None if a is None else a.ctypes.data for a in spk_keep]), C.c_void_p)
         caps = None if max_new_per_utt is None else np.ascontiguousarray(max_new_per_utt, np.int32)
         if caps is not None and caps.shape != (n,):

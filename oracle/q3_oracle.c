@@ -788,8 +788,18 @@ int q3o_trailing(q3o_model* m, float* out, int cap_rows, float* pad) {
 /* generation loop — tts_onnx.cpp:782-872                                                     */
 /* ------------------------------------------------------------------------------------------ */
 
-int q3o_generate(q3o_model* m, const float* prompt, int S, const q3o_sampling* sp, uint64_t seed, uint32_t stream,
-                 int cp_cached, int ignore_eos, int64_t* codes) {
+/* top-1 minus top-2 of a logits row (finite entries only): how far the greedy decision is from flipping */
+static float top2_margin(const float* x, int n) {
+    float a = -INFINITY, b = -INFINITY;
+    for (int i = 0; i < n; ++i) { float v = x[i]; if (v > a) { b = a; a = v; } else if (v > b) b = v; }
+    return a - b;
+}
+
+/* margins (optional, [max_new_tokens][2]): per generated frame, the top-2 logit margin of the code0 decision (after suppression, before
+ * temperature) and the smallest top-2 margin over the frame's sub-code decisions — the "how close did parity come to flipping"
+ * diagnostic of SURVEY.md section 7 (hard parts). */
+static int generate_impl(q3o_model* m, const float* prompt, int S, const q3o_sampling* sp, uint64_t seed, uint32_t stream,
+                         int cp_cached, int ignore_eos, int64_t* codes, float* margins) {
     const q3o_config* c = &m->c;
     int H = c->hidden, V = c->vocab, G = c->n_groups, SV = c->sub_vocab;
     float* logits_all = zalloc((size_t)S * V);
@@ -807,6 +817,7 @@ int q3o_generate(q3o_model* m, const float* prompt, int S, const q3o_sampling* s
             if (i != c->codec_eos || ignore_eos) last[i] = -INFINITY;
         int64_t code0 = q3o_sample(last, V, sp, q3o_rng_uniform(seed, stream, (uint32_t)step, 0)); /* :810 */
         if (code0 == c->codec_eos) break;                                                          /* :812 */
+        if (margins) { margins[2 * F] = top2_margin(last, V); margins[2 * F + 1] = INFINITY; }
         /* predict_subcodes (:851-872): seq = [last_hidden, codec_embed(code0), sub embeds...] */
         int64_t* frame = codes + (size_t)F * G;
         frame[0] = code0;
@@ -818,6 +829,7 @@ int q3o_generate(q3o_model* m, const float* prompt, int S, const q3o_sampling* s
             else cp_cached_step(m, seq + (size_t)(j + 1) * H, j + 1, j + 2, j, sub_logits);
             int64_t sc = q3o_sample(sub_logits, SV, sp, q3o_rng_uniform(seed, stream, (uint32_t)step, (uint32_t)(j + 1))); /* :864 */
             frame[j + 1] = sc;
+            if (margins) { float mg = top2_margin(sub_logits, SV); if (mg < margins[2 * F + 1]) margins[2 * F + 1] = mg; }
             q3o_cp_embed(m, sc, j, seq + (size_t)(j + 2) * H);                                     /* :867-868 */
         }
         ++F;
@@ -834,6 +846,15 @@ int q3o_generate(q3o_model* m, const float* prompt, int S, const q3o_sampling* s
     }
     free(logits_all); free(last); free(sub_logits); free(seq); free(x); free(e);
     return F;
+}
+
+int q3o_generate(q3o_model* m, const float* prompt, int S, const q3o_sampling* sp, uint64_t seed, uint32_t stream,
+                 int cp_cached, int ignore_eos, int64_t* codes) {
+    return generate_impl(m, prompt, S, sp, seed, stream, cp_cached, ignore_eos, codes, NULL);
+}
+int q3o_generate_margins(q3o_model* m, const float* prompt, int S, const q3o_sampling* sp, uint64_t seed, uint32_t stream,
+                         int cp_cached, int ignore_eos, int64_t* codes, float* margins) {
+    return generate_impl(m, prompt, S, sp, seed, stream, cp_cached, ignore_eos, codes, margins);
 }
 
 /* ------------------------------------------------------------------------------------------ */

@@ -114,6 +114,9 @@ int q3o_trailing(q3o_model* m, float* out /*[trailing_len][H]*/, int cap_rows, f
  * ignore_eos: keep generating past CODEC_EOS (benchmark mode, never samples EOS as a frame) */
 int q3o_generate(q3o_model* m, const float* prompt, int S, const q3o_sampling* p, uint64_t seed, uint32_t stream,
                  int cp_cached, int ignore_eos, int64_t* codes /*[max_new][G]*/);
+/* the same, also reporting per frame the top-2 logit margin of the code0 decision and the smallest margin over its sub-codes */
+int q3o_generate_margins(q3o_model* m, const float* prompt, int S, const q3o_sampling* p, uint64_t seed, uint32_t stream,
+                         int cp_cached, int ignore_eos, int64_t* codes, float* margins /*[max_new][2]*/);
 int64_t q3o_synthesize_tokens(q3o_model* m, const int64_t* ids, int n_ids, int lang, const q3o_sampling* p,
                               uint64_t seed, uint32_t stream, float* pcm, int64_t cap, int64_t* codes, int* n_frames);
 

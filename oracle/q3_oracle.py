@@ -331,6 +331,8 @@ def lib():
         L.q3o_trailing.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.q3o_generate.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(Sampling), C.c_uint64, C.c_uint32,
                                    C.c_int, C.c_int, C.c_void_p]
+        L.q3o_generate_margins.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(Sampling), C.c_uint64, C.c_uint32,
+                                           C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.q3o_synthesize_tokens.restype = C.c_int64
         L.q3o_synthesize_tokens.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(Sampling), C.c_uint64,
                                             C.c_uint32, C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(C.c_int)]
@@ -469,6 +471,15 @@ class Oracle:
         F = self._check(self.L.q3o_generate(self.h, _p(p), p.shape[0], C.byref(sp), seed, stream,
                                             int(cp_cached), int(ignore_eos), _p(codes)))
         return codes[:F].copy()
+
+    def generate_margins(self, prompt, sp, seed=0, stream=0, cp_cached=True, ignore_eos=False):
+        """generate() plus margins [F][2]: top-2 logit margin of each frame's code0 decision, smallest margin over its sub-codes"""
+        p = np.ascontiguousarray(prompt, dtype=np.float32)
+        codes = np.zeros((sp.max_new_tokens, self.cfg.n_groups), np.int64)
+        mg = np.zeros((sp.max_new_tokens, 2), np.float32)
+        F = self._check(self.L.q3o_generate_margins(self.h, _p(p), p.shape[0], C.byref(sp), seed, stream,
+                                                    int(cp_cached), int(ignore_eos), _p(codes), _p(mg)))
+        return codes[:F].copy(), mg[:F].copy()
 
 
 def rng_uniform(seed, stream, frame, group):

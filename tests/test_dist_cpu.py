@@ -35,9 +35,11 @@ def _worker(rank, world, port, q):
     mine = q3dist.shard_utterances([len(t) for t in texts], world, rank)
     sp = qo.Sampling(temperature=1.0, top_p=1.0, top_k=1, max_new_tokens=6)
     codes = [orc.generate(orc.build_prompt(frame_tokens(texts[i]), 0), sp, seed=5, stream=i, ignore_eos=True) for i in mine]
-    allc = q3dist.gather_codes(dist, codes, mine, len(texts), 6, cfg.n_groups)
+    allc, alln = q3dist.gather_codes(dist, codes, mine, len(texts), 6, cfg.n_groups, pcm_lens=[orc.vocoder_len(len(c)) for c in codes])
     ref = [orc.generate(orc.build_prompt(frame_tokens(t), 0), sp, seed=5, stream=i, ignore_eos=True) for i, t in enumerate(texts)]
     ok = all(a is not None and np.array_equal(a, b) for a, b in zip(allc, ref))
+    ok = ok and alln == [orc.vocoder_len(len(r)) for r in ref]          # configs[3]'s gather carries every utterance's PCM length too
+    ok = ok and all(np.array_equal(a, b) for a, b in zip(q3dist.gather_codes(dist, codes, mine, len(texts), 6, cfg.n_groups), ref))
     q.put((rank, mine, ok))
     dist.barrier()
     dist.destroy_process_group()
@@ -69,3 +71,23 @@ def test_two_rank_gloo_gather():
     seen = sorted(i for _, mine, _ in res for i in mine)
     assert seen == [0, 1, 2, 3, 4]
     assert all(ok for _, _, ok in res)
+
+
+def test_bench_gpus2_self_launches_two_ranks():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset (the way the driver calls it) must start two ranks itself — child processes
+    spawned before anything touches a GPU — rendezvous on 127.0.0.1 and run the gather; --dry-launch keeps it to that plumbing (gloo, no
+    GPU work).  Rank 0's single JSON line comes through the parent, a failing rank fails the parent."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-launch", "--batch", "3"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["dry_launch"] and j["n_gpus"] == 2 and j["ranks_ok"] and j["gathered_utterances"] == 6
+    # a rank count that does not match --gpus is refused (exit code 2), not silently run as one rank
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-launch"], env=env2, capture_output=True, text=True, timeout=120)
+    assert r2.returncode == 2 and "WORLD_SIZE=1" in r2.stderr

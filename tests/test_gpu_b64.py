@@ -1,0 +1,85 @@
+"""BASELINE.json configs[2] at its own dims: Qwen3-TTS-0.6B, 64 utterances decoding in one batch (the 17..128-row bf16-MFMA GEMM
+path: k_gemm2 + its finish kernels / prologues, batched attention, 64-row sampler grids), against the CPU oracle.
+
+Reference semantics per utterance: generate_codes / predict_subcodes, /root/reference/src/tts_onnx.cpp:782-872 (the reference runs them
+one utterance at a time; batching is this build's, so every utterance of the batch must equal its own single-utterance oracle run)."""
+import numpy as np
+import pytest
+
+import q3_oracle as qo
+from util import frame_tokens, to_ocfg, to_osampling
+
+pytestmark = pytest.mark.gpu
+
+CHECK = (0, 16, 17, 31, 63)     # oracle cost: a spread of utterances, both sides of the 16/17-row kernel switch
+
+
+@pytest.fixture(scope="module")
+def wide():
+    import q3tts
+    cfg = q3tts.default_config("0.6b")
+    eng = q3tts.Engine(cfg, device=0, max_batch=64, max_ctx=64)
+    eng.fill_synthetic(seed=0)
+    orc = qo.Oracle(to_ocfg(cfg), max_ctx=48)
+    for name, shape in eng.tensor_infos():
+        if not name.startswith(("cd.", "spk.")):
+            orc.set_tensor(name, eng.get_tensor(name, shape))
+    rng = np.random.default_rng(64)
+    toks = [frame_tokens(rng.integers(0, 151643, int(n))) for n in rng.integers(3, 20, 64)]
+    yield eng, orc, toks
+    eng.close()
+    orc.close()
+
+
+@pytest.mark.parametrize("nb", [24, 64])
+@pytest.mark.parametrize("sampled", [False, True])
+def test_batched_generation_full_size(wide, nb, sampled):
+    """nb utterances x 8 frames at 0.6B dims through q3tts_synthesize_schedule_host (batched prefill of nb x 8 prompt rows, then the
+    hipGraph step at nb rows; predictor pass 0 runs 2 nb rows): codec ids bit-exact vs the oracle for a spread of utterances."""
+    import q3tts
+    eng, orc, toks = wide
+    kw = dict(temperature=0.8, top_p=0.95, top_k=50) if sampled else dict(temperature=1.0, top_p=1.0, top_k=1)
+    sp = q3tts.Sampling(max_new_tokens=8, **kw)
+    pcm, codes, nfr = eng.synthesize_batch(toks[:nb], sp, lang=0, seed=77, ignore_eos=True)
+    assert all(int(n) == 8 for n in nfr)
+    bad = []
+    for u in [u for u in CHECK if u < nb] + [nb - 1]:
+        ref = orc.generate(orc.build_prompt(toks[u], 0), to_osampling(sp), seed=77, stream=u, cp_cached=True, ignore_eos=True)
+        if not np.array_equal(codes[u], ref):
+            bad.append((u, np.argwhere(codes[u] != ref)[:3].tolist()))
+        assert np.isfinite(pcm[u]).all() and len(pcm[u]) == eng.codec_decode_len(8)
+    assert not bad, bad
+    # the batch is deterministic and every utterance independent of its neighbours: the first 24 of a 64-batch == the 24-batch
+    if nb == 24:
+        _, codes64, _ = eng.synthesize_batch(toks, sp, lang=0, seed=77, ignore_eos=True)
+        for u in range(24):
+            assert np.array_equal(codes64[u], codes[u]), u
+
+
+def test_teacher_forced_logits_64_rows_full_size(wide):
+    """One 64-row decode step, teacher-forced: after the scheduler's batched prefill (64 x 8 prompt rows in 128-row GEMM blocks) and one
+    hipGraph step (64-row talker pass, 128- and 64-row predictor passes: every k_gemm2 / finish variant of the layer), the talker logits
+    and last_hidden the fused path holds for frame 1 stay within 2e-4 of the oracle fed with the same frame-0 codes."""
+    import q3tts
+    eng, orc, toks = wide
+    sp = q3tts.Sampling(temperature=0.8, top_p=0.95, top_k=50, max_new_tokens=1)
+    G = eng.cfg.n_groups
+    _, codes, nfr = eng.synthesize_batch(toks, sp, seed=5, ignore_eos=True)      # utterance u runs in slot u
+    assert all(int(n) == 1 for n in nfr)
+    worst = 0.0
+    for u in CHECK:
+        po = orc.build_prompt(toks[u], 0)
+        ref = orc.generate(po, to_osampling(sp), seed=5, stream=u, cp_cached=True, ignore_eos=True)
+        assert np.array_equal(codes[u], ref), u
+        # teacher forcing: frame 0's embedding sum (tts_onnx.cpp:824-842) into the oracle's run_decode
+        tro, _ = orc.trailing()
+        orc.prefill(po)
+        x = orc.codec_embed([int(ref[0, 0])])[0].copy()
+        for j in range(G - 1):
+            x = x + orc.cp_embed(int(ref[0, j + 1]), j)
+        x = x + tro[0]
+        lo, ho = orc.decode(x)
+        lg, lh = eng.slot_logits(u)
+        worst = max(worst, float(np.abs(lg - lo).max()), float(np.abs(lh - ho).max()))
+    print("teacher-forced 64-row step: max |logit / hidden error| %.3g" % worst)
+    assert worst < 2e-4, worst

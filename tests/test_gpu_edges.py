@@ -115,6 +115,61 @@ def test_scheduler_error_leaves_the_engine_usable():
     orc.close()
 
 
+@pytest.mark.parametrize("fail_at,caps", [(2, None), (1, (9, 9, 8, 8, 3)), (4, (9, 2, 8, 1, 3))])
+def test_vocoder_phase_error_leaves_the_engine_usable(fail_at, caps):
+    """A failure INSIDE the vocoder phase (here injected at the fail_at-th lane submit; in the field an arena or pinned-buffer allocation
+    failing) used to leave lanes busy with the failed job's pcm_out / pcm_len pointers: the next job's drain then wrote through freed
+    host memory.  Now the job fails as a whole with the reason, nothing is delivered, and the next job on the same handle matches the
+    oracle.  (This config's decoder is too narrow for the batched kernels: one utterance per lane.  The batched-group path is covered at
+    0.6B dims by tests/test_gpu_full.py::test_vocoder_group_failure_leaves_the_engine_usable.)"""
+    import gc
+    import os
+    import q3tts
+    eng, orc, _ = tiny_pair(seed=33, max_batch=3, max_ctx=64)
+    sp = q3tts.Sampling(temperature=0.8, top_p=0.95, top_k=50, max_new_tokens=9)
+    rng = np.random.default_rng(41)
+    toks = [frame_tokens(rng.integers(0, 151643, int(n))) for n in (3, 5, 2, 7, 4)]
+    mx = None if caps is None else np.array(caps, np.int32)
+    os.environ["Q3TTS_TEST_FAIL_VOCODER_SUBMIT"] = str(fail_at)
+    try:
+        with pytest.raises(RuntimeError, match="injected"):
+            eng.synthesize_batch(toks, sp, seed=8, ignore_eos=True, max_new_per_utt=mx)
+    finally:
+        del os.environ["Q3TTS_TEST_FAIL_VOCODER_SUBMIT"]
+    gc.collect()                      # the failed job's PCM buffers are gone: a stale pending item would now be a use-after-free
+    junk = [np.full(200000, 7.0, np.float32) for _ in range(8)]
+    pcm, codes, nfr = eng.synthesize_batch(toks, sp, seed=8, ignore_eos=True, max_new_per_utt=mx)
+    assert all(np.all(j == 7.0) for j in junk)
+    for u, t in enumerate(toks):
+        ref = orc.generate(orc.build_prompt(t, 0), to_osampling(sp), seed=8, stream=u, cp_cached=True, ignore_eos=True)
+        n = 9 if caps is None else caps[u]
+        assert nfr[u] == n and np.array_equal(codes[u], ref[:n]), u
+        ref_pcm = orc.vocoder(ref[:n])
+        assert pcm[u].shape == ref_pcm.shape and float(np.sqrt(np.mean((pcm[u] - ref_pcm) ** 2))) < 1e-4, u
+    eng.close()
+    orc.close()
+
+
+def test_speaker_embedding_length_is_checked():
+    """build_prompts copies `hidden` floats from a speaker row: a shorter caller-supplied vector must be refused, not read out of bounds."""
+    import q3tts
+    eng, orc, _ = tiny_pair(seed=35, max_batch=1, max_ctx=64)
+    ids = frame_tokens([5, 6, 7])
+    sp = q3tts.Sampling(max_new_tokens=2)
+    short = np.zeros(eng.cfg.hidden - 8, np.float32)
+    with pytest.raises(ValueError, match="speaker embedding"):
+        eng.synthesize_batch([ids], sp, speakers=[short])
+    with pytest.raises(ValueError, match="speaker embedding"):
+        eng.build_prompt(ids, 0, speaker=short)
+    with pytest.raises(ValueError, match="per utterance"):
+        eng.synthesize_batch([ids, ids], sp, speakers=[None])
+    bad = q3tts.Config.from_dict(dict(eng.cfg.to_dict(), spk_enc_dim=eng.cfg.hidden // 2))
+    with pytest.raises(RuntimeError, match="spk_enc_dim"):
+        q3tts.Engine(bad, device=0, max_batch=1, max_ctx=32)
+    eng.close()
+    orc.close()
+
+
 def test_corrupt_weight_files_are_rejected(tmp_path):
     """The weight file is user input: a wrong magic, a truncated file, an absurd element count or an unknown tensor name end in an error
     message, never in a huge allocation or a partially loaded engine being used."""
@@ -135,12 +190,33 @@ def test_corrupt_weight_files_are_rejected(tmp_path):
         "name": raw[:first + 2] + b"Z" * nl + raw[first + 2 + nl:],
         "cfg": raw[:8] + struct.pack("<I", 4096) + raw[12:],
     }
+    # record boundaries: u16 name length, name, u8 dtype, u64 numel, payload (2 or 4 bytes per element)
+    recs, off = [], first
+    while off < len(raw):
+        n_l = struct.unpack("<H", raw[off:off + 2])[0]
+        dt = raw[off + 2 + n_l]
+        ne = struct.unpack("<Q", raw[off + 3 + n_l:off + 11 + n_l])[0]
+        end = off + 11 + n_l + ne * (2 if dt == 1 else 4)
+        recs.append((off, end))
+        off = end
+    n_off = first - 4
+    n_rec = struct.unpack("<I", raw[n_off:n_off + 4])[0]
+    assert n_rec == len(recs) and recs[-1][1] == len(raw)
+    # a shorter tensor list (count patched, records dropped) and a duplicated record in place of its successor both used to load
+    # "successfully" and leave tensors as uninitialised HBM
+    cases["short_list"] = raw[:n_off] + struct.pack("<I", n_rec - 3) + raw[first:recs[-4][1]]
+    cases["duplicate"] = raw[:recs[1][0]] + raw[recs[0][0]:recs[0][1]] + raw[recs[1][1]:]
+    cases["one_missing"] = raw[:n_off] + struct.pack("<I", n_rec - 1) + raw[first:recs[4][0]] + raw[recs[4][1]:]
     for tag, blob in cases.items():
         p = tmp_path / f"{tag}.q3w"
         p.write_bytes(blob)
         e2 = q3tts.Engine(eng.cfg, device=0, max_batch=1, max_ctx=64)
-        with pytest.raises(RuntimeError):
+        with pytest.raises(RuntimeError) as ei:
             e2.load_weights(str(p))
+        if tag in ("short_list", "one_missing"):
+            assert "missing" in str(ei.value), (tag, str(ei.value))
+        if tag == "duplicate":
+            assert "twice" in str(ei.value), str(ei.value)
         e2.close()
     e3 = q3tts.Engine(eng.cfg, device=0, max_batch=1, max_ctx=64)
     e3.load_weights(str(good))

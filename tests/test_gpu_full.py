@@ -17,7 +17,7 @@ def full():
     cfg = q3tts.default_config("0.6b")
     eng = q3tts.Engine(cfg, device=0, max_batch=2, max_ctx=512)
     eng.fill_synthetic(seed=0)
-    orc = qo.Oracle(to_ocfg(cfg), max_ctx=64)
+    orc = qo.Oracle(to_ocfg(cfg), max_ctx=192)
     for name, shape in eng.tensor_infos():
         orc.set_tensor(name, eng.get_tensor(name, shape))
     yield eng, orc
@@ -68,20 +68,29 @@ def test_greedy_generation_full_size(full):
 
 
 @pytest.mark.parametrize("sampled", [False, True])
-def test_forty_frames_full_size(full, sampled):
-    """0.6B dims, 40 frames = 640 codec decisions on one utterance (configs[1] sampling when `sampled`): ids bit-exact vs the oracle,
-    through the context growing across the first split boundary of the predictor-fused step."""
+def test_free_running_160_frames_full_size(full, sampled):
+    """0.6B dims, 160 FREE-RUNNING frames = 2560 codec decisions on one utterance (configs[1] sampling when `sampled`, configs[0] greedy
+    otherwise): ids bit-exact vs the oracle (KV-cached predictor), with the talker context growing from 8 to 168 tokens — across the
+    first 128-token attention split of the fused step.  Reports what SURVEY.md section 7 asks for: the first divergence index (none
+    expected) and the smallest top-2 logit margins the run came across (how close parity came to flipping).
+    Reference loop: /root/reference/src/tts_onnx.cpp:782-872, sampler :878-950."""
     import q3tts
     eng, orc = full
+    F = 160
     ids = frame_tokens(np.random.default_rng(4).integers(0, 151643, 16))
     kw = dict(temperature=0.8, top_p=0.95, top_k=50) if sampled else dict(temperature=1.0, top_p=1.0, top_k=1)
-    sp = q3tts.Sampling(max_new_tokens=40, **kw)
+    sp = q3tts.Sampling(max_new_tokens=F, **kw)
     p, t = eng.build_prompt(ids, 0)
     codes = eng.generate(p, t, sp, seed=5, stream_id=2, ignore_eos=True)
-    ref = orc.generate(orc.build_prompt(ids, 0), to_osampling(sp), seed=5, stream=2, cp_cached=True, ignore_eos=True)
-    assert codes.shape == ref.shape == (40, 16)
+    ref, mg = orc.generate_margins(orc.build_prompt(ids, 0), to_osampling(sp), seed=5, stream=2, cp_cached=True, ignore_eos=True)
+    assert codes.shape == ref.shape == (F, 16)
     bad = np.argwhere(codes != ref)
-    assert bad.size == 0, bad[:4]
+    first = "none" if bad.size == 0 else "frame %d group %d" % (bad[0][0], bad[0][1])
+    print("free-running %s, %d frames: first divergence %s; min top-2 margin code0 %.3g (frame %d), sub-codes %.3g (frame %d); "
+          "frames past the 128-token split: %d"
+          % ("sampled" if sampled else "greedy", F, first, float(mg[:, 0].min()), int(mg[:, 0].argmin()), float(mg[:, 1].min()),
+             int(mg[:, 1].argmin()), F - (128 - 8)))
+    assert bad.size == 0, (first, bad[:4].tolist())
 
 
 def test_fused_predictor_attention_matches_separate_launches(full):
@@ -233,5 +242,28 @@ def test_vocoder_blocks_of_mixed_lengths_full_size(full):
     pcm, codes, nfr = eng.synthesize_batch(toks[:2] + toks[2:], sp, lang=0, seed=6, ignore_eos=True, max_new_per_utt=caps)
     assert np.array_equal(nfr, caps)
     for u in range(6):
+        single = eng.codec_decode(codes[u])
+        assert pcm[u].shape == single.shape and float(np.sqrt(np.mean((pcm[u] - single) ** 2))) < 1e-5, u
+
+
+def test_vocoder_group_failure_leaves_the_engine_usable(full):
+    """0.6B dims: utterances of similar length are vocoded as one block (batched pre-transformer + grouped conv decoder).  A failure injected
+    at the block's first group submit fails the job; the same job run again on the same handle delivers every PCM (== single decodes)."""
+    import os
+    import q3tts
+    eng, _ = full
+    sp = q3tts.Sampling(temperature=0.8, top_p=0.95, top_k=50, max_new_tokens=8)
+    rng = np.random.default_rng(31)
+    toks = [frame_tokens(rng.integers(0, 151643, int(n))) for n in (4, 6, 5)]
+    caps = np.array([8, 7, 8], np.int32)
+    os.environ["Q3TTS_TEST_FAIL_VOCODER_SUBMIT"] = "1"
+    try:
+        with pytest.raises(RuntimeError, match="injected"):
+            eng.synthesize_batch(toks, sp, seed=9, ignore_eos=True, max_new_per_utt=caps)
+    finally:
+        del os.environ["Q3TTS_TEST_FAIL_VOCODER_SUBMIT"]
+    pcm, codes, nfr = eng.synthesize_batch(toks, sp, seed=9, ignore_eos=True, max_new_per_utt=caps)
+    assert np.array_equal(nfr, caps)
+    for u in range(3):
         single = eng.codec_decode(codes[u])
         assert pcm[u].shape == single.shape and float(np.sqrt(np.mean((pcm[u] - single) ** 2))) < 1e-5, u

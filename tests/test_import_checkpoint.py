@@ -114,3 +114,59 @@ def test_importer_does_not_touch_the_oracle(tmp_path):
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, cwd=str(tmp_path))
     assert r.returncode == 0, r.stderr
     assert int(r.stdout.strip()) == 710
+
+
+def test_list_explains_unmapped_ambiguous_and_duplicate_keys(tmp_path):
+    """--list must make a wrong prefix visible: a component stored under another prefix is unmapped WITH the --prefix that would claim
+    it, a key no rule knows says so, two keys landing on one registry tensor are flagged, and the registry tensors left without a
+    source are counted per component.  None of this is verified against a real Qwen3-TTS checkpoint (none in the image)."""
+    import subprocess
+    from tools.import_safetensors import explain_names, write_safetensors
+    keys = json.load(open(os.path.join(GOLD, "hf_state_dict_keys.json")))
+    names = ["talker." + k for k in keys["talker"].values()]
+    names += ["mtp." + k for k in keys["predictor"].values()]                      # predictor under an unexpected prefix
+    names += ["talker.model.rotary_emb.inv_freq", "talker.lm_head.weight", "talker.codec_head.weight"]
+    ex = explain_names(names)
+    assert ex["talker.model.norm.weight"] == ("talker.norm", "") or ex["talker.model.norm.weight"][0] == "talker.norm"
+    d, note = ex["mtp.model.layers.0.mlp.up_proj.weight"]
+    assert d is None and "--prefix predictor=mtp." in note and "cp.layers.0.up_proj" in note
+    d, note = ex["talker.model.rotary_emb.inv_freq"]
+    assert d is None and "no rule" in note and "talker prefix" in note
+    assert ex["talker.lm_head.weight"][0] == ex["talker.codec_head.weight"][0] == "talker.codec_head"
+    assert "DUPLICATE" in ex["talker.lm_head.weight"][1] and "DUPLICATE" in ex["talker.codec_head.weight"][1]
+    # with the right prefix everything maps
+    ex2 = explain_names(names, {"predictor": "mtp."})
+    assert ex2["mtp.model.layers.0.mlp.up_proj.weight"][0] == "cp.layers.0.up_proj"
+    # the CLI prints the same and the per-component summary of what is still missing
+    path = str(tmp_path / "x.safetensors")
+    write_safetensors(path, {n: np.zeros(2, np.float32) for n in names[:4] + names[-3:]})
+    cfgp = str(tmp_path / "cfg.json")
+    json.dump(qo.config_tiny().to_dict(), open(cfgp, "w"))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "import_safetensors.py"), "--list", "--config", cfgp, path],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert "registry tensors without a source" in r.stdout and "missing cd.*" in r.stdout and "DUPLICATE" in r.stdout
+
+
+def test_pack_refuses_an_incomplete_tensor_set(tmp_path):
+    """tools/pack_weights.write_q3w validates against the registry (the loader would refuse the file anyway, naming what is missing)."""
+    import pytest
+    sys.path.insert(0, os.path.join(ROOT, "leaxer-qwen3-tts_amd"))
+    import q3tts
+    from tools.pack_weights import check_complete, write_q3w
+    oc = qo.config_tiny()
+    cfg = q3tts.Config.from_dict(oc.to_dict())
+    w = qo.random_weights(oc, 0)
+    check_complete(cfg, w)
+    short = {k: v for k, v in w.items() if k != "cp.norm"}
+    with pytest.raises(ValueError, match="1 missing"):
+        write_q3w(str(tmp_path / "a.q3w"), cfg, short)
+    with pytest.raises(ValueError, match="unknown"):
+        write_q3w(str(tmp_path / "b.q3w"), cfg, dict(w, bogus=np.zeros(3, np.float32)))
+    with pytest.raises(ValueError, match="wrong size"):
+        write_q3w(str(tmp_path / "c.q3w"), cfg, dict(w, **{"cp.norm": np.zeros(3, np.float32)}))
+    write_q3w(str(tmp_path / "d.q3w"), cfg, w)
+    cfg.cd_tconv_trim = 1                                  # the trim convention travels in the file's config
+    write_q3w(str(tmp_path / "e.q3w"), cfg, w)
+    back = q3tts.Config()
+    assert q3tts.lib().q3tts_read_weights_config(os.fsencode(str(tmp_path / "e.q3w")), back) == 0 and back.cd_tconv_trim == 1

@@ -162,6 +162,44 @@ def map_names(names, prefixes=None, extra_rules=()):
     return out
 
 
+def explain_names(names, prefixes=None, extra_rules=()):
+    """For --list: per checkpoint name, (registry name | None, note).  An unmapped name gets the rules that WOULD claim it under another
+    component prefix (name = <implied prefix> + <rule match>): the usual reason for a missing component is a wrong --prefix.  A mapped
+    name that another component's rules would also claim under some prefix is flagged ambiguous."""
+    prefixes = dict(DEFAULT_PREFIX, **(prefixes or {}))
+    mapping = map_names(names, prefixes, extra_rules)
+    compiled = {c: [(re.compile(pat + r"\Z"), dst, pat) for pat, dst in RULES[c]] for c in RULES}
+    out = {}
+    targets = {}
+    for name in names:
+        claims = []          # (component, implied prefix, registry name, rule)
+        parts = name.split(".")
+        for cut in range(len(parts)):
+            pre, rest = ".".join(parts[:cut]) + ("." if cut else ""), ".".join(parts[cut:])
+            for comp, rules in compiled.items():
+                for rx, dst, pat in rules:
+                    m = rx.match(rest)
+                    if m:
+                        claims.append((comp, pre, m.expand(dst) if isinstance(dst, str) else dst(m), pat))
+                        break
+        dst = mapping.get(name)
+        if dst is not None:
+            targets.setdefault(dst, []).append(name)
+            others = sorted({(c, pre) for c, pre, d, _ in claims if d != dst})
+            note = "" if not others else "ambiguous: also claimed by " + ", ".join(f"{c} rules under prefix '{pre}'" for c, pre in others[:3])
+        elif claims:
+            note = "unmapped; would map with " + "; ".join(f"--prefix {c}={pre} -> {d} (rule {pat})" for c, pre, d, pat in claims[:3])
+        else:
+            owner = [c for c, pre in prefixes.items() if name.startswith(pre)]
+            note = "unmapped; no rule of any component matches" + (f" (inside the {owner[0]} prefix)" if owner else "") + ": add a --map entry"
+        out[name] = (dst, note)
+    for dst, srcs in targets.items():
+        if len(srcs) > 1:
+            for nme in srcs:
+                out[nme] = (dst, "DUPLICATE target: " + ", ".join(srcs))
+    return out
+
+
 def _binding():
     """The product's ctypes binding: configs and the tensor registry come from libq3tts_hip.so (host-only calls, no GPU needed)."""
     sys.path.insert(0, os.path.join(ROOT, "leaxer-qwen3-tts_amd"))
@@ -203,7 +241,11 @@ def main():
     ap.add_argument("--config", default="0.6b", help='"0.6b", "1.7b" or a JSON file of q3tts_config fields')
     ap.add_argument("--prefix", action="append", default=[], help="component=prefix (talker, predictor, code2wav, speaker)")
     ap.add_argument("--map", help='JSON list of [regex, replacement] applied to the full checkpoint name first')
-    ap.add_argument("--allow-missing", action="store_true")
+    ap.add_argument("--allow-missing", action="store_true", help="write the file although registry tensors have no source (for inspection: "
+                    "q3tts_load_weights_file refuses a file that does not carry every tensor, naming the missing ones)")
+    ap.add_argument("--tconv-trim", type=int, choices=[0, 1], default=None, help="cd_tconv_trim stored in the file's config: 0 = transposed convs "
+                    "trimmed on both sides (transformers Code2Wav: 1920 F - 555 samples), 1 = right side only (1920 F samples); unverifiable "
+                    "without the real graph's `lengths` output (reference src/tts_onnx.cpp:759-776)")
     ap.add_argument("--list", action="store_true", help="print the checkpoint's tensor names with their mapping and exit")
     a = ap.parse_args()
     sys.path.insert(0, ROOT)
@@ -211,19 +253,37 @@ def main():
     cfg = q3tts.default_config(a.config.lower()) if a.config.lower() in ("0.6b", "1.7b") else q3tts.Config.from_dict(json.load(open(a.config)))
     prefixes = dict(p.split("=", 1) for p in a.prefix)
     extra = [tuple(r) for r in json.load(open(a.map))] if a.map else []
+    if a.tconv_trim is not None:
+        cfg.cd_tconv_trim = a.tconv_trim
     if a.list:
         names = {}
         for p in a.files:
             names.update({k: v.shape for k, v in read_safetensors(p).items()})
-        m = map_names(names, prefixes, extra)
+        ex = explain_names(names, prefixes, extra)
+        specs = {n: tuple(sh) for n, sh, _ in q3tts.tensor_specs(cfg)}
         for k in sorted(names):
-            print(f"{k:80s} {str(tuple(names[k])):24s} -> {m.get(k, '(unmapped)')}")
+            dst, note = ex[k]
+            shape_note = ""
+            if dst is not None and dst in specs and int(np.prod(names[k])) != int(np.prod(specs[dst])):
+                shape_note = f"  SHAPE MISMATCH: registry {specs[dst]}"
+            if dst is not None and dst not in specs:
+                shape_note = "  NOT A TENSOR OF THIS CONFIG"
+            print(f"{k:80s} {str(tuple(names[k])):24s} -> {dst or '(unmapped)'}{shape_note}" + (f"   [{note}]" if note else ""))
+        got = {d for d, _ in ex.values() if d}
+        missing = [n for n in specs if n not in got]
+        print(f"\n{len(names)} checkpoint tensors, {sum(d is not None for d, _ in ex.values())} mapped, "
+              f"{sum(d is None for d, _ in ex.values())} unmapped; {len(missing)} of {len(specs)} registry tensors without a source")
+        by_comp = {}
+        for n in missing:
+            by_comp.setdefault(n.split(".")[0], []).append(n)
+        for c, ns in sorted(by_comp.items()):
+            print(f"  missing {c}.*: {len(ns)} (e.g. {', '.join(ns[:4])})")
         return
     tensors, unused, missing = import_checkpoint(a.files, cfg, prefixes, extra, a.allow_missing)
     from tools.pack_weights import write_q3w
     if not a.out:
         ap.error("--out is required")
-    write_q3w(a.out, cfg, tensors)
+    write_q3w(a.out, cfg, tensors, validate=not a.allow_missing)
     print(f"wrote {a.out}: {len(tensors)} tensors; {len(unused)} checkpoint tensors unused; {len(missing)} registry tensors missing")
 
 

@@ -20,8 +20,28 @@ def _bf16_bits(a):
     return ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16)
 
 
-def write_q3w(path, cfg, tensors, bf16_prefixes=("talker.", "cp.", "text.")):
-    """cfg: a ctypes q3tts.Config; tensors: dict name -> array."""
+def check_complete(cfg, tensors, specs=None):
+    """Raise ValueError unless `tensors` holds exactly the registry of `cfg` (every name once, every shape right): the loader rejects an
+    incomplete file, so fail here, where the offending names can still be mapped back to checkpoint keys."""
+    if specs is None:
+        import os
+        import sys
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "leaxer-qwen3-tts_amd"))
+        import q3tts
+        specs = q3tts.tensor_specs(cfg)
+    want = {name: tuple(int(x) for x in shape) for name, shape in ((s[0], s[1]) for s in specs)}
+    missing = [n for n in want if n not in tensors]
+    extra = [n for n in tensors if n not in want]
+    bad = [(n, tuple(np.shape(tensors[n])), want[n]) for n in want if n in tensors and int(np.size(tensors[n])) != int(np.prod(want[n]))]
+    if missing or extra or bad:
+        raise ValueError("weight set does not match the registry: %d missing %s, %d unknown %s, %d wrong size %s"
+                         % (len(missing), missing[:8], len(extra), extra[:8], len(bad), bad[:4]))
+
+
+def write_q3w(path, cfg, tensors, bf16_prefixes=("talker.", "cp.", "text."), validate=True, specs=None):
+    """cfg: a ctypes q3tts.Config; tensors: dict name -> array.  validate: refuse a tensor set that is not the registry of cfg."""
+    if validate:
+        check_complete(cfg, tensors, specs)
     with open(path, "wb") as f:
         f.write(MAGIC)
         raw = bytes(ctypes.string_at(ctypes.addressof(cfg), ctypes.sizeof(cfg)))

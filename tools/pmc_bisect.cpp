@@ -5,9 +5,10 @@
 #include "../include/q3tts.h"
 int main(int argc, char** argv) {
     const int steps = argc > 1 ? atoi(argv[1]) : 4;
+    const int batch = argc > 2 ? atoi(argv[2]) : 1;   // armed slots: 1 = configs[1], 64 = configs[2]
     q3tts_config c; q3tts_default_config("0.6b", &c);
     fprintf(stderr, "[1] create\n");
-    q3tts_engine* e = q3tts_create(&c, 0, 1, steps + 64, 0);
+    q3tts_engine* e = q3tts_create(&c, 0, batch, steps + 64, 0);
     if (!e) { fprintf(stderr, "create failed: %s\n", q3tts_last_error(nullptr)); return 1; }
     fprintf(stderr, "[2] fill\n");
     q3tts_fill_synthetic(e, 0);
@@ -24,7 +25,7 @@ int main(int argc, char** argv) {
     fprintf(stderr, "[7] slot_begin\n");
     q3tts_sampling sp{0.8f, 0.95f, 50, 1.0f, steps};
     std::vector<float> tr(4 * 1024, 0.01f);
-    q3tts_slot_begin(e, 0, x.data(), 8, tr.data(), 4, &sp, 1, 0, 1);
+    for (int b = 0; b < batch; ++b) q3tts_slot_begin(e, b, x.data(), 8, tr.data(), 4, &sp, 1, (uint32_t)b, 1);
     fprintf(stderr, "[8] decode_steps\n");
     int act = q3tts_decode_steps(e, steps);
     fprintf(stderr, "[9] active=%d codec\n", act);
