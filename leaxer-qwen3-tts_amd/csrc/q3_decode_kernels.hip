@@ -1094,6 +1094,146 @@ static __device__ __forceinline__ float wave_scan_f(float v, int lane) {
     return v;
 }
 
+// exp() of the sampler, fully specified so that this kernel and the CPU oracle (oracle/q3_oracle.c: q3o_expf, the same lines) agree BIT FOR
+// BIT: the device library's expf and libm's differ in the last place on a few per cent of the inputs, and a probability that differs in
+// its last bit can flip a top-p cut or a draw that lands on a boundary.  IEEE-exact operations only (mul, fma, rint, power-of-two
+// scaling); the file is built with -ffp-contract=off.  Within 1 ulp of expf.
+static __device__ __forceinline__ float q3_expf(float x) {
+    if (!(x > -103.0f)) return 0.0f;
+    x = x > 88.0f ? 88.0f : x;
+    const float n = __builtin_rintf(x * 1.44269504088896341f);
+    float r = __builtin_fmaf(n, -0.693359375f, x);
+    r = __builtin_fmaf(n, 2.12194440e-4f, r);
+    const float z = r * r;
+    float p = 1.9875691500e-4f;
+    p = __builtin_fmaf(p, r, 1.3981999507e-3f);
+    p = __builtin_fmaf(p, r, 8.3334519073e-3f);
+    p = __builtin_fmaf(p, r, 4.1665795894e-2f);
+    p = __builtin_fmaf(p, r, 1.6666665459e-1f);
+    p = __builtin_fmaf(p, r, 5.0000001201e-1f);
+    const float y = __builtin_fmaf(p, z, r) + 1.0f;
+    const int ni = (int)n;
+    return (y * __uint_as_float((uint32_t)(ni + 64 + 127) << 23)) * __uint_as_float((uint32_t)(-64 + 127) << 23);
+}
+
+// The reference's sampler sums in plain loops (tts_onnx.cpp:907-915, 893-898, 929-950): `sum += x[i]` in index order, one fp32 rounding
+// per element.  A tree / scan order gives sums that differ in the last bits, and with thousands of candidates (top_k = 0) or exact ties
+// (running sums landing ON top_p) that is enough to move a cut or a draw by one element.  So the sums that feed a decision are left
+// folds here too: every lane of the calling wave walks the same LDS array (same address in every lane = a broadcast read) and performs
+// the same dependent chain of adds; n is a multiple of 32, the entries past the last candidate are +0 (s + 0 == s).
+static __device__ __forceinline__ float seq_sum_lds(const float* a, int n) {
+    float s = 0.f;
+    for (int i = 0; i < n; i += 32) {
+        float4 v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = *reinterpret_cast<const float4*>(a + i + 4 * q);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { s += v[q].x; s += v[q].y; s += v[q].z; s += v[q].w; }
+    }
+    return s;
+}
+// first index whose left-fold running sum exceeds `target` (entries are >= 0, so the running sum never decreases), -1 if none
+static __device__ __forceinline__ int seq_find_lds(const float* a, int n, float target) {
+    float s = 0.f;
+    int found = 0x7FFFFFFF;
+    for (int i = 0; i < n; i += 32) {
+        float4 v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = *reinterpret_cast<const float4*>(a + i + 4 * q);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            s += v[q].x; found = s > target ? min(found, i + 4 * q) : found;
+            s += v[q].y; found = s > target ? min(found, i + 4 * q + 1) : found;
+            s += v[q].z; found = s > target ? min(found, i + 4 * q + 2) : found;
+            s += v[q].w; found = s > target ? min(found, i + 4 * q + 3) : found;
+        }
+        if (__builtin_amdgcn_readfirstlane(found) != 0x7FFFFFFF) break;   // wave-uniform
+    }
+    found = __builtin_amdgcn_readfirstlane(found);
+    return found == 0x7FFFFFFF ? -1 : found;
+}
+static __device__ __forceinline__ void wave_lds_sync() {   // wave-private LDS staging: the wave's own in-order LDS queue is the synchronisation
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// softmax -> top-p -> renormalise -> inverse-CDF draw (tts_onnx.cpp:886-904) over at most 64 candidates, one per lane IN INDEX ORDER
+// (lanes >= nk hold e = 0): e = exp(logit - max) numerators, id = token ids.  Every sum is the reference's left fold.  sb: 3 x 64 floats
+// of wave-private LDS.  Returns the drawn token id (wave-uniform).
+static __device__ __forceinline__ int draw_small_exact(float e, int id, int nk, float top_p, float u, int lane, float (*sb)[64]) {
+    sb[0][lane] = e;
+    wave_lds_sync();
+    const float S = seq_sum_lds(sb[0], 64);
+    float p = e / S;                                                          // :913-914
+    if (top_p < 1.0f) {                                                       // :929-950: order (p desc, index asc), keep through the first running sum > top_p
+        float sk = lane < nk ? p : -INFINITY;
+        int tag = lane;
+        wave_sort_desc_kv(sk, tag, lane);
+        sb[1][lane] = lane < nk ? sk : 0.f;
+        wave_lds_sync();
+        const int cut = seq_find_lds(sb[1], 64, top_p);
+        const int keep_rank = (lane < nk && (cut < 0 || lane <= cut)) ? 1 : 0;
+        const int keep_here = __builtin_amdgcn_ds_permute(tag << 2, keep_rank); // the tags are a permutation of 0..63: every lane receives its flag
+        p = keep_here ? p : 0.f;
+        sb[2][lane] = p;
+        wave_lds_sync();
+        const float s2 = seq_sum_lds(sb[2], 64);
+        if (s2 > 0.f) p = p / s2;                                              // :893-898
+    }
+    wave_lds_sync();                                                           // sb[0] is rewritten: its readers are done (same wave, in order)
+    sb[0][lane] = p;
+    wave_lds_sync();
+    const float total = seq_sum_lds(sb[0], 64);
+    const float target = u * total;
+    int pick = seq_find_lds(sb[0], 64, target);
+    if (pick < 0) {                                                            // rounding left target >= the last running sum: last positive entry
+        const unsigned long long pos = __ballot(p > 0.f);
+        pick = pos ? 63 - __clzll((long long)pos) : 0;
+    }
+    return lane_bcast_i(id, pick);
+}
+
+// The same decisions from tree-ordered sums (DPP reductions / scans, ~1 us instead of ~5 for the left folds), taken only when they
+// provably equal the left-fold ones: a sum of <= 64 non-negative terms differs between any two summation orders by at most
+// 2 * 63 * 2^-24 = 7.6e-6 relative, which bounds every quantity a decision compares — running sums of p = e / S against top_p (<= 1.6e-5
+// apart between the two evaluations) and against u * total after the renormalisation (<= 5e-5 * total apart).  If no comparison is
+// closer to its threshold than that (with a 2x margin), and the element right behind the top-p cut is not within 1e-5 relative of the cut
+// element (equal-p elements are ordered by index, and whether two p values collide may differ between the evaluations), both
+// evaluations decide alike; otherwise (a few per cent of the calls) the left-fold evaluation decides.
+static __device__ __forceinline__ int draw_small(float e, int id, int nk, float top_p, float u, int lane, float (*sb)[64]) {
+    const float Sa = wave_sum(e);
+    float p = e / Sa;
+    bool amb = false;
+    if (top_p < 1.0f) {
+        float sk = lane < nk ? p : -INFINITY;
+        int tag = lane;
+        wave_sort_desc_kv(sk, tag, lane);
+        const float cs = wave_scan_incl_f(lane < nk ? sk : 0.f);
+        const unsigned long long over = __ballot(lane < nk && cs > top_p);
+        const int rcut = over ? __ffsll((long long)over) - 1 : 63;
+        amb = __ballot(lane < nk && fabsf(cs - top_p) <= 4e-5f) != 0ull;
+        const float pcut = lane_bcast(sk, rcut), pnext = lane_bcast(sk, rcut < 63 ? rcut + 1 : 63);
+        amb = amb || (rcut + 1 < nk && pnext >= pcut * (1.0f - 1e-5f));
+        const int keep_rank = (lane < nk && lane <= rcut) ? 1 : 0;
+        const int keep_here = __builtin_amdgcn_ds_permute(tag << 2, keep_rank);
+        p = keep_here ? p : 0.f;
+        const float s2 = wave_sum(p);
+        if (s2 > 0.f) p = p / s2;
+    }
+    const float total = wave_sum(p);
+    const float target = u * total;
+    const float cum = wave_scan_incl_f(p);
+    amb = amb || __ballot(p > 0.f && fabsf(cum - target) <= 1e-4f * total) != 0ull;
+    if (!amb) {
+        const unsigned long long hit = __ballot(p > 0.f && cum > target);
+        const unsigned long long pos = __ballot(p > 0.f);
+        const int pick = hit ? __ffsll((long long)hit) - 1 : (pos ? 63 - __clzll((long long)pos) : 0);
+        return lane_bcast_i(id, pick);
+    }
+    return draw_small_exact(e, id, nk, top_p, u, lane, sb);
+}
+
 // k-th largest of one value per lane (ties allowed), -inf when fewer than k lanes hold a finite value: the wave sorts its 64
 // values in registers (q3_wave_sort.h) and reads rank k-1.  (A 64-broadcast rank count did the same in 1.4 us; this is ~0.3.)
 static __device__ __forceinline__ float kth_largest_of_lanes(float v, int k) {
@@ -1122,9 +1262,10 @@ __global__ __launch_bounds__(256) void k_sample(const float* plogits, SlotState*
     __shared__ float svb[256 + 64];              // wave 0: survivor rounds
     __shared__ int cnt_s[SAMP_MAXV / 64];        // survivors per 64-slice (index-ordered compaction)
     __shared__ int cand_idx[SAMP_MAXV + 64];
-    __shared__ float cand_p[SAMP_MAXV + 64];
-    __shared__ float sorted_p[SAMP_MAXV];        // general path only
-    __shared__ float esum_s[4];
+    __shared__ __attribute__((aligned(16))) float cand_p[SAMP_MAXV + 64];
+    __shared__ __attribute__((aligned(16))) float sorted_p[SAMP_MAXV];        // general path only
+    __shared__ int cand_rank[SAMP_MAXV];         // general path only: position in (p desc, index asc) order
+    __shared__ __attribute__((aligned(16))) float sb[3][64];                  // wave 0: staging of the left-fold sums (draw_small)
     __shared__ float sh_f[4];
     __shared__ int sh_i[4];
 
@@ -1217,34 +1358,19 @@ __global__ __launch_bounds__(256) void k_sample(const float* plogits, SlotState*
                 const int kk = __builtin_amdgcn_readfirstlane(top_k);
                 const float thrf = n >= kk ? lane_bcast(v, kk - 1) : -INFINITY;     // ties at the threshold stay (:917-927)
                 const bool kept = lane < n && v >= thrf;
+                const int nk = __popcll(__ballot(kept));
                 SP_MARK(5);
-                const float e = kept ? expf(v - mxf) : 0.f;                          // softmax over the kept entries (:907-915)
-                float p = e / wave_sum(e);
-                SP_MARK(6);
-                if (top_p < 1.0f) { // :929-950 — already in (p desc, index asc) order: keep through the first cumulative sum > top_p
-                    const float cum = wave_scan_incl_f(p);
-                    const unsigned long long over = __ballot(kept && cum > top_p);
-                    const int rcut = over ? __ffsll((long long)over) - 1 : 0x7FFFFFFF;
-                    if (lane > rcut) p = 0.f;
-                    const float s2 = wave_sum(p);
-                    if (s2 > 0.f) p = p / s2; // :893-898
-                }
-                SP_MARK(7);
-                // back to index order for the draw: sort by index, pull (p, index) along with a backward permute
+                // index order first: the reference's sums (softmax denominator, renormalisation, the draw's running sum) walk the kept
+                // entries in index order — sort by index, pull (logit, index) along with a backward permute
                 float key = kept ? -(float)id : -INFINITY;
                 int from = lane;
                 wave_sort_desc_kv(key, from, lane);
-                const float pi = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(from << 2, __builtin_bit_cast(int, p)));
+                const float vi = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(from << 2, __builtin_bit_cast(int, v)));
                 const int idi = __builtin_amdgcn_ds_bpermute(from << 2, id);
-                const float total = wave_sum(pi);
-                const float target = u * total;
-                const float cum = wave_scan_incl_f(pi);
-                const unsigned long long hit = __ballot(pi > 0.f && cum > target);
-                const unsigned long long pos_mask = __ballot(pi > 0.f);
-                int pick;
-                if (hit) pick = __ffsll((long long)hit) - 1;
-                else pick = pos_mask ? 63 - __clzll((long long)pos_mask) : 0;
-                tok = lane_bcast_i(idi, pick);
+                const float e = lane < nk ? q3_expf(vi - mxf) : 0.f;                  // softmax numerators over the kept entries (:907-915)
+                SP_MARK(6);
+                tok = draw_small(e, idi, nk, top_p, u, lane, sb);
+                SP_MARK(7);
                 if (lane == 0) sh_i[3] = tok;
             }
         }
@@ -1353,7 +1479,6 @@ __global__ __launch_bounds__(256) void k_sample(const float* plogits, SlotState*
         const int cmine = lane < PER ? cnt_s[lane] : 0;
         const int cincl = wave_scan_incl_i(cmine);
         const int n_kept = lane_bcast_i(cincl, 63);
-        float esum = 0.f;
     #pragma unroll
         for (int jj = 0; jj < SAMP_PERW; ++jj) {
             const int j = jj * 4 + wave;
@@ -1361,54 +1486,29 @@ __global__ __launch_bounds__(256) void k_sample(const float* plogits, SlotState*
                 const int base = lane_bcast_i(cincl, j) - lane_bcast_i(cmine, j);
                 const bool keep = (km[jj] >> lane) & 1ull;
                 const int wpos = keep ? base + __popcll(km[jj] & lt_mask) : SAMP_MAXV + lane;
-                const float e = keep ? expf(x[jj] - mx) : 0.f;
                 cand_idx[wpos] = j * 64 + lane;
-                cand_p[wpos] = e;
-                esum += e;
+                cand_p[wpos] = keep ? q3_expf(x[jj] - mx) : 0.f;                      // softmax numerators, index order (:907-915)
             }
         }
-        esum = wave_sum(esum);
-        if (lane == 0) esum_s[wave] = esum;
         __syncthreads();
-        esum = ((esum_s[0] + esum_s[1]) + esum_s[2]) + esum_s[3];
         SP_MARK(6);
 
         if (wave == 0) {
             if (n_kept <= 64) {
-                // ---- wave path: one candidate per lane, everything in registers ----
+                // ---- wave path: one candidate per lane (already in index order) ----
                 const bool have = lane < n_kept;
-                float p = have ? cand_p[lane] / esum : 0.f;
-                const int myidx = have ? cand_idx[lane] : 0;
-                if (top_p < 1.0f) { // :929-950 — order by (p desc, index asc); keep through the first cumulative sum > top_p
-                    // sort (p, position) pairs across the lanes, scan the sorted probabilities, cut, and send every keep flag back to
-                    // the lane it came from (ds_permute pushes; the tags are a permutation of 0..63)
-                    float sk = have ? p : -INFINITY;
-                    int tag = lane;
-                    wave_sort_desc_kv(sk, tag, lane);
-                    const float cum = wave_scan_incl_f(lane < n_kept ? sk : 0.f);
-                    const unsigned long long over = __ballot(lane < n_kept && cum > top_p);
-                    const int rcut = over ? __ffsll((long long)over) - 1 : 0x7FFFFFFF;
-                    const int keep_rank = (lane < n_kept && lane <= rcut) ? 1 : 0;
-                    const int keep_here = __builtin_amdgcn_ds_permute(tag << 2, keep_rank);
-                    if (!(have && keep_here)) p = 0.f;
-                    const float s2 = wave_sum(p);
-                    if (s2 > 0.f) p = p / s2; // :893-898
-                }
+                tok = draw_small(have ? cand_p[lane] : 0.f, have ? cand_idx[lane] : 0, n_kept, top_p, u, lane, sb);
                 SP_MARK(7);
-                // draw: inverse CDF in index order
-                const float total = wave_sum(p);
-                const float target = u * total;
-                const float cum = wave_scan_incl_f(p);
-                const unsigned long long hit = __ballot(p > 0.f && cum > target);
-                const unsigned long long pos_mask = __ballot(p > 0.f);
-                int pick;
-                if (hit) pick = __ffsll((long long)hit) - 1;
-                else pick = pos_mask ? 63 - __clzll((long long)pos_mask) : 0;
-                tok = lane_bcast_i(myidx, pick);
             } else {
-                // ---- general path (top_k == 0 or > 64, or many ties): LDS-resident candidates, wave 0 only ----
-                for (int c = lane; c < n_kept; c += 64) cand_p[c] = cand_p[c] / esum;
-                if (top_p < 1.0f) {
+                // ---- general path (top_k == 0 or > 64, or many ties): LDS-resident candidates in index order, wave 0 only; the same
+                // left-fold sums as draw_small, over arrays padded with +0 to a multiple of 32 ----
+                const int npad = (n_kept + 31) & ~31;
+                for (int c = n_kept + lane; c < npad; c += 64) cand_p[c] = 0.f;
+                wave_lds_sync();
+                const float S = seq_sum_lds(cand_p, npad);
+                for (int c = lane; c < n_kept; c += 64) cand_p[c] = cand_p[c] / S;
+                wave_lds_sync();
+                if (top_p < 1.0f) {   // :929-950 — rank = position in (p desc, index asc) order; keep the ranks through the first running sum > top_p
                     for (int c = lane; c < n_kept; c += 64) {
                         const float pc = cand_p[c];
                         int rank = 0;
@@ -1417,46 +1517,28 @@ __global__ __launch_bounds__(256) void k_sample(const float* plogits, SlotState*
                             rank += (po > pc || (po == pc && o2 < c)) ? 1 : 0;
                         }
                         sorted_p[rank] = pc;
+                        cand_rank[c] = rank;
                     }
-                    int cutoff = n_kept;
-                    if (lane == 0) {
-                        float cum = 0.f;
-                        for (int i = 0; i < n_kept; ++i) { cum += sorted_p[i]; if (cum > top_p) { cutoff = i + 1; break; } }
-                    }
-                    cutoff = lane_bcast_i(cutoff, 0);
-                    const float pcut = sorted_p[cutoff - 1]; // probability of the last kept rank
-                    int n_gt = 0;
-                    for (int c = lane; c < n_kept; c += 64) n_gt += cand_p[c] > pcut ? 1 : 0;
-                    n_gt = wave_sum_i(n_gt);
-                    const int n_eq_keep = cutoff - n_gt; // equal-p candidates kept, lowest indices first
-                    if (lane == 0) {
-                        int seen = 0;
-                        for (int c = 0; c < n_kept; ++c) {
-                            const float pc = cand_p[c];
-                            if (pc > pcut) continue;
-                            if (pc == pcut && seen < n_eq_keep) { ++seen; continue; }
-                            cand_p[c] = 0.f;
-                        }
-                    }
-                    float s2 = 0.f;
-                    for (int c = lane; c < n_kept; c += 64) s2 += cand_p[c];
-                    s2 = wave_sum(s2);
-                    if (s2 > 0.f) for (int c = lane; c < n_kept; c += 64) cand_p[c] = cand_p[c] / s2;
+                    for (int c = n_kept + lane; c < npad; c += 64) sorted_p[c] = 0.f;
+                    wave_lds_sync();
+                    const int cut = seq_find_lds(sorted_p, npad, top_p);
+                    const int cutoff = cut < 0 ? n_kept : cut + 1;
+                    for (int c = lane; c < n_kept; c += 64) if (cand_rank[c] >= cutoff) cand_p[c] = 0.f;
+                    wave_lds_sync();
+                    const float s2 = seq_sum_lds(cand_p, npad);
+                    if (s2 > 0.f) for (int c = lane; c < n_kept; c += 64) cand_p[c] = cand_p[c] / s2; // :893-898
+                    wave_lds_sync();
                 }
-                int picked = 0;
-                if (lane == 0) {
-                    float total = 0.f;
-                    for (int c = 0; c < n_kept; ++c) total += cand_p[c];
-                    const float target = u * total;
-                    float cum = 0.f;
-                    int pick = -1, last = -1;
-                    for (int c = 0; c < n_kept; ++c) {
-                        if (cand_p[c] > 0.f) { last = c; cum += cand_p[c]; if (cum > target) { pick = c; break; } }
-                    }
-                    if (pick < 0) pick = last;
-                    picked = pick >= 0 ? cand_idx[pick] : 0;
+                const float total = seq_sum_lds(cand_p, npad);
+                const float target = u * total;
+                int pick = seq_find_lds(cand_p, npad, target);
+                if (pick < 0) {   // rounding left target >= the last running sum: last positive entry
+                    float last = -1.f;
+                    for (int c = lane; c < n_kept; c += 64) if (cand_p[c] > 0.f) last = (float)c;
+                    last = wave_max(last);
+                    pick = last < 0.f ? 0 : (int)last;
                 }
-                tok = lane_bcast_i(picked, 0);
+                tok = cand_idx[pick];
             }
             if (lane == 0) sh_i[3] = tok;
         }

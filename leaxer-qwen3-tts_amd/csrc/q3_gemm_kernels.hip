@@ -13,6 +13,7 @@
 //                            shared by 64 columns, split-K slabs reduced in fixed order by k_finish / k_finish_swiglu
 // Summation order is fixed everywhere: results are bit-reproducible run to run.
 #include <algorithm>
+#include <cstdlib>
 
 #include "q3_common.h"
 
@@ -171,6 +172,8 @@ static void gemm2_epi(const GemmArgs& a, int ksplit, hipStream_t s) {
     default: throw Error("gemm2: unsupported epilogue");
     }
 }
+static bool gemm3_ok(const GemmArgs& a, int ksplit);                       // third generation of the slab GEMM, below
+static void launch_gemm3(const GemmArgs& a, int ksplit, hipStream_t s);
 template <int MTILES>
 static void gemm2_nw(const GemmArgs& a, int ksplit, int nw, hipStream_t s) {
     if (nw == 2) gemm2_epi<MTILES, 2>(a, ksplit, s); else gemm2_epi<MTILES, 4>(a, ksplit, s);
@@ -190,11 +193,176 @@ void launch_gemm2(const GemmArgs& a0, int ksplit, int nw, hipStream_t s) {
         if (a0.out2) a.out2 = a0.out2 + (size_t)m0 * a0.ldo;
         if (a0.oh) { a.oh = a0.oh + (size_t)m0 * a0.ldp; a.ol = a0.ol + (size_t)m0 * a0.ldp; }
         if (a0.res) a.res = a0.res + (size_t)m0 * a0.ldres;
+        if (nw == 4 && gemm3_ok(a, ksplit)) { launch_gemm3(a, ksplit, s); continue; }
         if (a.M <= 16) gemm2_nw<1>(a, ksplit, nw, s);
         else if (a.M <= 32) gemm2_nw<2>(a, ksplit, nw, s);
         else if (a.M <= 64) gemm2_nw<4>(a, ksplit, nw, s);
         else gemm2_nw<8>(a, ksplit, nw, s);
     }
+}
+
+// ================================================================================================
+// k_gemm3 — the split-K slab GEMM of the batched decode step (17..128 rows), third generation: k_gemm2's decomposition (workgroup = 64
+// columns x one K slice, (hi, lo) activation planes through LDS, fp32 partial slabs reduced in fixed order by the consumer) with the
+// instruction stream laid out by hand where hipcc's schedule had cost microseconds per launch (profiles/r02_gemm3_notes.txt):
+//  * straight-line code, no load under a runtime condition: k_gemm2 issued its second K chunk inside `if (k0 + KC < kend)`, and at the
+//    join hipcc waits for the FEWEST loads either path could have outstanding — in practice vmcnt(0..4): the first MFMA waited for
+//    every byte of the slice (chunk 0 "landed" at 3.0 us of a 5.4 us launch);
+//  * the K slice is cut into NCH chunks of 64: weights of the whole slice first (the HBM stream, one latency deep), then the
+//    activation chunks in order; chunk c is multiplied while chunks c+1.. are still arriving (in-order vmcnt counts do the rest);
+//  * a two-buffer LDS ring with ONE barrier per chunk (a wave that writes chunk c+2 has passed the barrier of chunk c+1, which every
+//    wave reaches only after its reads of chunk c);
+//  * a chunk's A fragments are all read before its first MFMA, the second k-step's behind the first one's MFMAs (k_gemm2 waited ~100
+//    cycles of LDS latency in front of every MFMA pair: 0.75 us per 128-wide chunk for 0.23 us of matrix work);
+//  * rows padded by 32 B: every ds_read_b128 lane group hits 16 distinct 16-byte slots (8 bytes of padding left one 2-way conflict);
+//  * the 64 x 64 fp32 tile leaves through LDS as 16-byte row-contiguous stores (k_gemm2: sixteen 4-byte stores per lane).
+// Same operations on the same operands in the same order as k_gemm2: bit-identical slabs.
+// ================================================================================================
+#define G3_CH 64
+#define G3_LD (G3_CH + 16)
+#define G3_LDE 68
+
+template <int MTILES, int EPI, int NCH, int LA>
+__global__ __launch_bounds__(256) void k_gemm3(const bf16_t* pW, const bf16_t* pW2, const bf16_t* pxh, const bf16_t* pxl, int pldx, int pM, int pN, int pK,
+                                                GemmArgs a) {   // leading scalars: kernarg-preloaded
+    static_assert(EPI == EPI_SLAB || EPI == EPI_SLAB2, "k_gemm3 writes split-K slabs");
+    constexpr bool DUAL = EPI == EPI_SLAB2;
+    constexpr int ROWS = MTILES * 16, RPP = 32, PASSES = (ROWS + RPP - 1) / RPP;
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, q = lane >> 4;
+    const int n0 = (blockIdx.x * 4 + wave) * 16;
+    const int K = pK, M = pM;
+    const int kbeg = blockIdx.y * (NCH * G3_CH);
+    // ring of two chunk buffers [plane][row][k]; the epilogue reuses the same bytes as a [row][64 + 4] fp32 tile (x 2 for the dual product)
+    constexpr int XS_BYTES = 2 * 2 * ROWS * G3_LD * 2, EP_BYTES = (DUAL ? 2 : 1) * ROWS * G3_LDE * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[XS_BYTES > EP_BYTES ? XS_BYTES : EP_BYTES];
+    bf16_t (*xs)[2][ROWS][G3_LD] = reinterpret_cast<bf16_t (*)[2][ROWS][G3_LD]>(smem);
+
+    // 1. every weight fragment of the slice: lane (r16, q) = weight row n0 + r16, k = 8 q .. 8 q + 7 of each 32-wide k-step
+    int nrow = n0 + r16;
+    nrow = nrow < pN ? nrow : pN - 1;
+    const bf16_t* wp = pW + (size_t)nrow * K + kbeg + q * 8;
+    const bf16_t* wp2 = DUAL ? pW2 + (size_t)nrow * K + kbeg + q * 8 : nullptr;
+    bf16x8 b[NCH][2], b2[DUAL ? NCH : 1][2];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            b[c][st] = *reinterpret_cast<const bf16x8*>(wp + c * G3_CH + st * 32);
+            if (DUAL) b2[DUAL ? c : 0][st] = *reinterpret_cast<const bf16x8*>(wp2 + c * G3_CH + st * 32);
+        }
+    // 2. activation chunks: 8 threads per row (16 B each), 32 rows per pass; rows past M repeat row M - 1 (their products are never stored)
+    const int srow = tid >> 3, scol = (tid & 7) * 8;
+    u32x4 sh[NCH][PASSES], sl[NCH][PASSES];
+    auto issue = [&](int c) {
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p) {
+            int row = srow + p * RPP;
+            row = row < M ? row : M - 1;
+            sh[c][p] = *reinterpret_cast<const u32x4*>(pxh + (size_t)row * pldx + kbeg + c * G3_CH + scol);
+            sl[c][p] = *reinterpret_cast<const u32x4*>(pxl + (size_t)row * pldx + kbeg + c * G3_CH + scol);
+        }
+    };
+#pragma unroll
+    for (int c = 0; c < LA; ++c) issue(c);
+    __builtin_amdgcn_sched_barrier(0);   // the loads above stay above everything below, in this order
+
+    f32x4 acc[MTILES], acc2[DUAL ? MTILES : 1];
+#pragma unroll
+    for (int mt = 0; mt < MTILES; ++mt) { acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f}; if (DUAL) acc2[DUAL ? mt : 0] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int buf = c & 1;
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p) {
+            const int row = srow + p * RPP;
+            if (ROWS % RPP == 0 || row < ROWS) {
+                *reinterpret_cast<u32x4*>(&xs[buf][0][row][scol]) = sh[c][p];
+                *reinterpret_cast<u32x4*>(&xs[buf][1][row][scol]) = sl[c][p];
+            }
+        }
+        if (c + LA < NCH) issue(c + LA);     // compile-time condition: the freed registers take a later chunk
+        __syncthreads();
+        // both k-steps' A fragments are read before the first MFMA (pinned: left alone, hipcc re-reads one register set per MFMA pair and
+        // waits ~100 cycles of LDS latency in front of each); the second k-step's reads land behind the first one's MFMAs
+        bf16x8 fh[2][MTILES], fl[2][MTILES];
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+#pragma unroll
+            for (int mt = 0; mt < MTILES; ++mt) {
+                fh[st][mt] = *reinterpret_cast<const bf16x8*>(&xs[buf][0][mt * 16 + r16][st * 32 + q * 8]);
+                fl[st][mt] = *reinterpret_cast<const bf16x8*>(&xs[buf][1][mt * 16 + r16][st * 32 + q * 8]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+#pragma unroll
+            for (int mt = 0; mt < MTILES; ++mt) {
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh[st][mt], b[c][st], acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fl[st][mt], b[c][st], acc[mt], 0, 0, 0);
+                if (DUAL) {
+                    acc2[DUAL ? mt : 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh[st][mt], b2[DUAL ? c : 0][st], acc2[DUAL ? mt : 0], 0, 0, 0);
+                    acc2[DUAL ? mt : 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fl[st][mt], b2[DUAL ? c : 0][st], acc2[DUAL ? mt : 0], 0, 0, 0);
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // 3. the tile leaves through LDS: D layout (col = lane & 15, row = 4 q + reg) -> [row][64 columns] -> one 16-byte store per thread and row pass
+    __syncthreads();   // the last chunk's fragment reads are done
+    float (*ep)[ROWS][G3_LDE] = reinterpret_cast<float (*)[ROWS][G3_LDE]>(smem);
+#pragma unroll
+    for (int mt = 0; mt < MTILES; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            ep[0][mt * 16 + q * 4 + r][wave * 16 + r16] = acc[mt][r];
+            if (DUAL) ep[DUAL ? 1 : 0][mt * 16 + q * 4 + r][wave * 16 + r16] = acc2[DUAL ? mt : 0][r];
+        }
+    __syncthreads();
+    const int erow = tid >> 4, ecol = (tid & 15) * 4, ng = blockIdx.x * 64 + ecol;
+    const size_t sbase = (size_t)blockIdx.y * a.slab_rows;
+#pragma unroll
+    for (int p = 0; p < ROWS / 16; ++p) {
+        const int m = erow + p * 16;
+        if (m < M && ng < a.N) {
+            const float4 v = *reinterpret_cast<const float4*>(&ep[0][m][ecol]);
+            float* dst = a.out + (sbase + m) * a.ldo + ng;
+            if (ng + 3 < a.N) *reinterpret_cast<float4*>(dst) = v;
+            else { dst[0] = v.x; if (ng + 1 < a.N) dst[1] = v.y; if (ng + 2 < a.N) dst[2] = v.z; }
+            if (DUAL) {
+                const float4 v2 = *reinterpret_cast<const float4*>(&ep[DUAL ? 1 : 0][m][ecol]);
+                float* dst2 = a.out2 + (sbase + m) * a.ldo + ng;
+                if (ng + 3 < a.N) *reinterpret_cast<float4*>(dst2) = v2;
+                else { dst2[0] = v2.x; if (ng + 1 < a.N) dst2[1] = v2.y; if (ng + 2 < a.N) dst2[2] = v2.z; }
+            }
+        }
+    }
+}
+
+template <int MTILES, int EPI>
+static void gemm3_go(const GemmArgs& a, int ksplit, hipStream_t s) {
+    const dim3 grid((a.N + 63) / 64, ksplit), block(256);
+    const int nch = a.K / ksplit / G3_CH;
+    constexpr int LA4 = MTILES <= 4 ? 4 : 2;
+    if (nch == 2) hipLaunchKernelGGL((k_gemm3<MTILES, EPI, 2, 2>), grid, block, 0, s, a.W, a.W2, a.xh, a.xl, a.ldx, a.M, a.N, a.K, a);
+    else hipLaunchKernelGGL((k_gemm3<MTILES, EPI, 4, LA4>), grid, block, 0, s, a.W, a.W2, a.xh, a.xl, a.ldx, a.M, a.N, a.K, a);
+}
+// the shapes k_gemm3 is built for: slab epilogues, K slices of 128 or 256, 16-byte aligned slab rows
+static bool gemm3_ok(const GemmArgs& a, int ksplit) {
+    if (a.epi != EPI_SLAB && a.epi != EPI_SLAB2) return false;
+    if (getenv("Q3TTS_GEMM2")) return false;   // A/B knob: the second-generation kernel
+    const int ksl = a.K / ksplit;
+    return a.K % ksplit == 0 && (ksl == 128 || ksl == 256) && a.ldo % 4 == 0 && a.ldx % 8 == 0 && a.M >= 1 && a.M <= 128;
+}
+static void launch_gemm3(const GemmArgs& a, int ksplit, hipStream_t s) {
+    const bool dual = a.epi == EPI_SLAB2;
+#define Q3_G3(MT) do { if (dual) gemm3_go<MT, EPI_SLAB2>(a, ksplit, s); else gemm3_go<MT, EPI_SLAB>(a, ksplit, s); } while (0)
+    if (a.M <= 16) Q3_G3(1); else if (a.M <= 32) Q3_G3(2); else if (a.M <= 64) Q3_G3(4); else Q3_G3(8);
+#undef Q3_G3
 }
 
 // ================================================================================================

@@ -648,8 +648,42 @@ float q3o_rng_uniform(uint64_t seed, uint32_t stream, uint32_t frame, uint32_t g
     return (float)(k >> 40) * (1.0f / 16777216.0f);
 }
 
+/* exp() of the sampler, fully specified so that the CPU oracle and the HIP sampler (csrc/q3_decode_kernels.hip: q3_expf) agree BIT FOR BIT:
+ * libm's expf and the device library's differ in the last place on a few per cent of the inputs, and a probability that differs in its
+ * last bit can flip a top-p cut or a draw that lands on a boundary.  Only IEEE-exact operations (mul, fma, rint, scaling by powers of
+ * two), in a fixed order; -ffp-contract=off on both sides.  Cody-Waite reduction + the degree-5 Cephes polynomial: within 1 ulp of
+ * libm's expf (the reference uses std::exp, tts_onnx.cpp:912). */
+float q3o_expf(float x) {
+    if (!(x > -103.0f)) return 0.0f;                    /* underflows past the smallest subnormal; also -inf */
+    if (x > 88.0f) x = 88.0f;
+    const float n = rintf(x * 1.44269504088896341f);
+    float r = fmaf(n, -0.693359375f, x);
+    r = fmaf(n, 2.12194440e-4f, r);
+    const float z = r * r;
+    float p = 1.9875691500e-4f;
+    p = fmaf(p, r, 1.3981999507e-3f);
+    p = fmaf(p, r, 8.3334519073e-3f);
+    p = fmaf(p, r, 4.1665795894e-2f);
+    p = fmaf(p, r, 1.6666665459e-1f);
+    p = fmaf(p, r, 5.0000001201e-1f);
+    float y = fmaf(p, z, r) + 1.0f;
+    /* y * 2^n in two exact-or-correctly-rounded steps: 2^(n+64) is normal for n >= -151, the second factor may round into a subnormal */
+    union { uint32_t u; float f; } s1, s2;
+    const int ni = (int)n;
+    s1.u = (uint32_t)(ni + 64 + 127) << 23;
+    s2.u = (uint32_t)(-64 + 127) << 23;
+    return (y * s1.f) * s2.f;
+}
+
 /* :907-915 */
 void q3o_softmax(float* x, int n) {
+    float mx = x[0];
+    for (int i = 1; i < n; ++i) if (x[i] > mx) mx = x[i];
+    float sum = 0.f;
+    for (int i = 0; i < n; ++i) { x[i] = q3o_expf(x[i] - mx); sum += x[i]; }
+    for (int i = 0; i < n; ++i) x[i] /= sum;
+}
+static void softmax_libm(float* x, int n) {
     float mx = x[0];
     for (int i = 1; i < n; ++i) if (x[i] > mx) mx = x[i];
     float sum = 0.f;
@@ -691,17 +725,24 @@ void q3o_top_p_filter(float* probs, int n, float p) {
     free(idx);
 }
 
-/* :878-905.  NB temperature 0 does NOT mean greedy in the reference (:882 skips the division,
- * sampling proceeds at T=1); greedy is top_k=1.  The final discrete_distribution draw becomes an
- * inverse-CDF walk in index order driven by the supplied uniform u. */
-int64_t q3o_sample(const float* logits, int n, const q3o_sampling* sp, float u) {
+/* The running sums q3o_sample compares against top_p (sorted order, topp_cum[0..n)) and against u * total (index order, draw_cum[i], -1
+ * where p[i] == 0), and total: lets a test aim u or top_p a few ulps to either side of a boundary, where a sampler that sums in
+ * another order would decide differently. */
+void q3o_sample_trace(const float* logits, int n, const q3o_sampling* sp, float* topp_cum, float* draw_cum, float* total_out) {
     float* p = (float*)malloc((size_t)n * sizeof(float));
     memcpy(p, logits, (size_t)n * sizeof(float));
     if (sp->temperature > 0.0f && sp->temperature != 1.0f)
         for (int i = 0; i < n; ++i) p[i] /= sp->temperature;
     if (sp->top_k > 0) q3o_top_k_filter(p, n, sp->top_k);
     q3o_softmax(p, n);
+    for (int i = 0; i < n; ++i) topp_cum[i] = 0.f;
     if (sp->top_p < 1.0f) {
+        pi_t* idx = (pi_t*)malloc((size_t)n * sizeof(pi_t));
+        for (int i = 0; i < n; ++i) { idx[i].p = p[i]; idx[i].i = i; }
+        qsort(idx, n, sizeof(pi_t), cmp_pi);
+        float cum = 0.f;
+        for (int i = 0; i < n; ++i) { cum += idx[i].p; topp_cum[i] = cum; }
+        free(idx);
         q3o_top_p_filter(p, n, sp->top_p);
         float sum = 0.f;
         for (int i = 0; i < n; ++i) sum += p[i];
@@ -709,14 +750,84 @@ int64_t q3o_sample(const float* logits, int n, const q3o_sampling* sp, float u) 
     }
     float total = 0.f;
     for (int i = 0; i < n; ++i) total += p[i];
-    float target = u * total, cum = 0.f;
+    float cum = 0.f;
+    for (int i = 0; i < n; ++i) { if (p[i] > 0.f) { cum += p[i]; draw_cum[i] = cum; } else draw_cum[i] = -1.f; }
+    *total_out = total;
+    free(p);
+}
+
+/* :878-905.  NB temperature 0 does NOT mean greedy in the reference (:882 skips the division,
+ * sampling proceeds at T=1); greedy is top_k=1.  The final discrete_distribution draw becomes an
+ * inverse-CDF walk in index order driven by the supplied uniform u. */
+/* margin (optional): how far the decision was from flipping — the smallest of (a) the gap between the top-k threshold and the largest
+ * logit below it (after temperature), (b) the distance of the top-p cut's two running sums from top_p, (c) the distance of u * total from
+ * the two edges of the drawn element's interval, all relative to a total probability of 1.  A HIP logit that differs from the oracle's
+ * in the 5th digit can legitimately change a decision whose margin is smaller than that. */
+int64_t q3o_sample_margin(const float* logits, int n, const q3o_sampling* sp, float u, float* margin) {
+    float* p = (float*)malloc((size_t)n * sizeof(float));
+    memcpy(p, logits, (size_t)n * sizeof(float));
+    float mg = INFINITY;
+    if (sp->temperature > 0.0f && sp->temperature != 1.0f)
+        for (int i = 0; i < n; ++i) p[i] /= sp->temperature;
+    if (sp->top_k > 0) {
+        if (margin && sp->top_k < n) {
+            float* srt = (float*)malloc((size_t)n * sizeof(float));
+            memcpy(srt, p, (size_t)n * sizeof(float));
+            qsort(srt, n, sizeof(float), cmp_desc);
+            float thr = srt[sp->top_k - 1];
+            for (int i = sp->top_k; i < n; ++i) if (srt[i] < thr) { if (srt[i] != -INFINITY && thr - srt[i] < mg) mg = thr - srt[i]; break; }
+            free(srt);
+        }
+        q3o_top_k_filter(p, n, sp->top_k);
+    }
+    q3o_softmax(p, n);
+    if (sp->top_p < 1.0f) {
+        if (margin) {   /* the running sums on either side of the cut (same order as q3o_top_p_filter) */
+            pi_t* idx = (pi_t*)malloc((size_t)n * sizeof(pi_t));
+            for (int i = 0; i < n; ++i) { idx[i].p = p[i]; idx[i].i = i; }
+            qsort(idx, n, sizeof(pi_t), cmp_pi);
+            float cum = 0.f, prev = 0.f;
+            for (int i = 0; i < n; ++i) {
+                prev = cum; cum += idx[i].p;
+                if (cum > sp->top_p) {
+                    if (cum - sp->top_p < mg) mg = cum - sp->top_p;
+                    if (i > 0 && sp->top_p - prev < mg) mg = sp->top_p - prev;
+                    break;
+                }
+            }
+            free(idx);
+        }
+        q3o_top_p_filter(p, n, sp->top_p);
+        float sum = 0.f;
+        for (int i = 0; i < n; ++i) sum += p[i];
+        if (sum > 0.f) for (int i = 0; i < n; ++i) p[i] /= sum;
+    }
+    float total = 0.f;
+    for (int i = 0; i < n; ++i) total += p[i];
+    float target = u * total, cum = 0.f, prev = 0.f;
     int64_t pick = -1, last = -1;
     for (int i = 0; i < n; ++i) {
-        if (p[i] > 0.f) { last = i; cum += p[i]; if (cum > target) { pick = i; break; } }
+        if (p[i] > 0.f) {
+            last = i; prev = cum; cum += p[i];
+            if (cum > target) {
+                pick = i;
+                if (margin && total > 0.f) {
+                    if ((cum - target) / total < mg) mg = (cum - target) / total;
+                    if (prev > 0.f && (target - prev) / total < mg) mg = (target - prev) / total;
+                }
+                break;
+            }
+        }
     }
     free(p);
+    if (margin) *margin = mg;
     return pick >= 0 ? pick : last;
 }
+
+/* :878-905.  NB temperature 0 does NOT mean greedy in the reference (:882 skips the division,
+ * sampling proceeds at T=1); greedy is top_k=1.  The final discrete_distribution draw becomes an
+ * inverse-CDF walk in index order driven by the supplied uniform u. */
+int64_t q3o_sample(const float* logits, int n, const q3o_sampling* sp, float u) { return q3o_sample_margin(logits, n, sp, u, NULL); }
 
 /* ------------------------------------------------------------------------------------------ */
 /* prompt assembly — tts_onnx.cpp:442-539                                                     */
@@ -795,9 +906,10 @@ static float top2_margin(const float* x, int n) {
     return a - b;
 }
 
-/* margins (optional, [max_new_tokens][2]): per generated frame, the top-2 logit margin of the code0 decision (after suppression, before
- * temperature) and the smallest top-2 margin over the frame's sub-code decisions — the "how close did parity come to flipping"
- * diagnostic of SURVEY.md section 7 (hard parts). */
+/* margins (optional, [max_new_tokens][2 + n_groups]): per generated frame, the top-2 logit margin of the code0 decision (after
+ * suppression, before temperature), the smallest top-2 margin over the frame's sub-code decisions, and the SAMPLER decision margin
+ * (q3o_sample_margin) of each of the frame's n_groups decisions — the "how close did parity come to flipping" diagnostic of SURVEY.md
+ * section 7. */
 static int generate_impl(q3o_model* m, const float* prompt, int S, const q3o_sampling* sp, uint64_t seed, uint32_t stream,
                          int cp_cached, int ignore_eos, int64_t* codes, float* margins) {
     const q3o_config* c = &m->c;
@@ -815,9 +927,10 @@ static int generate_impl(q3o_model* m, const float* prompt, int S, const q3o_sam
         /* suppress 2048..3071 except EOS (:803-807); benchmark mode also suppresses EOS */
         for (int i = c->suppress_begin; i < c->suppress_end; ++i)
             if (i != c->codec_eos || ignore_eos) last[i] = -INFINITY;
-        int64_t code0 = q3o_sample(last, V, sp, q3o_rng_uniform(seed, stream, (uint32_t)step, 0)); /* :810 */
+        float dm = INFINITY, dm1 = INFINITY;
+        int64_t code0 = q3o_sample_margin(last, V, sp, q3o_rng_uniform(seed, stream, (uint32_t)step, 0), margins ? &dm : NULL); /* :810 */
         if (code0 == c->codec_eos) break;                                                          /* :812 */
-        if (margins) { margins[2 * F] = top2_margin(last, V); margins[2 * F + 1] = INFINITY; }
+        if (margins) { margins[(size_t)(2 + G) * F] = top2_margin(last, V); margins[(size_t)(2 + G) * F + 1] = INFINITY; margins[(size_t)(2 + G) * F + 2] = dm; }
         /* predict_subcodes (:851-872): seq = [last_hidden, codec_embed(code0), sub embeds...] */
         int64_t* frame = codes + (size_t)F * G;
         frame[0] = code0;
@@ -827,9 +940,13 @@ static int generate_impl(q3o_model* m, const float* prompt, int S, const q3o_sam
             if (!cp_cached) q3o_code_predictor(m, seq, j + 2, j, sub_logits);                      /* :863 */
             else if (j == 0) cp_cached_step(m, seq, 0, 2, 0, sub_logits);
             else cp_cached_step(m, seq + (size_t)(j + 1) * H, j + 1, j + 2, j, sub_logits);
-            int64_t sc = q3o_sample(sub_logits, SV, sp, q3o_rng_uniform(seed, stream, (uint32_t)step, (uint32_t)(j + 1))); /* :864 */
+            int64_t sc = q3o_sample_margin(sub_logits, SV, sp, q3o_rng_uniform(seed, stream, (uint32_t)step, (uint32_t)(j + 1)), margins ? &dm1 : NULL); /* :864 */
             frame[j + 1] = sc;
-            if (margins) { float mg = top2_margin(sub_logits, SV); if (mg < margins[2 * F + 1]) margins[2 * F + 1] = mg; }
+            if (margins) {
+                float mg = top2_margin(sub_logits, SV);
+                if (mg < margins[(size_t)(2 + G) * F + 1]) margins[(size_t)(2 + G) * F + 1] = mg;
+                margins[(size_t)(2 + G) * F + 3 + j] = dm1;
+            }
             q3o_cp_embed(m, sc, j, seq + (size_t)(j + 2) * H);                                     /* :867-868 */
         }
         ++F;
@@ -1117,7 +1234,7 @@ int q3o_speaker_encoder(q3o_model* m, const float* mel, int T, float* out) {
     for (int ch = 0; ch < C3; ++ch) {
         float* wr = w + (size_t)ch * T;
         const float* x = mf + (size_t)ch * T;
-        q3o_softmax(wr, T);
+        softmax_libm(wr, T);
         float mu = 0.f;
         for (int t = 0; t < T; ++t) mu += wr[t] * x[t];
         float var = 0.f;

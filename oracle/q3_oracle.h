@@ -101,7 +101,13 @@ int q3o_speaker_encoder(q3o_model* m, const float* mel, int frames, float* out);
 /* ---- sampler (tts_onnx.cpp:878-950) with a counter-based RNG instead of mt19937 ---- */
 float q3o_rng_uniform(uint64_t seed, uint32_t stream, uint32_t frame, uint32_t group);
 int64_t q3o_sample(const float* logits, int n, const q3o_sampling* p, float u);
+/* the same, also reporting how far the decision was from flipping (top-k gap, top-p cut, draw edge; relative to total probability 1) */
+int64_t q3o_sample_margin(const float* logits, int n, const q3o_sampling* p, float u, float* margin);
+/* the running sums behind q3o_sample's decisions (top-p: sorted order; draw: index order, -1 where p == 0) and the draw's total */
+void q3o_sample_trace(const float* logits, int n, const q3o_sampling* p, float* topp_cum, float* draw_cum, float* total);
 void q3o_softmax(float* x, int n);
+/* the sampler's exp: IEEE-exact operations only, bit-identical to the HIP sampler's q3_expf */
+float q3o_expf(float x);
 void q3o_top_k_filter(float* x, int n, int k);
 void q3o_top_p_filter(float* probs, int n, float p);
 
@@ -116,7 +122,7 @@ int q3o_generate(q3o_model* m, const float* prompt, int S, const q3o_sampling* p
                  int cp_cached, int ignore_eos, int64_t* codes /*[max_new][G]*/);
 /* the same, also reporting per frame the top-2 logit margin of the code0 decision and the smallest margin over its sub-codes */
 int q3o_generate_margins(q3o_model* m, const float* prompt, int S, const q3o_sampling* p, uint64_t seed, uint32_t stream,
-                         int cp_cached, int ignore_eos, int64_t* codes, float* margins /*[max_new][2]*/);
+                         int cp_cached, int ignore_eos, int64_t* codes, float* margins /*[max_new][2 + n_groups]*/);
 int64_t q3o_synthesize_tokens(q3o_model* m, const int64_t* ids, int n_ids, int lang, const q3o_sampling* p,
                               uint64_t seed, uint32_t stream, float* pcm, int64_t cap, int64_t* codes, int* n_frames);
 

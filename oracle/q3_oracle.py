@@ -325,6 +325,11 @@ def lib():
         L.q3o_sample.restype = C.c_int64
         L.q3o_sample.argtypes = [C.c_void_p, C.c_int, C.POINTER(Sampling), C.c_float]
         L.q3o_softmax.argtypes = [C.c_void_p, C.c_int]
+        L.q3o_sample_trace.argtypes = [C.c_void_p, C.c_int, C.POINTER(Sampling), C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]
+        L.q3o_expf.restype = C.c_float
+        L.q3o_expf.argtypes = [C.c_float]
+        L.q3o_sample_margin.restype = C.c_int64
+        L.q3o_sample_margin.argtypes = [C.c_void_p, C.c_int, C.POINTER(Sampling), C.c_float, C.POINTER(C.c_float)]
         L.q3o_top_k_filter.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.q3o_top_p_filter.argtypes = [C.c_void_p, C.c_int, C.c_float]
         L.q3o_build_prompt.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
@@ -447,6 +452,20 @@ class Oracle:
         a = np.ascontiguousarray(logits, dtype=np.float32)
         return int(self.L.q3o_sample(_p(a), a.size, C.byref(sp), C.c_float(u)))
 
+    def sample_trace(self, logits, sp):
+        """(top-p running sums in sorted order, draw running sums in index order (-1 where p == 0), total): see q3o_sample_trace"""
+        a = np.ascontiguousarray(logits, dtype=np.float32)
+        tc, dc, tot = np.zeros(a.size, np.float32), np.zeros(a.size, np.float32), C.c_float(0)
+        self.L.q3o_sample_trace(_p(a), a.size, C.byref(sp), _p(tc), _p(dc), C.byref(tot))
+        return tc, dc, float(tot.value)
+
+    def sample_margin(self, logits, sp, u):
+        """(token, decision margin): see q3o_sample_margin"""
+        a = np.ascontiguousarray(logits, dtype=np.float32)
+        m = C.c_float(0)
+        t = int(self.L.q3o_sample_margin(_p(a), a.size, C.byref(sp), C.c_float(u), C.byref(m)))
+        return t, float(m.value)
+
     def build_prompt(self, ids, lang=0, speaker=None):
         ids = np.ascontiguousarray(ids, dtype=np.int64)
         prompt = np.zeros((16, self.cfg.hidden), np.float32)
@@ -473,10 +492,11 @@ class Oracle:
         return codes[:F].copy()
 
     def generate_margins(self, prompt, sp, seed=0, stream=0, cp_cached=True, ignore_eos=False):
-        """generate() plus margins [F][2]: top-2 logit margin of each frame's code0 decision, smallest margin over its sub-codes"""
+        """generate() plus margins [F][2 + n_groups]: top-2 logit margin of each frame's code0 decision, smallest top-2 margin over its
+        sub-codes, then the sampler decision margin (top-k gap / top-p cut / draw edge) of each of the frame's decisions"""
         p = np.ascontiguousarray(prompt, dtype=np.float32)
         codes = np.zeros((sp.max_new_tokens, self.cfg.n_groups), np.int64)
-        mg = np.zeros((sp.max_new_tokens, 2), np.float32)
+        mg = np.zeros((sp.max_new_tokens, 2 + self.cfg.n_groups), np.float32)
         F = self._check(self.L.q3o_generate_margins(self.h, _p(p), p.shape[0], C.byref(sp), seed, stream,
                                                     int(cp_cached), int(ignore_eos), _p(codes), _p(mg)))
         return codes[:F].copy(), mg[:F].copy()

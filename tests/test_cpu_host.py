@@ -168,3 +168,39 @@ def test_no_cpu_fallback():
         pytest.skip("GPU present")
     with pytest.raises(RuntimeError, match="no HIP device|q3tts_create failed"):
         q3tts.Engine(q3tts.default_config(), device=0)
+
+
+def test_sampler_exp_is_within_one_ulp_and_fully_specified():
+    """q3o_expf (== the HIP sampler's q3_expf, same operations in the same order) stays within 1 ulp of exp over the range the sampler
+    uses it on (x - max <= 0), underflows to +0 like expf, and is exact at 0."""
+    L = qo.lib()
+    rng = np.random.default_rng(0)
+    xs = np.concatenate([-rng.random(20000) * 104.0, -np.logspace(-8, 2, 500)]).astype(np.float32)
+    got = np.array([L.q3o_expf(float(x)) for x in xs], np.float64)
+    ref = np.exp(xs.astype(np.float64))
+    normal = ref > 1.2e-38
+    ulp = np.spacing(ref[normal].astype(np.float32)).astype(np.float64)
+    assert (np.abs(got[normal] - ref[normal]) / ulp).max() < 1.0
+    assert np.abs(got[~normal] - ref[~normal]).max() < 3e-45
+    assert L.q3o_expf(0.0) == 1.0 and L.q3o_expf(-104.0) == 0.0 and L.q3o_expf(float("-inf")) == 0.0
+
+
+def test_sample_margin_reports_how_close_a_decision_was():
+    """q3o_sample_margin returns q3o_sample's token plus the distance of the decision from flipping (top-k gap / top-p cut / draw edge)."""
+    import q3_oracle as q
+    o_cfg = q.config_tiny()
+    orc = q.Oracle(o_cfg, max_ctx=16, weights=q.random_weights(o_cfg, 0))
+    lg = np.array([0.0, 1.0, 0.5, 0.2], np.float32)
+    sp = q.Sampling(temperature=1.0, top_p=1.0, top_k=0, max_new_tokens=1)
+    p = np.exp(lg - lg.max()); p /= p.sum(); cum = np.cumsum(p)
+    for u in (0.05, 0.3, 0.6, 0.95):
+        tok, m = orc.sample_margin(lg, sp, u)
+        assert tok == orc.sample(lg, sp, u) == int(np.searchsorted(cum, u, side="right"))
+        edges = [abs(cum[tok] - u)] + ([abs(u - cum[tok - 1])] if tok > 0 else [])
+        assert abs(m - min(edges)) < 1e-5, (u, m, edges)
+    # top-k: the gap between the threshold and the best excluded logit bounds the margin
+    sp2 = q.Sampling(temperature=1.0, top_p=1.0, top_k=2, max_new_tokens=1)
+    lg2 = np.array([0.0, 1.0, 0.5, 0.4999], np.float32)
+    _, m2 = orc.sample_margin(lg2, sp2, 0.3)
+    assert m2 <= 1.001e-4
+    orc.close()

@@ -83,3 +83,28 @@ def test_teacher_forced_logits_64_rows_full_size(wide):
         worst = max(worst, float(np.abs(lg - lo).max()), float(np.abs(lh - ho).max()))
     print("teacher-forced 64-row step: max |logit / hidden error| %.3g" % worst)
     assert worst < 2e-4, worst
+
+
+def test_gemm3_slabs_are_bit_identical_to_gemm2(wide):
+    """k_gemm3 (straight-line K chunks, pinned fragment reads, LDS-transposed stores) performs the same operations on the same operands
+    in the same order as the second-generation kernel it replaces: with Q3TTS_GEMM2=1 (the A/B knob) the same engine must produce
+    bit-identical logits after a batched prefill + one 64-row step, and identical codes over 6 frames."""
+    import os
+    import q3tts
+    eng, _, toks = wide
+    sp = q3tts.Sampling(temperature=0.8, top_p=0.95, top_k=50, max_new_tokens=6)
+    _, codes3, _ = eng.synthesize_batch(toks, sp, seed=21, ignore_eos=True)
+    lg3 = [eng.slot_logits(u) for u in (0, 17, 63)]
+    os.environ["Q3TTS_GEMM2"] = "1"
+    try:
+        e2 = q3tts.Engine(eng.cfg, device=0, max_batch=64, max_ctx=64)     # a fresh engine: its step graph is captured with the old kernel
+        e2.fill_synthetic(seed=0)
+        _, codes2, _ = e2.synthesize_batch(toks, sp, seed=21, ignore_eos=True)
+        lg2 = [e2.slot_logits(u) for u in (0, 17, 63)]
+        e2.close()
+    finally:
+        del os.environ["Q3TTS_GEMM2"]
+    for u in range(64):
+        assert np.array_equal(codes3[u], codes2[u]), u
+    for (a, ah), (b, bh) in zip(lg3, lg2):
+        assert np.array_equal(a, b) and np.array_equal(ah, bh)

@@ -67,30 +67,62 @@ def test_greedy_generation_full_size(full):
     assert np.array_equal(codes, again)            # deterministic, slot-independent
 
 
-@pytest.mark.parametrize("sampled", [False, True])
-def test_free_running_160_frames_full_size(full, sampled):
-    """0.6B dims, 160 FREE-RUNNING frames = 2560 codec decisions on one utterance (configs[1] sampling when `sampled`, configs[0] greedy
-    otherwise): ids bit-exact vs the oracle (KV-cached predictor), with the talker context growing from 8 to 168 tokens — across the
-    first 128-token attention split of the fused step.  Reports what SURVEY.md section 7 asks for: the first divergence index (none
-    expected) and the smallest top-2 logit margins the run came across (how close parity came to flipping).
+def test_free_running_160_frames_greedy_full_size(full):
+    """0.6B dims, 160 FREE-RUNNING greedy frames (configs[0] sampling: top_k = 1) = 2560 codec decisions on one utterance: ids bit-exact
+    vs the oracle (KV-cached predictor), with the talker context growing from 8 to 168 tokens — across the first 128-token attention
+    split of the fused step.  Reports what SURVEY.md section 7 asks for: the first divergence index (none expected) and the smallest
+    top-2 logit margins the run came across (how close parity came to flipping; the HIP logits sit within ~3e-5 of the oracle's).
     Reference loop: /root/reference/src/tts_onnx.cpp:782-872, sampler :878-950."""
     import q3tts
     eng, orc = full
     F = 160
     ids = frame_tokens(np.random.default_rng(4).integers(0, 151643, 16))
-    kw = dict(temperature=0.8, top_p=0.95, top_k=50) if sampled else dict(temperature=1.0, top_p=1.0, top_k=1)
-    sp = q3tts.Sampling(max_new_tokens=F, **kw)
+    sp = q3tts.Sampling(max_new_tokens=F, temperature=1.0, top_p=1.0, top_k=1)
     p, t = eng.build_prompt(ids, 0)
     codes = eng.generate(p, t, sp, seed=5, stream_id=2, ignore_eos=True)
     ref, mg = orc.generate_margins(orc.build_prompt(ids, 0), to_osampling(sp), seed=5, stream=2, cp_cached=True, ignore_eos=True)
     assert codes.shape == ref.shape == (F, 16)
     bad = np.argwhere(codes != ref)
     first = "none" if bad.size == 0 else "frame %d group %d" % (bad[0][0], bad[0][1])
-    print("free-running %s, %d frames: first divergence %s; min top-2 margin code0 %.3g (frame %d), sub-codes %.3g (frame %d); "
+    print("free-running greedy, %d frames: first divergence %s; min top-2 margin code0 %.3g (frame %d), sub-codes %.3g (frame %d); "
           "frames past the 128-token split: %d"
-          % ("sampled" if sampled else "greedy", F, first, float(mg[:, 0].min()), int(mg[:, 0].argmin()), float(mg[:, 1].min()),
-             int(mg[:, 1].argmin()), F - (128 - 8)))
+          % (F, first, float(mg[:, 0].min()), int(mg[:, 0].argmin()), float(mg[:, 1].min()), int(mg[:, 1].argmin()), F - (128 - 8)))
     assert bad.size == 0, (first, bad[:4].tolist())
+
+
+NOISE = 2e-4    # bound asserted on |HIP logit - oracle logit| by the teacher-forced tests (measured: 2-3e-5)
+
+
+@pytest.mark.parametrize("seed", [5, 6, 7])
+def test_free_running_sampled_margin_aware_full_size(full, seed):
+    """0.6B dims, configs[1] sampling (temp 0.8 / top-k 50 / top-p 0.95), 160 free-running frames.  A sampled decision compares running
+    probability sums with u and top_p; two correct fp32 implementations whose logits differ in the 5th digit legitimately part at a
+    decision whose margin is below that noise — and from then on the streams are different utterances.  Up to the first differing code
+    both sides are in the same state, so exactly one decision has to be explained: the test requires the ORACLE's margin of that
+    decision (q3o_sample_margin: top-k gap, top-p cut, distance of u * total from the drawn interval's edges) to be under NOISE; a
+    divergence at a comfortable margin is a bug.  The sampler itself is exact by construction (test_sampler_vs_oracle,
+    test_sampler_on_decision_boundaries) and greedy runs never part (test_free_running_160_frames_greedy_full_size).
+    SURVEY.md section 7: margin-aware comparison, first-divergence report."""
+    import q3tts
+    eng, orc = full
+    F = 160
+    ids = frame_tokens(np.random.default_rng(4).integers(0, 151643, 16))
+    sp = q3tts.Sampling(max_new_tokens=F, temperature=0.8, top_p=0.95, top_k=50)
+    p, t = eng.build_prompt(ids, 0)
+    codes = eng.generate(p, t, sp, seed=seed, stream_id=2, ignore_eos=True)
+    ref, mg = orc.generate_margins(orc.build_prompt(ids, 0), to_osampling(sp), seed=seed, stream=2, cp_cached=True, ignore_eos=True)
+    assert codes.shape == ref.shape == (F, 16)
+    dm = mg[:, 2:]                                   # [F][16] decision margins
+    bad = np.argwhere(codes != ref)
+    if bad.size == 0:
+        print("free-running sampled seed %d: %d frames bit-exact (%d decisions; smallest decision margin %.3g)" % (seed, F, F * 16, float(dm.min())))
+        return
+    f, g = int(bad[0][0]), int(bad[0][1])
+    print("free-running sampled seed %d: %d frames + %d decisions bit-exact, first divergence at frame %d group %d where the oracle's "
+          "decision margin is %.3g (noise bound %.0e); smallest margin of the matching decisions before it %.3g"
+          % (seed, f, g, f, g, float(dm[f, g]), NOISE, float(np.concatenate([dm[:f].ravel(), dm[f, :g]]).min()) if f + g else float("nan")))
+    assert float(dm[f, g]) < NOISE, "ids differ at frame %d group %d although the oracle's decision margin there is %g" % (f, g, float(dm[f, g]))
+    assert np.array_equal(codes[:f], ref[:f]) and np.array_equal(codes[f, :g], ref[f, :g])
 
 
 def test_fused_predictor_attention_matches_separate_launches(full):
