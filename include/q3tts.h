@@ -216,6 +216,11 @@ int q3tts_counters(q3tts_engine* e, double* decode_ms, int64_t* decode_steps, do
  * events at the stage boundaries.  out_ms[0] sampler (n_groups launches), [1] code predictor (layer passes + heads; predict_subcodes,
  * tts_onnx.cpp:851-872), [2] talker decode (layers + codec head; run_decode :667-732), [3] their sum — milliseconds per step. */
 int q3tts_stage_profile(q3tts_engine* e, int n_steps, double* out_ms /* [4] */);
+/* Parity aid: ONE eager decode step of the armed slots (they advance like q3tts_decode_steps(1)) that also returns, for `slot`, the
+ * logits row each of the frame's n_groups decisions was sampled from — out[n_groups][cols], cols >= max(vocab, sub_vocab); row 0 the
+ * code0 logits (run_decode's output, before suppression), row j the code predictor's logits for sub-code j-1 (run_code_predictor,
+ * tts_onnx.cpp:734-757).  Lets a test compare every head of the fused step with the oracle at a chosen frame. */
+int q3tts_step_logits_host(q3tts_engine* e, int slot, float* out, int cols);
 /* algorithmic bytes one decode step streams (weights + KV at the slots' current contexts) */
 int q3tts_decode_step_bytes(q3tts_engine* e, double* weight_bytes, double* kv_bytes);
 

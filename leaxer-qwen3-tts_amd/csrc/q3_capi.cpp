@@ -488,6 +488,13 @@ int q3tts_stage_profile(q3tts_engine* h, int n_steps, double* out_ms) {
     return 0;
     Q3_API_END(h)
 }
+int q3tts_step_logits_host(q3tts_engine* h, int slot, float* out, int cols) {
+    Q3_API_BEGIN(h)
+    if (!out) throw q3::Error("step_logits: null output");
+    h->e->step_logits(slot, out, cols);
+    return 0;
+    Q3_API_END(h)
+}
 int q3tts_decode_step_bytes(q3tts_engine* h, double* wb, double* kvb) {
     Q3_API_BEGIN(h) h->e->step_bytes(wb, kvb); return 0; Q3_API_END(h)
 }

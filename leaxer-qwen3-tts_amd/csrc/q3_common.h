@@ -163,6 +163,7 @@ static_assert(sizeof(SlotState) == 64, "SlotState must be 64 bytes");
 struct SampleArgs {
     const float* logits = nullptr; // [nb][ld]
     int ld = 0, V = 0, nb = 0;
+    int nslab = 1; size_t slab_stride = 0; // > 1: the logits are the sum of that many split-K partial slabs (batched predictor heads), summed in slab order
     int sup_begin = 0, sup_end = 0, eos_id = -1; // suppress [sup_begin,sup_end) except eos_id (group 0 only)
     int group = 0, n_groups = 0;
     SlotState* st = nullptr;       // [nb]; null -> standalone mode (params below, token_out)

@@ -1225,13 +1225,53 @@ static __device__ __forceinline__ int draw_small(float e, int id, int nk, float 
     const float target = u * total;
     const float cum = wave_scan_incl_f(p);
     amb = amb || __ballot(p > 0.f && fabsf(cum - target) <= 1e-4f * total) != 0ull;
-    if (!amb) {
+    if (__builtin_expect(!amb, 1)) {
         const unsigned long long hit = __ballot(p > 0.f && cum > target);
         const unsigned long long pos = __ballot(p > 0.f);
         const int pick = hit ? __ffsll((long long)hit) - 1 : (pos ? 63 - __clzll((long long)pos) : 0);
         return lane_bcast_i(id, pick);
     }
     return draw_small_exact(e, id, nk, top_p, u, lane, sb);
+}
+
+// draw_small for candidates that arrive sorted by (logit desc, index asc), one per lane, the kept ones in lanes [0, nk) — the order the
+// fast path's threshold sort leaves them in, which is also the top-p order (p is monotone in the logit; two different logits whose
+// probabilities collide are covered by the neighbour test at the cut).  One more sort (by index) instead of two.
+static __device__ __forceinline__ int draw_sorted(float v, int id, int nk, float mx, float top_p, float u, int lane, float (*sb)[64]) {
+    const bool kept = lane < nk;
+    const float e = kept ? q3_expf(v - mx) : 0.f;                              // softmax numerators over the kept entries (:907-915)
+    const float Sa = wave_sum(e);
+    float p = e / Sa;
+    bool amb = false;
+    if (top_p < 1.0f) {
+        const float cs = wave_scan_incl_f(p);
+        const unsigned long long over = __ballot(kept && cs > top_p);
+        const int rcut = over ? __ffsll((long long)over) - 1 : 63;
+        amb = __ballot(kept && fabsf(cs - top_p) <= 4e-5f) != 0ull;
+        const float pcut = lane_bcast(p, rcut), pnext = lane_bcast(p, rcut < 63 ? rcut + 1 : 63);
+        amb = amb || (rcut + 1 < nk && pnext >= pcut * (1.0f - 1e-5f));
+        p = lane <= rcut ? p : 0.f;
+        const float s2 = wave_sum(p);
+        if (s2 > 0.f) p = p / s2;
+    }
+    // index order for the draw: sort by index, pull (p, index) along with a backward permute
+    float key = kept ? -(float)id : -INFINITY;
+    int from = lane;
+    wave_sort_desc_kv(key, from, lane);
+    const float pi = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(from << 2, __builtin_bit_cast(int, p)));
+    const int idi = __builtin_amdgcn_ds_bpermute(from << 2, id);
+    const float total = wave_sum(pi);
+    const float target = u * total;
+    const float cum = wave_scan_incl_f(pi);
+    amb = amb || __ballot(pi > 0.f && fabsf(cum - target) <= 1e-4f * total) != 0ull;
+    if (__builtin_expect(!amb, 1)) {   // the left-fold evaluation is the cold path: laid out behind the quick one
+        const unsigned long long hit = __ballot(pi > 0.f && cum > target);
+        const unsigned long long pos = __ballot(pi > 0.f);
+        const int pick = hit ? __ffsll((long long)hit) - 1 : (pos ? 63 - __clzll((long long)pos) : 0);
+        return lane_bcast_i(idi, pick);
+    }
+    const float ei = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(from << 2, __builtin_bit_cast(int, e)));
+    return draw_small_exact(ei, idi, nk, top_p, u, lane, sb);
 }
 
 // k-th largest of one value per lane (ties allowed), -inf when fewer than k lanes hold a finite value: the wave sorts its 64
@@ -1252,6 +1292,7 @@ static __device__ __forceinline__ float kth_largest_of_lanes(float v, int k) {
 #else
 #define SP_MARK(k) do { } while (0)
 #endif
+template <bool SLABS>   // SLABS: the logits row is the ordered sum of a.nslab (<= 4) split-K partial slabs of the head projection
 __global__ __launch_bounds__(256) void k_sample(const float* plogits, SlotState* pst, int pld, int pV, SampleArgs a) {   // leading scalars: preloaded (see k_gemv1)
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1284,10 +1325,28 @@ __global__ __launch_bounds__(256) void k_sample(const float* plogits, SlotState*
     const float* lg = plogits + (size_t)b * pld;
     const int PER = (V + 63) / 64;               // 64-element slices in the row
     float x[SAMP_PERW];
+    if (SLABS) {   // every load first (clamped slab index: a load under a runtime condition is a serial round trip), then the sums in slab order
+        float xp[SAMP_PERW][4];
 #pragma unroll
-    for (int jj = 0; jj < SAMP_PERW; ++jj) {
-        const int i = (jj * 4 + wave) * 64 + lane;
-        x[jj] = lg[i < V ? i : V - 1];           // clamped, unconditional
+        for (int jj = 0; jj < SAMP_PERW; ++jj) {
+            const int i = (jj * 4 + wave) * 64 + lane;
+#pragma unroll
+            for (int sb = 0; sb < 4; ++sb) xp[jj][sb] = lg[(size_t)(sb < a.nslab ? sb : 0) * a.slab_stride + (i < V ? i : V - 1)];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int jj = 0; jj < SAMP_PERW; ++jj) {
+            float t = xp[jj][0];
+#pragma unroll
+            for (int sb = 1; sb < 4; ++sb) t = sb < a.nslab ? t + xp[jj][sb] : t;
+            x[jj] = t;
+        }
+    } else {
+#pragma unroll
+        for (int jj = 0; jj < SAMP_PERW; ++jj) {
+            const int i = (jj * 4 + wave) * 64 + lane;
+            x[jj] = lg[i < V ? i : V - 1];           // clamped, unconditional
+        }
     }
     __builtin_amdgcn_sched_barrier(0);
     if (st) {
@@ -1360,22 +1419,14 @@ __global__ __launch_bounds__(256) void k_sample(const float* plogits, SlotState*
                 const bool kept = lane < n && v >= thrf;
                 const int nk = __popcll(__ballot(kept));
                 SP_MARK(5);
-                // index order first: the reference's sums (softmax denominator, renormalisation, the draw's running sum) walk the kept
-                // entries in index order — sort by index, pull (logit, index) along with a backward permute
-                float key = kept ? -(float)id : -INFINITY;
-                int from = lane;
-                wave_sort_desc_kv(key, from, lane);
-                const float vi = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(from << 2, __builtin_bit_cast(int, v)));
-                const int idi = __builtin_amdgcn_ds_bpermute(from << 2, id);
-                const float e = lane < nk ? q3_expf(vi - mxf) : 0.f;                  // softmax numerators over the kept entries (:907-915)
                 SP_MARK(6);
-                tok = draw_small(e, idi, nk, top_p, u, lane, sb);
+                tok = draw_sorted(v, id, nk, mxf, top_p, u, lane, sb);   // lanes [0, nk) are the kept ones: the sort put them first
                 SP_MARK(7);
                 if (lane == 0) sh_i[3] = tok;
             }
         }
     }
-    if (!fast_done) {   // top_k == 1, 0 or > 64, or more than 64 survivors (mass ties): the general machinery
+    if (__builtin_expect(!fast_done, 0)) {   // top_k == 1, 0 or > 64, or more than 64 survivors (mass ties): the general machinery
         gmax[wave][lane] = lmax;
         __syncthreads();
         // 64 group maxima (group = lane, over all four waves) -> global max and the prefilter bound
@@ -1595,7 +1646,9 @@ __global__ __launch_bounds__(256) void k_sample(const float* plogits, SlotState*
 
 void launch_sample(const SampleArgs& a, hipStream_t s) {
     if (a.V > SAMP_MAXV) throw Error("sample: vocabulary larger than 4096");
-    hipLaunchKernelGGL(k_sample, dim3(a.nb), dim3(256), 0, s, a.logits, a.st, a.ld, a.V, a);
+    if (a.nslab < 1 || a.nslab > 4) throw Error("sample: 1..4 logits slabs");
+    if (a.nslab > 1) hipLaunchKernelGGL(k_sample<true>, dim3(a.nb), dim3(256), 0, s, a.logits, a.st, a.ld, a.V, a);
+    else hipLaunchKernelGGL(k_sample<false>, dim3(a.nb), dim3(256), 0, s, a.logits, a.st, a.ld, a.V, a);
 }
 
 // ================================================================================================

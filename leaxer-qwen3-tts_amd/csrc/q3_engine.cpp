@@ -230,6 +230,7 @@ Engine::Engine(const q3tts_config& cfg, int device_, int max_batch, int max_ctx_
     act = fm((size_t)rows_max * std::max(c.ffn, c.cp_ffn));
     logits_t = fm((size_t)B * c.vocab);
     logits_cp = fm((size_t)B * c.sub_vocab);
+    cp_logit_slab_d = fm((size_t)4 * B * c.sub_vocab);
     x_cp = fm((size_t)B * 2 * H);
     x_cp1 = fm((size_t)B * H);
     if (cp_projected()) x_cpp = fm((size_t)std::max(rows_max, 16) * Hc);
@@ -517,8 +518,8 @@ bool Engine::run_layers(const DecStack& W, float* x, int ldx, int nb, int n_new,
 }
 
 // final RMSNorm + output head (codec_head / cp.head.j); optionally keeps the normalised rows
-void Engine::head_proj(const bf16_t* Wm, const float* x, int ldx, const float* gamma, float eps, float* xn_out, int ld_xn,
-                       float* out, int ldo, int M, int N, int K, bool nt, bool planes_ready, int plane_row0, int plane_row_stride) {
+int Engine::head_proj(const bf16_t* Wm, const float* x, int ldx, const float* gamma, float eps, float* xn_out, int ld_xn,
+                      float* out, int ldo, int M, int N, int K, bool nt, bool planes_ready, int plane_row0, int plane_row_stride, float* slab_out) {
     if (planes_ready || (M >= mfma_min_rows && K % 128 == 0 && K <= 4096)) {
         if (!planes_ready) {
             launch_finish(const_cast<float*>(x), ldx, nullptr, 0, 0, 0, gamma, eps, M, K, pl0h, pl0l, ldp, xn_out, ld_xn, stream);
@@ -527,13 +528,21 @@ void Engine::head_proj(const bf16_t* Wm, const float* x, int ldx, const float* g
         GemmArgs g;
         g.W = Wm; g.xh = pl0h + (size_t)plane_row0 * ldp; g.xl = pl0l + (size_t)plane_row0 * ldp; g.ldx = ldp * plane_row_stride;
         g.out = out; g.ldo = ldo; g.M = M; g.N = N; g.K = K; g.epi = EPI_STORE;
+        // a head of N columns is N / 64 workgroups walking all of K (32 for the predictor's 2048 columns: 14.8 us per launch at 64 rows);
+        // with the consumer summing 4 K slices it is 4x the workgroups on a quarter of the bytes each
+        if (slab_out != nullptr && M <= 128 && (K == 512 || K == 1024) && ldo % 4 == 0 && !getenv("Q3TTS_NO_HEAD_SLABS")) {
+            g.out = slab_out; g.epi = EPI_SLAB; g.slab_rows = M;
+            launch_gemm2(g, 4, 4, stream);
+            return 4;
+        }
         launch_gemm2(g, 1, 4, stream);
-        return;
+        return 1;
     }
     GemvArgs g;
     g.W = Wm; g.x = x; g.ldx = ldx; g.gamma = gamma; g.eps = eps; g.xn_out = xn_out; g.ld_xn = ld_xn;
     g.out = out; g.ldo = ldo; g.M = M; g.N = N; g.K = K; g.epi = EPI_STORE; g.nt = nt;
     launch_gemv(g, stream);
+    return 1;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -756,6 +765,7 @@ void Engine::record_step(int nb) {
     size_t mk = 0;
     auto mark = [&]() { if (!stage_ev.empty()) Q3_HIP_CHECK(hipEventRecord(stage_ev[mk++], stream)); };
     mark();
+    if (trace_d) launch_copy_rows(logits_t + (size_t)trace_slot * V, V, trace_d, trace_cols, 1, V, stream);
     launch_sample(s0, stream);                                  // code0 (tts_onnx.cpp:803-812)
     mark();
     for (int j = 0; j < G - 1; ++j) {                           // predict_subcodes (:851-872), KV-cached
@@ -765,11 +775,16 @@ void Engine::record_step(int nb) {
         if (j == 0) pr = run_layers(cp, xin, Hc, nb, 2, 0, nullptr, 0, cp_norm, c.cp_rms_eps);
         else pr = run_layers(cp, xin, Hc, nb, 1, 0, nullptr, j + 1, cp_norm, c.cp_rms_eps);
         // head j on the last row of every utterance (pass 0 holds two rows per utterance: planes row b*2+1)
-        head_proj(cp_head[j], j == 0 ? xin + Hc : xin, j == 0 ? 2 * Hc : Hc, cp_norm, c.cp_rms_eps, nullptr, 0, logits_cp, SV, nb, SV, Hc, false,
-                  pr, j == 0 ? 1 : 0, j == 0 ? 2 : 1);
+        const int nsl = head_proj(cp_head[j], j == 0 ? xin + Hc : xin, j == 0 ? 2 * Hc : Hc, cp_norm, c.cp_rms_eps, nullptr, 0, logits_cp, SV, nb, SV, Hc, false,
+                                  pr, j == 0 ? 1 : 0, j == 0 ? 2 : 1, cp_logit_slab_d);
         mark();
+        if (trace_d) {
+            if (nsl > 1) throw Error("step_logits: run it on a batch below the split-K head threshold");
+            launch_copy_rows(logits_cp + (size_t)trace_slot * SV, SV, trace_d + (size_t)(j + 1) * trace_cols, trace_cols, 1, SV, stream);
+        }
         SampleArgs s = s0;
-        s.logits = logits_cp; s.ld = SV; s.V = SV; s.group = j + 1; s.embed = cp_embed_w[j];
+        s.logits = nsl > 1 ? cp_logit_slab_d : logits_cp; s.nslab = nsl; s.slab_stride = (size_t)nb * SV;
+        s.ld = SV; s.V = SV; s.group = j + 1; s.embed = cp_embed_w[j];
         s.x_next = j + 1 < G - 1 ? x_cp1 : nullptr; s.ld_xnext = H;
         launch_sample(s, stream);
         mark();
@@ -807,6 +822,22 @@ void Engine::stage_profile(int n_steps, double* out) {
     stage_ev.clear();
     for (int k = 0; k < 3; ++k) out[k] = acc[k] / n_steps;
     out[3] = out[0] + out[1] + out[2];
+}
+
+void Engine::step_logits(int slot, float* out, int cols) {
+    if (!finalized) throw Error("weights not finalized");
+    const int nb = nb_in_use(), G = c.n_groups;
+    if (nb == 0 || slot < 0 || slot >= nb) throw Error("step_logits: slot not armed");
+    if (cols < std::max(c.vocab, c.sub_vocab)) throw Error("step_logits: row buffer too narrow");
+    float* buf = nullptr;
+    Q3_HIP_CHECK(hipMalloc((void**)&buf, (size_t)G * cols * sizeof(float)));
+    Q3_HIP_CHECK(hipMemsetAsync(buf, 0, (size_t)G * cols * sizeof(float), stream));
+    trace_d = buf; trace_slot = slot; trace_cols = cols;
+    try { record_step(nb); sync(); } catch (...) { trace_d = nullptr; (void)hipFree(buf); throw; }
+    trace_d = nullptr;
+    hipError_t e = hipMemcpy(out, buf, (size_t)G * cols * sizeof(float), hipMemcpyDeviceToHost);
+    (void)hipFree(buf);
+    Q3_HIP_CHECK(e);
 }
 
 int Engine::nb_in_use() const {

@@ -109,6 +109,10 @@ public:
     void slot_release(int slot);
     void step_bytes(double* wbytes, double* kvbytes);
     void stage_profile(int n_steps, double* out_ms4);   // eager steps with events at the stage boundaries (diagnostic)
+    // one EAGER step of the armed slots that also keeps, for slot `slot`, the logits row every one of the frame's n_groups decisions was
+    // sampled from (out: [n_groups][cols], cols >= max(vocab, sub_vocab)); the slots advance like decode_steps(1)
+    void step_logits(int slot, float* out, int cols);
+    float* trace_d = nullptr; int trace_slot = 0, trace_cols = 0;
     std::vector<hipEvent_t> stage_ev;
 
     float last_decode_ms = 0.f;
@@ -170,6 +174,7 @@ public:
     int ldp = 0;
     float* slab_d = nullptr; // split-K partial sums [ks][rows][H]
     float* gu_slab_d = nullptr;  // gate | up split-K partial sums, 2 x [<=4][rows][ffn]
+    float* cp_logit_slab_d = nullptr; // split-K partial sums of the batched predictor heads [4][B][sub_vocab]: the sampler sums them
     float* qkv_slab_d = nullptr; // split-K partial sums of the QKV projection [<=4][rows][QKV]
     int32_t* codes_d = nullptr;
     int32_t* codes_scratch_d = nullptr;
@@ -191,8 +196,11 @@ public:
                     const float* final_gamma = nullptr, float final_eps = 0.f, float* final_xn = nullptr, int final_ld_xn = 0,
                     const int* slot_map = nullptr);   // slot_map (device, nb ints): row group bi belongs to slot slot_map[bi]
     void record_step(int nb);
-    void head_proj(const bf16_t* Wm, const float* x, int ldx, const float* gamma, float eps, float* xn_out, int ld_xn,
-                   float* out, int ldo, int M, int N, int K, bool nt, bool planes_ready = false, int plane_row0 = 0, int plane_row_stride = 1);
+    // returns the number of split-K slabs `out` was written as (1: plain rows).  slab_out non-null: the caller's consumer can sum slabs
+    // ([nslab][M][ldo] at slab_out), which lets a 17..128-row head split K over 4x the workgroups
+    int head_proj(const bf16_t* Wm, const float* x, int ldx, const float* gamma, float eps, float* xn_out, int ld_xn,
+                  float* out, int ldo, int M, int N, int K, bool nt, bool planes_ready = false, int plane_row0 = 0, int plane_row_stride = 1,
+                  float* slab_out = nullptr);
     int nb_in_use() const;
     void sync();
 };

@@ -348,6 +348,10 @@ static void gemm3_go(const GemmArgs& a, int ksplit, hipStream_t s) {
     const dim3 grid((a.N + 63) / 64, ksplit), block(256);
     const int nch = a.K / ksplit / G3_CH;
     constexpr int LA4 = MTILES <= 4 ? 4 : 2;
+    // activation chunks two ahead (default) or all four at once (Q3TTS_GEMM3_LA=4, the A/B knob): issuing 24-32 loads per lane before the
+    // first ds_write keeps the wave in its issue queue for ~2.5 us (the CU takes ~50 GB/s); two ahead measured 5.49 vs 5.63 ms per b=64 step
+    static const bool la2 = !(getenv("Q3TTS_GEMM3_LA") && atoi(getenv("Q3TTS_GEMM3_LA")) == 4);
+    if (nch == 4 && la2) { hipLaunchKernelGGL((k_gemm3<MTILES, EPI, 4, 2>), grid, block, 0, s, a.W, a.W2, a.xh, a.xl, a.ldx, a.M, a.N, a.K, a); return; }
     if (nch == 2) hipLaunchKernelGGL((k_gemm3<MTILES, EPI, 2, 2>), grid, block, 0, s, a.W, a.W2, a.xh, a.xl, a.ldx, a.M, a.N, a.K, a);
     else hipLaunchKernelGGL((k_gemm3<MTILES, EPI, 4, LA4>), grid, block, 0, s, a.W, a.W2, a.xh, a.xl, a.ldx, a.M, a.N, a.K, a);
 }

@@ -85,7 +85,7 @@ EXPORTS = [
     "q3tts_tokenizer_ready", "q3tts_tokenize",
     "q3tts_synthesize_clone_batch_host", "q3tts_synthesize_schedule_host", "q3tts_read_wav_host", "q3tts_resample_host", "q3tts_mel_host",
     "q3tts_has_speaker_encoder", "q3tts_speaker_encoder_host", "q3tts_extract_speaker_embedding_host",
-    "q3tts_codec_decode_chunked_host", "q3tts_slot_codec_decode_range_host", "q3tts_slot_logits_host",
+    "q3tts_codec_decode_chunked_host", "q3tts_slot_codec_decode_range_host", "q3tts_slot_logits_host", "q3tts_step_logits_host",
 ]
 
 _lib = None
@@ -132,6 +132,7 @@ def lib():
     L.q3tts_slot_codec_decode_host.argtypes = [vp, i32, vp, i64, C.POINTER(i64)]
     L.q3tts_slot_release.argtypes = [vp, i32]
     L.q3tts_slot_logits_host.argtypes = [vp, i32, vp, vp]
+    L.q3tts_step_logits_host.argtypes = [vp, i32, vp, i32]
     L.q3tts_synthesize_batch_host.argtypes = [vp, i32, vp, vp, i32, C.POINTER(Sampling), C.c_uint64, i32,
                                               vp, i64, vp, vp, vp]
     L.q3tts_last_decode_ms.argtypes = [vp, C.POINTER(f32), C.POINTER(i32)]
@@ -374,6 +375,13 @@ class Engine:
         lh = np.empty(self.cfg.hidden, np.float32)
         self._ck(self.L.q3tts_slot_logits_host(self.h, slot, _p(lg), _p(lh)))
         return lg, lh
+
+    def step_logits(self, slot):
+        """one eager decode step; returns [n_groups][max(vocab, sub_vocab)]: the logits row behind each of the frame's decisions of `slot`"""
+        cols = max(self.cfg.vocab, self.cfg.sub_vocab)
+        out = np.zeros((self.cfg.n_groups, cols), np.float32)
+        self._ck(self.L.q3tts_step_logits_host(self.h, slot, _p(out), cols))
+        return out
 
     def slot_codec_decode(self, slot):
         nf, _ = self.slot_status(slot)

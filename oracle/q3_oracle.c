@@ -761,7 +761,8 @@ void q3o_sample_trace(const float* logits, int n, const q3o_sampling* sp, float*
  * inverse-CDF walk in index order driven by the supplied uniform u. */
 /* margin (optional): how far the decision was from flipping — the smallest of (a) the gap between the top-k threshold and the largest
  * logit below it (after temperature), (b) the distance of the top-p cut's two running sums from top_p, (c) the distance of u * total from
- * the two edges of the drawn element's interval, all relative to a total probability of 1.  A HIP logit that differs from the oracle's
+ * the two edges of the drawn element's interval, (d) the relative probability gap between the last element the top-p cut keeps and the
+ * first it drops, all relative to a total probability of 1.  A HIP logit that differs from the oracle's
  * in the 5th digit can legitimately change a decision whose margin is smaller than that. */
 int64_t q3o_sample_margin(const float* logits, int n, const q3o_sampling* sp, float u, float* margin) {
     float* p = (float*)malloc((size_t)n * sizeof(float));
@@ -792,6 +793,9 @@ int64_t q3o_sample_margin(const float* logits, int n, const q3o_sampling* sp, fl
                 if (cum > sp->top_p) {
                     if (cum - sp->top_p < mg) mg = cum - sp->top_p;
                     if (i > 0 && sp->top_p - prev < mg) mg = sp->top_p - prev;
+                    /* (d) WHICH element is the last one kept: the relative gap to the first one dropped (~ their logit gap); if they swap
+                     * places the cut keeps a different token, and every running sum behind it in index order moves by a whole probability */
+                    if (i + 1 < n && idx[i + 1].p > 0.f) { float gap = (idx[i].p - idx[i + 1].p) / idx[i + 1].p; if (gap < mg) mg = gap; }
                     break;
                 }
             }
@@ -910,6 +914,11 @@ static float top2_margin(const float* x, int n) {
  * suppression, before temperature), the smallest top-2 margin over the frame's sub-code decisions, and the SAMPLER decision margin
  * (q3o_sample_margin) of each of the frame's n_groups decisions — the "how close did parity come to flipping" diagnostic of SURVEY.md
  * section 7. */
+/* debugging aid for the parity tests: the logits row of ONE decision (frame, group) of the next q3o_generate* call */
+static int g_dump_frame = -1, g_dump_group = -1;
+static float* g_dump_buf = NULL;
+void q3o_set_logits_dump(int frame, int group, float* buf) { g_dump_frame = frame; g_dump_group = group; g_dump_buf = buf; }
+
 static int generate_impl(q3o_model* m, const float* prompt, int S, const q3o_sampling* sp, uint64_t seed, uint32_t stream,
                          int cp_cached, int ignore_eos, int64_t* codes, float* margins) {
     const q3o_config* c = &m->c;
@@ -928,6 +937,7 @@ static int generate_impl(q3o_model* m, const float* prompt, int S, const q3o_sam
         for (int i = c->suppress_begin; i < c->suppress_end; ++i)
             if (i != c->codec_eos || ignore_eos) last[i] = -INFINITY;
         float dm = INFINITY, dm1 = INFINITY;
+        if (g_dump_buf && F == g_dump_frame && g_dump_group == 0) memcpy(g_dump_buf, last, (size_t)V * sizeof(float));
         int64_t code0 = q3o_sample_margin(last, V, sp, q3o_rng_uniform(seed, stream, (uint32_t)step, 0), margins ? &dm : NULL); /* :810 */
         if (code0 == c->codec_eos) break;                                                          /* :812 */
         if (margins) { margins[(size_t)(2 + G) * F] = top2_margin(last, V); margins[(size_t)(2 + G) * F + 1] = INFINITY; margins[(size_t)(2 + G) * F + 2] = dm; }
@@ -940,6 +950,7 @@ static int generate_impl(q3o_model* m, const float* prompt, int S, const q3o_sam
             if (!cp_cached) q3o_code_predictor(m, seq, j + 2, j, sub_logits);                      /* :863 */
             else if (j == 0) cp_cached_step(m, seq, 0, 2, 0, sub_logits);
             else cp_cached_step(m, seq + (size_t)(j + 1) * H, j + 1, j + 2, j, sub_logits);
+            if (g_dump_buf && F == g_dump_frame && g_dump_group == j + 1) memcpy(g_dump_buf, sub_logits, (size_t)SV * sizeof(float));
             int64_t sc = q3o_sample_margin(sub_logits, SV, sp, q3o_rng_uniform(seed, stream, (uint32_t)step, (uint32_t)(j + 1)), margins ? &dm1 : NULL); /* :864 */
             frame[j + 1] = sc;
             if (margins) {

@@ -103,6 +103,8 @@ float q3o_rng_uniform(uint64_t seed, uint32_t stream, uint32_t frame, uint32_t g
 int64_t q3o_sample(const float* logits, int n, const q3o_sampling* p, float u);
 /* the same, also reporting how far the decision was from flipping (top-k gap, top-p cut, draw edge; relative to total probability 1) */
 int64_t q3o_sample_margin(const float* logits, int n, const q3o_sampling* p, float u, float* margin);
+/* debugging aid: the next q3o_generate* call copies the logits row of decision (frame, group) into buf (NULL: off) */
+void q3o_set_logits_dump(int frame, int group, float* buf);
 /* the running sums behind q3o_sample's decisions (top-p: sorted order; draw: index order, -1 where p == 0) and the draw's total */
 void q3o_sample_trace(const float* logits, int n, const q3o_sampling* p, float* topp_cum, float* draw_cum, float* total);
 void q3o_softmax(float* x, int n);

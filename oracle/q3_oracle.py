@@ -325,6 +325,7 @@ def lib():
         L.q3o_sample.restype = C.c_int64
         L.q3o_sample.argtypes = [C.c_void_p, C.c_int, C.POINTER(Sampling), C.c_float]
         L.q3o_softmax.argtypes = [C.c_void_p, C.c_int]
+        L.q3o_set_logits_dump.argtypes = [C.c_int, C.c_int, C.c_void_p]
         L.q3o_sample_trace.argtypes = [C.c_void_p, C.c_int, C.POINTER(Sampling), C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]
         L.q3o_expf.restype = C.c_float
         L.q3o_expf.argtypes = [C.c_float]
@@ -451,6 +452,13 @@ class Oracle:
     def sample(self, logits, sp, u):
         a = np.ascontiguousarray(logits, dtype=np.float32)
         return int(self.L.q3o_sample(_p(a), a.size, C.byref(sp), C.c_float(u)))
+
+    def dump_logits_of(self, frame, group, n):
+        """the next generate*() call copies the logits row of decision (frame, group) into the returned array (debugging aid)"""
+        buf = np.zeros(n, np.float32)
+        self._dump_keep = buf
+        self.L.q3o_set_logits_dump(int(frame), int(group), _p(buf))
+        return buf
 
     def sample_trace(self, logits, sp):
         """(top-p running sums in sorted order, draw running sums in index order (-1 where p == 0), total): see q3o_sample_trace"""
