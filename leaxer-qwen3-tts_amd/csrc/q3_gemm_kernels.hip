@@ -606,15 +606,17 @@ __global__ __launch_bounds__(256) void k_finish(float* x, int ldx, const float* 
     __shared__ float red[4];
     const int m = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float* xr = x + (size_t)m * ldx;
-    float4 v[4]; // K <= 4096
+    float4 v[4], gv[4]; // K <= 4096
     float ss = 0.f;
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
         int k = (it * 256 + threadIdx.x) * 4;
+        gv[it] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (it * 1024 >= K) { v[it] = make_float4(0.f, 0.f, 0.f, 0.f); continue; }   // workgroup-uniform
         const bool inr = k < K;
         k = inr ? k : K - 4;
         float4 t = *reinterpret_cast<const float4*>(xr + k);
+        gv[it] = *reinterpret_cast<const float4*>((gamma != nullptr ? gamma : xr) + k);   // with the slabs, not behind the block barrier: one memory round per launch (address select, no conditional load)
         float4 p[NS > 0 ? NS : 1];
 #pragma unroll
         for (int sidx = 0; sidx < NS; ++sidx) {
@@ -639,7 +641,7 @@ __global__ __launch_bounds__(256) void k_finish(float* x, int ldx, const float* 
     for (int it = 0; it < 4; ++it) {
         const int k = (it * 256 + threadIdx.x) * 4;
         if (k < K) {
-            const float4 g = *reinterpret_cast<const float4*>(gamma + k);
+            const float4 g = gv[it];
             const float y[4] = { g.x * (v[it].x * r), g.y * (v[it].y * r), g.z * (v[it].z * r), g.w * (v[it].w * r) };
             split_store4(y, oh + (size_t)m * ldp + k, ol + (size_t)m * ldp + k);
             if (xn_out) *reinterpret_cast<float4*>(xn_out + (size_t)m * ld_xn + k) = make_float4(y[0], y[1], y[2], y[3]);
@@ -659,7 +661,9 @@ void launch_finish(float* x, int ldx, const float* slab, int nslab, size_t slab_
 __global__ __launch_bounds__(256) void k_finish_swiglu(const float* gs, const float* us, int nslab, size_t slab_stride, int N,
                                                         bf16_t* oh, bf16_t* ol, int ldp) {
     const int m = blockIdx.x;
-    for (int n0 = threadIdx.x * 4; n0 < N; n0 += 1024) {
+    // blockIdx.y = 1024-column chunk of the row: one memory round per workgroup (a loop over the chunks ran them back to back, three
+    // dependent round trips per launch at ffn = 3072)
+    for (int n0 = (blockIdx.y * 256 + threadIdx.x) * 4; n0 < N; n0 += 1024 * gridDim.y) {
         float4 pg[4], pu[4];   // split-K of gate/up is at most 4 (Engine::run_layers): every load first, sums in slab order
 #pragma unroll
         for (int sidx = 0; sidx < 4; ++sidx) {
@@ -682,7 +686,7 @@ __global__ __launch_bounds__(256) void k_finish_swiglu(const float* gs, const fl
 void launch_finish_swiglu(const float* gs, const float* us, int nslab, size_t slab_stride, int rows, int N,
                           bf16_t* oh, bf16_t* ol, int ldp, hipStream_t s) {
     if (N % 4 || nslab < 1 || nslab > 4) throw Error("finish_swiglu: N must be a multiple of 4 and 1 <= nslab <= 4");
-    if (rows > 0) hipLaunchKernelGGL(k_finish_swiglu, dim3(rows), dim3(256), 0, s, gs, us, nslab, slab_stride, N, oh, ol, ldp);
+    if (rows > 0) hipLaunchKernelGGL(k_finish_swiglu, dim3(rows, (N + 1023) / 1024), dim3(256), 0, s, gs, us, nslab, slab_stride, N, oh, ol, ldp);
 }
 
 } // namespace q3

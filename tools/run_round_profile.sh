@@ -1,44 +1,60 @@
 set -e
-# Round-end evidence run on the GPU box: tests, bench lines, eager kernel trace summary, PMC traffic.  Heavy rocprof outputs are
+# Round-end evidence run on the GPU box: tests, bench lines, eager kernel trace summaries, PMC traffic.  Heavy rocprof outputs are
 # reduced to summaries and deleted (gpurun copies back at most 64 MiB).  Usage: bash tools/run_round_profile.sh [tag] [--skip-tests]
-TAG=${1:-r01f}
+# Modes (second argument): main = tests, bench lines, kernel traces, codec; pmc = the rocprofv3 --pmc passes + the default bench line that quotes
+# them.  The counter passes run LAST and in a call of their own: rocprofv3 --pmc has hung on this image (a WRITE_SIZE pass over 24 eager
+# steps sat in hipStreamSynchronize until its timeout), and after a killed GPU step nothing else should run in the same call.
+TAG=${1:-r02}
+MODE=${2:-main}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && mkdir -p gpurun_out/$TAG
-# 1. full GPU test suite
-if [ "$2" != "--skip-tests" ]; then timeout -k 10 1000 python -m pytest tests -m gpu -x -q --timeout 600 2>&1 | tail -3 | tee gpurun_out/$TAG/gpu_tests.log; fi
-# 2. headline bench (with cpu baseline) + b=64
-timeout -k 10 600 python bench.py > gpurun_out/$TAG/bench_b1.json 2> gpurun_out/$TAG/bench_b1.err
-cat gpurun_out/$TAG/bench_b1.json
-timeout -k 10 600 python bench.py --batch 64 --frames 256 --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/$TAG/bench_b64.json 2> gpurun_out/$TAG/bench_b64.err
-cat gpurun_out/$TAG/bench_b64.json
-timeout -k 10 600 python bench.py --batch 8 --frames 256 --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/$TAG/bench_b8.json 2> gpurun_out/$TAG/bench_b8.err
-cat gpurun_out/$TAG/bench_b8.json
-timeout -k 10 600 python bench.py --model 1.7b --batch 8 --frames 256 --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/$TAG/bench_1p7b_b8.json 2> gpurun_out/$TAG/bench_1p7b_b8.err
-cat gpurun_out/$TAG/bench_1p7b_b8.json
-# 3. kernel trace (eager) of the b=1 workload, 1024 frames
-rocprofv3 --kernel-trace --stats -d gpurun_out/$TAG/trace_b1 -o b1 -- python bench.py --frames 1024 --steps 1 --warmup 0 --no-cpu-baseline --no-graph > gpurun_out/$TAG/trace_b1.log 2>&1
-python tools/rocpd_summary.py gpurun_out/$TAG/trace_b1/b1_results.db 40 > gpurun_out/$TAG/decode_b1_f1024_eager_by_grid.txt
-head -20 gpurun_out/$TAG/decode_b1_f1024_eager_by_grid.txt
-rm -rf gpurun_out/$TAG/trace_b1
-# 3a. the batched decode steps (b=8: k_gemv16 family, b=64: k_gemm2 + finish), 48 frames each
-for BB in 8 64; do
-  rocprofv3 --kernel-trace --stats -d gpurun_out/$TAG/trace_b$BB -o b -- python bench.py --batch $BB --frames 48 --steps 1 --warmup 0 --no-cpu-baseline --no-graph > gpurun_out/$TAG/trace_b$BB.log 2>&1
-  python tools/rocpd_summary.py gpurun_out/$TAG/trace_b$BB/b_results.db 30 > gpurun_out/$TAG/decode_b${BB}_f48_eager_by_grid.txt
-  rm -rf gpurun_out/$TAG/trace_b$BB
+O=gpurun_out/$TAG
+if [ "$MODE" = "pmc" ]; then
+# PMC traffic, separate passes, eager steps on the default stream; two step counts so that the prefill cancels in the difference
+for B in 1 64; do
+  if [ $B = 1 ]; then S1=6; S2=12; else S1=4; S2=8; fi
+  for S in $S1 $S2; do
+    Q3TTS_NULL_STREAM=1 timeout -k 10 90 rocprofv3 --pmc FETCH_SIZE -d $O/pmc_f_${B}_$S -o f --output-format csv -- tools/pmc_bisect $S $B > $O/pmc_fetch.log 2>&1
+    Q3TTS_NULL_STREAM=1 timeout -k 10 90 rocprofv3 --pmc WRITE_SIZE -d $O/pmc_w_${B}_$S -o w --output-format csv -- tools/pmc_bisect $S $B > $O/pmc_write.log 2>&1
+  done
+  python tools/pmc_traffic.py --batch $B --fetch $(ls $O/pmc_f_${B}_$S1/*/f_counter_collection.csv $O/pmc_f_${B}_$S1/f_counter_collection.csv 2>/dev/null | head -1) --write $(ls $O/pmc_w_${B}_$S1/*/w_counter_collection.csv $O/pmc_w_${B}_$S1/w_counter_collection.csv 2>/dev/null | head -1) --frames $S1 \
+      --fetch2 $(ls $O/pmc_f_${B}_$S2/*/f_counter_collection.csv $O/pmc_f_${B}_$S2/f_counter_collection.csv 2>/dev/null | head -1) --write2 $(ls $O/pmc_w_${B}_$S2/*/w_counter_collection.csv $O/pmc_w_${B}_$S2/w_counter_collection.csv 2>/dev/null | head -1) --frames2 $S2 \
+      --merge-into $O/decode_step_traffic.json > $O/pmc_traffic_b$B.json
+  cat $O/pmc_traffic_b$B.json
+  rm -rf $O/pmc_f_${B}_* $O/pmc_w_${B}_*
 done
-# 3b. codec decoder alone, 2048 frames
-rocprofv3 --kernel-trace --stats -d gpurun_out/$TAG/trace_codec -o c -- python tools/codec_bench.py --reps 2 > gpurun_out/$TAG/codec_bench.log 2>&1
-python tools/rocpd_summary.py gpurun_out/$TAG/trace_codec/c_results.db 45 > gpurun_out/$TAG/codec_f2048_by_grid.txt
-rm -rf gpurun_out/$TAG/trace_codec
-grep frames= gpurun_out/$TAG/codec_bench.log
-# 4. PMC traffic, separate passes, 12 eager steps on the default stream
-Q3TTS_NULL_STREAM=1 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE -d gpurun_out/$TAG/pmc_fetch -o f --output-format csv -- tools/pmc_bisect 12 > gpurun_out/$TAG/pmc_fetch.log 2>&1
-Q3TTS_NULL_STREAM=1 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE -d gpurun_out/$TAG/pmc_write -o w --output-format csv -- tools/pmc_bisect 12 > gpurun_out/$TAG/pmc_write.log 2>&1
-ls gpurun_out/$TAG/pmc_fetch gpurun_out/$TAG/pmc_write
-python tools/pmc_traffic.py gpurun_out/$TAG/pmc_fetch/f_counter_collection.csv gpurun_out/$TAG/pmc_write/w_counter_collection.csv 12 1 > gpurun_out/$TAG/pmc_traffic_b1.json
-cat gpurun_out/$TAG/pmc_traffic_b1.json
-rm -rf gpurun_out/$TAG/pmc_fetch gpurun_out/$TAG/pmc_write
+cp $O/decode_step_traffic.json profiles/decode_step_traffic.json   # on the box only: the committed copy is made from gpurun_out/ afterwards
+timeout -k 10 600 python bench.py > $O/bench_default_with_traffic.json 2> $O/bench_default_with_traffic.err
+python -c "import json;j=json.load(open('$O/bench_default_with_traffic.json'));print('b1', j['value'], j['roofline']['frac'], j['roofline']['traffic'], '| b64', j['b64']['value'], j['b64']['roofline']['traffic'])"
+exit 0
+fi
+# 1. full GPU test suite
+if [ "$3" != "--skip-tests" ]; then timeout -k 10 1000 python -m pytest tests -m gpu -x -q --timeout 600 -s > $O/gpu_tests.log 2>&1 || true; grep -E "passed|failed|free-running|teacher" $O/gpu_tests.log | tail -8; fi
+# 2. headline bench (configs[1] + the b64 sub-record + cpu baseline), then b=8 and 1.7B b=8
+timeout -k 10 600 python bench.py > $O/bench_default.json 2> $O/bench_default.err
+python -c "import json;j=json.load(open('$O/bench_default.json'));print('b1', j['value'], j['decode_ms_per_frame_step'], j['roofline']['frac'], '| b64', j['b64']['value'], j['b64']['decode_ms_per_frame_step'], j['b64']['roofline']['frac'], '| cpu', j['cpu_baseline']['value'])"
+timeout -k 10 600 python bench.py --batch 8 --frames 256 --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_b8.json 2> $O/bench_b8.err
+timeout -k 10 600 python bench.py --model 1.7b --batch 8 --frames 256 --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_1p7b_b8.json 2> $O/bench_1p7b_b8.err
+timeout -k 10 600 python bench.py --batch 128 --frames 256 --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_b128.json 2> $O/bench_b128.err
+python -c "import json;print(*[(t, json.load(open('$O/bench_%s.json' % t))['value']) for t in ('b8','1p7b_b8','b128')])"
+# 3. kernel traces (eager launches: rocprofv3 cannot trace hipGraphLaunch on this ROCm): b=1 x 1024 frames, b=8 / b=64 x 48 frames
+rocprofv3 --kernel-trace --stats -d $O/trace_b1 -o b1 -- python bench.py --frames 1024 --steps 1 --warmup 0 --no-cpu-baseline --no-graph --no-b64 > $O/trace_b1.log 2>&1
+python tools/rocpd_summary.py $O/trace_b1/b1_results.db 40 > $O/decode_b1_f1024_eager_by_grid.txt
+head -14 $O/decode_b1_f1024_eager_by_grid.txt
+rm -rf $O/trace_b1
+for BB in 8 64; do
+  rocprofv3 --kernel-trace --stats -d $O/trace_b$BB -o b -- python bench.py --batch $BB --frames 48 --steps 1 --warmup 0 --no-cpu-baseline --no-graph > $O/trace_b$BB.log 2>&1
+  python tools/rocpd_summary.py $O/trace_b$BB/b_results.db 30 > $O/decode_b${BB}_f48_eager_by_grid.txt
+  rm -rf $O/trace_b$BB
+done
+head -22 $O/decode_b64_f48_eager_by_grid.txt
+# 3b. codec decoder alone, 2048 frames + short utterances
+rocprofv3 --kernel-trace --stats -d $O/trace_codec -o c -- python tools/codec_bench.py --reps 2 > $O/codec_bench.log 2>&1
+python tools/rocpd_summary.py $O/trace_codec/c_results.db 45 > $O/codec_f2048_by_grid.txt
+rm -rf $O/trace_codec
+for FF in 25 64 256 2048; do python tools/codec_bench.py --frames $FF --reps 3 | grep frames= >> $O/codec_sizes.txt; done
+cat $O/codec_sizes.txt
 # 5. matrix-core issue rate of the codec decoder from hardware counters (SQ_INSTS_VALU_MFMA_MOPS_*: FLOP / 512), default stream
-Q3TTS_NULL_STREAM=1 timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_VALU_MFMA_MOPS_F32 -d gpurun_out/$TAG/pmc_mfma -o m --output-format csv -- python tools/codec_bench.py --frames 2048 --reps 1 > gpurun_out/$TAG/pmc_mfma.log 2>&1
-python tools/pmc_mfma.py gpurun_out/$TAG/pmc_mfma/m_counter_collection.csv 4096 > gpurun_out/$TAG/pmc_mfma_codec.json
-cat gpurun_out/$TAG/pmc_mfma_codec.json
-rm -rf gpurun_out/$TAG/pmc_mfma
+Q3TTS_NULL_STREAM=1 timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_VALU_MFMA_MOPS_F32 -d $O/pmc_mfma -o m --output-format csv -- python tools/codec_bench.py --frames 2048 --reps 1 > $O/pmc_mfma.log 2>&1
+python tools/pmc_mfma.py $(ls $O/pmc_mfma/*/m_counter_collection.csv $O/pmc_mfma/m_counter_collection.csv 2>/dev/null | head -1) 4096 > $O/pmc_mfma_codec.json || true
+cat $O/pmc_mfma_codec.json
+rm -rf $O/pmc_mfma
