@@ -307,9 +307,23 @@ int64_t Engine::codec_run(const int32_t* codes_dev, int F, float** pcm_dev, int 
               a.out2 = ns; a.snake_alpha = B.res[0].a1.alpha; a.snake_beta = B.res[0].a1.beta; conv(a); }
             for (int u = 0; u < 3; ++u) {
                 const CodecW::Res& R = B.res[u];
+                const SnakeP nxt = u < 2 ? B.res[u + 1].a1 : (i + 1 < c.cd_n_blocks ? W.blocks[i + 1].act : W.snake_out);
+                // 96-channel block: the whole residual unit (7-tap conv, SnakeBeta, 1x1 conv, + x) in one launch — the intermediate stays in
+                // the CU (k_conv_split<..., F2>): 4 activation passes through HBM instead of 6, one launch instead of two.  The unit reads
+                // snake(x) with a tap halo reaching into its neighbours' rows, so the next layer's snake(x') goes to the OTHER buffer
+                // (ns <-> nt); x itself is updated in place (every element is read and written by the same thread).
+                const auto p2 = W.planes.find(R.c2.w);
+                if (Co == 96 && p2 != W.planes.end() && W.planes.count(R.c1.w) && !getenv("Q3TTS_NO_FUSED_RES")) {
+                    ConvArgs a; a.in = ns; a.T_in = To; a.C_in = Co; a.out = nx; a.T_out = To; a.C_out = Co; a.W = R.c1.w; a.bias = R.c1.b;
+                    a.taps = 7; a.dil = dil[u]; a.mid_alpha = R.a2.alpha; a.mid_beta = R.a2.beta;
+                    a.W2 = R.c2.w; a.W2h = p2->second.hi; a.W2l = p2->second.lo; a.w2_scale_inv = p2->second.scale_inv; a.bias2 = R.c2.b;
+                    a.res = nx; a.out2 = nt; a.snake_alpha = nxt.alpha; a.snake_beta = nxt.beta;
+                    conv(a);
+                    std::swap(ns, nt);
+                    continue;
+                }
                 { ConvArgs a; a.in = ns; a.T_in = To; a.C_in = Co; a.out = nullptr; a.T_out = To; a.C_out = Co; a.W = R.c1.w; a.bias = R.c1.b;
                   a.taps = 7; a.dil = dil[u]; a.out2 = nt; a.snake_alpha = R.a2.alpha; a.snake_beta = R.a2.beta; conv(a); }
-                const SnakeP nxt = u < 2 ? B.res[u + 1].a1 : (i + 1 < c.cd_n_blocks ? W.blocks[i + 1].act : W.snake_out);
                 { ConvArgs a; a.in = nt; a.T_in = To; a.C_in = Co; a.out = nx; a.T_out = To; a.C_out = Co; a.W = R.c2.w; a.bias = R.c2.b;
                   a.taps = 1; a.res = nx; a.out2 = ns; a.snake_alpha = nxt.alpha; a.snake_beta = nxt.beta; conv(a); }
             }

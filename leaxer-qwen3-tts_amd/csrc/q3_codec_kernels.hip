@@ -60,6 +60,8 @@ struct ConvKArgs {
     int ksplit; float* slab;            // k_conv_split, 1-tap GEMMs: blockIdx.z = K slice, raw partial sums -> slab[z][T_out][C_out] (k_conv_finish)
     int batch_tiles;                    // > 0: blockIdx.x = sequence * batch_tiles + row tile; sequences are in_ustride / T_out * C_out floats apart
     size_t in_ustride;
+    // fused residual unit (k_conv_split<..., F2 = true>): second (1x1) conv behind a SnakeBeta on the first conv's output
+    const bf16_t* W2h; const bf16_t* W2l; float acc_scale2; const float* bias2; const float* s1_alpha; const float* s1_beta;
 };
 
 // batched launch: rebase the sequence-shaped pointers to this workgroup's sequence and return its row-tile index
@@ -277,7 +279,7 @@ static __device__ __forceinline__ void split_epilogue_block(const ConvKArgs& a, 
 
 // KC = C_in columns per staged chunk (32, or 128 for the short-and-wide GEMMs of the pre-transformer, whose few workgroups walk K
 // serially: a chunk costs one memory latency whatever its size, so 4x wider chunks are 4x fewer latencies); NBUF = weight-tile buffers.
-template <int MB, int NB, int WM, int WN, int PA, int KC = 32, int NBUF = 2>
+template <int MB, int NB, int WM, int WN, int PA, int KC = 32, int NBUF = 2, bool F2 = false>
 // <= 96 accumulator registers and 32-column chunks: two workgroups per CU (256 registers each); otherwise ONE wave per SIMD with the
 // whole 512-register file — said explicitly, or hipcc still budgets 256 and spills the prefetch registers right behind their loads
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MB * NB <= 6 && KC == 32 ? 2 : 1), (MB * NB <= 6 && KC == 32 ? 2 : 1))))
@@ -409,6 +411,87 @@ void k_conv_split(ConvKArgs a0) {
     CP_MARK(62);
     __syncthreads();                                          // the staging slices below overlay the operand tiles
     float* stage = reinterpret_cast<float*>(smem) + wave * 32 * (NB * 32 + 8);
+    if constexpr (F2) {
+        // ---- fused residual unit: t = SnakeBeta(conv1 + bias) never leaves the CU.  A 1x1 conv needs, for a wave's 32 time rows, those
+        // same 32 rows of t and nothing else: each wave turns its accumulator block into (hi, lo) fp16 planes in its OWN LDS slice (the
+        // bytes its epilogue staging uses afterwards), multiplies them with the 96 x 96 weight planes (B fragments straight from
+        // global: 36 KB, L1 / L2 resident) and runs the ordinary epilogue (bias2, residual, SnakeBeta for the next layer) on the result.
+        // No block barrier past this point.  TN == C_out == the whole channel range (grid.y == 1).
+        static_assert(WN == 1 && KC == 32, "fused residual unit: one column tile, 32-wide chunks");
+        constexpr int C2 = NB * 32, TLD = C2 + 8;
+        _Float16* ts = reinterpret_cast<_Float16*>(stage);                       // [2][32][TLD] halves == 32 x (C2 + 8) floats: the wave's slice
+        const int col0 = lane & 31, rsel = lane >> 5;
+        float b1[NB], ea1[NB], ib1[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int co = j * 32 + col0;
+            b1[j] = a.bias ? a.bias[co] : 0.f;
+            ea1[j] = expf(a.s1_alpha[co]);
+            ib1[j] = 1.0f / (expf(a.s1_beta[co]) + 0.000000001f);
+        }
+        const float sc1 = a.acc_scale;
+        a.bias = a.bias2; a.acc_scale = a.acc_scale2;          // from here on `a` describes the second conv's epilogue (no struct copy: it would live in scratch)
+        // statically indexed row blocks (a rolled loop over i gives the accumulators a scratch home that the main loop keeps in sync)
+        auto unit = [&](auto itag) {
+            constexpr int i = decltype(itag)::value;
+            // accumulator layout: column = lane & 31 (+ 32 j), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int row = (reg & 3) + 8 * (reg >> 2) + 4 * rsel;
+                    const float v = acc[i][j][reg] * sc1 + b1[j];
+                    const float t = v + ib1[j] * sin_sq(v * ea1[j]);
+                    const float h = f16_hi_of(t);
+                    ts[row * TLD + j * 32 + col0] = (_Float16)h;
+                    ts[(32 + row) * TLD + j * 32 + col0] = (_Float16)f16_hi_of(t - h);
+                }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            f32x16 acc2[NB];
+#pragma unroll
+            for (int j = 0; j < NB; ++j) acc2[j] = zero16;
+            // weight fragments one k-step ahead, pinned: left alone hipcc hoists all 36 loads (144 registers) above the loop and spills
+            f16x8 wbh[2][NB], wbl[2][NB];
+            auto loadW = [&](int buf, int st) {
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    const size_t wo = (size_t)(j * 32 + col0) * C2 + st * 16 + 8 * rsel;   // weight row = output channel, [C_out][C_in] with C_in == C2
+                    wbh[buf][j] = *reinterpret_cast<const f16x8*>(reinterpret_cast<const _Float16*>(a.W2h) + wo);
+                    wbl[buf][j] = *reinterpret_cast<const f16x8*>(reinterpret_cast<const _Float16*>(a.W2l) + wo);
+                }
+            };
+            loadW(0, 0);
+#pragma unroll
+            for (int st = 0; st < C2 / 16; ++st) {
+                if (st + 1 < C2 / 16) loadW((st + 1) & 1, st + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                const int kof = st * 16 + 8 * rsel;
+                const f16x8 ah = *reinterpret_cast<const f16x8*>(&ts[col0 * TLD + kof]);
+                const f16x8 al = *reinterpret_cast<const f16x8*>(&ts[(32 + col0) * TLD + kof]);
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, wbh[st & 1][j], acc2[j], 0, 0, 0);
+                    acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wbl[st & 1][j], acc2[j], 0, 0, 0);
+                    acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wbh[st & 1][j], acc2[j], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();                                     // the plane reads are done: the same bytes become the epilogue's staging
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            split_epilogue_block<NB>(a, acc2, stage, m0 + wm * MB * 32 + i * 32, co0, lane, 0, NT);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        };
+        unit(std::integral_constant<int, 0>{});
+        if constexpr (MB > 1) unit(std::integral_constant<int, MB - 1>{});
+        static_assert(MB <= 2, "fused residual unit: at most two row blocks per wave");
+        CP_MARK(63);
+        return;
+    }
     // statically indexed row blocks (a rolled loop would give the accumulators a scratch home that the main loop keeps in sync)
     if constexpr (KC == 128) {
         if (ksp) {   // raw partial sums of this K slice; bias / activation / residual belong to k_conv_finish
@@ -534,6 +617,7 @@ void launch_conv(const ConvArgs& c, hipStream_t s) {
     a.Wh = c.Wh; a.Wl = c.Wl;
     a.acc_scale = 1.0f;
     a.ksplit = 0; a.slab = nullptr; a.batch_tiles = 0;
+    a.W2h = nullptr; a.W2l = nullptr; a.acc_scale2 = 1.0f; a.bias2 = nullptr; a.s1_alpha = nullptr; a.s1_beta = nullptr;
     a.in_ustride = c.in_ustride ? c.in_ustride : (size_t)c.T_in * c.C_in;
     const int nb = c.batch > 1 ? c.batch : 1;
     if (c.transposed && c.taps % c.stride != 0) throw Error("conv: transposed kernel must be a multiple of the stride");
@@ -552,6 +636,19 @@ void launch_conv(const ConvArgs& c, hipStream_t s) {
     }
     const int NTt = c.transposed ? c.taps / c.stride : c.taps;
     const int halo = c.transposed ? NTt - 1 : (c.taps - 1) * c.dil;
+    if (c.W2h != nullptr) {   // fused residual unit: 7-tap conv -> SnakeBeta -> 1x1 conv -> + residual, 96 channels, 256-row tiles
+        if (!(c.Wh && c.Wl && c.W2l && c.C_in == 96 && c.C_out == 96 && !c.transposed && halo <= 64 && c.mid_alpha && c.mid_beta && c.res && !c.res_scale && !c.clamp && c.act == 0 && !c.mul))
+            throw Error("conv: fused residual unit needs 96 -> 96 channels on the split-precision path");
+        a.acc_scale = c.w_scale_inv;
+        a.W2h = c.W2h; a.W2l = c.W2l; a.acc_scale2 = c.w2_scale_inv; a.bias2 = c.bias2; a.s1_alpha = c.mid_alpha; a.s1_beta = c.mid_beta;
+        const int extra = (halo + 31) / 32, tiles = (rows + 255) / 256;
+        if (nb > 1) a.batch_tiles = tiles;
+        const dim3 g((unsigned)(tiles * nb), 1, 1);
+        if (extra <= 1) hipLaunchKernelGGL((k_conv_split<2, 3, 4, 1, 9, 32, 2, true>), g, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((k_conv_split<2, 3, 4, 1, 10, 32, 2, true>), g, dim3(256), 0, s, a);
+        Q3_HIP_CHECK(hipGetLastError());
+        return;
+    }
     if (c.Wh && c.Wl && c.C_in % 32 == 0 && c.C_out >= 32 && c.C_out % 4 == 0 && halo <= 64 && !c.clamp) {   // fp16 hi/lo split path
         a.acc_scale = c.w_scale_inv;
         const int extra = (halo + 31) / 32, z = c.transposed ? c.stride : 1;

@@ -214,6 +214,10 @@ struct ConvArgs { // out[t][co] = epi(bias[co] + sum_{tap,ci} W[tap][co][ci] * i
     const float* snake_alpha = nullptr;
     const float* snake_beta = nullptr;
     float* slab = nullptr; size_t slab_floats = 0; // optional scratch for split-K partial sums of short 1-tap GEMMs ([slice][T_out][C_out])
+    // fused residual unit (96-channel decoder block): out = res + bias2 + W2 . snake_mid(bias + W . in) — the 7-tap conv, the SnakeBeta
+    // between, the 1x1 conv and the residual add in ONE launch; the intermediate never leaves the CU.  W2 = the 1x1 conv's [1][C_out][C_out]
+    const float* W2 = nullptr; const bf16_t* W2h = nullptr; const bf16_t* W2l = nullptr; float w2_scale_inv = 1.0f;
+    const float* bias2 = nullptr; const float* mid_alpha = nullptr; const float* mid_beta = nullptr;
     int batch = 1;               // independent sequences of the same shape: sequence u at in + u * in_ustride, out / out2 / res / mul at + u * T_out * C_out
     size_t in_ustride = 0;       // floats between the sequences' inputs (0: T_in * C_in, i.e. densely packed)
 };
