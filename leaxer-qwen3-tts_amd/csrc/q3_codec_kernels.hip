@@ -34,6 +34,17 @@ static __device__ __forceinline__ float silu2_f(float x) { return x / (1.0f + ex
 // sin(x)^2 for SnakeBeta: three-term FMA reduction by pi/2 (exact products; good to |x| ~ 1e5, far past anything a*x reaches here),
 // then the fdlibm single-precision kernels on [-pi/4, pi/4]; the quadrant only picks sine or cosine since the square drops the sign.
 // ~25 instructions instead of libm sinf's ~65 (the snake is evaluated 5e9 times per 2048-frame utterance); within 2 ulp of it.
+// Q3_SIN_SQ_EXACT (build knob): the 25-instruction evaluation below.  Default: the hardware's v_sin_f32 on the fractional number of
+// revolutions (4 instructions).  The snake's VALU work had become the bound of the fused residual unit (two SnakeBeta evaluations per
+// output element: 34k VALU cycles per tile against 28k matrix-core cycles); PCM error vs the fp32 oracle with the hardware sine is
+// measured by tests/test_gpu_full.py::test_codec_split_precision_matrix_path_full_size (budget 1e-4 RMS; the exact-fp32 codec,
+// Q3TTS_FLAG_FP32_CODEC, keeps libm's sinf).
+#ifndef Q3_SIN_SQ_EXACT
+static __device__ __forceinline__ float sin_sq(float x) {
+    const float s = __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(x * 0.15915494309189535f));   // sin(2 pi frac(x / 2 pi))
+    return s * s;
+}
+#else
 static __device__ __forceinline__ float sin_sq(float x) {
     const float kf = rintf(x * 0.63661977236758134308f);
     float r = fmaf(-kf, 1.57079637050628662109375f, x);
@@ -45,6 +56,7 @@ static __device__ __forceinline__ float sin_sq(float x) {
     const float v = ((int)kf & 1) ? cp : sp;
     return v * v;
 }
+#endif
 
 struct ConvKArgs {
     const float* in; int T_in, C_in;
