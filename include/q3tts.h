@@ -65,6 +65,13 @@ typedef struct q3tts_engine q3tts_engine;
 /* ---- lifecycle (replaces TTSEngine ctor / load_model, tts_onnx.cpp:84-232) ---- */
 int q3tts_default_config(const char* name /* "0.6b" | "1.7b" */, q3tts_config* out);
 q3tts_engine* q3tts_create(const q3tts_config* cfg, int device, int max_batch, int max_ctx, uint32_t flags);
+/* The same with a bounded KV page pool.  The talker's cache (the reference's KVCache, tts_onnx.h:108-115, grown by one token per run_decode)
+ * is a pool of 64-token pages; a slot takes pages for prompt + max_new_tokens when it is armed (q3tts_slot_begin / the scheduler) or as its
+ * context grows (q3tts_talker_prefill_host / q3tts_talker_decode_host) and returns them at q3tts_slot_release.  kv_pool_tokens = 0 sizes the
+ * pool for max_batch x max_ctx (q3tts_create); a smaller pool admits as many utterances as fit — the scheduler keeps the rest queued,
+ * q3tts_slot_begin fails with "KV page pool exhausted" and arms nothing. */
+q3tts_engine* q3tts_create_pooled(const q3tts_config* cfg, int device, int max_batch, int max_ctx, int64_t kv_pool_tokens, uint32_t flags);
+int q3tts_kv_pool_info(q3tts_engine* e, int* page_tokens, int* total_pages, int* free_pages);
 void q3tts_destroy(q3tts_engine* e);
 const char* q3tts_last_error(q3tts_engine* e); /* e may be NULL: error of the last failed create */
 

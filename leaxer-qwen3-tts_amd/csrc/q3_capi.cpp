@@ -74,6 +74,10 @@ int q3tts_config_tensor_info(const q3tts_config* cfg, int index, char* name, int
 }
 
 q3tts_engine* q3tts_create(const q3tts_config* cfg, int device, int max_batch, int max_ctx, uint32_t flags) {
+    return q3tts_create_pooled(cfg, device, max_batch, max_ctx, 0, flags);
+}
+
+q3tts_engine* q3tts_create_pooled(const q3tts_config* cfg, int device, int max_batch, int max_ctx, int64_t kv_pool_tokens, uint32_t flags) {
     if (!cfg) { g_create_err = "null config"; return nullptr; }
     try {
         int n = 0;
@@ -81,7 +85,7 @@ q3tts_engine* q3tts_create(const q3tts_config* cfg, int device, int max_batch, i
         if (device < 0 || device >= n) throw q3::Error("device index out of range");
         if (const char* ng = getenv("Q3TTS_NO_GRAPH")) if (ng[0] == '1') flags |= Q3TTS_FLAG_NO_GRAPH; // profiling aid
         q3tts_engine* h = new q3tts_engine;
-        h->e = new Engine(*cfg, device, max_batch, max_ctx, flags);
+        h->e = new Engine(*cfg, device, max_batch, max_ctx, flags, kv_pool_tokens);
         return h;
     } catch (const q3::Error& ex) { g_create_err = ex.msg; }
     catch (const std::exception& ex) { g_create_err = ex.what(); }
@@ -230,6 +234,15 @@ int q3tts_slot_codec_decode_host(q3tts_engine* h, int slot, float* pcm, int64_t 
     return 0;
     Q3_API_END(h)
 }
+int q3tts_kv_pool_info(q3tts_engine* h, int* page_tokens, int* total_pages, int* free_pages) {
+    Q3_API_BEGIN(h)
+    if (page_tokens) *page_tokens = 1 << h->e->talker.page_shift;
+    if (total_pages) *total_pages = h->e->kv_total_pages();
+    if (free_pages) *free_pages = h->e->kv_free_pages();
+    return 0;
+    Q3_API_END(h)
+}
+
 int q3tts_slot_release(q3tts_engine* h, int slot) {
     Q3_API_BEGIN(h) h->e->slot_release(slot); return 0; Q3_API_END(h)
 }
@@ -293,8 +306,18 @@ int q3tts_synthesize_schedule_host(q3tts_engine* h, int n_utt, const int64_t* id
     try {
         while (next < n_utt || live > 0) {
             fresh.clear();
-            for (int b = 0; b < B && next < n_utt; ++b)
-                if (slot_utt[(size_t)b] < 0) { slot_utt[(size_t)b] = next++; fresh.push_back(b); }
+            int pages_left = e.kv_free_pages();   // admission in queue order while the talker's KV page pool covers prompt + frame cap (released slots own none)
+            for (int b = 0; b < B && next < n_utt; ++b) {
+                if (slot_utt[(size_t)b] >= 0) continue;
+                const int cap_u = max_new_per_utt ? std::min(std::max(1, (int)max_new_per_utt[next]), p->max_new_tokens) : p->max_new_tokens;
+                const int need = e.kv_pages_for(prep[(size_t)next].S + cap_u);
+                if (need > pages_left) {
+                    if (live == 0 && fresh.empty()) throw q3::Error("synthesize: one utterance (prompt + max_new_tokens) needs more KV pages than the pool holds");
+                    break;                        // waits for a running utterance to give its pages back
+                }
+                pages_left -= need;
+                slot_utt[(size_t)b] = next++; fresh.push_back(b);
+            }
             if (!fresh.empty()) {
                 init.assign(fresh.size(), Engine::SlotInit());
                 for (size_t i = 0; i < fresh.size(); ++i) {

@@ -164,9 +164,10 @@ std::vector<TensorSpec> tensor_specs(const q3tts_config& c) {
 // ------------------------------------------------------------------------------------------------
 // construction
 // ------------------------------------------------------------------------------------------------
-Engine::Engine(const q3tts_config& cfg, int device_, int max_batch, int max_ctx_, uint32_t flags_)
+Engine::Engine(const q3tts_config& cfg, int device_, int max_batch, int max_ctx_, uint32_t flags_, int64_t kv_pool_tokens)
     : c(cfg), device(device_), B(max_batch), max_ctx(max_ctx_), flags(flags_) {
     if (B < 1 || B > 1024) throw Error("max_batch out of range");
+    if (kv_pool_tokens < 0) throw Error("kv_pool_tokens must be >= 0");
     if (c.cp_hidden < 0) throw Error("cp_hidden must be >= 0");
     if (c.cp_hidden == c.hidden) c.cp_hidden = 0;
     if (c.hidden % 8 || c.ffn % 8 || c.text_hidden % 8 || c.cp_ffn % 8 || cp_width() % 8) throw Error("hidden/ffn sizes must be multiples of 8");
@@ -262,18 +263,34 @@ Engine::Engine(const q3tts_config& cfg, int device_, int max_batch, int max_ctx_
     active_d = (int32_t*)dmalloc(sizeof(int32_t));
     Q3_HIP_CHECK(hipHostMalloc((void**)&active_h, sizeof(int32_t)));
 
-    // ---- paged KV caches (fp32), identity page allocation: slot b owns pages [b*pps, (b+1)*pps) ----
-    auto setup_stack = [&](DecStack& S, int Hh, int L, int nq, int nkv, int d, int ffn, float eps, int shift, int ctx, float theta, bool nt) {
+    // ---- paged KV caches (fp32).  Talker: a pool of 64-token pages + a host free list (kv_reserve / kv_release), page 0 = scratch.
+    // Code predictor: 32 tokens per slot, rewritten every frame — one fixed page per slot (identity table).
+    auto setup_stack = [&](DecStack& S, int Hh, int L, int nq, int nkv, int d, int ffn, float eps, int shift, int ctx, float theta, bool nt, int64_t pool_tokens, bool pooled) {
         S.H = Hh; S.L = L; S.nq = nq; S.nkv = nkv; S.d = d; S.ffn = ffn; S.eps = eps; S.page_shift = shift; S.nt = nt;
         const int ptok = 1 << shift;
         S.pages_per_slot = (ctx + ptok - 1) / ptok;
-        const size_t n = (size_t)B * S.pages_per_slot * L * nkv * ptok * d;
-        S.kc = (float*)dmalloc(n * sizeof(float));
-        S.vc = (float*)dmalloc(n * sizeof(float));
+        size_t n_pages = (size_t)B * S.pages_per_slot;
+        if (pooled) {
+            if (pool_tokens > 0) n_pages = (size_t)((pool_tokens + ptok - 1) / ptok);
+            if (n_pages < 1 || n_pages > (size_t)B * S.pages_per_slot) n_pages = std::min(std::max<size_t>(n_pages, 1), (size_t)B * S.pages_per_slot);
+            kv_pages_total = (int)n_pages;
+            n_pages += 1;   // scratch page 0
+        }
+        const size_t page_elems = (size_t)L * nkv * ptok * d;
+        S.kc = (float*)dmalloc(n_pages * page_elems * sizeof(float));
+        S.vc = (float*)dmalloc(n_pages * page_elems * sizeof(float));
         std::vector<int> pt((size_t)B * S.pages_per_slot);
-        for (size_t i = 0; i < pt.size(); ++i) pt[i] = (int)i;
+        for (size_t i = 0; i < pt.size(); ++i) pt[i] = pooled ? 0 : (int)i;
         S.page_table = (int*)dmalloc(pt.size() * sizeof(int));
         Q3_HIP_CHECK(hipMemcpy(S.page_table, pt.data(), pt.size() * sizeof(int), hipMemcpyHostToDevice));
+        if (pooled) {
+            Q3_HIP_CHECK(hipMemsetAsync(S.kc, 0, page_elems * sizeof(float), stream));
+            Q3_HIP_CHECK(hipMemsetAsync(S.vc, 0, page_elems * sizeof(float), stream));
+            kv_table_h = pt;
+            kv_owned.assign((size_t)B, std::vector<int>());
+            kv_free.resize((size_t)kv_pages_total);
+            for (int i = 0; i < kv_pages_total; ++i) kv_free[(size_t)i] = kv_pages_total - i;   // popped from the back: 1, 2, 3, ...
+        }
         // RoPE tables with the oracle's formula (fp32 libm): inv = 1/powf(theta, 2i/d); ang = pos*inv
         const int half = d / 2, npos = S.pages_per_slot * ptok;
         std::vector<float> cs((size_t)npos * half), sn((size_t)npos * half);
@@ -289,8 +306,8 @@ Engine::Engine(const q3tts_config& cfg, int device_, int max_batch, int max_ctx_
         Q3_HIP_CHECK(hipMemcpy(S.rope_cos, cs.data(), cs.size() * sizeof(float), hipMemcpyHostToDevice));
         Q3_HIP_CHECK(hipMemcpy(S.rope_sin, sn.data(), sn.size() * sizeof(float), hipMemcpyHostToDevice));
     };
-    setup_stack(talker, H, c.n_layers, c.n_heads, c.n_kv_heads, c.head_dim, c.ffn, c.rms_eps, 6, max_ctx, c.rope_theta, true);
-    setup_stack(cp, Hc, c.cp_layers, c.cp_heads, c.cp_kv_heads, c.cp_head_dim, c.cp_ffn, c.cp_rms_eps, 5, 32, c.cp_rope_theta, false);
+    setup_stack(talker, H, c.n_layers, c.n_heads, c.n_kv_heads, c.head_dim, c.ffn, c.rms_eps, 6, max_ctx, c.rope_theta, true, kv_pool_tokens, true);
+    setup_stack(cp, Hc, c.cp_layers, c.cp_heads, c.cp_kv_heads, c.cp_head_dim, c.cp_ffn, c.cp_rms_eps, 5, 32, c.cp_rope_theta, false, 0, false);
     // split-T attention: 128 cache tokens per workgroup (16 lane groups x 8 tokens in flight)
     talker.chunk = 128;
     talker.n_splits = (max_ctx + 127) / 128;
@@ -608,6 +625,7 @@ void Engine::talker_prefill(int slot, const float* embeds, int S, float* logits,
     if (slot < 0 || slot >= B) throw Error("slot out of range");
     if (S < 1 || S > 16) throw Error("prefill length must be 1..16 rows");
     const int H = c.hidden, V = c.vocab;
+    kv_reserve(slot, S, false);
     Q3_HIP_CHECK(hipMemcpyAsync(xp, embeds, (size_t)S * H * sizeof(float), hipMemcpyHostToDevice, stream));
     const bool pr = run_layers(talker, xp, H, 1, S, slot, nullptr, 0, talker_norm, c.rms_eps, hn, H);
     // final norm + codec head on every row; normalised rows kept for last_hidden
@@ -631,6 +649,7 @@ void Engine::talker_decode(int slot, const float* embed, float* logits, float* l
     int32_t pos = 0;
     Q3_HIP_CHECK(hipMemcpy(&pos, talker_pos_d + slot, sizeof(int32_t), hipMemcpyDeviceToHost));
     if (pos >= max_ctx) throw Error("KV cache full");
+    kv_reserve(slot, pos + 1, false);
     Q3_HIP_CHECK(hipMemcpyAsync(xp, embed, (size_t)H * sizeof(float), hipMemcpyHostToDevice, stream));
     run_layers(talker, xp, H, 1, 1, slot, nullptr, pos);
     GemvArgs g;
@@ -840,6 +859,27 @@ void Engine::step_logits(int slot, float* out, int cols) {
     Q3_HIP_CHECK(e);
 }
 
+void Engine::kv_reserve(int slot, int tokens, bool exact) {
+    if (slot < 0 || slot >= B) throw Error("slot out of range");
+    if (tokens < 0 || tokens > max_ctx) throw Error("KV reservation exceeds max_ctx");
+    std::vector<int>& own = kv_owned[(size_t)slot];
+    const int want = kv_pages_for(tokens), have = (int)own.size();
+    if (want == have || (want < have && !exact)) return;
+    if (want > have && want - have > (int)kv_free.size()) {
+        char msg[160];
+        snprintf(msg, sizeof msg, "KV page pool exhausted: slot %d needs %d more pages of %d tokens, %d of %d free", slot, want - have, 1 << talker.page_shift,
+                 (int)kv_free.size(), kv_pages_total);
+        throw Error(msg);
+    }
+    int* row = kv_table_h.data() + (size_t)slot * talker.pages_per_slot;
+    while ((int)own.size() < want) { own.push_back(kv_free.back()); kv_free.pop_back(); row[own.size() - 1] = own.back(); }
+    while ((int)own.size() > want) { kv_free.push_back(own.back()); row[own.size() - 1] = 0; own.pop_back(); }
+    // the slot is not in flight here (every entry point that steps it synchronises before returning); the mirror row outlives the copy
+    Q3_HIP_CHECK(hipMemcpyAsync(talker.page_table + (size_t)slot * talker.pages_per_slot, row, (size_t)talker.pages_per_slot * sizeof(int), hipMemcpyHostToDevice, stream));
+}
+
+void Engine::kv_release(int slot) { kv_reserve(slot, 0, true); }
+
 int Engine::nb_in_use() const {
     int nb = 0;
     for (int b = 0; b < B; ++b) if (st_h[b].active) nb = b + 1;
@@ -864,6 +904,20 @@ void Engine::slots_begin(const SlotInit* in, int n, const q3tts_sampling& p, uin
         if (in[i].n_trailing < 0 || in[i].n_trailing > max_trailing) throw Error("too many trailing text rows");
         if (in[i].S < 1 || in[i].S > 16) throw Error("prefill length must be 1..16 rows");
         if (p.max_new_tokens < 1 || in[i].S + p.max_new_tokens > max_ctx) throw Error("prompt + max_new_tokens exceeds max_ctx");
+    }
+    {   // KV pages for the prompt and every frame the slot may generate, all or nothing: nothing is armed if the pool cannot hold the set
+        int need = 0;
+        auto tokens_of = [&](const SlotInit& q) { return q.S + (q.max_frames > 0 ? std::min(q.max_frames, p.max_new_tokens) : p.max_new_tokens); };
+        auto want_of = [&](const SlotInit& q) { return kv_pages_for(tokens_of(q)); };
+        for (int i = 0; i < n; ++i) need += want_of(in[i]) - kv_slot_pages(in[i].slot);
+        if (need > kv_free_pages()) {
+            char msg[160];
+            snprintf(msg, sizeof msg, "KV page pool exhausted: %d slots need %d more pages, %d of %d free", n, need, kv_free_pages(), kv_pages_total);
+            throw Error(msg);
+        }
+        for (int pass = 0; pass < 2; ++pass)   // slots that give pages back first
+            for (int i = 0; i < n; ++i)
+                if ((want_of(in[i]) <= kv_slot_pages(in[i].slot)) == (pass == 0)) kv_reserve(in[i].slot, tokens_of(in[i]), true);
     }
     int i0 = 0;
     std::vector<int32_t> pos_h, map_h;
@@ -990,6 +1044,7 @@ void Engine::slot_release(int slot) {
     if (slot < 0 || slot >= B) throw Error("slot out of range");
     st_h[slot].active = 0;
     Q3_HIP_CHECK(hipMemcpy(st_d + slot, &st_h[slot], sizeof(SlotState), hipMemcpyHostToDevice));
+    kv_release(slot);
 }
 
 int64_t Engine::slot_codec_decode(int slot, float* pcm, int64_t cap) {

@@ -54,11 +54,25 @@ struct SpeakerW; // q3_speaker.cpp
 
 class Engine {
 public:
-    Engine(const q3tts_config& cfg, int device, int max_batch, int max_ctx, uint32_t flags);
+    // kv_pool_tokens: capacity of the talker's KV page pool in tokens (0: max_batch x max_ctx, every slot can reach max_ctx at once)
+    Engine(const q3tts_config& cfg, int device, int max_batch, int max_ctx, uint32_t flags, int64_t kv_pool_tokens = 0);
     ~Engine();
+
+    // ---- talker KV page pool: 64-token pages handed to slots on demand (page 0 is a scratch page every unowned table entry points at,
+    // so masked rows of unarmed / released slots keep writing somewhere harmless).  Host-side free list; the device sees only the table.
+    int kv_total_pages() const { return kv_pages_total; }
+    int kv_free_pages() const { return (int)kv_free.size(); }
+    int kv_pages_for(int tokens) const { return (tokens + (1 << talker.page_shift) - 1) >> talker.page_shift; }
+    int kv_slot_pages(int slot) const { return (int)kv_owned[(size_t)slot].size(); }
+    void kv_reserve(int slot, int tokens, bool exact);   // the slot owns pages for positions [0, tokens): grows (and with `exact` shrinks) to that
+    void kv_release(int slot);
 
     q3tts_config c;
     int device, B, max_ctx;
+    int kv_pages_total = 0;                    // usable pages (without the scratch page)
+    std::vector<int> kv_free;                  // stack of free page ids, lowest on top
+    std::vector<std::vector<int>> kv_owned;    // per slot, in position order
+    std::vector<int> kv_table_h;               // host mirror of talker.page_table
     uint32_t flags;
     hipStream_t stream = nullptr;
     bool null_stream = false;

@@ -73,7 +73,7 @@ FLAG_FP32_CODEC = 4
 
 # every symbol include/q3tts.h declares
 EXPORTS = [
-    "q3tts_default_config", "q3tts_create", "q3tts_destroy", "q3tts_last_error", "q3tts_num_tensors",
+    "q3tts_default_config", "q3tts_create", "q3tts_create_pooled", "q3tts_kv_pool_info", "q3tts_destroy", "q3tts_last_error", "q3tts_num_tensors",
     "q3tts_tensor_info", "q3tts_set_tensor_host", "q3tts_get_tensor_host", "q3tts_fill_synthetic", "q3tts_finalize",
     "q3tts_text_project_host", "q3tts_codec_embed_host", "q3tts_cp_embed_host", "q3tts_talker_prefill_host",
     "q3tts_talker_decode_host", "q3tts_code_predictor_host", "q3tts_codec_decode_host", "q3tts_codec_decode_len",
@@ -103,6 +103,9 @@ def lib():
     L.q3tts_default_config.argtypes = [C.c_char_p, C.POINTER(Config)]
     L.q3tts_create.restype = vp
     L.q3tts_create.argtypes = [C.POINTER(Config), i32, i32, i32, C.c_uint32]
+    L.q3tts_create_pooled.restype = vp
+    L.q3tts_create_pooled.argtypes = [C.POINTER(Config), i32, i32, i32, C.c_int64, C.c_uint32]
+    L.q3tts_kv_pool_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
     L.q3tts_destroy.argtypes = [vp]
     L.q3tts_last_error.restype = C.c_char_p
     L.q3tts_last_error.argtypes = [vp]
@@ -200,14 +203,21 @@ def _p(a):
 class Engine:
     """One engine = one GPU, `max_batch` utterance slots, device-resident weights + KV cache."""
 
-    def __init__(self, cfg, device=0, max_batch=1, max_ctx=2304, flags=0):
+    def __init__(self, cfg, device=0, max_batch=1, max_ctx=2304, flags=0, kv_pool_tokens=0):
+        """kv_pool_tokens > 0 bounds the talker's KV page pool (q3tts_create_pooled); 0 reserves max_batch x max_ctx."""
         self.L = lib()
         self.cfg = cfg
         self.max_batch = max_batch
         self.max_ctx = max_ctx
-        self.h = self.L.q3tts_create(C.byref(cfg), device, max_batch, max_ctx, flags)
+        self.h = self.L.q3tts_create_pooled(C.byref(cfg), device, max_batch, max_ctx, kv_pool_tokens, flags)
         if not self.h:
             raise RuntimeError("q3tts_create failed: " + self.L.q3tts_last_error(None).decode())
+
+    def kv_pool_info(self):
+        """(tokens per page, pages in the pool, pages free)"""
+        a, b, c = C.c_int32(), C.c_int32(), C.c_int32()
+        self._ck(self.L.q3tts_kv_pool_info(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
 
     def close(self):
         if getattr(self, "h", None):
