@@ -68,10 +68,15 @@ q3tts_engine* q3tts_create(const q3tts_config* cfg, int device, int max_batch, i
 /* The same with a bounded KV page pool.  The talker's cache (the reference's KVCache, tts_onnx.h:108-115, grown by one token per run_decode)
  * is a pool of 64-token pages; a slot takes pages for prompt + max_new_tokens when it is armed (q3tts_slot_begin / the scheduler) or as its
  * context grows (q3tts_talker_prefill_host / q3tts_talker_decode_host) and returns them at q3tts_slot_release.  kv_pool_tokens = 0 sizes the
- * pool for max_batch x max_ctx (q3tts_create); a smaller pool admits as many utterances as fit — the scheduler keeps the rest queued,
- * q3tts_slot_begin fails with "KV page pool exhausted" and arms nothing. */
+ * pool for max_batch x max_ctx (q3tts_create); a smaller pool admits as many utterances as fit — q3tts_slot_begin fails with "KV page pool
+ * exhausted" and arms nothing; the scheduler (q3tts_synthesize_*) keeps the rest queued.  There, with ignore_eos (lengths known) an
+ * utterance is admitted when prompt + cap fit; otherwise slots grow page by page as they generate, so utterances that stop early never
+ * hold the pages of their cap, and when the pool runs dry the youngest running utterance is preempted and generated again later. */
 q3tts_engine* q3tts_create_pooled(const q3tts_config* cfg, int device, int max_batch, int max_ctx, int64_t kv_pool_tokens, uint32_t flags);
 int q3tts_kv_pool_info(q3tts_engine* e, int* page_tokens, int* total_pages, int* free_pages);
+/* The last q3tts_synthesize_* call on this engine: utterances admitted to a slot (re-admissions count), utterances preempted because the
+ * pool ran dry (each is generated again from its prompt: same RNG stream, same codes), most utterances running at once. */
+int q3tts_sched_stats(q3tts_engine* e, int64_t* admitted, int64_t* preempted, int* peak_live);
 void q3tts_destroy(q3tts_engine* e);
 const char* q3tts_last_error(q3tts_engine* e); /* e may be NULL: error of the last failed create */
 

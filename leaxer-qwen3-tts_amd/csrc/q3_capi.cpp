@@ -2,6 +2,7 @@
 #include <cstddef>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <vector>
 
 #include "q3_audio.h"
@@ -243,6 +244,15 @@ int q3tts_kv_pool_info(q3tts_engine* h, int* page_tokens, int* total_pages, int*
     Q3_API_END(h)
 }
 
+int q3tts_sched_stats(q3tts_engine* h, int64_t* admitted, int64_t* preempted, int* peak_live) {
+    Q3_API_BEGIN(h)
+    if (admitted) *admitted = h->e->sched_admitted;
+    if (preempted) *preempted = h->e->sched_preempted;
+    if (peak_live) *peak_live = h->e->sched_peak_live;
+    return 0;
+    Q3_API_END(h)
+}
+
 int q3tts_slot_release(q3tts_engine* h, int slot) {
     Q3_API_BEGIN(h) h->e->slot_release(slot); return 0; Q3_API_END(h)
 }
@@ -299,24 +309,39 @@ int q3tts_synthesize_schedule_host(q3tts_engine* h, int n_utt, const int64_t* id
         e.build_prompts(ids, offsets, n_utt, lang, speakers, prompts.data(), Ss.data(), trailing.data(), toffs.data(), nts.data());
         for (int u = 0; u < n_utt; ++u) { prep[(size_t)u].S = Ss[(size_t)u]; prep[(size_t)u].nt = nts[(size_t)u]; }
     }
+    // KV pages.  With EOS suppressed every length is known: an utterance is admitted when the pool holds prompt + cap and never waits again.
+    // Otherwise a slot owns what its context has reached plus the coming look (on-demand growth), so utterances that end early never hold
+    // the pages of their cap; when the pool runs dry the YOUNGEST live utterance is preempted — its pages go back, it returns to the head
+    // of the queue and is generated again from its prompt later (same RNG stream, same codes) — so the oldest always finishes.
     std::vector<Engine::SlotInit> init;
     std::vector<int> slot_utt((size_t)B, -1), done_frames((size_t)B, 0), fresh, retired;
     std::vector<q3::SlotState> st;
-    int next = 0, live = 0;
+    std::deque<int> pending;
+    auto cap_of = [&](int u) { return max_new_per_utt ? std::min(std::max(1, (int)max_new_per_utt[u]), p->max_new_tokens) : p->max_new_tokens; };
+    for (int u = 0; u < n_utt; ++u) {
+        if (e.kv_pages_for(prep[(size_t)u].S + cap_of(u)) > e.kv_total_pages())
+            throw q3::Error("synthesize: one utterance (prompt + max_new_tokens) needs more KV pages than the pool holds");
+        pending.push_back(u);
+    }
+    const bool reserve_all = ignore_eos != 0;
+    const int first_look = 8;
+    int live = 0;
+    e.sched_admitted = e.sched_preempted = 0; e.sched_peak_live = 0;
     try {
-        while (next < n_utt || live > 0) {
+        while (!pending.empty() || live > 0) {
             fresh.clear();
-            int pages_left = e.kv_free_pages();   // admission in queue order while the talker's KV page pool covers prompt + frame cap (released slots own none)
-            for (int b = 0; b < B && next < n_utt; ++b) {
+            int pages_left = e.kv_free_pages();
+            for (int b = 0; b < B && !pending.empty(); ++b) {
                 if (slot_utt[(size_t)b] >= 0) continue;
-                const int cap_u = max_new_per_utt ? std::min(std::max(1, (int)max_new_per_utt[next]), p->max_new_tokens) : p->max_new_tokens;
-                const int need = e.kv_pages_for(prep[(size_t)next].S + cap_u);
-                if (need > pages_left) {
-                    if (live == 0 && fresh.empty()) throw q3::Error("synthesize: one utterance (prompt + max_new_tokens) needs more KV pages than the pool holds");
-                    break;                        // waits for a running utterance to give its pages back
-                }
+                const int u = pending.front();
+                const int all = prep[(size_t)u].S + cap_of(u);
+                const int need = e.kv_pages_for(reserve_all ? all : std::min(all, prep[(size_t)u].S + first_look));
+                // on-demand mode keeps a page of head-room per running utterance, so that admitting one more does not preempt at the next look
+                const int headroom = reserve_all ? 0 : live + (int)fresh.size();
+                if (need + headroom > pages_left && (live > 0 || !fresh.empty())) break;   // waits for pages; alone, it always fits (checked above)
                 pages_left -= need;
-                slot_utt[(size_t)b] = next++; fresh.push_back(b);
+                pending.pop_front();
+                slot_utt[(size_t)b] = u; fresh.push_back(b);
             }
             if (!fresh.empty()) {
                 init.assign(fresh.size(), Engine::SlotInit());
@@ -327,24 +352,54 @@ int q3tts_synthesize_schedule_host(q3tts_engine* h, int n_utt, const int64_t* id
                     q.slot = b; q.prompt = prompts.data() + pr.poff * H; q.S = pr.S; q.trailing = trailing.data() + pr.toff * H; q.n_trailing = pr.nt;
                     q.stream_id = (uint32_t)u;
                     q.max_frames = max_new_per_utt ? std::max(1, (int)max_new_per_utt[u]) : 0;
+                    q.kv_tokens = reserve_all ? 0 : pr.S + first_look;
                 }
                 e.slots_begin(init.data(), (int)init.size(), *p, seed, ignore_eos);   // equal-length prompts in consecutive slots share one prefill pass
                 live += (int)fresh.size();
+                e.sched_admitted += (int64_t)fresh.size();
+                e.sched_peak_live = std::max(e.sched_peak_live, live);
             }
             // steps until the next look: never past the earliest slot that can reach max_new_tokens, short when few utterances are live
             int rem = p->max_new_tokens;
             for (int b = 0; b < B; ++b) {
                 const int u = slot_utt[(size_t)b];
-                if (u < 0) continue;
-                const int cap_u = max_new_per_utt ? std::min(std::max(1, (int)max_new_per_utt[u]), p->max_new_tokens) : p->max_new_tokens;
-                rem = std::min(rem, cap_u - done_frames[(size_t)b]);
+                if (u >= 0) rem = std::min(rem, cap_of(u) - done_frames[(size_t)b]);
             }
             // (with EOS suppressed nothing can finish earlier than that, so the look-ahead only bounds how long the host is away)
             // While utterances wait in the queue a look is at least `quantum` steps away: a finished slot idles a few (masked, nearly free)
             // steps, and the slots that finish within the quantum are re-armed together, sharing one prefill pass.
             static const int quantum = getenv("Q3TTS_SCHED_QUANTUM") ? std::max(1, atoi(getenv("Q3TTS_SCHED_QUANTUM"))) : 4;
             const int look = std::min(rem, ignore_eos ? 64 : (live <= 16 ? 4 : 8));
-            e.decode_steps(std::max(next < n_utt && live > 16 ? quantum : 1, look));
+            const int steps = std::max(!pending.empty() && live > 16 ? quantum : 1, look);
+            if (!reserve_all) {
+                // every live slot gets pages for the positions these steps write; oldest first, so that when the pool runs dry it is the
+                // youngest that goes back to the queue
+                std::vector<int> order;
+                for (int b = 0; b < B; ++b) if (slot_utt[(size_t)b] >= 0) order.push_back(b);
+                std::sort(order.begin(), order.end(), [&](int x, int y) {
+                    return done_frames[(size_t)x] != done_frames[(size_t)y] ? done_frames[(size_t)x] > done_frames[(size_t)y] : slot_utt[(size_t)x] < slot_utt[(size_t)y]; });
+                size_t keep = order.size();
+                auto preempt = [&](int vb) {
+                    const int vu = slot_utt[(size_t)vb];
+                    e.slot_release(vb);
+                    pending.push_front(vu);
+                    slot_utt[(size_t)vb] = -1; done_frames[(size_t)vb] = 0;
+                    --live; ++e.sched_preempted;
+                };
+                for (size_t i = 0; i < keep; ++i) {
+                    const int b = order[i], u = slot_utt[(size_t)b];
+                    const int want = std::min(prep[(size_t)u].S + cap_of(u), prep[(size_t)u].S + done_frames[(size_t)b] + steps);
+                    bool gone = false;
+                    while (!gone && e.kv_pages_for(want) - e.kv_slot_pages(b) > e.kv_free_pages()) {
+                        const size_t v = keep > i + 1 ? keep - 1 : i;   // the youngest still running; in the end this one itself
+                        preempt(order[v]);
+                        keep = v;
+                        gone = v == i;                                  // (never the oldest: alone it fits, checked before the first admission)
+                    }
+                    if (!gone) e.kv_reserve(b, want, false);
+                }
+            }
+            e.decode_steps(steps);
             e.slots_state(B, st);
             retired.clear();
             for (int b = 0; b < B; ++b) {

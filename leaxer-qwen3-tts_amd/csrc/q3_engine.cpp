@@ -907,7 +907,10 @@ void Engine::slots_begin(const SlotInit* in, int n, const q3tts_sampling& p, uin
     }
     {   // KV pages for the prompt and every frame the slot may generate, all or nothing: nothing is armed if the pool cannot hold the set
         int need = 0;
-        auto tokens_of = [&](const SlotInit& q) { return q.S + (q.max_frames > 0 ? std::min(q.max_frames, p.max_new_tokens) : p.max_new_tokens); };
+        auto tokens_of = [&](const SlotInit& q) {
+            const int all = q.S + (q.max_frames > 0 ? std::min(q.max_frames, p.max_new_tokens) : p.max_new_tokens);
+            return q.kv_tokens > 0 ? std::min(all, std::max(q.kv_tokens, q.S)) : all;   // a caller that grows the share itself (the scheduler)
+        };
         auto want_of = [&](const SlotInit& q) { return kv_pages_for(tokens_of(q)); };
         for (int i = 0; i < n; ++i) need += want_of(in[i]) - kv_slot_pages(in[i].slot);
         if (need > kv_free_pages()) {

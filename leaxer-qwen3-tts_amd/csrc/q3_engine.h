@@ -73,6 +73,7 @@ public:
     std::vector<int> kv_free;                  // stack of free page ids, lowest on top
     std::vector<std::vector<int>> kv_owned;    // per slot, in position order
     std::vector<int> kv_table_h;               // host mirror of talker.page_table
+    int64_t sched_admitted = 0, sched_preempted = 0; int sched_peak_live = 0;   // the last scheduler call (q3tts_sched_stats)
     uint32_t flags;
     hipStream_t stream = nullptr;
     bool null_stream = false;
@@ -111,7 +112,8 @@ public:
 
     // ---- fused generation ----
     struct SlotInit { int slot = 0; const float* prompt = nullptr; int S = 0; const float* trailing = nullptr; int n_trailing = 0; uint32_t stream_id = 0;
-                      int max_frames = 0; /* 0: the call's max_new_tokens */ };
+                      int max_frames = 0; /* 0: the call's max_new_tokens */
+                      int kv_tokens = 0;  /* KV pages reserved now, in tokens; 0: prompt + max_frames (the slot never needs more) */ };
     void slots_begin(const SlotInit* in, int n, const q3tts_sampling& p, uint64_t seed, int ignore_eos); // batched prefill of equal-length prompts
     void slot_begin(int slot, const float* prompt, int S, const float* trailing, int n_trailing,
                     const q3tts_sampling& p, uint64_t seed, uint32_t stream_id, int ignore_eos);

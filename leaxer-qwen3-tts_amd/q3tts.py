@@ -73,7 +73,7 @@ FLAG_FP32_CODEC = 4
 
 # every symbol include/q3tts.h declares
 EXPORTS = [
-    "q3tts_default_config", "q3tts_create", "q3tts_create_pooled", "q3tts_kv_pool_info", "q3tts_destroy", "q3tts_last_error", "q3tts_num_tensors",
+    "q3tts_default_config", "q3tts_create", "q3tts_create_pooled", "q3tts_kv_pool_info", "q3tts_sched_stats", "q3tts_destroy", "q3tts_last_error", "q3tts_num_tensors",
     "q3tts_tensor_info", "q3tts_set_tensor_host", "q3tts_get_tensor_host", "q3tts_fill_synthetic", "q3tts_finalize",
     "q3tts_text_project_host", "q3tts_codec_embed_host", "q3tts_cp_embed_host", "q3tts_talker_prefill_host",
     "q3tts_talker_decode_host", "q3tts_code_predictor_host", "q3tts_codec_decode_host", "q3tts_codec_decode_len",
@@ -106,6 +106,7 @@ def lib():
     L.q3tts_create_pooled.restype = vp
     L.q3tts_create_pooled.argtypes = [C.POINTER(Config), i32, i32, i32, C.c_int64, C.c_uint32]
     L.q3tts_kv_pool_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
+    L.q3tts_sched_stats.argtypes = [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i32)]
     L.q3tts_destroy.argtypes = [vp]
     L.q3tts_last_error.restype = C.c_char_p
     L.q3tts_last_error.argtypes = [vp]
@@ -217,6 +218,12 @@ class Engine:
         """(tokens per page, pages in the pool, pages free)"""
         a, b, c = C.c_int32(), C.c_int32(), C.c_int32()
         self._ck(self.L.q3tts_kv_pool_info(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def sched_stats(self):
+        """(admitted, preempted, peak live) of the last synthesize_batch call"""
+        a, b, c = C.c_int64(), C.c_int64(), C.c_int32()
+        self._ck(self.L.q3tts_sched_stats(self.h, C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value
 
     def close(self):

@@ -101,3 +101,33 @@ def test_scattered_pages_and_bounded_admission_give_the_same_codes(setup):
         assert np.array_equal(codes2[0][:caps[0]], codes[0][:caps[0]])
     finally:
         small.close()
+
+
+def test_on_demand_growth_and_preemption(setup):
+    """EOS-terminated generation (lengths unknown): slots grow page by page, and a pool too small for every running utterance's cap
+    preempts the youngest, which is generated again later — codes and frame counts equal the unbounded engine's."""
+    import q3tts
+    ocfg, w, orc = setup
+    rng = np.random.default_rng(4)
+    toks = [frame_tokens(rng.integers(0, 1000, n)) for n in (5, 2, 12, 7, 3, 9)]
+    sp = q3tts.Sampling(temperature=0.9, top_p=0.95, top_k=30, max_new_tokens=150)      # up to 3 pages each, 12 for four slots
+    full = _engine(w, ocfg, 4, 320, 0)
+    try:
+        _, codes_full, nfr_full = full.synthesize_batch(toks, sp, lang=2, seed=13)
+        assert full.sched_stats()[1] == 0
+    finally:
+        full.close()
+    small = _engine(w, ocfg, 4, 320, 5 * 64)
+    try:
+        pcm, codes, nfr = small.synthesize_batch(toks, sp, lang=2, seed=13)
+        admitted, preempted, peak = small.sched_stats()
+        print(f"5-page pool, 4 slots, 6 utterances of up to 3 pages: admitted {admitted}, preempted {preempted}, peak live {peak}, frames {list(nfr)}")
+        assert list(nfr) == list(nfr_full)
+        for u in range(len(toks)):
+            assert np.array_equal(codes[u][:nfr[u]], codes_full[u][:nfr[u]]), u
+        assert preempted > 0 and admitted == len(toks) + preempted and peak >= 2
+        assert small.kv_pool_info() == (64, 5, 5)
+        ref = orc.generate(orc.build_prompt(toks[0], 2), to_osampling(sp), seed=13, stream=0, cp_cached=True)
+        assert np.array_equal(codes[0][:nfr[0]], ref)
+    finally:
+        small.close()
