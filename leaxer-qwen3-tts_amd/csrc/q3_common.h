@@ -83,6 +83,7 @@ struct AttnArgs {
     float* vcache = nullptr;
     const int* page_table = nullptr; // [slot][pages_per_slot]
     int pages_per_slot = 0, page_shift = 0;
+    bool identity_pages = false;     // page_table[slot][i] == slot * pages_per_slot + i by construction (code predictor): kernels may skip the table
     int layer = 0, n_layers = 0;
     const float* q_norm = nullptr; // [d] or null
     const float* k_norm = nullptr;

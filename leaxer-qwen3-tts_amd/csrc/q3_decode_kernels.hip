@@ -512,7 +512,7 @@ void launch_gemv(const GemvArgs& a0, hipStream_t s) {
 #define ATT_MAX_NEW 16
 #define ATT_MAX_GRP 4
 
-template <int D, int U, int G>
+template <int D, int U, int G, bool IDENT = false>
 __global__ __launch_bounds__(256) void k_attn(const int* ppage_table, const int* ppos_dev, const float* pqkv, const float* pkcache, const float* pvcache,
                                                const float* pcos, const float* psin, int ppos_scalar, int pn_splits, AttnArgs a) {
     // leading scalars: preloaded into SGPRs, so the first memory round (page ids, position) leaves at once (see k_gemv1)
@@ -540,7 +540,11 @@ __global__ __launch_bounds__(256) void k_attn(const int* ppage_table, const int*
     const int pbase = (split * a.chunk) >> pshift;
     int pg[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) { const int pi = pbase + q < a.pages_per_slot ? pbase + q : a.pages_per_slot - 1; pg[q] = pt[pi]; }
+    for (int q = 0; q < 4; ++q) {
+        const int pi = pbase + q < a.pages_per_slot ? pbase + q : a.pages_per_slot - 1;
+        // IDENT (code predictor: one fixed page per slot): no table read, so the K/V batch is not a memory round behind the page ids
+        pg[q] = IDENT ? slot * a.pages_per_slot + pi : pt[pi];
+    }
     int base = ppos_scalar;
     if (ppos_dev) base = ppos_dev[slot];
     const int pos = base + inew;
@@ -790,15 +794,20 @@ void launch_attn(const AttnArgs& a, hipStream_t s) {
     if (a.n_splits > 1 && (a.chunk >> a.page_shift) + 1 > 4) throw Error("attn: a split may touch at most 4 KV pages");
     dim3 grid(a.nkv, a.n_new * a.n_splits, a.nb);
 #define Q3_ATT_ARGS a.page_table, a.pos_dev, a.qkv, (const float*)a.kcache, (const float*)a.vcache, a.rope_cos, a.rope_sin, a.pos_scalar, a.n_splits, a
-#define Q3_ATT(D, U) do { if (grp == 1) hipLaunchKernelGGL((k_attn<D, U, 1>), grid, dim3(256), 0, s, Q3_ATT_ARGS); \
-        else if (grp == 2) hipLaunchKernelGGL((k_attn<D, U, 2>), grid, dim3(256), 0, s, Q3_ATT_ARGS); \
-        else hipLaunchKernelGGL((k_attn<D, U, 4>), grid, dim3(256), 0, s, Q3_ATT_ARGS); } while (0)
+#define Q3_ATT_I(D, U, I) do { if (grp == 1) hipLaunchKernelGGL((k_attn<D, U, 1, I>), grid, dim3(256), 0, s, Q3_ATT_ARGS); \
+        else if (grp == 2) hipLaunchKernelGGL((k_attn<D, U, 2, I>), grid, dim3(256), 0, s, Q3_ATT_ARGS); \
+        else hipLaunchKernelGGL((k_attn<D, U, 4, I>), grid, dim3(256), 0, s, Q3_ATT_ARGS); } while (0)
+#define Q3_ATT(D, U) Q3_ATT_I(D, U, false)
     const bool tiny_ctx = a.n_splits == 1 && a.window == 0 && (a.pages_per_slot << a.page_shift) <= 32; // code predictor
-    if (a.d == 128 && tiny_ctx) Q3_ATT(128, 2);
+    // identity_pages: the decode stacks with a fixed run of pages per slot (slot_map == null: slot ids are computed too)
+    if (a.d == 128 && tiny_ctx && a.identity_pages) Q3_ATT_I(128, 2, true);
+    else if (a.d == 128 && a.identity_pages) Q3_ATT_I(128, 8, true);
+    else if (a.d == 128 && tiny_ctx) Q3_ATT(128, 2);
     else if (a.d == 128) Q3_ATT(128, 8);
     else if (a.d == 64) Q3_ATT(64, 8);
     else if (a.d == 16) Q3_ATT(16, 4);
     else throw Error("attn: head_dim must be 16, 64 or 128");
+#undef Q3_ATT_I
 #undef Q3_ATT
 }
 

@@ -263,19 +263,20 @@ Engine::Engine(const q3tts_config& cfg, int device_, int max_batch, int max_ctx_
     active_d = (int32_t*)dmalloc(sizeof(int32_t));
     Q3_HIP_CHECK(hipHostMalloc((void**)&active_h, sizeof(int32_t)));
 
-    // ---- paged KV caches (fp32).  Talker: a pool of 64-token pages + a host free list (kv_reserve / kv_release), page 0 = scratch.
-    // Code predictor: 32 tokens per slot, rewritten every frame — one fixed page per slot (identity table).
-    auto setup_stack = [&](DecStack& S, int Hh, int L, int nq, int nkv, int d, int ffn, float eps, int shift, int ctx, float theta, bool nt, int64_t pool_tokens, bool pooled) {
+    // ---- paged KV caches (fp32).  Talker: 64-token pages handed out by kv_reserve / kv_release.  With the default pool (every slot can
+    // reach max_ctx at once) slot b owns the fixed run [b*pps, (b+1)*pps): the table is the identity, never changes, and k_attn computes
+    // the page ids instead of reading them (one memory round less in front of the K/V batch).  A bounded pool (kv_pool_tokens > 0) hands
+    // pages out from a free list; page 0 is then a scratch page every unowned table entry points at, so masked rows of unarmed slots
+    // write somewhere harmless.  Code predictor: 32 tokens per slot, rewritten every frame — one fixed page per slot.
+    auto setup_stack = [&](DecStack& S, int Hh, int L, int nq, int nkv, int d, int ffn, float eps, int shift, int ctx, float theta, bool nt, int64_t pool_tokens, bool talker_stack) {
         S.H = Hh; S.L = L; S.nq = nq; S.nkv = nkv; S.d = d; S.ffn = ffn; S.eps = eps; S.page_shift = shift; S.nt = nt;
         const int ptok = 1 << shift;
         S.pages_per_slot = (ctx + ptok - 1) / ptok;
         size_t n_pages = (size_t)B * S.pages_per_slot;
-        if (pooled) {
-            if (pool_tokens > 0) n_pages = (size_t)((pool_tokens + ptok - 1) / ptok);
-            if (n_pages < 1 || n_pages > (size_t)B * S.pages_per_slot) n_pages = std::min(std::max<size_t>(n_pages, 1), (size_t)B * S.pages_per_slot);
-            kv_pages_total = (int)n_pages;
-            n_pages += 1;   // scratch page 0
-        }
+        const bool pooled = talker_stack && pool_tokens > 0 && (size_t)((pool_tokens + ptok - 1) / ptok) < n_pages;
+        S.identity_pages = !pooled;
+        if (pooled) n_pages = (size_t)((pool_tokens + ptok - 1) / ptok) + 1;   // + scratch page 0
+        if (talker_stack) kv_pages_total = pooled ? (int)n_pages - 1 : (int)n_pages;
         const size_t page_elems = (size_t)L * nkv * ptok * d;
         S.kc = (float*)dmalloc(n_pages * page_elems * sizeof(float));
         S.vc = (float*)dmalloc(n_pages * page_elems * sizeof(float));
@@ -283,13 +284,16 @@ Engine::Engine(const q3tts_config& cfg, int device_, int max_batch, int max_ctx_
         for (size_t i = 0; i < pt.size(); ++i) pt[i] = pooled ? 0 : (int)i;
         S.page_table = (int*)dmalloc(pt.size() * sizeof(int));
         Q3_HIP_CHECK(hipMemcpy(S.page_table, pt.data(), pt.size() * sizeof(int), hipMemcpyHostToDevice));
-        if (pooled) {
-            Q3_HIP_CHECK(hipMemsetAsync(S.kc, 0, page_elems * sizeof(float), stream));
-            Q3_HIP_CHECK(hipMemsetAsync(S.vc, 0, page_elems * sizeof(float), stream));
+        if (talker_stack) {
             kv_table_h = pt;
             kv_owned.assign((size_t)B, std::vector<int>());
-            kv_free.resize((size_t)kv_pages_total);
-            for (int i = 0; i < kv_pages_total; ++i) kv_free[(size_t)i] = kv_pages_total - i;   // popped from the back: 1, 2, 3, ...
+            kv_free_count = kv_pages_total;
+            if (pooled) {
+                Q3_HIP_CHECK(hipMemsetAsync(S.kc, 0, page_elems * sizeof(float), stream));
+                Q3_HIP_CHECK(hipMemsetAsync(S.vc, 0, page_elems * sizeof(float), stream));
+                kv_free.resize((size_t)kv_pages_total);
+                for (int i = 0; i < kv_pages_total; ++i) kv_free[(size_t)i] = kv_pages_total - i;   // popped from the back: 1, 2, 3, ...
+            }
         }
         // RoPE tables with the oracle's formula (fp32 libm): inv = 1/powf(theta, 2i/d); ang = pos*inv
         const int half = d / 2, npos = S.pages_per_slot * ptok;
@@ -474,7 +478,7 @@ bool Engine::run_layers(const DecStack& W, float* x, int ldx, int nb, int n_new,
         AttnArgs a;
         a.qkv = qkv; a.ld_qkv = QKV; a.out = attn; a.ld_out = AO; a.kcache = W.kc; a.vcache = W.vc;
         if (mfma) { a.qkv = qkv_slab_d; a.qkv_nslab = ks_q; a.qkv_slab_stride = (size_t)M * QKV; }
-        a.page_table = W.page_table; a.pages_per_slot = W.pages_per_slot; a.page_shift = W.page_shift;
+        a.page_table = W.page_table; a.pages_per_slot = W.pages_per_slot; a.page_shift = W.page_shift; a.identity_pages = W.identity_pages;
         a.layer = l; a.n_layers = W.L; a.q_norm = w.q_norm; a.k_norm = w.k_norm; a.eps = W.eps;
         a.rope_cos = W.rope_cos; a.rope_sin = W.rope_sin; a.pos_dev = pos_dev; a.pos_scalar = pos_scalar;
         a.slot_offset = slot_offset; a.slot_map = slot_map; a.nb = nb; a.n_new = n_new; a.nq = W.nq; a.nkv = W.nkv; a.d = W.d;
@@ -865,11 +869,17 @@ void Engine::kv_reserve(int slot, int tokens, bool exact) {
     std::vector<int>& own = kv_owned[(size_t)slot];
     const int want = kv_pages_for(tokens), have = (int)own.size();
     if (want == have || (want < have && !exact)) return;
-    if (want > have && want - have > (int)kv_free.size()) {
+    if (want - have > kv_free_count) {
         char msg[160];
         snprintf(msg, sizeof msg, "KV page pool exhausted: slot %d needs %d more pages of %d tokens, %d of %d free", slot, want - have, 1 << talker.page_shift,
-                 (int)kv_free.size(), kv_pages_total);
+                 kv_free_count, kv_pages_total);
         throw Error(msg);
+    }
+    kv_free_count -= want - have;
+    if (talker.identity_pages) {   // fixed run per slot: accounting only, the table never changes
+        own.resize((size_t)want);
+        for (int i = 0; i < want; ++i) own[(size_t)i] = slot * talker.pages_per_slot + i;
+        return;
     }
     int* row = kv_table_h.data() + (size_t)slot * talker.pages_per_slot;
     while ((int)own.size() < want) { own.push_back(kv_free.back()); kv_free.pop_back(); row[own.size() - 1] = own.back(); }

@@ -43,6 +43,7 @@ struct DecStack {
     float *kc = nullptr, *vc = nullptr; // paged cache
     int* page_table = nullptr;
     int pages_per_slot = 0, page_shift = 0;
+    bool identity_pages = false;
     float *rope_cos = nullptr, *rope_sin = nullptr;
     bool nt = false; // weights streamed once per step -> non-temporal loads
     int n_splits = 1, chunk = 1 << 30; // split-T attention
@@ -61,7 +62,7 @@ public:
     // ---- talker KV page pool: 64-token pages handed to slots on demand (page 0 is a scratch page every unowned table entry points at,
     // so masked rows of unarmed / released slots keep writing somewhere harmless).  Host-side free list; the device sees only the table.
     int kv_total_pages() const { return kv_pages_total; }
-    int kv_free_pages() const { return (int)kv_free.size(); }
+    int kv_free_pages() const { return kv_free_count; }
     int kv_pages_for(int tokens) const { return (tokens + (1 << talker.page_shift) - 1) >> talker.page_shift; }
     int kv_slot_pages(int slot) const { return (int)kv_owned[(size_t)slot].size(); }
     void kv_reserve(int slot, int tokens, bool exact);   // the slot owns pages for positions [0, tokens): grows (and with `exact` shrinks) to that
@@ -70,7 +71,8 @@ public:
     q3tts_config c;
     int device, B, max_ctx;
     int kv_pages_total = 0;                    // usable pages (without the scratch page)
-    std::vector<int> kv_free;                  // stack of free page ids, lowest on top
+    int kv_free_count = 0;
+    std::vector<int> kv_free;                  // bounded pool: stack of free page ids, lowest on top
     std::vector<std::vector<int>> kv_owned;    // per slot, in position order
     std::vector<int> kv_table_h;               // host mirror of talker.page_table
     int64_t sched_admitted = 0, sched_preempted = 0; int sched_peak_live = 0;   // the last scheduler call (q3tts_sched_stats)
