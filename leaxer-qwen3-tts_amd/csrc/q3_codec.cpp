@@ -16,7 +16,7 @@
 namespace q3 {
 
 struct PackedConv { const float* w = nullptr; const float* b = nullptr; int cin = 0, cout = 0, k = 0; };
-struct SnakeP { const float *alpha = nullptr, *beta = nullptr; };
+struct SnakeP { const float *alpha = nullptr, *beta = nullptr; int C = 0; };
 
 struct CodecW {
     struct Layer { const float *in_norm, *post_norm, *qkv, *o, *gate, *up, *down, *attn_scale, *mlp_scale; };
@@ -33,6 +33,8 @@ struct CodecW {
     // (hi, lo) bf16 planes of every conv / linear weight, keyed by the fp32 pointer the layer list holds (owned)
     struct Planes { bf16_t* hi; bf16_t* lo; float scale_inv; };
     std::unordered_map<const float*, Planes> planes;
+    // SnakeBeta constants [2][C] (exp(alpha) | 1 / (exp(beta) + 1e-9)) keyed by the alpha pointer (owned; split-precision path only)
+    std::unordered_map<const float*, float*> snake_pre;
     // run-time workspace: one bump arena per codec stream (lane 0 = the engine's own stream)
     static constexpr int NLANE = 32;   // capacity; `nlane` of them are used (Q3TTS_CODEC_LANES)
     int nlane = 9;                      // lane 0 = the engine's stream (synchronous entry points), the others decode asynchronously
@@ -59,6 +61,7 @@ void Engine::codec_free() {
     if (!codec) return;
     for (float* p : codec->packed) (void)hipFree(p);
     for (auto& kv : codec->planes) { (void)hipFree(kv.second.hi); (void)hipFree(kv.second.lo); }
+    for (auto& kv : codec->snake_pre) (void)hipFree(kv.second);
     for (int i = 0; i < CodecW::NLANE; ++i) {
         if (codec->arena[i]) (void)hipFree(codec->arena[i]);
         if (codec->pinned[i]) (void)hipHostFree(codec->pinned[i]);
@@ -89,7 +92,7 @@ void Engine::codec_finalize() {
         PackedConv p; p.w = out; p.b = fp(prefix + ".b"); p.cin = cin; p.cout = cout; p.k = k;
         return p;
     };
-    auto snake = [&](const std::string& prefix) { SnakeP s; s.alpha = fp(prefix + ".alpha"); s.beta = fp(prefix + ".beta"); return s; };
+    auto snake = [&](const std::string& prefix) { SnakeP s; s.alpha = fp(prefix + ".alpha"); s.beta = fp(prefix + ".beta"); s.C = (int)T(prefix + ".alpha").numel; return s; };
     const int CH = c.cd_hidden, D = c.cd_decoder_dim;
     for (int i = 0; i < c.cd_layers; ++i) {
         const std::string p = "cd.layers." + std::to_string(i) + ".";
@@ -159,6 +162,15 @@ void Engine::codec_finalize() {
         auto pc = [&](const PackedConv& p) { split(p.w, (size_t)p.cin * p.cout * p.k); };
         pc(W.conv_in);
         for (const CodecW::Block& B : W.blocks) { pc(B.tconv); for (int u = 0; u < 3; ++u) { pc(B.res[u].c1); pc(B.res[u].c2); } }
+        auto pre = [&](const SnakeP& sp) {   // exp(alpha), 1 / (exp(beta) + 1e-9) once per activation instead of once per 32-row block of every launch
+            if (!sp.alpha || !sp.beta || sp.C <= 0 || W.snake_pre.count(sp.alpha)) return;
+            float* d = nullptr;
+            Q3_HIP_CHECK(hipMalloc((void**)&d, (size_t)2 * sp.C * sizeof(float)));
+            launch_snake_pre(sp.alpha, sp.beta, d, sp.C, stream);
+            W.snake_pre[sp.alpha] = d;
+        };
+        for (const CodecW::Block& B : W.blocks) { pre(B.act); for (int u = 0; u < 3; ++u) { pre(B.res[u].a1); pre(B.res[u].a2); } }
+        pre(W.snake_out);
     }
     if (const char* ev = getenv("Q3TTS_CODEC_LANES")) W.nlane = std::max(1, std::min((int)CodecW::NLANE, atoi(ev)));
     W.lane_stream[0] = stream;
@@ -230,6 +242,8 @@ int64_t Engine::codec_run(const int32_t* codes_dev, int F, float** pcm_dev, int 
             a.slab = kslab; a.slab_floats = kslab_floats; a.batch = nbatch;
             const auto it = W.planes.find(a.W);
             if (it != W.planes.end()) { a.Wh = it->second.hi; a.Wl = it->second.lo; a.w_scale_inv = it->second.scale_inv; }
+            if (a.snake_alpha) { const auto sp = W.snake_pre.find(a.snake_alpha); if (sp != W.snake_pre.end()) a.snake_pre = sp->second; }
+            if (a.mid_alpha) { const auto sp = W.snake_pre.find(a.mid_alpha); if (sp != W.snake_pre.end()) a.mid_pre = sp->second; }
             launch_conv(a, stream);
         };
         auto gemm = [&](const float* in, int T, int Cin, const float* Wm, const float* bias, int Cout, float* out) {
@@ -406,6 +420,7 @@ const float* Engine::codec_pre_batch(const int32_t* codes_dev, int codes_stride_
         a.slab = kslab; a.slab_floats = kslab_floats;
         const auto it = W.planes.find(a.W);
         if (it != W.planes.end()) { a.Wh = it->second.hi; a.Wl = it->second.lo; a.w_scale_inv = it->second.scale_inv; }
+        if (a.snake_alpha) { const auto sp = W.snake_pre.find(a.snake_alpha); if (sp != W.snake_pre.end()) a.snake_pre = sp->second; }
         launch_conv(a, stream);
     };
     auto gemm = [&](const float* in, int Cin, const float* Wm, int Cout, float* out) {

@@ -23,10 +23,23 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 __device__ long long g_conv_prof[64];
 void conv_prof_read(long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_conv_prof), sizeof(long long) * 64); }
 // the stamped launch: the pre-transformer's down projection (C_in 3072 -> C_out 1024, one tap), i.e. the longest serial K walk
-#define CP_MARK(k) do { if ((k) < 64 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0 && a.taps == 1 && a.C_in == 3072 && a.C_out == 1024) \
-        g_conv_prof[k] = wall_clock64(); } while (0)
+// (-DQ3_CONV_PROF_SEL="..." / -DQ3_CONV_PROF_WG=n pick another launch shape / another workgroup, e.g. a mid-grid one of a 7-tap conv)
+#ifndef Q3_CONV_PROF_SEL
+#define Q3_CONV_PROF_SEL (a.taps == 1 && a.C_in == 3072 && a.C_out == 1024)
+#endif
+#ifndef Q3_CONV_PROF_WG
+#define Q3_CONV_PROF_WG 0
+#endif
+// slots 0..45: the loop (4 per iteration, first 11 iterations); 48..55: the fused tail (4 per row block); 60..63: after the loop.
+// Pinned on both sides: the clock read has no dependences, left alone it is scheduled far from where it is written.
+#define CP_MARK_IF(k, lim) do { __builtin_amdgcn_sched_barrier(0); \
+        if ((k) < (lim) && blockIdx.x == Q3_CONV_PROF_WG && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0 && (Q3_CONV_PROF_SEL)) g_conv_prof[k] = wall_clock64(); \
+        __builtin_amdgcn_sched_barrier(0); } while (0)
+#define CP_MARK(k) CP_MARK_IF(k, 64)
+#define CP_MARK_L(k) CP_MARK_IF(k, 46)
 #else
 #define CP_MARK(k) do { } while (0)
+#define CP_MARK_L(k) do { } while (0)
 #endif
 
 static __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
@@ -70,6 +83,9 @@ struct ConvKArgs {
     const bf16_t* Wh; const bf16_t* Wl; // optional (hi, lo) fp16 planes of W * 2^k for k_conv_split (16-bit storage)
     float acc_scale;                    // 2^-k (1 on the fp32 path)
     int ksplit; float* slab;            // k_conv_split, 1-tap GEMMs: blockIdx.z = K slice, raw partial sums -> slab[z][T_out][C_out] (k_conv_finish)
+    int xcd_map;                        // k_conv_split: XCD-aware tile ids (conv_tile_ids)
+    int no_fast_epi;                    // A/B switch: decoder convs through the generic epilogue
+    const float* s2_pre; const float* s1_pre;   // SnakeBeta constants [2][C_out] (exp(alpha) | 1 / (exp(beta) + 1e-9)), precomputed at finalize
     int batch_tiles;                    // > 0: blockIdx.x = sequence * batch_tiles + row tile; sequences are in_ustride / T_out * C_out floats apart
     size_t in_ustride;
     // fused residual unit (k_conv_split<..., F2 = true>): second (1x1) conv behind a SnakeBeta on the first conv's output
@@ -77,8 +93,25 @@ struct ConvKArgs {
 };
 
 // batched launch: rebase the sequence-shaped pointers to this workgroup's sequence and return its row-tile index
-static __device__ __forceinline__ int conv_batch_rebase(ConvKArgs& a) {
-    int bx = blockIdx.x;
+// XCD-aware tile ids.  Workgroups leave the dispatcher in linear order (x fastest) and go round-robin to the 8 XCDs, each with its own L2.
+// With the launch grid read literally, the gridDim.y x gridDim.z workgroups that walk the SAME input rows (other output-channel tiles,
+// other phases of a transposed conv) are a whole grid row apart: each fetches its rows from HBM again (2-8x the input traffic; a block's
+// activation, 0.2-1.5 GB, does not fit MALL either).  Remapped, every run of 8 * ny * nz consecutive workgroups covers 8 row tiles, and
+// the ny * nz workgroups of one row tile sit 8 ids apart — same XCD, same moment: one fetches, the rest hit L2.
+static __device__ __forceinline__ void conv_tile_ids(bool remap, int& bx, int& by, int& bz) {
+    bx = blockIdx.x; by = blockIdx.y; bz = blockIdx.z;
+    const int nx = gridDim.x, ny = gridDim.y, nyz = ny * gridDim.z;
+    if (!remap || nyz == 1) return;
+    const int L = bx + nx * (by + ny * bz), gsz = 8 * nyz, full = nx >> 3;
+    int G = L / gsz, w = 8;
+    if (G >= full) { G = full; w = nx & 7; }              // the last nx % 8 row tiles form a narrower group
+    const int r = L - G * gsz;
+    bx = G * 8 + r % w;
+    const int yz = r / w;
+    by = yz % ny; bz = yz / ny;
+}
+
+static __device__ __forceinline__ int conv_batch_rebase(ConvKArgs& a, int bx) {
     if (a.batch_tiles > 0) {
         const int u = bx / a.batch_tiles;
         bx -= u * a.batch_tiles;
@@ -190,23 +223,98 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 #define B3_LD 40
 
-static __device__ __forceinline__ float f16_hi_of(float x) {
-    const float c = x > 65504.f ? 65504.f : (x < -65504.f ? -65504.f : x);
-    return (float)(_Float16)c;
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// x = hi + lo in two fp16 values, two elements at a time: v_med3_f32 clamps (one instruction instead of two compare + select pairs),
+// v_cvt_pk_f16_f32 rounds both to nearest-even at once.  This runs for every staged input element and for every element of the fused
+// unit's intermediate: the scalar version was ~15 % of the fused tail's VALU work.
+static __device__ __forceinline__ void split_f16x2(float a, float b, f16x2& hi, f16x2& lo) {
+    const f32x2 c = { __builtin_amdgcn_fmed3f(a, -65504.f, 65504.f), __builtin_amdgcn_fmed3f(b, -65504.f, 65504.f) };
+    hi = __builtin_convertvector(c, f16x2);
+    const f32x2 back = __builtin_convertvector(hi, f32x2);
+    const f32x2 r = { __builtin_amdgcn_fmed3f(a - back.x, -65504.f, 65504.f), __builtin_amdgcn_fmed3f(b - back.y, -65504.f, 65504.f) };
+    lo = __builtin_convertvector(r, f16x2);
 }
-static __device__ __forceinline__ uint2 pack_f16x4(float a, float b, float c, float d) {
-    f16x4 v = { (_Float16)a, (_Float16)b, (_Float16)c, (_Float16)d };
-    return __builtin_bit_cast(uint2, v);
-}
-
 // Epilogue of one 32-row block of a wave's tile (32 x NB*32 outputs).  The accumulator layout (lane = column) would
 // make every global access a 4-byte-per-lane, two-rows-per-instruction affair — measured: half of the decoder's time.
 // The block is transposed through the wave's LDS slice instead, so each lane owns 4 consecutive channels of a row:
 // residual / multiplier rows come in as 16-byte loads issued up front (clamped addresses, never conditional), results
 // leave as 16-byte stores.
-template <int NB>
+// The decoder's own convs (no activation, no multiplier, no LayerScale; SnakeBeta of the result for the next layer): everything the
+// generic epilogue below decides per element at run time is a template parameter here, so the residual rows are plain 16-byte loads —
+// ALL 16 of the block issued before the first is needed — and the row loop is straight-line.  (The generic version's `has_res ? load :
+// zero` compiled to four 4-byte loads per row, each behind its own uniform branch, one group of rows ahead: 11-16 us per 32-row block
+// measured with in-kernel stamps, as long as the block's whole main loop.)  Same operations in the same order as the generic path.
+// RH = residual rows in flight (16: the whole block up front; 8: two halves, the second requested after the first four rows are
+// done — for the fused residual unit, whose other row block's accumulators are still live).
+template <int NB, bool OUT, bool RES, int RH>
+static __device__ __forceinline__ void split_epilogue_snake(const ConvKArgs& a, const f32x16 (&acc)[NB], float* stage, int mrow0, int co0w,
+                                                            int lane, int phase, int NT) {
+    constexpr int W = NB * 32, LDE = W + 8;
+    const int c4 = lane & 31, rsel = lane >> 5;
+    const int co = co0w + c4 * 4;
+    const bool colok = c4 * 4 < W && co < a.C_out;
+    const int coc = colok ? co : 0, lc = c4 * 4 < W ? c4 * 4 : 0;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto row_off = [&](int p, bool* okp) -> size_t {
+        const int m = mrow0 + p * 2 + rsel;
+        int t = a.transposed ? m * a.stride + phase - a.left : m;
+        *okp = colok && t >= 0 && t < a.T_out && !(a.transposed && m >= a.T_in + NT - 1);
+        t = t < 0 ? 0 : (t < a.T_out ? t : a.T_out - 1);
+        return (size_t)t * a.C_out + coc;
+    };
+    float4 resv[RH];
+    auto load_res = [&](int slot0, int p0, int n) {
+#pragma unroll
+        for (int k = 0; k < n; ++k) { bool okk; resv[slot0 + k] = *reinterpret_cast<const float4*>(a.res + row_off(p0 + k, &okk)); }
+    };
+    if (RES) load_res(0, 0, RH);
+    const float4 bias4 = a.bias ? *reinterpret_cast<const float4*>(a.bias + coc) : zero4;
+    // exp(alpha) and 1 / (exp(beta) + 1e-9) come precomputed (k_snake_pre, same expressions): 8 expf + 4 divisions per block were ~10 % of the tail
+    const float4 ea4 = *reinterpret_cast<const float4*>(a.s2_pre + coc), ib4 = *reinterpret_cast<const float4*>(a.s2_pre + a.C_out + coc);
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) stage[((reg & 3) + 8 * (reg >> 2) + 4 * rsel) * LDE + j * 32 + c4] = acc[j][reg];
+    const float ea[4] = { ea4.x, ea4.y, ea4.z, ea4.w }, ib[4] = { ib4.x, ib4.y, ib4.z, ib4.w };
+    const float bs[4] = { bias4.x, bias4.y, bias4.z, bias4.w };
+#pragma unroll
+    for (int p = 0; p < 16; ++p) {
+        bool okp;
+        const size_t o = row_off(p, &okp);
+        const float4 raw = *reinterpret_cast<const float4*>(&stage[(p * 2 + rsel) * LDE + lc]);
+        float v[4] = { raw.x, raw.y, raw.z, raw.w }, s2[4];
+        const float4 r4 = RES ? resv[p % RH] : zero4;
+        const float rv[4] = { r4.x, r4.y, r4.z, r4.w };
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float x = v[e] * a.acc_scale + bs[e];
+            if (RES) x = rv[e] + x;
+            v[e] = x;
+            s2[e] = x + ib[e] * sin_sq(x * ea[e]);
+        }
+        if (okp) {
+            if (OUT) *reinterpret_cast<float4*>(a.out + o) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4*>(a.out2 + o) = make_float4(s2[0], s2[1], s2[2], s2[3]);
+        }
+        if ((p & 3) == 3) {                               // groups of four rows stay groups: left alone hipcc hoists all 16 LDS reads and addresses
+            __builtin_amdgcn_sched_barrier(0);
+            if (RES && RH == 8 && p < 8) load_res(p - 3, p + 5, 4);      // slots of the rows just finished take rows 8..11 / 12..15
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+template <int NB, int RH = 16>
 static __device__ __forceinline__ void split_epilogue_block(const ConvKArgs& a, const f32x16 (&acc)[NB], float* stage, int mrow0, int co0w,
                                                             int lane, int phase, int NT) {
+    if (a.out2 && a.s2_pre && a.act == 0 && !a.mul && !a.res_scale && !a.no_fast_epi) {   // uniform: the decoder's convs
+        if (a.res) { if (a.out) split_epilogue_snake<NB, true, true, RH>(a, acc, stage, mrow0, co0w, lane, phase, NT);
+                     else split_epilogue_snake<NB, false, true, RH>(a, acc, stage, mrow0, co0w, lane, phase, NT); }
+        else { if (a.out) split_epilogue_snake<NB, true, false, RH>(a, acc, stage, mrow0, co0w, lane, phase, NT);
+               else split_epilogue_snake<NB, false, false, RH>(a, acc, stage, mrow0, co0w, lane, phase, NT); }
+        return;
+    }
     constexpr int W = NB * 32, LDE = W + 8;      // padded row: the two 32-lane halves of a transposing write hit disjoint banks
     const int c4 = lane & 31, rsel = lane >> 5;
     const int co = co0w + c4 * 4;
@@ -297,7 +405,9 @@ template <int MB, int NB, int WM, int WN, int PA, int KC = 32, int NBUF = 2, boo
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MB * NB <= 6 && KC == 32 ? 2 : 1), (MB * NB <= 6 && KC == 32 ? 2 : 1))))
 void k_conv_split(ConvKArgs a0) {
     ConvKArgs a = a0;
-    const int bx = conv_batch_rebase(a);
+    int bx, by, bz;
+    conv_tile_ids(a.xcd_map != 0, bx, by, bz);
+    bx = conv_batch_rebase(a, bx);
     constexpr int TM = WM * MB * 32, TN = WN * NB * 32, AROWS = PA * 32;
     constexpr int CB = KC / 32, SEG = KC / 8, LD = KC + 8;       // 32-column blocks, 16-byte segments and padded halves per staged row
     constexpr int PB = TN * SEG * 2 / 256;                       // 16-B segments per thread of one weight tile (2 planes x TN rows x SEG)
@@ -311,11 +421,11 @@ void k_conv_split(ConvKArgs a0) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const bool ksp = KC == 128 && a.ksplit > 1;               // split-K (short pre-transformer GEMMs): blockIdx.z is the K slice, not a phase
-    const int m0 = bx * TM, co0 = blockIdx.y * TN, phase = ksp ? 0 : blockIdx.z;
+    const int m0 = bx * TM, co0 = by * TN, phase = ksp ? 0 : bz;
     const int NT = a.transposed ? a.taps / a.stride : a.taps;
     const int halo = a.transposed ? NT - 1 : (a.taps - 1) * a.dil;
     const int n_chunks = ksp ? a.C_in / KC / a.ksplit : a.C_in / KC, total = n_chunks * NT;
-    const int c_first = ksp ? (int)blockIdx.z * n_chunks : 0;
+    const int c_first = ksp ? bz * n_chunks : 0;
 
     f32x16 acc[MB][NB];
     const f32x16 zero16 = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
@@ -357,10 +467,11 @@ void k_conv_split(ConvKArgs a0) {
             for (int cb = 0; cb < CB; ++cb) {
                 const f32x4v r = areg[i][cb];
                 const float4 v = make_float4(inr ? r.x : 0.f, inr ? r.y : 0.f, inr ? r.z : 0.f, inr ? r.w : 0.f);
-                const float h0 = f16_hi_of(v.x), h1 = f16_hi_of(v.y), h2 = f16_hi_of(v.z), h3 = f16_hi_of(v.w);
-                *reinterpret_cast<uint2*>(&As[0][arow + 32 * i][cb * 32 + acol]) = pack_f16x4(h0, h1, h2, h3);
-                *reinterpret_cast<uint2*>(&As[1][arow + 32 * i][cb * 32 + acol]) =
-                    pack_f16x4(f16_hi_of(v.x - h0), f16_hi_of(v.y - h1), f16_hi_of(v.z - h2), f16_hi_of(v.w - h3));
+                f16x2 h01, h23, l01, l23;
+                split_f16x2(v.x, v.y, h01, l01);
+                split_f16x2(v.z, v.w, h23, l23);
+                *reinterpret_cast<uint2*>(&As[0][arow + 32 * i][cb * 32 + acol]) = make_uint2(__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23));
+                *reinterpret_cast<uint2*>(&As[1][arow + 32 * i][cb * 32 + acol]) = make_uint2(__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23));
             }
         }
     };
@@ -378,13 +489,13 @@ void k_conv_split(ConvKArgs a0) {
     int chunk = c_first, ti = 0;
     for (int it = 0; it < total; ++it) {
         const int buf = NBUF == 2 ? (it & 1) : 0;
-        CP_MARK(1 + it * 4);
+        CP_MARK_L(1 + it * 4);
         if (ti == 0 || NBUF == 1) __syncthreads();            // every wave is done with the rows (and, single-buffered, the weight tile) it read last
         if (ti == 0) storeA();
         storeB(buf);                                          // double-buffered: this buffer was last read two taps ago
-        CP_MARK(2 + it * 4);
+        CP_MARK_L(2 + it * 4);
         __syncthreads();
-        CP_MARK(3 + it * 4);
+        CP_MARK_L(3 + it * 4);
         int nchunk = chunk, nti = ti + 1;
         if (nti == NT) { nti = 0; ++nchunk; }
         if (it + 1 < total) {                                 // next tap's weights (and next chunk's rows) fly during the MFMAs below
@@ -418,7 +529,7 @@ void k_conv_split(ConvKArgs a0) {
                 }
         }
         chunk = nchunk; ti = nti;
-        CP_MARK(4 + it * 4);
+        CP_MARK_L(4 + it * 4);
     }
     CP_MARK(62);
     __syncthreads();                                          // the staging slices below overlay the operand tiles
@@ -438,29 +549,34 @@ void k_conv_split(ConvKArgs a0) {
         for (int j = 0; j < NB; ++j) {
             const int co = j * 32 + col0;
             b1[j] = a.bias ? a.bias[co] : 0.f;
-            ea1[j] = expf(a.s1_alpha[co]);
-            ib1[j] = 1.0f / (expf(a.s1_beta[co]) + 0.000000001f);
+            ea1[j] = a.s1_pre[co];
+            ib1[j] = a.s1_pre[C2 + co];
         }
         const float sc1 = a.acc_scale;
         a.bias = a.bias2; a.acc_scale = a.acc_scale2;          // from here on `a` describes the second conv's epilogue (no struct copy: it would live in scratch)
         // statically indexed row blocks (a rolled loop over i gives the accumulators a scratch home that the main loop keeps in sync)
         auto unit = [&](auto itag) {
             constexpr int i = decltype(itag)::value;
+            CP_MARK(48 + 4 * i);
             // accumulator layout: column = lane & 31 (+ 32 j), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
 #pragma unroll
             for (int j = 0; j < NB; ++j)
 #pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    const int row = (reg & 3) + 8 * (reg >> 2) + 4 * rsel;
-                    const float v = acc[i][j][reg] * sc1 + b1[j];
-                    const float t = v + ib1[j] * sin_sq(v * ea1[j]);
-                    const float h = f16_hi_of(t);
-                    ts[row * TLD + j * 32 + col0] = (_Float16)h;
-                    ts[(32 + row) * TLD + j * 32 + col0] = (_Float16)f16_hi_of(t - h);
+                for (int reg = 0; reg < 16; reg += 2) {
+                    const int row = (reg & 3) + 8 * (reg >> 2) + 4 * rsel;      // reg, reg + 1: rows row, row + 1
+                    const float v0 = acc[i][j][reg] * sc1 + b1[j], v1 = acc[i][j][reg + 1] * sc1 + b1[j];
+                    const float t0 = v0 + ib1[j] * sin_sq(v0 * ea1[j]), t1 = v1 + ib1[j] * sin_sq(v1 * ea1[j]);
+                    f16x2 h, l;
+                    split_f16x2(t0, t1, h, l);
+                    ts[row * TLD + j * 32 + col0] = h.x;
+                    ts[(row + 1) * TLD + j * 32 + col0] = h.y;
+                    ts[(32 + row) * TLD + j * 32 + col0] = l.x;
+                    ts[(33 + row) * TLD + j * 32 + col0] = l.y;
                 }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            CP_MARK(49 + 4 * i);
             f32x16 acc2[NB];
 #pragma unroll
             for (int j = 0; j < NB; ++j) acc2[j] = zero16;
@@ -493,10 +609,12 @@ void k_conv_split(ConvKArgs a0) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();                                     // the plane reads are done: the same bytes become the epilogue's staging
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            split_epilogue_block<NB>(a, acc2, stage, m0 + wm * MB * 32 + i * 32, co0, lane, 0, NT);
+            CP_MARK(50 + 4 * i);
+            split_epilogue_snake<NB, true, true, 8>(a, acc2, stage, m0 + wm * MB * 32 + i * 32, co0, lane, 0, NT);   // launch_conv guarantees out, out2, res, no activation
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            CP_MARK(51 + 4 * i);
         };
         unit(std::integral_constant<int, 0>{});
         if constexpr (MB > 1) unit(std::integral_constant<int, MB - 1>{});
@@ -508,14 +626,16 @@ void k_conv_split(ConvKArgs a0) {
     if constexpr (KC == 128) {
         if (ksp) {   // raw partial sums of this K slice; bias / activation / residual belong to k_conv_finish
             ConvKArgs b = a;
-            b.out = a.slab + (size_t)blockIdx.z * a.T_out * a.C_out;
+            b.out = a.slab + (size_t)bz * a.T_out * a.C_out;
             b.bias = nullptr; b.res = nullptr; b.res_scale = nullptr; b.mul = nullptr; b.out2 = nullptr; b.act = 0; b.acc_scale = 1.0f;
             split_epilogue_block<NB>(b, acc[0], stage, m0 + wm * MB * 32, co0 + wn * NB * 32, lane, 0, NT);
             if (MB > 1) split_epilogue_block<NB>(b, acc[MB - 1], stage, m0 + wm * MB * 32 + 32, co0 + wn * NB * 32, lane, 0, NT);
             return;
         }
     }
+    CP_MARK(60);
     split_epilogue_block<NB>(a, acc[0], stage, m0 + wm * MB * 32, co0 + wn * NB * 32, lane, phase, NT);
+    CP_MARK(61);
     if (MB > 1) split_epilogue_block<NB>(a, acc[MB - 1], stage, m0 + wm * MB * 32 + 32, co0 + wn * NB * 32, lane, phase, NT);
     CP_MARK(63);
 }
@@ -572,6 +692,15 @@ __global__ void k_absmax(const float* w, size_t n, unsigned* out) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(w[i]));
     atomicMax(out, __float_as_uint(m));   // non-negative floats order like their bit patterns
 }
+// SnakeBeta constants of one activation, with the expressions the epilogues used to evaluate per block
+__global__ void k_snake_pre(const float* alpha, const float* beta, float* pre, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) { pre[c] = expf(alpha[c]); pre[C + c] = 1.0f / (expf(beta[c]) + 0.000000001f); }
+}
+void launch_snake_pre(const float* alpha, const float* beta, float* pre, int C, hipStream_t s) {
+    hipLaunchKernelGGL(k_snake_pre, dim3((C + 255) / 256), dim3(256), 0, s, alpha, beta, pre, C);
+}
+
 void launch_split_planes(const float* w, bf16_t* hi, bf16_t* lo, size_t n, float scale, hipStream_t s) {
     hipLaunchKernelGGL(k_split_planes, dim3((unsigned)std::min<size_t>((n + 255) / 256, 8192)), dim3(256), 0, s, w, hi, lo, n, scale);
     Q3_HIP_CHECK(hipGetLastError());
@@ -595,7 +724,7 @@ static void launch_split_pa(const ConvKArgs& a, dim3 grid, int extra, hipStream_
 __global__ __launch_bounds__(CO1_T) void k_conv_cout1(ConvKArgs a0) {
     extern __shared__ float xs[];                    // [(CO1_T + halo)][C_in + 1]
     ConvKArgs a = a0;
-    const int bx = conv_batch_rebase(a);
+    const int bx = conv_batch_rebase(a, blockIdx.x);
     const int ld = a.C_in + 1, halo = (a.taps - 1) * a.dil, t0 = bx * CO1_T, rows = CO1_T + halo;
     for (int i = threadIdx.x; i < rows * (a.C_in / 4); i += CO1_T) {
         const int r = i / (a.C_in / 4), c4 = (i % (a.C_in / 4)) * 4, src = t0 - halo + r;
@@ -625,10 +754,14 @@ void launch_conv(const ConvArgs& c, hipStream_t s) {
     a.in = c.in; a.T_in = c.T_in; a.C_in = c.C_in; a.out = c.out; a.T_out = c.T_out; a.C_out = c.C_out;
     a.W = c.W; a.bias = c.bias; a.taps = c.taps; a.dil = c.dil; a.transposed = c.transposed; a.stride = c.stride; a.left = c.left;
     a.res = c.res; a.res_scale = c.res_scale; a.mul = c.mul; a.act = c.act; a.clamp = c.clamp;
-    a.out2 = c.out2; a.s2_alpha = c.snake_alpha; a.s2_beta = c.snake_beta;
+    a.out2 = c.out2; a.s2_alpha = c.snake_alpha; a.s2_beta = c.snake_beta; a.s2_pre = c.snake_pre; a.s1_pre = nullptr;
     a.Wh = c.Wh; a.Wl = c.Wl;
     a.acc_scale = 1.0f;
     a.ksplit = 0; a.slab = nullptr; a.batch_tiles = 0;
+    static const bool no_xcd_map = getenv("Q3TTS_CONV_NO_XCD_MAP") != nullptr;   // A/B switch
+    a.xcd_map = no_xcd_map ? 0 : 1;
+    static const bool no_fast_epi = getenv("Q3TTS_CONV_GENERIC_EPILOGUE") != nullptr;
+    a.no_fast_epi = no_fast_epi ? 1 : 0;
     a.W2h = nullptr; a.W2l = nullptr; a.acc_scale2 = 1.0f; a.bias2 = nullptr; a.s1_alpha = nullptr; a.s1_beta = nullptr;
     a.in_ustride = c.in_ustride ? c.in_ustride : (size_t)c.T_in * c.C_in;
     const int nb = c.batch > 1 ? c.batch : 1;
@@ -649,10 +782,10 @@ void launch_conv(const ConvArgs& c, hipStream_t s) {
     const int NTt = c.transposed ? c.taps / c.stride : c.taps;
     const int halo = c.transposed ? NTt - 1 : (c.taps - 1) * c.dil;
     if (c.W2h != nullptr) {   // fused residual unit: 7-tap conv -> SnakeBeta -> 1x1 conv -> + residual, 96 channels, 256-row tiles
-        if (!(c.Wh && c.Wl && c.W2l && c.C_in == 96 && c.C_out == 96 && !c.transposed && halo <= 64 && c.mid_alpha && c.mid_beta && c.res && !c.res_scale && !c.clamp && c.act == 0 && !c.mul))
+        if (!(c.Wh && c.Wl && c.W2l && c.C_in == 96 && c.C_out == 96 && !c.transposed && halo <= 64 && c.mid_pre && c.snake_pre && c.res && c.out && c.out2 && !c.res_scale && !c.clamp && c.act == 0 && !c.mul))
             throw Error("conv: fused residual unit needs 96 -> 96 channels on the split-precision path");
         a.acc_scale = c.w_scale_inv;
-        a.W2h = c.W2h; a.W2l = c.W2l; a.acc_scale2 = c.w2_scale_inv; a.bias2 = c.bias2; a.s1_alpha = c.mid_alpha; a.s1_beta = c.mid_beta;
+        a.W2h = c.W2h; a.W2l = c.W2l; a.acc_scale2 = c.w2_scale_inv; a.bias2 = c.bias2; a.s1_alpha = c.mid_alpha; a.s1_beta = c.mid_beta; a.s1_pre = c.mid_pre;
         const int extra = (halo + 31) / 32, tiles = (rows + 255) / 256;
         if (nb > 1) a.batch_tiles = tiles;
         const dim3 g((unsigned)(tiles * nb), 1, 1);

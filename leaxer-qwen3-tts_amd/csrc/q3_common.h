@@ -214,16 +214,18 @@ struct ConvArgs { // out[t][co] = epi(bias[co] + sum_{tap,ci} W[tap][co][ci] * i
     float* out2 = nullptr;       // optional second output: SnakeBeta(value) for the NEXT layer
     const float* snake_alpha = nullptr;
     const float* snake_beta = nullptr;
+    const float* snake_pre = nullptr;   // [2][C_out]: exp(alpha) | 1 / (exp(beta) + 1e-9), launch_snake_pre (split-precision path)
     float* slab = nullptr; size_t slab_floats = 0; // optional scratch for split-K partial sums of short 1-tap GEMMs ([slice][T_out][C_out])
     // fused residual unit (96-channel decoder block): out = res + bias2 + W2 . snake_mid(bias + W . in) — the 7-tap conv, the SnakeBeta
     // between, the 1x1 conv and the residual add in ONE launch; the intermediate never leaves the CU.  W2 = the 1x1 conv's [1][C_out][C_out]
     const float* W2 = nullptr; const bf16_t* W2h = nullptr; const bf16_t* W2l = nullptr; float w2_scale_inv = 1.0f;
-    const float* bias2 = nullptr; const float* mid_alpha = nullptr; const float* mid_beta = nullptr;
+    const float* bias2 = nullptr; const float* mid_alpha = nullptr; const float* mid_beta = nullptr; const float* mid_pre = nullptr;
     int batch = 1;               // independent sequences of the same shape: sequence u at in + u * in_ustride, out / out2 / res / mul at + u * T_out * C_out
     size_t in_ustride = 0;       // floats between the sequences' inputs (0: T_in * C_in, i.e. densely packed)
 };
 void launch_conv(const ConvArgs& a, hipStream_t s);
 void launch_split_planes(const float* w, bf16_t* hi, bf16_t* lo, size_t n, float scale, hipStream_t s);
+void launch_snake_pre(const float* alpha, const float* beta, float* pre /* [2][C] */, int C, hipStream_t s);
 void launch_absmax(const float* w, size_t n, unsigned* out, hipStream_t s);
 void launch_repack_conv(const float* w, float* out, int cin, int cout, int k, int transposed, hipStream_t s);
 void launch_code_embed_mean(const float* table, const int32_t* codes, int F, int G, int codebook, int C, float* out, hipStream_t s,

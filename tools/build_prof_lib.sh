@@ -2,11 +2,13 @@
 # Builds tools/exp/libprof.so = libq3tts_hip.so with -DQ3_SAMPLE_PROF (phase timestamps inside k_sample / k_gemv1 / k_cp_attn_oproj) plus
 # an accessor; use with Q3TTS_LIB=$PWD/tools/exp/libprof.so python tools/kernel_phases.py.  Needs a prior `python leaxer-qwen3-tts_amd/build.py`.
 set -e
+PROF_DEFS=("$@")
+# PROF_DEFS (bash array, e.g. PROF_DEFS=('-DQ3_CONV_PROF_SEL=(a.taps==7&&a.C_in==192)' -DQ3_CONV_PROF_WG=2000); source this script or export is not enough for arrays: pass them as arguments instead): extra -D flags for the codec kernels (Q3_CONV_PROF_SEL / Q3_CONV_PROF_WG: which k_conv_split launch and workgroup is stamped)
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 mkdir -p "$ROOT/tools/exp" /tmp/q3prof
 cd /tmp/q3prof
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -DQ3_SAMPLE_PROF -mllvm -amdgpu-kernarg-preload-count=16 -x hip -c "$ROOT/leaxer-qwen3-tts_amd/csrc/q3_decode_kernels.hip" -o dk_prof.o
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -DQ3_SAMPLE_PROF -x hip -c "$ROOT/leaxer-qwen3-tts_amd/csrc/q3_codec_kernels.hip" -o ck_prof.o
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -DQ3_SAMPLE_PROF "${PROF_DEFS[@]}" -x hip -c "$ROOT/leaxer-qwen3-tts_amd/csrc/q3_codec_kernels.hip" -o ck_prof.o
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -DQ3_SAMPLE_PROF -mllvm -amdgpu-kernarg-preload-count=16 -x hip -c "$ROOT/leaxer-qwen3-tts_amd/csrc/q3_gemm_kernels.hip" -o gk_prof.o
 cat > prof_api.cpp <<'EOC'
 namespace q3 { void sample_prof_read(long long* out); void conv_prof_read(long long* out); void gemm_prof_read(long long* out); }

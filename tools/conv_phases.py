@@ -24,8 +24,16 @@ for _ in range(2):
 buf = (C.c_longlong * 64)()
 L.q3_conv_prof(buf)
 t = np.array(buf[:], dtype=np.float64) * 10.0
-print("down-projection k_conv_split launch (last layer): total", t[63] - t[0], "ns; loop", t[62] - t[0], "ns; epilogue", t[63] - t[62])
-for it in range(8):
+print("stamped k_conv_split launch (its last occurrence in the decode): total", t[63] - t[0], "ns; loop", t[62] - t[0], "ns; tail + epilogue", t[63] - t[62])
+print(f"  after the loop: block barrier {t[60] - t[62]:.0f} ns" if t[60] > 0 else "  (fused tail)")
+if t[48] > 0:
+    for i in range(2):
+        b = 48 + 4 * i
+        if t[b + 3] > t[b]:
+            print(f"  fused tail, row block {i}: SnakeBeta + (hi, lo) planes to LDS {t[b + 1] - t[b]:.0f} ns, 1x1 conv MFMAs {t[b + 2] - t[b + 1]:.0f} ns, epilogue {t[b + 3] - t[b + 2]:.0f} ns")
+elif t[61] > t[60] > 0:
+    print(f"  epilogue of row block 0 {t[61] - t[60]:.0f} ns, of row block 1 {t[63] - t[61]:.0f} ns")
+for it in range(11):
     b = 1 + it * 4
     if t[b + 3] <= t[b]:
         break

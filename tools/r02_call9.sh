@@ -1,0 +1,14 @@
+set -e
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && mkdir -p gpurun_out/r02o
+O=gpurun_out/r02o
+timeout -k 10 600 python -m pytest tests/test_gpu_codec.py tests/test_gpu_full.py -x -q --timeout 500 > $O/tests.log 2>&1 || { tail -40 $O/tests.log; exit 1; }
+tail -2 $O/tests.log
+for FF in 64 256 2048; do python tools/codec_bench.py --frames $FF --reps 3 | grep frames= >> $O/codec_sizes.txt; done
+for FF in 256 2048; do Q3TTS_CONV_NO_XCD_MAP=1 python tools/codec_bench.py --frames $FF --reps 3 | grep frames= >> $O/codec_sizes_nomap.txt; done
+echo map; cat $O/codec_sizes.txt; echo nomap; cat $O/codec_sizes_nomap.txt
+rocprofv3 --kernel-trace --stats -d $O/trace_codec -o c -- python tools/codec_bench.py --reps 2 > $O/codec_bench.log 2>&1
+python tools/rocpd_summary.py $O/trace_codec/c_results.db 30 > $O/codec_f2048_by_grid.txt
+rm -rf $O/trace_codec
+cut -c1-125 $O/codec_f2048_by_grid.txt | head -24
+Q3TTS_LIB=$PWD/tools/exp/libprof.so python tools/conv_phases.py --frames 2048 > $O/conv_phases_c192.txt 2>&1 || true
+cat $O/conv_phases_c192.txt
