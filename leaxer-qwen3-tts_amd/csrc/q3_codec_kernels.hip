@@ -247,6 +247,10 @@ static __device__ __forceinline__ void split_f16x2(float a, float b, f16x2& hi, 
 // measured with in-kernel stamps, as long as the block's whole main loop.)  Same operations in the same order as the generic path.
 // RH = residual rows in flight (16: the whole block up front; 8: two halves, the second requested after the first four rows are
 // done — for the fused residual unit, whose other row block's accumulators are still live).
+// No branch inside the row loop: rows outside the output (tile tails, the rows a transposed conv's last phase does not own) are stored
+// to a dump line instead of being predicated.  Behind a branch hipcc cannot count the stores in flight, so every wait for an
+// (older) operand load — s_waitcnt counts in order — also waited for the previous rows' STORES to complete: ~0.4 us per row.
+__device__ float g_conv_dump[2][64 * 4];
 template <int NB, bool OUT, bool RES, int RH>
 static __device__ __forceinline__ void split_epilogue_snake(const ConvKArgs& a, const f32x16 (&acc)[NB], float* stage, int mrow0, int co0w,
                                                             int lane, int phase, int NT) {
@@ -255,21 +259,19 @@ static __device__ __forceinline__ void split_epilogue_snake(const ConvKArgs& a, 
     const int co = co0w + c4 * 4;
     const bool colok = c4 * 4 < W && co < a.C_out;
     const int coc = colok ? co : 0, lc = c4 * 4 < W ? c4 * 4 : 0;
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    auto row_off = [&](int p, bool* okp) -> size_t {
-        const int m = mrow0 + p * 2 + rsel;
-        int t = a.transposed ? m * a.stride + phase - a.left : m;
-        *okp = colok && t >= 0 && t < a.T_out && !(a.transposed && m >= a.T_in + NT - 1);
-        t = t < 0 ? 0 : (t < a.T_out ? t : a.T_out - 1);
-        return (size_t)t * a.C_out + coc;
-    };
+    // output row of row pair p: t = t0 + p * tstep, valid while 0 <= t < T_out and the input row m0r + 2 p is below mlim
+    const int m0r = mrow0 + rsel;
+    const int t0 = a.transposed ? m0r * a.stride + phase - a.left : m0r, tstep = a.transposed ? 2 * a.stride : 2;
+    const int mlim = a.transposed ? a.T_in + NT - 1 : 0x7fffffff;
+    auto row_ok = [&](int p) { const int t = t0 + p * tstep; return colok && t >= 0 && t < a.T_out && m0r + 2 * p < mlim; };
+    auto row_off = [&](int p) -> size_t { return row_ok(p) ? (size_t)(t0 + p * tstep) * a.C_out + coc : (size_t)coc; };   // row 0 stands in for a row outside (loads only)
     float4 resv[RH];
     auto load_res = [&](int slot0, int p0, int n) {
 #pragma unroll
-        for (int k = 0; k < n; ++k) { bool okk; resv[slot0 + k] = *reinterpret_cast<const float4*>(a.res + row_off(p0 + k, &okk)); }
+        for (int k = 0; k < n; ++k) resv[slot0 + k] = *reinterpret_cast<const float4*>(a.res + row_off(p0 + k));
     };
     if (RES) load_res(0, 0, RH);
-    const float4 bias4 = a.bias ? *reinterpret_cast<const float4*>(a.bias + coc) : zero4;
+    const float4 bias4 = *reinterpret_cast<const float4*>(a.bias + coc);
     // exp(alpha) and 1 / (exp(beta) + 1e-9) come precomputed (k_snake_pre, same expressions): 8 expf + 4 divisions per block were ~10 % of the tail
     const float4 ea4 = *reinterpret_cast<const float4*>(a.s2_pre + coc), ib4 = *reinterpret_cast<const float4*>(a.s2_pre + a.C_out + coc);
 #pragma unroll
@@ -278,13 +280,15 @@ static __device__ __forceinline__ void split_epilogue_snake(const ConvKArgs& a, 
         for (int reg = 0; reg < 16; ++reg) stage[((reg & 3) + 8 * (reg >> 2) + 4 * rsel) * LDE + j * 32 + c4] = acc[j][reg];
     const float ea[4] = { ea4.x, ea4.y, ea4.z, ea4.w }, ib[4] = { ib4.x, ib4.y, ib4.z, ib4.w };
     const float bs[4] = { bias4.x, bias4.y, bias4.z, bias4.w };
+    float* const dump1 = &g_conv_dump[0][lane * 4];
+    float* const dump2 = &g_conv_dump[1][lane * 4];
 #pragma unroll
     for (int p = 0; p < 16; ++p) {
-        bool okp;
-        const size_t o = row_off(p, &okp);
+        const bool okp = row_ok(p);
+        const size_t o = row_off(p);
         const float4 raw = *reinterpret_cast<const float4*>(&stage[(p * 2 + rsel) * LDE + lc]);
         float v[4] = { raw.x, raw.y, raw.z, raw.w }, s2[4];
-        const float4 r4 = RES ? resv[p % RH] : zero4;
+        const float4 r4 = RES ? resv[p % RH] : make_float4(0.f, 0.f, 0.f, 0.f);
         const float rv[4] = { r4.x, r4.y, r4.z, r4.w };
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -293,10 +297,8 @@ static __device__ __forceinline__ void split_epilogue_snake(const ConvKArgs& a, 
             v[e] = x;
             s2[e] = x + ib[e] * sin_sq(x * ea[e]);
         }
-        if (okp) {
-            if (OUT) *reinterpret_cast<float4*>(a.out + o) = make_float4(v[0], v[1], v[2], v[3]);
-            *reinterpret_cast<float4*>(a.out2 + o) = make_float4(s2[0], s2[1], s2[2], s2[3]);
-        }
+        if (OUT) *reinterpret_cast<float4*>(okp ? a.out + o : dump1) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(okp ? a.out2 + o : dump2) = make_float4(s2[0], s2[1], s2[2], s2[3]);
         if ((p & 3) == 3) {                               // groups of four rows stay groups: left alone hipcc hoists all 16 LDS reads and addresses
             __builtin_amdgcn_sched_barrier(0);
             if (RES && RH == 8 && p < 8) load_res(p - 3, p + 5, 4);      // slots of the rows just finished take rows 8..11 / 12..15
@@ -308,7 +310,7 @@ static __device__ __forceinline__ void split_epilogue_snake(const ConvKArgs& a, 
 template <int NB, int RH = 16>
 static __device__ __forceinline__ void split_epilogue_block(const ConvKArgs& a, const f32x16 (&acc)[NB], float* stage, int mrow0, int co0w,
                                                             int lane, int phase, int NT) {
-    if (a.out2 && a.s2_pre && a.act == 0 && !a.mul && !a.res_scale && !a.no_fast_epi) {   // uniform: the decoder's convs
+    if (a.out2 && a.s2_pre && a.bias && a.act == 0 && !a.mul && !a.res_scale && !a.no_fast_epi) {   // uniform: the decoder's convs
         if (a.res) { if (a.out) split_epilogue_snake<NB, true, true, RH>(a, acc, stage, mrow0, co0w, lane, phase, NT);
                      else split_epilogue_snake<NB, false, true, RH>(a, acc, stage, mrow0, co0w, lane, phase, NT); }
         else { if (a.out) split_epilogue_snake<NB, true, false, RH>(a, acc, stage, mrow0, co0w, lane, phase, NT);
@@ -782,7 +784,7 @@ void launch_conv(const ConvArgs& c, hipStream_t s) {
     const int NTt = c.transposed ? c.taps / c.stride : c.taps;
     const int halo = c.transposed ? NTt - 1 : (c.taps - 1) * c.dil;
     if (c.W2h != nullptr) {   // fused residual unit: 7-tap conv -> SnakeBeta -> 1x1 conv -> + residual, 96 channels, 256-row tiles
-        if (!(c.Wh && c.Wl && c.W2l && c.C_in == 96 && c.C_out == 96 && !c.transposed && halo <= 64 && c.mid_pre && c.snake_pre && c.res && c.out && c.out2 && !c.res_scale && !c.clamp && c.act == 0 && !c.mul))
+        if (!(c.Wh && c.Wl && c.W2l && c.C_in == 96 && c.C_out == 96 && !c.transposed && halo <= 64 && c.mid_pre && c.snake_pre && c.bias2 && c.res && c.out && c.out2 && !c.res_scale && !c.clamp && c.act == 0 && !c.mul))
             throw Error("conv: fused residual unit needs 96 -> 96 channels on the split-precision path");
         a.acc_scale = c.w_scale_inv;
         a.W2h = c.W2h; a.W2l = c.W2l; a.acc_scale2 = c.w2_scale_inv; a.bias2 = c.bias2; a.s1_alpha = c.mid_alpha; a.s1_beta = c.mid_beta; a.s1_pre = c.mid_pre;

@@ -1,6 +1,6 @@
 set -e
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && mkdir -p gpurun_out/r02r
-O=gpurun_out/r02r
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && mkdir -p gpurun_out/r02s
+O=gpurun_out/r02s
 timeout -k 10 600 python -m pytest tests/test_gpu_codec.py tests/test_gpu_full.py -x -q --timeout 500 > $O/tests.log 2>&1 || { tail -40 $O/tests.log; exit 1; }
 tail -2 $O/tests.log
 for FF in 64 256 2048; do python tools/codec_bench.py --frames $FF --reps 3 | grep frames= >> $O/codec_sizes.txt; done
