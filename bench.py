@@ -149,7 +149,7 @@ def roofline_record(cfg, B, F, step_ms, model):
     traffic, note = measured_traffic(B, model)
     return {"bound": "hbm", "kernel": "decode step = one hipGraph replay per frame ("
             + ("q3::k_gemv1 (QKV / o_proj / gate-up / down / heads), k_cp_attn_oproj x75, k_attn x28, k_sample x16" if B <= 2 else
-               ("q3::k_gemv16 family" if B <= 16 else "q3::k_gemm2 (+ split-K finish) + k_attn + k_sample")) + ")",
+               ("q3::k_gemv16 family" if B <= 16 else "q3::k_gemm3 (+ split-K k_finish*) + k_attn + k_sample")) + ")",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_note": note,
             "algorithmic_bytes_per_launch": int(abytes), "launch_ms": round(step_ms, 4),
