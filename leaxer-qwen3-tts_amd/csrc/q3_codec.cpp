@@ -60,7 +60,7 @@ struct CodecW {
 void Engine::codec_free() {
     if (!codec) return;
     for (float* p : codec->packed) (void)hipFree(p);
-    for (auto& kv : codec->planes) { (void)hipFree(kv.second.hi); (void)hipFree(kv.second.lo); }
+    for (auto& kv : codec->planes) (void)hipFree(kv.second.hi);   // lo lives in the same allocation
     for (auto& kv : codec->snake_pre) (void)hipFree(kv.second);
     for (int i = 0; i < CodecW::NLANE; ++i) {
         if (codec->arena[i]) (void)hipFree(codec->arena[i]);
@@ -144,9 +144,10 @@ void Engine::codec_finalize() {
             int e = 0;
             if (amax > 0.f && std::isfinite(amax)) (void)frexpf(amax, &e);   // amax = m * 2^e, m in [0.5, 1)
             const int k = amax > 0.f ? 12 - e : 0;
-            bf16_t *hi = nullptr, *lo = nullptr;
-            Q3_HIP_CHECK(hipMalloc((void**)&hi, n * sizeof(bf16_t)));
-            Q3_HIP_CHECK(hipMalloc((void**)&lo, n * sizeof(bf16_t)));
+            bf16_t *hi = nullptr, *lo = nullptr;   // one allocation, lo right behind hi: k_conv_split addresses both planes as base + 32-bit offset
+            const size_t np = (n + 7) / 8 * 8;
+            Q3_HIP_CHECK(hipMalloc((void**)&hi, 2 * np * sizeof(bf16_t)));
+            lo = hi + np;
             launch_split_planes(w, hi, lo, n, ldexpf(1.0f, k), stream);
             W.planes[w] = { hi, lo, ldexpf(1.0f, -k) };
         };

@@ -85,6 +85,7 @@ struct ConvKArgs {
     int ksplit; float* slab;            // k_conv_split, 1-tap GEMMs: blockIdx.z = K slice, raw partial sums -> slab[z][T_out][C_out] (k_conv_finish)
     int xcd_map;                        // k_conv_split: XCD-aware tile ids (conv_tile_ids)
     int no_fast_epi;                    // A/B switch: decoder convs through the generic epilogue
+    int peel_taps;                      // k_conv_split: >= 3-tap convs request the next chunk's rows two iterations ahead (A/B switch)
     const float* s2_pre; const float* s1_pre;   // SnakeBeta constants [2][C_out] (exp(alpha) | 1 / (exp(beta) + 1e-9)), precomputed at finalize
     int batch_tiles;                    // > 0: blockIdx.x = sequence * batch_tiles + row tile; sequences are in_ustride / T_out * C_out floats apart
     size_t in_ustride;
@@ -401,7 +402,8 @@ static __device__ __forceinline__ void split_epilogue_block(const ConvKArgs& a, 
 
 // KC = C_in columns per staged chunk (32, or 128 for the short-and-wide GEMMs of the pre-transformer, whose few workgroups walk K
 // serially: a chunk costs one memory latency whatever its size, so 4x wider chunks are 4x fewer latencies); NBUF = weight-tile buffers.
-template <int MB, int NB, int WM, int WN, int PA, int KC = 32, int NBUF = 2, bool F2 = false>
+// PEEL: plain convs with >= 3 taps, next chunk's rows two iterations ahead (see the loop)
+template <int MB, int NB, int WM, int WN, int PA, int KC = 32, int NBUF = 2, bool F2 = false, bool PEEL = false>
 // <= 96 accumulator registers and 32-column chunks: two workgroups per CU (256 registers each); otherwise ONE wave per SIMD with the
 // whole 512-register file — said explicitly, or hipcc still budgets 256 and spills the prefetch registers right behind their loads
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MB * NB <= 6 && KC == 32 ? 2 : 1), (MB * NB <= 6 && KC == 32 ? 2 : 1))))
@@ -441,24 +443,40 @@ void k_conv_split(ConvKArgs a0) {
     typedef float f32x4v __attribute__((ext_vector_type(4)));
     f32x4v areg[PA][CB];   // native vector types: hipcc keeps arrays of the HIP uint4 / float4 structs beyond 128 bytes in scratch
     u32x4 breg[PB];
+    // row addresses as a uniform base (SGPR pair, moves with the chunk) + a 32-bit byte offset per staged row (loop-invariant): half the
+    // address registers of 64-bit pointers, which is what kept the peeled loop from fitting 256 registers (launch_conv checks < 4 GB)
+    const char* const in_bytes = reinterpret_cast<const char*>(a.in);
+    unsigned aoff[PA];
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+        const int src = m0 - halo + arow + 32 * i;
+        const int sc = src < 0 ? 0 : (src < a.T_in ? src : a.T_in - 1);          // clamped address; out-of-range rows are zeroed in storeA
+        aoff[i] = ((unsigned)sc * (unsigned)a.C_in + (unsigned)acol) * 4u;
+    }
     auto loadA = [&](int ci0) {
+        const char* const base = in_bytes + (size_t)ci0 * 4;
 #pragma unroll
-        for (int i = 0; i < PA; ++i) {
-            const int src = m0 - halo + arow + 32 * i;
-            const int sc = src < 0 ? 0 : (src < a.T_in ? src : a.T_in - 1);      // clamped address; out-of-range rows are zeroed in storeA
+        for (int i = 0; i < PA; ++i)
 #pragma unroll
-            for (int cb = 0; cb < CB; ++cb) areg[i][cb] = *reinterpret_cast<const f32x4v*>(a.in + (size_t)sc * a.C_in + ci0 + cb * 32 + acol);
-        }
+            for (int cb = 0; cb < CB; ++cb) areg[i][cb] = *reinterpret_cast<const f32x4v*>(base + cb * 128 + aoff[i]);
     };
+    // weights likewise: uniform base (tap, chunk) + a 32-bit byte offset per staged segment (plane, row, segment); the lo plane sits
+    // behind the hi plane in one allocation (launch_conv checks the distance)
+    const char* const w_bytes = reinterpret_cast<const char*>(a.Wh);
+    const unsigned w_lo = (unsigned)(reinterpret_cast<const char*>(a.Wl) - reinterpret_cast<const char*>(a.Wh));
+    unsigned boff[PB];
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+        const int idx = tid + 256 * i, plane = idx / (TN * SEG), rem = idx % (TN * SEG), brow = rem / SEG, bseg = rem % SEG;
+        const int co = co0 + brow;
+        const int cc = co < a.C_out ? co : a.C_out - 1;                   // rows past C_out repeat the last one; their columns are never stored
+        boff[i] = (plane ? w_lo : 0u) + ((unsigned)cc * (unsigned)a.C_in + (unsigned)bseg * 8u) * 2u;
+    }
     auto loadB = [&](int ci0, int ti) {
         const int wtap = a.transposed ? phase + ti * a.stride : ti;
+        const char* const base = w_bytes + ((size_t)wtap * a.C_out * a.C_in + ci0) * 2;
 #pragma unroll
-        for (int i = 0; i < PB; ++i) {
-            const int idx = tid + 256 * i, plane = idx / (TN * SEG), rem = idx % (TN * SEG), brow = rem / SEG, bseg = rem % SEG;
-            const int co = co0 + brow;
-            const int cc = co < a.C_out ? co : a.C_out - 1;               // rows past C_out repeat the last one; their columns are never stored
-            breg[i] = *reinterpret_cast<const u32x4*>((plane ? a.Wl : a.Wh) + ((size_t)wtap * a.C_out + cc) * a.C_in + ci0 + bseg * 8);
-        }
+        for (int i = 0; i < PB; ++i) breg[i] = *reinterpret_cast<const u32x4*>(base + boff[i]);
     };
     auto storeA = [&]() {
 #pragma unroll
@@ -485,26 +503,8 @@ void k_conv_split(ConvKArgs a0) {
         }
     };
 
-    CP_MARK(0);
-    loadA(c_first * KC);
-    loadB(c_first * KC, 0);
-    int chunk = c_first, ti = 0;
-    for (int it = 0; it < total; ++it) {
-        const int buf = NBUF == 2 ? (it & 1) : 0;
-        CP_MARK_L(1 + it * 4);
-        if (ti == 0 || NBUF == 1) __syncthreads();            // every wave is done with the rows (and, single-buffered, the weight tile) it read last
-        if (ti == 0) storeA();
-        storeB(buf);                                          // double-buffered: this buffer was last read two taps ago
-        CP_MARK_L(2 + it * 4);
-        __syncthreads();
-        CP_MARK_L(3 + it * 4);
-        int nchunk = chunk, nti = ti + 1;
-        if (nti == NT) { nti = 0; ++nchunk; }
-        if (it + 1 < total) {                                 // next tap's weights (and next chunk's rows) fly during the MFMAs below
-            loadB(nchunk * KC, nti);
-            if (nti == 0) loadA(nchunk * KC);
-        }
-        const int shift = a.transposed ? ti : (a.taps - 1 - ti) * a.dil;
+    // one (chunk, tap) step of the K walk on the staged tiles: KC / 16 k-steps of MB x NB x 3 MFMAs
+    auto mfma_step = [&](int buf, int shift) {
         const int roff = halo - shift + wm * MB * 32 + (lane & 31);
 #pragma unroll
         for (int st = 0; st < KC / 16; ++st) {
@@ -530,8 +530,67 @@ void k_conv_split(ConvKArgs a0) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
                 }
         }
+    };
+
+    CP_MARK(0);
+    loadA(c_first * KC);
+    loadB(c_first * KC, 0);
+    if constexpr (PEEL) {
+        static_assert(KC == 32 && NBUF == 2, "peeled taps: 32-wide chunks, double-buffered weights");   // launch_conv: !transposed, taps >= 3
+        // Plain convs with >= 3 taps (the decoder's 7-tap convs).  The NEXT chunk's activation rows are requested during tap 1, behind
+        // tap 2's weights in program order, and have until tap 3 to arrive: two iterations instead of one (the stamps showed 1.3-2.7 us
+        // of exposed HBM latency at every chunk boundary).  s_waitcnt counts in order and hipcc assumes the fewest loads in flight
+        // wherever control flow joins, so this only works if every wait sees the same loads on every path to it: taps 0, 1 and 2 are
+        // peeled (straight-line), the remaining taps run in a loop whose entry and back edge both have nothing but the weights younger
+        // than what is waited for, and nothing in a chunk's body is conditional — past the last chunk the loads are issued for the last
+        // chunk again (L2 hits, never used) instead of being skipped.
+        const int c_last = c_first + n_chunks - 1;
+        int it = 0;
+        auto tap = [&](int chunk, int nchunk, int ti, bool rows_in, bool rows_out) {
+            const int buf = it & 1;
+            CP_MARK_L(1 + it * 4);
+            if (rows_in) { __syncthreads(); storeA(); }
+            storeB(buf);
+            CP_MARK_L(2 + it * 4);
+            __syncthreads();
+            CP_MARK_L(3 + it * 4);
+            const bool more = ti + 1 < NT;
+            loadB((more ? chunk : nchunk) * KC, more ? ti + 1 : 0);
+            __builtin_amdgcn_sched_barrier(0);             // the rows go out BEHIND the weights, whatever the scheduler prefers
+            if (rows_out) loadA(nchunk * KC);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_step(buf, (a.taps - 1 - ti) * a.dil);
+            CP_MARK_L(4 + it * 4);
+            ++it;
+        };
+        for (int chunk = c_first; chunk <= c_last; ++chunk) {
+            const int nchunk = chunk < c_last ? chunk + 1 : c_last;
+            tap(chunk, nchunk, 0, true, false);
+            tap(chunk, nchunk, 1, false, true);
+            tap(chunk, nchunk, 2, false, false);
+            for (int ti = 3; ti < NT; ++ti) tap(chunk, nchunk, ti, false, false);
+        }
+    } else {
+    int chunk = c_first, ti = 0;
+    for (int it = 0; it < total; ++it) {
+        const int buf = NBUF == 2 ? (it & 1) : 0;
+        CP_MARK_L(1 + it * 4);
+        if (ti == 0 || NBUF == 1) __syncthreads();            // every wave is done with the rows (and, single-buffered, the weight tile) it read last
+        if (ti == 0) storeA();
+        storeB(buf);                                          // double-buffered: this buffer was last read two taps ago
+        CP_MARK_L(2 + it * 4);
+        __syncthreads();
+        CP_MARK_L(3 + it * 4);
+        int nchunk = chunk, nti = ti + 1;
+        if (nti == NT) { nti = 0; ++nchunk; }
+        if (it + 1 < total) {                                 // next tap's weights (and next chunk's rows) fly during the MFMAs below
+            loadB(nchunk * KC, nti);
+            if (nti == 0) loadA(nchunk * KC);
+        }
+        mfma_step(buf, a.transposed ? ti : (a.taps - 1 - ti) * a.dil);
         chunk = nchunk; ti = nti;
         CP_MARK_L(4 + it * 4);
+    }
     }
     CP_MARK(62);
     __syncthreads();                                          // the staging slices below overlay the operand tiles
@@ -715,6 +774,13 @@ void launch_absmax(const float* w, size_t n, unsigned* out, hipStream_t s) {
 template <int MB, int NB, int WM, int WN>
 static void launch_split_pa(const ConvKArgs& a, dim3 grid, int extra, hipStream_t s) {
     constexpr int P0 = WM * MB;
+    if constexpr (MB == 2 && NB == 3) {   // the decoder's 7-tap convs on 256 x 96 tiles
+        if (a.peel_taps && !a.transposed && a.taps >= 3 && extra >= 1) {
+            if (extra == 1) hipLaunchKernelGGL((k_conv_split<MB, NB, WM, WN, P0 + 1, 32, 2, false, true>), grid, dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((k_conv_split<MB, NB, WM, WN, P0 + 2, 32, 2, false, true>), grid, dim3(256), 0, s, a);
+            return;
+        }
+    }
     if (extra == 0) hipLaunchKernelGGL((k_conv_split<MB, NB, WM, WN, P0>), grid, dim3(256), 0, s, a);
     else if (extra == 1) hipLaunchKernelGGL((k_conv_split<MB, NB, WM, WN, P0 + 1>), grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((k_conv_split<MB, NB, WM, WN, P0 + 2>), grid, dim3(256), 0, s, a);
@@ -764,6 +830,8 @@ void launch_conv(const ConvArgs& c, hipStream_t s) {
     a.xcd_map = no_xcd_map ? 0 : 1;
     static const bool no_fast_epi = getenv("Q3TTS_CONV_GENERIC_EPILOGUE") != nullptr;
     a.no_fast_epi = no_fast_epi ? 1 : 0;
+    static const bool no_peel = getenv("Q3TTS_CONV_NO_PEEL") != nullptr;
+    a.peel_taps = no_peel ? 0 : 1;
     a.W2h = nullptr; a.W2l = nullptr; a.acc_scale2 = 1.0f; a.bias2 = nullptr; a.s1_alpha = nullptr; a.s1_beta = nullptr;
     a.in_ustride = c.in_ustride ? c.in_ustride : (size_t)c.T_in * c.C_in;
     const int nb = c.batch > 1 ? c.batch : 1;
@@ -783,6 +851,10 @@ void launch_conv(const ConvArgs& c, hipStream_t s) {
     }
     const int NTt = c.transposed ? c.taps / c.stride : c.taps;
     const int halo = c.transposed ? NTt - 1 : (c.taps - 1) * c.dil;
+    if (c.Wh && c.Wl && (size_t)c.T_in * c.C_in * sizeof(float) >= ((size_t)1 << 32))
+        throw Error("conv: one sequence's activation exceeds 4 GB (beyond ~5500 frames): decode it in chunks (q3tts_codec_decode_chunked_host)");
+    if (c.Wh && c.Wl && !(c.Wl > c.Wh && (size_t)((const char*)c.Wl - (const char*)c.Wh) < ((size_t)1 << 31)))
+        throw Error("conv: the lo weight plane must follow the hi plane within 2 GB (one allocation)");
     if (c.W2h != nullptr) {   // fused residual unit: 7-tap conv -> SnakeBeta -> 1x1 conv -> + residual, 96 channels, 256-row tiles
         if (!(c.Wh && c.Wl && c.W2l && c.C_in == 96 && c.C_out == 96 && !c.transposed && halo <= 64 && c.mid_pre && c.snake_pre && c.bias2 && c.res && c.out && c.out2 && !c.res_scale && !c.clamp && c.act == 0 && !c.mul))
             throw Error("conv: fused residual unit needs 96 -> 96 channels on the split-precision path");
@@ -791,7 +863,11 @@ void launch_conv(const ConvArgs& c, hipStream_t s) {
         const int extra = (halo + 31) / 32, tiles = (rows + 255) / 256;
         if (nb > 1) a.batch_tiles = tiles;
         const dim3 g((unsigned)(tiles * nb), 1, 1);
-        if (extra <= 1) hipLaunchKernelGGL((k_conv_split<2, 3, 4, 1, 9, 32, 2, true>), g, dim3(256), 0, s, a);
+        if (a.peel_taps && c.taps >= 3) {
+            if (extra <= 1) hipLaunchKernelGGL((k_conv_split<2, 3, 4, 1, 9, 32, 2, true, true>), g, dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((k_conv_split<2, 3, 4, 1, 10, 32, 2, true, true>), g, dim3(256), 0, s, a);
+        }
+        else if (extra <= 1) hipLaunchKernelGGL((k_conv_split<2, 3, 4, 1, 9, 32, 2, true>), g, dim3(256), 0, s, a);
         else hipLaunchKernelGGL((k_conv_split<2, 3, 4, 1, 10, 32, 2, true>), g, dim3(256), 0, s, a);
         Q3_HIP_CHECK(hipGetLastError());
         return;

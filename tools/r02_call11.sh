@@ -1,11 +1,11 @@
 set -e
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && mkdir -p gpurun_out/r02s
-O=gpurun_out/r02s
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && mkdir -p gpurun_out/r02u
+O=gpurun_out/r02u
 timeout -k 10 600 python -m pytest tests/test_gpu_codec.py tests/test_gpu_full.py -x -q --timeout 500 > $O/tests.log 2>&1 || { tail -40 $O/tests.log; exit 1; }
 tail -2 $O/tests.log
 for FF in 64 256 2048; do python tools/codec_bench.py --frames $FF --reps 3 | grep frames= >> $O/codec_sizes.txt; done
-for FF in 256 2048; do Q3TTS_CONV_GENERIC_EPILOGUE=1 python tools/codec_bench.py --frames $FF --reps 3 | grep frames= >> $O/codec_sizes_generic_epi.txt; done
-echo fast; cat $O/codec_sizes.txt; echo generic; cat $O/codec_sizes_generic_epi.txt
+for FF in 256 2048; do Q3TTS_CONV_NO_PEEL=1 python tools/codec_bench.py --frames $FF --reps 3 | grep frames= >> $O/codec_sizes_nopeel.txt; done
+echo fast; cat $O/codec_sizes.txt; echo nopeel; cat $O/codec_sizes_nopeel.txt
 for V in f96 c7; do
   Q3TTS_LIB=$PWD/tools/exp/libprof_$V.so python tools/conv_phases.py --frames 2048 > $O/conv_phases_$V.txt 2>&1
   echo == $V; head -5 $O/conv_phases_$V.txt
