@@ -165,3 +165,43 @@ def test_codec_decode_with_device_resident_ends():
     hip.hipFree(codes_d), hip.hipFree(pcm_d)
     eng.close()
     orc.close()
+
+
+_AB_CHILD = r"""
+import sys, hashlib
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+import q3tts
+cfg = q3tts.default_config("0.6b")
+eng = q3tts.Engine(cfg, device=0, max_batch=1, max_ctx=128)
+eng.fill_synthetic(seed=5)
+out = []
+for F in (9, 70):                      # one 256-row tile with a tail; several tiles, transposed-conv phase tails, a narrower last XCD group
+    codes = np.random.default_rng(F).integers(0, cfg.cd_codebook, (F, cfg.n_groups)).astype(np.int64)
+    pcm = eng.codec_decode(codes)
+    assert np.isfinite(pcm).all() and float(np.sqrt(np.mean(pcm ** 2))) > 1e-6
+    out.append(hashlib.sha1(pcm.tobytes()).hexdigest())
+print("PCM", *out)
+"""
+
+
+def test_conv_ab_switches_reproduce_the_default_bit_for_bit():
+    """The A/B switches of k_conv_split (XCD-aware tile ids, the straight-line decoder epilogue, peeled taps) change the schedule,
+    never the arithmetic: the full-size decoder's PCM is bit-identical under each of them.  The switches are read
+    once per process, hence child processes."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(root, "leaxer-qwen3-tts_amd")
+
+    def run(extra):
+        env = dict(os.environ)
+        env.update(extra)
+        r = subprocess.run([sys.executable, "-c", _AB_CHILD, pkg], env=env, capture_output=True, text=True, timeout=280)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return [ln for ln in r.stdout.splitlines() if ln.startswith("PCM")][-1]
+
+    base = run({})
+    for knob in ("Q3TTS_CONV_NO_XCD_MAP", "Q3TTS_CONV_GENERIC_EPILOGUE", "Q3TTS_CONV_NO_PEEL"):
+        assert run({knob: "1"}) == base, knob
