@@ -179,6 +179,12 @@ Engine::Engine(const q3tts_config& cfg, int device_, int max_batch, int max_ctx_
     if (const char* mr = getenv("Q3TTS_MFMA_MIN_ROWS")) mfma_min_rows = std::max(3, atoi(mr));   // A/B knob for the GEMV <-> GEMM crossover
     null_stream = getenv("Q3TTS_NULL_STREAM") && getenv("Q3TTS_NULL_STREAM")[0] == '1';
     if (null_stream) { stream = nullptr; flags |= Q3TTS_FLAG_NO_GRAPH; }
+    else if (const char* cm = getenv("Q3TTS_STREAM_CU_MASK")) {   // experiment aid (tools/overlap_probe.py): this engine's stream on a subset of the CUs;
+        const uint32_t pat = (uint32_t)strtoul(cm, nullptr, 16);    // the 32-bit pattern is repeated over the 256-CU mask
+        uint32_t mask[8];
+        for (int i = 0; i < 8; ++i) mask[i] = pat;
+        Q3_HIP_CHECK(hipExtStreamCreateWithCUMask(&stream, 8, mask));
+    }
     else {   // the decode chain is latency-bound: its launches go ahead of the vocoder lanes' (created at the lowest priority)
         int lo = 0, hi = 0;
         Q3_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
