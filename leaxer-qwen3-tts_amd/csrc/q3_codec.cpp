@@ -302,11 +302,21 @@ int64_t Engine::codec_run(const int32_t* codes_dev, int F, float** pcm_dev, int 
             cur = y; Tc = To;
         }
         // ---- SnakeBeta decoder: conv_in, 4 x (snake, transposed conv, 3 residual units), snake, conv_out ----
+        // SnakeBeta outputs travel between the decoder's convs as (hi, lo) fp16 pairs (ConvArgs::in_planes / out2_planes): the producer's
+        // epilogue splits each element once, the consumers stage it without converting.  Needs every decoder conv on the split-precision
+        // path with 96-multiple widths (0.6B / 1.7B: 1536 .. 96); the last activation feeds the fp32 C_out = 1 conv and stays fp32.
+        static const bool fp32_act = getenv("Q3TTS_CONV_FP32_ACT") != nullptr || getenv("Q3TTS_CONV_GENERIC_EPILOGUE") != nullptr;   // A/B switches
+        bool act_planes = !fp32_act && !W.planes.empty() && CH % 32 == 0 && W.planes.count(W.conv_in.w) && !W.snake_pre.empty();
+        for (int i = 0, Cw = D; i <= c.cd_n_blocks; ++i, Cw /= 2) act_planes = act_planes && Cw % 96 == 0;
+        for (const CodecW::Block& B : W.blocks) {
+            act_planes = act_planes && W.planes.count(B.tconv.w);
+            for (int u = 0; u < 3; ++u) act_planes = act_planes && W.planes.count(B.res[u].c1.w) && W.planes.count(B.res[u].c2.w);
+        }
         float* x = take(nbz * Tc * D);
         float* sx = take(nbz * Tc * D);
         { ConvArgs a; a.in = cur; a.T_in = Tc; a.C_in = CH; a.out = x; a.T_out = Tc; a.C_out = D; a.W = W.conv_in.w; a.bias = W.conv_in.b; a.taps = 7;
           a.in_ustride = nbatch > 1 ? h_ustride : 0;   // the batched front pads every utterance to the job's longest; a group runs at its own longest
-          a.out2 = sx; a.snake_alpha = W.blocks[0].act.alpha; a.snake_beta = W.blocks[0].act.beta; conv(a); }
+          a.out2 = sx; a.snake_alpha = W.blocks[0].act.alpha; a.snake_beta = W.blocks[0].act.beta; a.out2_planes = act_planes; conv(a); }
         int C = D;
         static const int dil[3] = { 1, 3, 9 };
         for (int i = 0; i < c.cd_n_blocks; ++i) {
@@ -318,11 +328,12 @@ int64_t Engine::codec_run(const int32_t* codes_dev, int F, float** pcm_dev, int 
             float* ns = take(nbz * To * Co);
             float* nt = take(nbz * To * Co);
             { ConvArgs a; a.in = sx; a.T_in = Tc; a.C_in = C; a.out = nx; a.T_out = To; a.C_out = Co; a.W = B.tconv.w; a.bias = B.tconv.b;
-              a.taps = 2 * r; a.transposed = 1; a.stride = r; a.left = left;
-              a.out2 = ns; a.snake_alpha = B.res[0].a1.alpha; a.snake_beta = B.res[0].a1.beta; conv(a); }
+              a.taps = 2 * r; a.transposed = 1; a.stride = r; a.left = left; a.in_planes = act_planes;
+              a.out2 = ns; a.snake_alpha = B.res[0].a1.alpha; a.snake_beta = B.res[0].a1.beta; a.out2_planes = act_planes; conv(a); }
             for (int u = 0; u < 3; ++u) {
                 const CodecW::Res& R = B.res[u];
                 const SnakeP nxt = u < 2 ? B.res[u + 1].a1 : (i + 1 < c.cd_n_blocks ? W.blocks[i + 1].act : W.snake_out);
+                const bool nxt_planes = act_planes && !(u == 2 && i + 1 == c.cd_n_blocks);   // the very last activation feeds the fp32 conv_out
                 // 96-channel block: the whole residual unit (7-tap conv, SnakeBeta, 1x1 conv, + x) in one launch — the intermediate stays in
                 // the CU (k_conv_split<..., F2>): 4 activation passes through HBM instead of 6, one launch instead of two.  The unit reads
                 // snake(x) with a tap halo reaching into its neighbours' rows, so the next layer's snake(x') goes to the OTHER buffer
@@ -333,14 +344,17 @@ int64_t Engine::codec_run(const int32_t* codes_dev, int F, float** pcm_dev, int 
                     a.taps = 7; a.dil = dil[u]; a.mid_alpha = R.a2.alpha; a.mid_beta = R.a2.beta;
                     a.W2 = R.c2.w; a.W2h = p2->second.hi; a.W2l = p2->second.lo; a.w2_scale_inv = p2->second.scale_inv; a.bias2 = R.c2.b;
                     a.res = nx; a.out2 = nt; a.snake_alpha = nxt.alpha; a.snake_beta = nxt.beta;
+                    a.in_planes = act_planes; a.out2_planes = nxt_planes;
                     conv(a);
                     std::swap(ns, nt);
                     continue;
                 }
                 { ConvArgs a; a.in = ns; a.T_in = To; a.C_in = Co; a.out = nullptr; a.T_out = To; a.C_out = Co; a.W = R.c1.w; a.bias = R.c1.b;
-                  a.taps = 7; a.dil = dil[u]; a.out2 = nt; a.snake_alpha = R.a2.alpha; a.snake_beta = R.a2.beta; conv(a); }
+                  a.taps = 7; a.dil = dil[u]; a.out2 = nt; a.snake_alpha = R.a2.alpha; a.snake_beta = R.a2.beta;
+                  a.in_planes = act_planes; a.out2_planes = act_planes; conv(a); }
                 { ConvArgs a; a.in = nt; a.T_in = To; a.C_in = Co; a.out = nx; a.T_out = To; a.C_out = Co; a.W = R.c2.w; a.bias = R.c2.b;
-                  a.taps = 1; a.res = nx; a.out2 = ns; a.snake_alpha = nxt.alpha; a.snake_beta = nxt.beta; conv(a); }
+                  a.taps = 1; a.res = nx; a.out2 = ns; a.snake_alpha = nxt.alpha; a.snake_beta = nxt.beta;
+                  a.in_planes = act_planes; a.out2_planes = nxt_planes; conv(a); }
             }
             x = nx; sx = ns; Tc = To; C = Co;
         }

@@ -86,6 +86,12 @@ struct ConvKArgs {
     int xcd_map;                        // k_conv_split: XCD-aware tile ids (conv_tile_ids)
     int no_fast_epi;                    // A/B switch: decoder convs through the generic epilogue
     int peel_taps;                      // k_conv_split: >= 3-tap convs request the next chunk's rows two iterations ahead (A/B switch)
+    // SnakeBeta outputs between the decoder's convs as (hi, lo) fp16 pairs instead of fp32: every group of 4 channels of `in` / `out2`
+    // holds its 4 hi halves followed by its 4 lo halves in the 16 bytes the 4 floats would take — the same addresses, the same 16-byte
+    // accesses — split ONCE by the producer's epilogue instead of by every consuming workgroup while it stages its rows (2-8
+    // output-channel tiles x 1.2 halo re-split each element; ~1.4 us per chunk).  (Two separate planes were tried first: the 8-byte
+    // accesses made every conv 5-18 % slower.)
+    int in_planes, out2_planes;
     const float* s2_pre; const float* s1_pre;   // SnakeBeta constants [2][C_out] (exp(alpha) | 1 / (exp(beta) + 1e-9)), precomputed at finalize
     int batch_tiles;                    // > 0: blockIdx.x = sequence * batch_tiles + row tile; sequences are in_ustride / T_out * C_out floats apart
     size_t in_ustride;
@@ -252,7 +258,7 @@ static __device__ __forceinline__ void split_f16x2(float a, float b, f16x2& hi, 
 // to a dump line instead of being predicated.  Behind a branch hipcc cannot count the stores in flight, so every wait for an
 // (older) operand load — s_waitcnt counts in order — also waited for the previous rows' STORES to complete: ~0.4 us per row.
 __device__ float g_conv_dump[2][64 * 4];
-template <int NB, bool OUT, bool RES, int RH>
+template <int NB, bool OUT, bool RES, int RH, bool O2P = false>
 static __device__ __forceinline__ void split_epilogue_snake(const ConvKArgs& a, const f32x16 (&acc)[NB], float* stage, int mrow0, int co0w,
                                                             int lane, int phase, int NT) {
     constexpr int W = NB * 32, LDE = W + 8;
@@ -299,6 +305,13 @@ static __device__ __forceinline__ void split_epilogue_snake(const ConvKArgs& a, 
             s2[e] = x + ib[e] * sin_sq(x * ea[e]);
         }
         if (OUT) *reinterpret_cast<float4*>(okp ? a.out + o : dump1) = make_float4(v[0], v[1], v[2], v[3]);
+        if (O2P) {   // 4 hi halves | 4 lo halves in the 16 bytes of the 4 floats
+            f16x2 h01, h23, l01, l23;
+            split_f16x2(s2[0], s2[1], h01, l01);
+            split_f16x2(s2[2], s2[3], h23, l23);
+            *reinterpret_cast<uint4*>(okp ? a.out2 + o : dump2) =
+                make_uint4(__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23), __builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23));
+        } else
         *reinterpret_cast<float4*>(okp ? a.out2 + o : dump2) = make_float4(s2[0], s2[1], s2[2], s2[3]);
         if ((p & 3) == 3) {                               // groups of four rows stay groups: left alone hipcc hoists all 16 LDS reads and addresses
             __builtin_amdgcn_sched_barrier(0);
@@ -312,6 +325,13 @@ template <int NB, int RH = 16>
 static __device__ __forceinline__ void split_epilogue_block(const ConvKArgs& a, const f32x16 (&acc)[NB], float* stage, int mrow0, int co0w,
                                                             int lane, int phase, int NT) {
     if (a.out2 && a.s2_pre && a.bias && a.act == 0 && !a.mul && !a.res_scale && !a.no_fast_epi) {   // uniform: the decoder's convs
+        if (a.out2_planes) {
+            if (a.res) { if (a.out) split_epilogue_snake<NB, true, true, RH, true>(a, acc, stage, mrow0, co0w, lane, phase, NT);
+                         else split_epilogue_snake<NB, false, true, RH, true>(a, acc, stage, mrow0, co0w, lane, phase, NT); }
+            else { if (a.out) split_epilogue_snake<NB, true, false, RH, true>(a, acc, stage, mrow0, co0w, lane, phase, NT);
+                   else split_epilogue_snake<NB, false, false, RH, true>(a, acc, stage, mrow0, co0w, lane, phase, NT); }
+            return;
+        }
         if (a.res) { if (a.out) split_epilogue_snake<NB, true, true, RH>(a, acc, stage, mrow0, co0w, lane, phase, NT);
                      else split_epilogue_snake<NB, false, true, RH>(a, acc, stage, mrow0, co0w, lane, phase, NT); }
         else { if (a.out) split_epilogue_snake<NB, true, false, RH>(a, acc, stage, mrow0, co0w, lane, phase, NT);
@@ -403,7 +423,8 @@ static __device__ __forceinline__ void split_epilogue_block(const ConvKArgs& a, 
 // KC = C_in columns per staged chunk (32, or 128 for the short-and-wide GEMMs of the pre-transformer, whose few workgroups walk K
 // serially: a chunk costs one memory latency whatever its size, so 4x wider chunks are 4x fewer latencies); NBUF = weight-tile buffers.
 // PEEL: plain convs with >= 3 taps, next chunk's rows two iterations ahead (see the loop)
-template <int MB, int NB, int WM, int WN, int PA, int KC = 32, int NBUF = 2, bool F2 = false, bool PEEL = false>
+// APL: the input is (hi, lo) fp16 planes (ConvKArgs::in_planes): staged without conversion
+template <int MB, int NB, int WM, int WN, int PA, int KC = 32, int NBUF = 2, bool F2 = false, bool PEEL = false, bool APL = false>
 // <= 96 accumulator registers and 32-column chunks: two workgroups per CU (256 registers each); otherwise ONE wave per SIMD with the
 // whole 512-register file — said explicitly, or hipcc still budgets 256 and spills the prefetch registers right behind their loads
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MB * NB <= 6 && KC == 32 ? 2 : 1), (MB * NB <= 6 && KC == 32 ? 2 : 1))))
@@ -458,7 +479,7 @@ void k_conv_split(ConvKArgs a0) {
 #pragma unroll
         for (int i = 0; i < PA; ++i)
 #pragma unroll
-            for (int cb = 0; cb < CB; ++cb) areg[i][cb] = *reinterpret_cast<const f32x4v*>(base + cb * 128 + aoff[i]);
+            for (int cb = 0; cb < CB; ++cb) areg[i][cb] = *reinterpret_cast<const f32x4v*>(base + cb * 128 + aoff[i]);   // APL: .xy = 4 hi halves, .zw = 4 lo halves
     };
     // weights likewise: uniform base (tap, chunk) + a 32-bit byte offset per staged segment (plane, row, segment); the lo plane sits
     // behind the hi plane in one allocation (launch_conv checks the distance)
@@ -487,6 +508,11 @@ void k_conv_split(ConvKArgs a0) {
             for (int cb = 0; cb < CB; ++cb) {
                 const f32x4v r = areg[i][cb];
                 const float4 v = make_float4(inr ? r.x : 0.f, inr ? r.y : 0.f, inr ? r.z : 0.f, inr ? r.w : 0.f);
+                if (APL) {   // already (hi, lo) halves: zeroed rows are 0.0 in both planes
+                    *reinterpret_cast<uint2*>(&As[0][arow + 32 * i][cb * 32 + acol]) = make_uint2(__float_as_uint(v.x), __float_as_uint(v.y));
+                    *reinterpret_cast<uint2*>(&As[1][arow + 32 * i][cb * 32 + acol]) = make_uint2(__float_as_uint(v.z), __float_as_uint(v.w));
+                    continue;
+                }
                 f16x2 h01, h23, l01, l23;
                 split_f16x2(v.x, v.y, h01, l01);
                 split_f16x2(v.z, v.w, h23, l23);
@@ -671,7 +697,8 @@ void k_conv_split(ConvKArgs a0) {
             __builtin_amdgcn_wave_barrier();                                     // the plane reads are done: the same bytes become the epilogue's staging
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             CP_MARK(50 + 4 * i);
-            split_epilogue_snake<NB, true, true, 8>(a, acc2, stage, m0 + wm * MB * 32 + i * 32, co0, lane, 0, NT);   // launch_conv guarantees out, out2, res, no activation
+            if (a.out2_planes) split_epilogue_snake<NB, true, true, 8, true>(a, acc2, stage, m0 + wm * MB * 32 + i * 32, co0, lane, 0, NT);
+            else split_epilogue_snake<NB, true, true, 8>(a, acc2, stage, m0 + wm * MB * 32 + i * 32, co0, lane, 0, NT);   // launch_conv guarantees out, out2, res, no activation
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -733,6 +760,13 @@ __global__ __launch_bounds__(256) void k_conv_finish(ConvKArgs a) {
         const float al[4] = { al4.x, al4.y, al4.z, al4.w }, be[4] = { be4.x, be4.y, be4.z, be4.w };
 #pragma unroll
         for (int e = 0; e < 4; ++e) s2[e] = x[e] + (1.0f / (expf(be[e]) + 0.000000001f)) * sin_sq(x[e] * expf(al[e]));
+        if (a.out2_planes) {
+            f16x2 h01, h23, l01, l23;
+            split_f16x2(s2[0], s2[1], h01, l01);
+            split_f16x2(s2[2], s2[3], h23, l23);
+            *reinterpret_cast<uint4*>(a.out2 + o) =
+                make_uint4(__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23), __builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23));
+        } else
         *reinterpret_cast<float4*>(a.out2 + o) = make_float4(s2[0], s2[1], s2[2], s2[3]);
     }
     if (a.out) *reinterpret_cast<float4*>(a.out + o) = make_float4(x[0], x[1], x[2], x[3]);
@@ -771,19 +805,25 @@ void launch_absmax(const float* w, size_t n, unsigned* out, hipStream_t s) {
     Q3_HIP_CHECK(hipGetLastError());
 }
 
-template <int MB, int NB, int WM, int WN>
+template <int MB, int NB, int WM, int WN, bool APL = false>
 static void launch_split_pa(const ConvKArgs& a, dim3 grid, int extra, hipStream_t s) {
     constexpr int P0 = WM * MB;
     if constexpr (MB == 2 && NB == 3) {   // the decoder's 7-tap convs on 256 x 96 tiles
         if (a.peel_taps && !a.transposed && a.taps >= 3 && extra >= 1) {
-            if (extra == 1) hipLaunchKernelGGL((k_conv_split<MB, NB, WM, WN, P0 + 1, 32, 2, false, true>), grid, dim3(256), 0, s, a);
-            else hipLaunchKernelGGL((k_conv_split<MB, NB, WM, WN, P0 + 2, 32, 2, false, true>), grid, dim3(256), 0, s, a);
+            if (extra == 1) hipLaunchKernelGGL((k_conv_split<MB, NB, WM, WN, P0 + 1, 32, 2, false, true, APL>), grid, dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((k_conv_split<MB, NB, WM, WN, P0 + 2, 32, 2, false, true, APL>), grid, dim3(256), 0, s, a);
             return;
         }
     }
-    if (extra == 0) hipLaunchKernelGGL((k_conv_split<MB, NB, WM, WN, P0>), grid, dim3(256), 0, s, a);
-    else if (extra == 1) hipLaunchKernelGGL((k_conv_split<MB, NB, WM, WN, P0 + 1>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((k_conv_split<MB, NB, WM, WN, P0 + 2>), grid, dim3(256), 0, s, a);
+    if (extra == 0) hipLaunchKernelGGL((k_conv_split<MB, NB, WM, WN, P0, 32, 2, false, false, APL>), grid, dim3(256), 0, s, a);
+    else if (extra == 1) hipLaunchKernelGGL((k_conv_split<MB, NB, WM, WN, P0 + 1, 32, 2, false, false, APL>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_conv_split<MB, NB, WM, WN, P0 + 2, 32, 2, false, false, APL>), grid, dim3(256), 0, s, a);
+}
+// (hi, lo)-plane inputs exist for the tile shapes the decoder's convs use (96-multiples); anything else reads fp32
+template <int MB, int NB, int WM, int WN>
+static void launch_split_in(const ConvKArgs& a, dim3 grid, int extra, hipStream_t s) {
+    if (a.in_planes) launch_split_pa<MB, NB, WM, WN, true>(a, grid, extra, s);
+    else launch_split_pa<MB, NB, WM, WN, false>(a, grid, extra, s);
 }
 
 // C_out == 1 (the decoder's last conv): one output sample per thread, the input rows of a 128-sample tile (+ tap halo) staged in
@@ -832,6 +872,12 @@ void launch_conv(const ConvArgs& c, hipStream_t s) {
     a.no_fast_epi = no_fast_epi ? 1 : 0;
     static const bool no_peel = getenv("Q3TTS_CONV_NO_PEEL") != nullptr;
     a.peel_taps = no_peel ? 0 : 1;
+    a.in_planes = c.in_planes ? 1 : 0; a.out2_planes = c.out2_planes ? 1 : 0;
+    if (c.in_planes || c.out2_planes) {   // only between convs of the split-precision path whose tiles have the plane variants
+        const bool split_ok = c.Wh && c.Wl && c.C_in % 32 == 0 && c.C_out >= 32 && c.C_out % 96 == 0 && !c.clamp;
+        if (!split_ok || (c.out2_planes && !(c.out2 && c.snake_pre && c.bias && c.act == 0 && !c.mul && !c.res_scale && !no_fast_epi)))
+            throw Error("conv: (hi, lo)-plane activations need a 96-multiple decoder conv on the split-precision path");
+    }
     a.W2h = nullptr; a.W2l = nullptr; a.acc_scale2 = 1.0f; a.bias2 = nullptr; a.s1_alpha = nullptr; a.s1_beta = nullptr;
     a.in_ustride = c.in_ustride ? c.in_ustride : (size_t)c.T_in * c.C_in;
     const int nb = c.batch > 1 ? c.batch : 1;
@@ -863,12 +909,11 @@ void launch_conv(const ConvArgs& c, hipStream_t s) {
         const int extra = (halo + 31) / 32, tiles = (rows + 255) / 256;
         if (nb > 1) a.batch_tiles = tiles;
         const dim3 g((unsigned)(tiles * nb), 1, 1);
-        if (a.peel_taps && c.taps >= 3) {
-            if (extra <= 1) hipLaunchKernelGGL((k_conv_split<2, 3, 4, 1, 9, 32, 2, true, true>), g, dim3(256), 0, s, a);
-            else hipLaunchKernelGGL((k_conv_split<2, 3, 4, 1, 10, 32, 2, true, true>), g, dim3(256), 0, s, a);
-        }
-        else if (extra <= 1) hipLaunchKernelGGL((k_conv_split<2, 3, 4, 1, 9, 32, 2, true>), g, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((k_conv_split<2, 3, 4, 1, 10, 32, 2, true>), g, dim3(256), 0, s, a);
+#define Q3_FUSED(PA_, PEEL_, APL_) hipLaunchKernelGGL((k_conv_split<2, 3, 4, 1, PA_, 32, 2, true, PEEL_, APL_>), g, dim3(256), 0, s, a)
+        const bool peel = a.peel_taps && c.taps >= 3, wide = extra > 1;
+        if (a.in_planes) { if (peel) { if (wide) Q3_FUSED(10, true, true); else Q3_FUSED(9, true, true); } else { if (wide) Q3_FUSED(10, false, true); else Q3_FUSED(9, false, true); } }
+        else { if (peel) { if (wide) Q3_FUSED(10, true, false); else Q3_FUSED(9, true, false); } else { if (wide) Q3_FUSED(10, false, false); else Q3_FUSED(9, false, false); } }
+#undef Q3_FUSED
         Q3_HIP_CHECK(hipGetLastError());
         return;
     }
@@ -895,25 +940,31 @@ void launch_conv(const ConvArgs& c, hipStream_t s) {
             }
             if (ks > 1) {
                 a.ksplit = ks; a.slab = c.slab;
-                hipLaunchKernelGGL((k_conv_split<2, 1, 1, 4, 2, 128, 1>), dim3(g.x, g.y, ks), dim3(256), 0, s, a);
+                if (a.in_planes) hipLaunchKernelGGL((k_conv_split<2, 1, 1, 4, 2, 128, 1, false, false, true>), dim3(g.x, g.y, ks), dim3(256), 0, s, a);
+                else hipLaunchKernelGGL((k_conv_split<2, 1, 1, 4, 2, 128, 1>), dim3(g.x, g.y, ks), dim3(256), 0, s, a);
                 const size_t n4 = (size_t)c.T_out * c.C_out / 4;
                 hipLaunchKernelGGL(k_conv_finish, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, a);
                 Q3_HIP_CHECK(hipGetLastError());
                 return;
             }
             if (c.C_in % 128 == 0) {
-                if (extra == 0) hipLaunchKernelGGL((k_conv_split<2, 1, 1, 4, 2, 128, 1>), g, dim3(256), 0, s, a);
+                if (a.in_planes) {
+                    if (extra == 0) hipLaunchKernelGGL((k_conv_split<2, 1, 1, 4, 2, 128, 1, false, false, true>), g, dim3(256), 0, s, a);
+                    else if (extra == 1) hipLaunchKernelGGL((k_conv_split<2, 1, 1, 4, 3, 128, 1, false, false, true>), g, dim3(256), 0, s, a);
+                    else hipLaunchKernelGGL((k_conv_split<2, 1, 1, 4, 4, 128, 1, false, false, true>), g, dim3(256), 0, s, a);
+                }
+                else if (extra == 0) hipLaunchKernelGGL((k_conv_split<2, 1, 1, 4, 2, 128, 1>), g, dim3(256), 0, s, a);
                 else if (extra == 1) hipLaunchKernelGGL((k_conv_split<2, 1, 1, 4, 3, 128, 1>), g, dim3(256), 0, s, a);
                 else hipLaunchKernelGGL((k_conv_split<2, 1, 1, 4, 4, 128, 1>), g, dim3(256), 0, s, a);
-            } else launch_split_pa<2, 1, 1, 4>(a, g, extra, s);
+            } else launch_split_in<2, 1, 1, 4>(a, g, extra, s);
         }
         else if (!deep || n_big < 1024) {
             const dim3 g2 = bgrid((rows + 127) / 128, ntile, z);
-            if (n96) launch_split_pa<1, 3, 4, 1>(a, g2, extra, s);
+            if (n96) launch_split_in<1, 3, 4, 1>(a, g2, extra, s);
             else launch_split_pa<1, 4, 4, 1>(a, g2, extra, s);
         } else {
             const dim3 g2 = bgrid((rows + 255) / 256, ntile, z);
-            if (n96) launch_split_pa<2, 3, 4, 1>(a, g2, extra, s);
+            if (n96) launch_split_in<2, 3, 4, 1>(a, g2, extra, s);
             else launch_split_pa<2, 4, 4, 1>(a, g2, extra, s);
         }
         (void)n_thin;

@@ -214,6 +214,7 @@ struct ConvArgs { // out[t][co] = epi(bias[co] + sum_{tap,ci} W[tap][co][ci] * i
     float* out2 = nullptr;       // optional second output: SnakeBeta(value) for the NEXT layer
     const float* snake_alpha = nullptr;
     const float* snake_beta = nullptr;
+    bool in_planes = false, out2_planes = false;   // `in` / `out2` hold, per 4 channels, 4 hi + 4 lo fp16 halves in place of the 4 floats (k_conv_split; see ConvKArgs)
     const float* snake_pre = nullptr;   // [2][C_out]: exp(alpha) | 1 / (exp(beta) + 1e-9), launch_snake_pre (split-precision path)
     float* slab = nullptr; size_t slab_floats = 0; // optional scratch for split-K partial sums of short 1-tap GEMMs ([slice][T_out][C_out])
     // fused residual unit (96-channel decoder block): out = res + bias2 + W2 . snake_mid(bias + W . in) — the 7-tap conv, the SnakeBeta

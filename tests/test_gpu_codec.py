@@ -186,7 +186,8 @@ print("PCM", *out)
 
 
 def test_conv_ab_switches_reproduce_the_default_bit_for_bit():
-    """The A/B switches of k_conv_split (XCD-aware tile ids, the straight-line decoder epilogue, peeled taps) change the schedule,
+    """The A/B switches of k_conv_split (XCD-aware tile ids, the straight-line decoder epilogue, peeled taps, fp16-plane activations) change the
+    schedule and the storage format,
     never the arithmetic: the full-size decoder's PCM is bit-identical under each of them.  The switches are read
     once per process, hence child processes."""
     import os
@@ -203,5 +204,5 @@ def test_conv_ab_switches_reproduce_the_default_bit_for_bit():
         return [ln for ln in r.stdout.splitlines() if ln.startswith("PCM")][-1]
 
     base = run({})
-    for knob in ("Q3TTS_CONV_NO_XCD_MAP", "Q3TTS_CONV_GENERIC_EPILOGUE", "Q3TTS_CONV_NO_PEEL"):
+    for knob in ("Q3TTS_CONV_NO_XCD_MAP", "Q3TTS_CONV_GENERIC_EPILOGUE", "Q3TTS_CONV_NO_PEEL", "Q3TTS_CONV_FP32_ACT"):
         assert run({knob: "1"}) == base, knob

@@ -1,12 +1,12 @@
 set -e
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && mkdir -p gpurun_out/r02u
-O=gpurun_out/r02u
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && mkdir -p gpurun_out/r02ac
+O=gpurun_out/r02ac
 timeout -k 10 600 python -m pytest tests/test_gpu_codec.py tests/test_gpu_full.py -x -q --timeout 500 > $O/tests.log 2>&1 || { tail -40 $O/tests.log; exit 1; }
 tail -2 $O/tests.log
 for FF in 64 256 2048; do python tools/codec_bench.py --frames $FF --reps 3 | grep frames= >> $O/codec_sizes.txt; done
-for FF in 256 2048; do Q3TTS_CONV_NO_PEEL=1 python tools/codec_bench.py --frames $FF --reps 3 | grep frames= >> $O/codec_sizes_nopeel.txt; done
-echo fast; cat $O/codec_sizes.txt; echo nopeel; cat $O/codec_sizes_nopeel.txt
-for V in f96 c7; do
+for FF in 256 2048; do Q3TTS_CONV_FP32_ACT=1 python tools/codec_bench.py --frames $FF --reps 3 | grep frames= >> $O/codec_sizes_fp32act.txt; done
+echo fast; cat $O/codec_sizes.txt; echo fp32act; cat $O/codec_sizes_fp32act.txt
+for V in; do
   Q3TTS_LIB=$PWD/tools/exp/libprof_$V.so python tools/conv_phases.py --frames 2048 > $O/conv_phases_$V.txt 2>&1
   echo == $V; head -5 $O/conv_phases_$V.txt
 done
