@@ -12,7 +12,7 @@ OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libq3tts_hip.so")
 SOURCES = ["q3_decode_kernels.hip", "q3_gemm_kernels.hip", "q3_codec_kernels.hip", "q3_speaker_kernels.hip", "q3_engine.cpp", "q3_codec.cpp",
            "q3_speaker.cpp", "q3_audio.cpp", "q3_bpe.cpp", "q3_capi.cpp"]
-HEADERS = ["q3_common.h", "q3_engine.h", "q3_bpe.h", "q3_audio.h", os.path.join("..", "..", "include", "q3tts.h")]
+HEADERS = ["q3_common.h", "q3_engine.h", "q3_kvpool.h", "q3_bpe.h", "q3_audio.h", os.path.join("..", "..", "include", "q3tts.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall", "-Wno-unused-function",
          "-Wno-unused-variable", "-Wno-unused-but-set-variable"]
 

@@ -330,18 +330,15 @@ int q3tts_synthesize_schedule_host(q3tts_engine* h, int n_utt, const int64_t* id
     try {
         while (!pending.empty() || live > 0) {
             fresh.clear();
-            int pages_left = e.kv_free_pages();
-            for (int b = 0; b < B && !pending.empty(); ++b) {
-                if (slot_utt[(size_t)b] >= 0) continue;
-                const int u = pending.front();
-                const int all = prep[(size_t)u].S + cap_of(u);
-                const int need = e.kv_pages_for(reserve_all ? all : std::min(all, prep[(size_t)u].S + first_look));
-                // on-demand mode keeps a page of head-room per running utterance, so that admitting one more does not preempt at the next look
-                const int headroom = reserve_all ? 0 : live + (int)fresh.size();
-                if (need + headroom > pages_left && (live > 0 || !fresh.empty())) break;   // waits for pages; alone, it always fits (checked above)
-                pages_left -= need;
-                pending.pop_front();
-                slot_utt[(size_t)b] = u; fresh.push_back(b);
+            {   // admission in queue order (q3_kvpool.h: sched_admit_count)
+                std::vector<int> free_slots, need;
+                for (int b = 0; b < B; ++b) if (slot_utt[(size_t)b] < 0) free_slots.push_back(b);
+                for (size_t i = 0; i < pending.size() && i < free_slots.size(); ++i) {
+                    const int u = pending[i], all = prep[(size_t)u].S + cap_of(u);
+                    need.push_back(e.kv_pages_for(reserve_all ? all : std::min(all, prep[(size_t)u].S + first_look)));
+                }
+                const int n_adm = q3::sched_admit_count(e.kv, need, (int)free_slots.size(), live, reserve_all);
+                for (int i = 0; i < n_adm; ++i) { slot_utt[(size_t)free_slots[(size_t)i]] = pending.front(); pending.pop_front(); fresh.push_back(free_slots[(size_t)i]); }
             }
             if (!fresh.empty()) {
                 init.assign(fresh.size(), Engine::SlotInit());
@@ -373,31 +370,24 @@ int q3tts_synthesize_schedule_host(q3tts_engine* h, int n_utt, const int64_t* id
             const int steps = std::max(!pending.empty() && live > 16 ? quantum : 1, look);
             if (!reserve_all) {
                 // every live slot gets pages for the positions these steps write; oldest first, so that when the pool runs dry it is the
-                // youngest that goes back to the queue
-                std::vector<int> order;
+                // youngest that goes back to the queue (q3_kvpool.h: sched_grow)
+                std::vector<int> order, want, changed;
                 for (int b = 0; b < B; ++b) if (slot_utt[(size_t)b] >= 0) order.push_back(b);
                 std::sort(order.begin(), order.end(), [&](int x, int y) {
                     return done_frames[(size_t)x] != done_frames[(size_t)y] ? done_frames[(size_t)x] > done_frames[(size_t)y] : slot_utt[(size_t)x] < slot_utt[(size_t)y]; });
-                size_t keep = order.size();
-                auto preempt = [&](int vb) {
+                for (int b : order) {
+                    const int u = slot_utt[(size_t)b];
+                    want.push_back(std::min(prep[(size_t)u].S + cap_of(u), prep[(size_t)u].S + done_frames[(size_t)b] + steps));
+                }
+                const std::vector<int> victims = q3::sched_grow(e.kv, order, want, &changed);
+                for (int vb : victims) {          // youngest first: pushed to the front one by one, the oldest of them ends up first in the queue
                     const int vu = slot_utt[(size_t)vb];
-                    e.slot_release(vb);
+                    e.slot_release(vb);           // deactivates the slot (its pages are already back in the pool)
                     pending.push_front(vu);
                     slot_utt[(size_t)vb] = -1; done_frames[(size_t)vb] = 0;
                     --live; ++e.sched_preempted;
-                };
-                for (size_t i = 0; i < keep; ++i) {
-                    const int b = order[i], u = slot_utt[(size_t)b];
-                    const int want = std::min(prep[(size_t)u].S + cap_of(u), prep[(size_t)u].S + done_frames[(size_t)b] + steps);
-                    bool gone = false;
-                    while (!gone && e.kv_pages_for(want) - e.kv_slot_pages(b) > e.kv_free_pages()) {
-                        const size_t v = keep > i + 1 ? keep - 1 : i;   // the youngest still running; in the end this one itself
-                        preempt(order[v]);
-                        keep = v;
-                        gone = v == i;                                  // (never the oldest: alone it fits, checked before the first admission)
-                    }
-                    if (!gone) e.kv_reserve(b, want, false);
                 }
+                for (int b : changed) e.kv_upload_row(b);
             }
             e.decode_steps(steps);
             e.slots_state(B, st);

@@ -279,27 +279,23 @@ Engine::Engine(const q3tts_config& cfg, int device_, int max_batch, int max_ctx_
         const int ptok = 1 << shift;
         S.pages_per_slot = (ctx + ptok - 1) / ptok;
         size_t n_pages = (size_t)B * S.pages_per_slot;
-        const bool pooled = talker_stack && pool_tokens > 0 && (size_t)((pool_tokens + ptok - 1) / ptok) < n_pages;
+        bool pooled = false;
+        if (talker_stack) {
+            kv.init(B, S.pages_per_slot, shift, pool_tokens > 0 ? (pool_tokens + ptok - 1) / ptok : 0);
+            pooled = !kv.identity;
+            n_pages = (size_t)kv.device_pages();
+        }
         S.identity_pages = !pooled;
-        if (pooled) n_pages = (size_t)((pool_tokens + ptok - 1) / ptok) + 1;   // + scratch page 0
-        if (talker_stack) kv_pages_total = pooled ? (int)n_pages - 1 : (int)n_pages;
         const size_t page_elems = (size_t)L * nkv * ptok * d;
         S.kc = (float*)dmalloc(n_pages * page_elems * sizeof(float));
         S.vc = (float*)dmalloc(n_pages * page_elems * sizeof(float));
         std::vector<int> pt((size_t)B * S.pages_per_slot);
-        for (size_t i = 0; i < pt.size(); ++i) pt[i] = pooled ? 0 : (int)i;
+        for (size_t i = 0; i < pt.size(); ++i) pt[i] = talker_stack ? kv.table[i] : (int)i;
         S.page_table = (int*)dmalloc(pt.size() * sizeof(int));
         Q3_HIP_CHECK(hipMemcpy(S.page_table, pt.data(), pt.size() * sizeof(int), hipMemcpyHostToDevice));
-        if (talker_stack) {
-            kv_table_h = pt;
-            kv_owned.assign((size_t)B, std::vector<int>());
-            kv_free_count = kv_pages_total;
-            if (pooled) {
-                Q3_HIP_CHECK(hipMemsetAsync(S.kc, 0, page_elems * sizeof(float), stream));
-                Q3_HIP_CHECK(hipMemsetAsync(S.vc, 0, page_elems * sizeof(float), stream));
-                kv_free.resize((size_t)kv_pages_total);
-                for (int i = 0; i < kv_pages_total; ++i) kv_free[(size_t)i] = kv_pages_total - i;   // popped from the back: 1, 2, 3, ...
-            }
+        if (pooled) {   // the scratch page
+            Q3_HIP_CHECK(hipMemsetAsync(S.kc, 0, page_elems * sizeof(float), stream));
+            Q3_HIP_CHECK(hipMemsetAsync(S.vc, 0, page_elems * sizeof(float), stream));
         }
         // RoPE tables with the oracle's formula (fp32 libm): inv = 1/powf(theta, 2i/d); ang = pos*inv
         const int half = d / 2, npos = S.pages_per_slot * ptok;
@@ -872,26 +868,16 @@ void Engine::step_logits(int slot, float* out, int cols) {
 void Engine::kv_reserve(int slot, int tokens, bool exact) {
     if (slot < 0 || slot >= B) throw Error("slot out of range");
     if (tokens < 0 || tokens > max_ctx) throw Error("KV reservation exceeds max_ctx");
-    std::vector<int>& own = kv_owned[(size_t)slot];
-    const int want = kv_pages_for(tokens), have = (int)own.size();
-    if (want == have || (want < have && !exact)) return;
-    if (want - have > kv_free_count) {
-        char msg[160];
-        snprintf(msg, sizeof msg, "KV page pool exhausted: slot %d needs %d more pages of %d tokens, %d of %d free", slot, want - have, 1 << talker.page_shift,
-                 kv_free_count, kv_pages_total);
-        throw Error(msg);
-    }
-    kv_free_count -= want - have;
-    if (talker.identity_pages) {   // fixed run per slot: accounting only, the table never changes
-        own.resize((size_t)want);
-        for (int i = 0; i < want; ++i) own[(size_t)i] = slot * talker.pages_per_slot + i;
-        return;
-    }
-    int* row = kv_table_h.data() + (size_t)slot * talker.pages_per_slot;
-    while ((int)own.size() < want) { own.push_back(kv_free.back()); kv_free.pop_back(); row[own.size() - 1] = own.back(); }
-    while ((int)own.size() > want) { kv_free.push_back(own.back()); row[own.size() - 1] = 0; own.pop_back(); }
-    // the slot is not in flight here (every entry point that steps it synchronises before returning); the mirror row outlives the copy
-    Q3_HIP_CHECK(hipMemcpyAsync(talker.page_table + (size_t)slot * talker.pages_per_slot, row, (size_t)talker.pages_per_slot * sizeof(int), hipMemcpyHostToDevice, stream));
+    std::string err;
+    const int rc = kv.reserve(slot, tokens, exact, &err);
+    if (rc < 0) throw Error(err);
+    if (rc > 0) kv_upload_row(slot);
+}
+
+// The slot is not in flight here (every entry point that steps it synchronises before returning); the mirror row outlives the copy.
+void Engine::kv_upload_row(int slot) {
+    if (kv.identity) return;
+    Q3_HIP_CHECK(hipMemcpyAsync(talker.page_table + (size_t)slot * talker.pages_per_slot, kv.row(slot), (size_t)talker.pages_per_slot * sizeof(int), hipMemcpyHostToDevice, stream));
 }
 
 void Engine::kv_release(int slot) { kv_reserve(slot, 0, true); }
@@ -931,7 +917,7 @@ void Engine::slots_begin(const SlotInit* in, int n, const q3tts_sampling& p, uin
         for (int i = 0; i < n; ++i) need += want_of(in[i]) - kv_slot_pages(in[i].slot);
         if (need > kv_free_pages()) {
             char msg[160];
-            snprintf(msg, sizeof msg, "KV page pool exhausted: %d slots need %d more pages, %d of %d free", n, need, kv_free_pages(), kv_pages_total);
+            snprintf(msg, sizeof msg, "KV page pool exhausted: %d slots need %d more pages, %d of %d free", n, need, kv_free_pages(), kv_total_pages());
             throw Error(msg);
         }
         for (int pass = 0; pass < 2; ++pass)   // slots that give pages back first

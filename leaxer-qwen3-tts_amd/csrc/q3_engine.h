@@ -6,6 +6,7 @@
 #include <vector>
 
 #include "q3_common.h"
+#include "q3_kvpool.h"
 
 namespace q3 {
 
@@ -61,20 +62,17 @@ public:
 
     // ---- talker KV page pool: 64-token pages handed to slots on demand (page 0 is a scratch page every unowned table entry points at,
     // so masked rows of unarmed / released slots keep writing somewhere harmless).  Host-side free list; the device sees only the table.
-    int kv_total_pages() const { return kv_pages_total; }
-    int kv_free_pages() const { return kv_free_count; }
-    int kv_pages_for(int tokens) const { return (tokens + (1 << talker.page_shift) - 1) >> talker.page_shift; }
-    int kv_slot_pages(int slot) const { return (int)kv_owned[(size_t)slot].size(); }
+    int kv_total_pages() const { return kv.total; }
+    int kv_free_pages() const { return kv.free_count; }
+    int kv_pages_for(int tokens) const { return kv.pages_for(tokens); }
+    int kv_slot_pages(int slot) const { return kv.slot_pages(slot); }
     void kv_reserve(int slot, int tokens, bool exact);   // the slot owns pages for positions [0, tokens): grows (and with `exact` shrinks) to that
+    void kv_upload_row(int slot);                        // after KvPool changed a slot's table row behind the engine's back (scheduler policy)
     void kv_release(int slot);
 
     q3tts_config c;
     int device, B, max_ctx;
-    int kv_pages_total = 0;                    // usable pages (without the scratch page)
-    int kv_free_count = 0;
-    std::vector<int> kv_free;                  // bounded pool: stack of free page ids, lowest on top
-    std::vector<std::vector<int>> kv_owned;    // per slot, in position order
-    std::vector<int> kv_table_h;               // host mirror of talker.page_table
+    KvPool kv;                                 // q3_kvpool.h: free list, per-slot pages, host mirror of talker.page_table
     int64_t sched_admitted = 0, sched_preempted = 0; int sched_peak_live = 0;   // the last scheduler call (q3tts_sched_stats)
     uint32_t flags;
     hipStream_t stream = nullptr;
