@@ -115,7 +115,9 @@ int q3tts_talker_prefill_host(q3tts_engine* e, int slot, const float* embeds, in
 int q3tts_talker_decode_host(q3tts_engine* e, int slot, const float* embed, float* logits, float* last_hidden);
 /* run_code_predictor, tts_onnx.cpp:734-757: seq[n][hidden], head #generation_step on the last row */
 int q3tts_code_predictor_host(q3tts_engine* e, const float* seq, int n, int generation_step, float* logits);
-/* run_vocoder, tts_onnx.cpp:759-776: codes[F][n_groups] (frame-major) -> pcm; *out_len = lengths[0] */
+/* run_vocoder, tts_onnx.cpp:759-776: codes[F][n_groups] (frame-major) -> pcm; *out_len = lengths[0].
+ * One call decodes at most ~5500 frames (7 minutes: a decoder activation must stay below 4 GB, the conv kernels address it with 32-bit
+ * offsets); longer utterances go through q3tts_codec_decode_chunked_host. */
 int q3tts_codec_decode_host(q3tts_engine* e, const int64_t* codes, int F, float* pcm, int64_t cap, int64_t* out_len);
 int64_t q3tts_codec_decode_len(const q3tts_config* cfg, int F);
 /* the same with both ends in HBM: codes_dev int32 [F][n_groups] and pcm_dev float [cap] are DEVICE pointers on the engine's GPU (any
