@@ -789,6 +789,181 @@ __global__ __launch_bounds__(256) void k_attn(const int* ppage_table, const int*
     KP_MARK(29);
 }
 
+// ================================================================================================
+// k_attn_tiny — the code predictor's attention in the batched step: at most 32 cached tokens (one fixed page per slot), 1 or 2 new
+// tokens, position a launch argument.  k_attn spreads one (kv head, row) over 256 threads — 16 lane groups, two block barriers, an LDS
+// merge of 16 partial softmaxes — for a context of 1..17 tokens: 4.7 us in-kernel, 75 launches per step.  Here ONE WAVE owns a
+// (kv head, row): every load is issued up front (raw q / k / v rows of the split-K slabs, norm and RoPE operands, the page's K rows as
+// (token, 32-dim chunk) per lane and V rows as (dim, dim + 64) per lane), q goes through the wave's own LDS slice to change layout, the
+// softmax is a handful of DPP reductions, p_t reaches the P.V loop through v_readlane.  No block barrier; two waves per workgroup.
+// Same arithmetic as k_attn for the new token (RMSNorm, RoPE, cache append); the softmax sums associate differently (fp32, ~1e-7).
+// ================================================================================================
+static __device__ __forceinline__ void wave_lds_sync();
+template <int G, int NN>
+__global__ __launch_bounds__(128) void k_attn_tiny(const float* pqkv, const float* pkcache, const float* pvcache, const float* pcos, const float* psin,
+                                                    int pbase, AttnArgs a) {
+    constexpr int D = 128, HALF = 64;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int pair = blockIdx.x * 2 + wave;
+    if (pair >= a.nb * a.nkv) return;                                   // wave-uniform
+    const int bi = pair / a.nkv, kvh = pair - bi * a.nkv;
+    const int slot = a.slot_offset + bi, base = pbase;
+    const int PT = 1 << a.page_shift;
+    const size_t cbase = ((((size_t)slot * a.pages_per_slot) * a.n_layers + a.layer) * a.nkv + kvh) * (size_t)PT * D;
+    const float* kc = pkcache + cbase;
+    const float* vc = pvcache + cbase;
+    __shared__ __attribute__((aligned(16))) float q_sh[2][NN][G][D];
+    float (*q_s)[G][D] = q_sh[wave];
+
+    // ---- every load of the launch, before any use ----
+    float qx0[NN][G][4], qx1[NN][G][4], kx0[NN][4], kx1[NN][4], vx0[NN][4], vx1[NN][4], cs[NN], sn[NN];
+#pragma unroll
+    for (int j = 0; j < NN; ++j) {
+        const float* rowp = pqkv + (size_t)(bi * NN + j) * a.ld_qkv;
+#pragma unroll
+        for (int sb = 0; sb < 4; ++sb) {
+            const size_t so = (size_t)(sb < a.qkv_nslab ? sb : 0) * a.qkv_slab_stride;
+#pragma unroll
+            for (int h = 0; h < G; ++h) { qx0[j][h][sb] = rowp[so + (kvh * G + h) * D + lane]; qx1[j][h][sb] = rowp[so + (kvh * G + h) * D + lane + HALF]; }
+            kx0[j][sb] = rowp[so + (a.nq + kvh) * D + lane]; kx1[j][sb] = rowp[so + (a.nq + kvh) * D + lane + HALF];
+            vx0[j][sb] = rowp[so + (a.nq + a.nkv + kvh) * D + lane]; vx1[j][sb] = rowp[so + (a.nq + a.nkv + kvh) * D + lane + HALF];
+        }
+        cs[j] = pcos[(size_t)(base + j) * HALF + lane]; sn[j] = psin[(size_t)(base + j) * HALF + lane];
+    }
+    const float* qnw = a.q_norm ? a.q_norm : pcos;      // address select: the loads stay unconditional, the values are replaced below
+    const float* knw = a.k_norm ? a.k_norm : pcos;
+    const float qn0 = qnw[lane], qn1 = qnw[lane + HALF], kn0 = knw[lane], kn1 = knw[lane + HALF];
+    // cached K as (token = lane / 4, 32-dim chunk = lane % 4), cached V as (dim = lane, lane + 64) per token; tokens past `base` repeat the last one
+    const int tk = lane >> 2, ch = lane & 3;
+    const int last = base > 0 ? base - 1 : 0;
+    float4 kr[8];
+    {
+        const int t = tk < base ? tk : last;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) kr[e] = *reinterpret_cast<const float4*>(kc + (size_t)t * D + ch * 32 + e * 4);
+    }
+    float vr0[16], vr1[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const int tt = t < base ? t : last;
+        vr0[t] = vc[(size_t)tt * D + lane]; vr1[t] = vc[(size_t)tt * D + lane + HALF];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < 16; ++t) { vr0[t] = t < base ? vr0[t] : 0.f; vr1[t] = t < base ? vr1[t] : 0.f; }   // never-written cache rows may hold anything: 0 x NaN
+
+    // ---- new tokens: slab sums (slab order), RMSNorm, RoPE; K / V appended to the cache; q to LDS ----
+    float ky0[NN], ky1[NN], vn0[NN], vn1[NN], qy0[NN][G], qy1[NN][G];
+#pragma unroll
+    for (int j = 0; j < NN; ++j) {
+        auto slabsum = [&](const float (&p)[4]) { float t = p[0];
+#pragma unroll
+            for (int sb = 1; sb < 4; ++sb) if (sb < a.qkv_nslab) t += p[sb];
+            return t; };
+        float k0 = slabsum(kx0[j]), k1 = slabsum(kx1[j]);
+        vn0[j] = slabsum(vx0[j]); vn1[j] = slabsum(vx1[j]);
+        if (a.k_norm != nullptr) {
+            const float ss = wave_sum(k0 * k0 + k1 * k1);
+            const float rr = 1.0f / sqrtf(ss / (float)D + a.eps);
+            k0 = kn0 * (k0 * rr); k1 = kn1 * (k1 * rr);
+        }
+        ky0[j] = k0 * cs[j] + (-k1) * sn[j];
+        ky1[j] = k1 * cs[j] + k0 * sn[j];
+        const size_t off = cbase + (size_t)(base + j) * D;
+        a.kcache[off + lane] = ky0[j]; a.kcache[off + lane + HALF] = ky1[j];
+        a.vcache[off + lane] = vn0[j]; a.vcache[off + lane + HALF] = vn1[j];
+#pragma unroll
+        for (int h = 0; h < G; ++h) {
+            float x0 = slabsum(qx0[j][h]), x1 = slabsum(qx1[j][h]);
+            if (a.q_norm != nullptr) {
+                const float ss = wave_sum(x0 * x0 + x1 * x1);
+                const float rr = 1.0f / sqrtf(ss / (float)D + a.eps);
+                x0 = qn0 * (x0 * rr); x1 = qn1 * (x1 * rr);
+            }
+            qy0[j][h] = x0 * cs[j] + (-x1) * sn[j];
+            qy1[j][h] = x1 * cs[j] + x0 * sn[j];
+            q_s[j][h][lane] = qy0[j][h]; q_s[j][h][lane + HALF] = qy1[j][h];
+        }
+    }
+    wave_lds_sync();
+
+    // ---- per new token: scores, softmax, P.V, output ----
+#pragma unroll
+    for (int j = 0; j < NN; ++j) {
+        const int row = bi * NN + j;
+#pragma unroll
+        for (int h = 0; h < G; ++h) {
+            // cached tokens 0..15 (and 16..31 below when the context is that long)
+            float part = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float4 q4 = *reinterpret_cast<const float4*>(&q_s[j][h][ch * 32 + e * 4]);
+                part = fmaf(q4.x, kr[e].x, part); part = fmaf(q4.y, kr[e].y, part); part = fmaf(q4.z, kr[e].z, part); part = fmaf(q4.w, kr[e].w, part);
+            }
+            part += dpp_f<Q3_DPP_XOR1, 0xF>(0.f, part);
+            part += dpp_f<Q3_DPP_XOR2, 0xF>(0.f, part);
+            float sc = tk < base ? part * a.scale : -INFINITY;            // all four lanes of a token hold its score
+            float scB = -INFINITY;
+            float4 krB[8];
+            if (base > 16) {                                               // wave-uniform, rare (more than 16 cached tokens)
+                const int t = 16 + tk < base ? 16 + tk : last;
+                float pb = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    krB[e] = *reinterpret_cast<const float4*>(kc + (size_t)t * D + ch * 32 + e * 4);
+                    const float4 q4 = *reinterpret_cast<const float4*>(&q_s[j][h][ch * 32 + e * 4]);
+                    pb = fmaf(q4.x, krB[e].x, pb); pb = fmaf(q4.y, krB[e].y, pb); pb = fmaf(q4.z, krB[e].z, pb); pb = fmaf(q4.w, krB[e].w, pb);
+                }
+                pb += dpp_f<Q3_DPP_XOR1, 0xF>(0.f, pb);
+                pb += dpp_f<Q3_DPP_XOR2, 0xF>(0.f, pb);
+                scB = 16 + tk < base ? pb * a.scale : -INFINITY;
+            }
+            // the new tokens up to and including this one
+            float sn_[NN];
+#pragma unroll
+            for (int jn = 0; jn < NN; ++jn) sn_[jn] = jn <= j ? wave_sum(qy0[j][h] * ky0[jn] + qy1[j][h] * ky1[jn]) * a.scale : -INFINITY;
+            float m = wave_max(fmaxf(sc, scB));
+#pragma unroll
+            for (int jn = 0; jn < NN; ++jn) m = fmaxf(m, sn_[jn]);        // the token itself is always there: m is finite
+            const float pA = __expf(sc - m), pB = __expf(scB - m);       // exp(-inf) = 0
+            float l = wave_sum(ch == 0 ? pA + pB : 0.f);
+            float pn[NN];
+#pragma unroll
+            for (int jn = 0; jn < NN; ++jn) { pn[jn] = __expf(sn_[jn] - m); l += pn[jn]; }
+            float o0 = 0.f, o1 = 0.f;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const float pt = lane_bcast(pA, 4 * t);
+                o0 = fmaf(pt, vr0[t], o0); o1 = fmaf(pt, vr1[t], o1);
+            }
+            if (base > 16) {
+                for (int t = 16; t < base; ++t) {
+                    const float pt = lane_bcast(pB, 4 * (t - 16));
+                    o0 = fmaf(pt, vc[(size_t)t * D + lane], o0); o1 = fmaf(pt, vc[(size_t)t * D + lane + HALF], o1);
+                }
+            }
+#pragma unroll
+            for (int jn = 0; jn < NN; ++jn) { o0 = fmaf(pn[jn], vn0[jn], o0); o1 = fmaf(pn[jn], vn1[jn], o1); }
+            o0 /= l; o1 /= l;
+            const int head = kvh * G + h;
+            if (a.out) { a.out[(size_t)row * a.ld_out + head * D + lane] = o0; a.out[(size_t)row * a.ld_out + head * D + lane + HALF] = o1; }
+            if (a.oh) {
+                const float ov[2] = { o0, o1 };
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const uint32_t u = __float_as_uint(ov[q]);
+                    const bf16_t hi = (bf16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+                    const float rem = ov[q] - __uint_as_float((uint32_t)hi << 16);
+                    const uint32_t v = __float_as_uint(rem);
+                    a.oh[(size_t)row * a.ldp + head * D + lane + q * HALF] = hi;
+                    a.ol[(size_t)row * a.ldp + head * D + lane + q * HALF] = (bf16_t)((v + 0x7FFFu + ((v >> 16) & 1u)) >> 16);
+                }
+            }
+        }
+    }
+}
+
 void launch_attn(const AttnArgs& a, hipStream_t s) {
     const int grp = a.nq / a.nkv;
     if (grp < 1 || grp > ATT_MAX_GRP || a.nq % a.nkv) throw Error("attn: unsupported GQA group size");
@@ -796,6 +971,20 @@ void launch_attn(const AttnArgs& a, hipStream_t s) {
     if (a.n_splits < 1 || (a.n_splits > 1 && (a.po == nullptr || a.window > 0))) throw Error("attn: split mode needs partial buffers and no window");
     if ((size_t)a.n_new * a.n_splits > 65535) throw Error("attn: grid too large");
     if (a.n_splits > 1 && (a.chunk >> a.page_shift) + 1 > 4) throw Error("attn: a split may touch at most 4 KV pages");
+    const bool tiny_ctx0 = a.n_splits == 1 && a.window == 0 && (a.pages_per_slot << a.page_shift) <= 32;
+    static const bool no_tiny = getenv("Q3TTS_NO_ATTN_TINY") != nullptr;   // A/B switch
+    if (!no_tiny && a.d == 128 && tiny_ctx0 && a.identity_pages && a.pages_per_slot == 1 && a.n_new >= 1 && a.n_new <= 2 && a.slot_map == nullptr &&
+        a.pos_dev == nullptr && a.new_from_raw && a.po == nullptr && (a.out || a.oh) && a.nb >= 2 && a.pos_scalar + a.n_new <= 32 && a.qkv_nslab >= 1 && a.qkv_nslab <= 4) {
+        const dim3 g((unsigned)((a.nb * a.nkv + 1) / 2));
+#define Q3_TINY(G_, NN_) hipLaunchKernelGGL((k_attn_tiny<G_, NN_>), g, dim3(128), 0, s, a.qkv, (const float*)a.kcache, (const float*)a.vcache, a.rope_cos, a.rope_sin, a.pos_scalar, a)
+        if (grp == 1) { if (a.n_new == 1) Q3_TINY(1, 1); else Q3_TINY(1, 2); }
+        else if (grp == 2) { if (a.n_new == 1) Q3_TINY(2, 1); else Q3_TINY(2, 2); }
+        else if (grp == 4) { if (a.n_new == 1) Q3_TINY(4, 1); else Q3_TINY(4, 2); }
+        else goto generic;
+#undef Q3_TINY
+        return;
+    }
+generic:;
     dim3 grid(a.nkv, a.n_new * a.n_splits, a.nb);
 #define Q3_ATT_ARGS a.page_table, a.pos_dev, a.qkv, (const float*)a.kcache, (const float*)a.vcache, a.rope_cos, a.rope_sin, a.pos_scalar, a.n_splits, a
 #define Q3_ATT_I(D, U, I) do { if (grp == 1) hipLaunchKernelGGL((k_attn<D, U, 1, I>), grid, dim3(256), 0, s, Q3_ATT_ARGS); \
