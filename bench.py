@@ -130,6 +130,7 @@ def stage_report(eng, cfg, toks, sp, B, F, ctr):
         return {"ms_per_step": round(ms, 4), "algorithmic_bytes": int(nbytes), "GB/s": round(gbs, 1), "frac_hbm": round(gbs / HBM_PEAK_GBS, 4)}
     codec_ms = ctr["codec_ms"] / max(ctr["codec_frames"], 1)
     tf = CODEC_GFLOP_PER_FRAME * 1e9 / (codec_ms * 1e-3) / 1e12 if codec_ms > 0 else 0.0
+    two, three = eng.codec_plane_stats()
     return {
         "talker_decode": dict(hbm(st["talker_decode_ms"], talker_bytes), context=ctx,
                               kv_bytes_actual_fp32=int(kv_step_bytes(cfg, B, ctx, 4.0))),
@@ -137,7 +138,10 @@ def stage_report(eng, cfg, toks, sp, B, F, ctr):
         "sampler": {"ms_per_step": round(st["sampler_ms"], 4), "launches_per_step": cfg.n_groups, "bound": "latency"},
         "codec_decode": {"ms_per_frame": round(codec_ms, 5), "GFLOP_per_frame": CODEC_GFLOP_PER_FRAME, "TFLOP/s": round(tf, 1),
                          "frac_mfma_16bit_dense": round(tf / MFMA_16BIT_DENSE_TFLOPS, 4),
-                         "note": "fp32 products as 3 fp16 MFMA passes: matrix-core issue is 3x the algorithmic rate"},
+                         "weight_tensors_2_products": two, "weight_tensors_3_products": three,
+                         "note": "fp32-grade products from fp16 (hi, lo) split operands: a weight tensor that is exact in fp16 (every bf16-origin tensor, "
+                                 "incl. these synthetic weights) takes 2 matrix-core products per fp32 product (exact), any other tensor 3; "
+                                 "matrix-core issue is that multiple of the algorithmic rate"},
         "prompt_and_prefill": {"ms_per_utterance_wall": round(prefill_ms, 3), "note": "host prompt assembly (text_project calls) + talker prefill"},
         "eager_step_ms": round(st["step_ms"], 4),
     }
@@ -352,6 +356,7 @@ def main():
     ap.add_argument("--model", default="0.6b", choices=["0.6b", "1.7b"], help="model dims (the headline is 0.6b; 1.7b = configs[4] dims)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-b64", action="store_true", help="skip the configs[2] sub-record (64 utterances x 256 frames) of the default line")
+    ap.add_argument("--no-long", action="store_true", help="skip the b64_f2048 sub-record (64 utterances x 2048 frames, ~45 s)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay (rocprofv3 kernel tracing "
                                                              "crashes inside hipGraphLaunch on this ROCm; same kernels either way)")
     ap.add_argument("--cpu-frames", type=int, default=160)
@@ -451,26 +456,35 @@ def main():
         eng.close()
         eng = None
         if world == 1 and dist is None and B == 1 and args.model == "0.6b" and not args.no_b64 and not args.no_graph:
-            # the other half of BASELINE.json's metric ("0.6B @ b1/b64"): configs[2], 64 utterances in one batch x 256 frames, same process
-            try:
-                B2, F2 = 64, 256
-                e2, toks2, sp2, dt2, fr2, smp2, ctr2, _ = run_workload(q3tts, cfg, local_rank, B2, F2, sp_kwargs, 2, 1, rank, False)
+            # the rest of BASELINE.json's metric ("0.6B @ b1/b64", north_star: "batch 1/8/64"), same process, after the timed region of `value`:
+            #   b64       configs[2], 64 utterances in one batch x 256 frames, 5 timed steps
+            #   b64_f2048 the same batch at the length configs[1] and the reference default (tts_onnx.h:65) state: 64 x 2048 frames, 1 timed step
+            #   b8        8 utterances x 256 frames
+            def sub_record(B2, F2, steps2, warm2, with_stages):
+                e2, toks2, sp2, dt2, fr2, smp2, ctr2, _ = run_workload(q3tts, cfg, local_rank, B2, F2, sp_kwargs, steps2, warm2, rank, False)
                 sm2 = ctr2["decode_ms"] / max(ctr2["decode_steps"], 1)
                 rec = {"config": {"workload": f"{MODEL}, batch={B2}/GPU, 16-token prompt, {sampling_txt}, max-tokens={F2} (EOS suppressed), "
                                               "hipGraph decode loop, synthetic seeded weights", "batch_per_gpu": B2, "frames_per_utterance": F2},
-                       "value": round(fr2 * FRAME_SECONDS / dt2, 3), "unit": "x real-time (audio s / wall s)", "steps": 2, "warmup": 1,
-                       "ms_per_step": round(dt2 / 2 * 1e3, 3), "codec_frames_per_s": round(fr2 / dt2, 2),
+                       "value": round(fr2 * FRAME_SECONDS / dt2, 3), "unit": "x real-time (audio s / wall s)", "steps": steps2, "warmup": warm2,
+                       "ms_per_step": round(dt2 / steps2 * 1e3, 3), "codec_frames_per_s": round(fr2 / dt2, 2),
                        "decode_ms_per_frame_step": round(sm2, 4),
                        "codec_decode_ms_per_frame": round(ctr2["codec_ms"] / max(ctr2["codec_frames"], 1), 5),
                        "roofline": roofline_record(cfg, B2, F2, sm2, args.model)}
-                try:
-                    rec["stages"] = stage_report(e2, cfg, toks2, sp2, B2, F2, ctr2)
-                except Exception as ex:
-                    rec["stages"] = {"error": str(ex)}
+                if with_stages:
+                    try:
+                        rec["stages"] = stage_report(e2, cfg, toks2, sp2, B2, F2, ctr2)
+                    except Exception as ex:
+                        rec["stages"] = {"error": str(ex)}
                 e2.close()
-                out["b64"] = rec
-            except Exception as ex:
-                out["b64"] = {"error": str(ex)}
+                return rec
+            for key, (B2, F2, steps2, warm2, with_stages) in (("b64", (64, 256, 5, 1, True)), ("b8", (8, 256, 5, 1, True)),
+                                                              ("b64_f2048", (64, 2048, 1, 1, False))):
+                if key == "b64_f2048" and args.no_long:
+                    continue
+                try:
+                    out[key] = sub_record(B2, F2, steps2, warm2, with_stages)
+                except Exception as ex:
+                    out[key] = {"error": str(ex)}
         if world == 1 and dist is None and not args.no_cpu_baseline:
             try:
                 e3 = q3tts.Engine(cfg, device=local_rank, max_batch=1, max_ctx=64)   # weights only: the oracle copies the same seeded tensors

@@ -226,6 +226,10 @@ int q3tts_last_codec_ms(q3tts_engine* e, float* ms);
 /* accumulated device time since the last reset: decode steps (HIP events around the graph
  * replays, on the engine's stream) and codec decodes */
 int q3tts_counters(q3tts_engine* e, double* decode_ms, int64_t* decode_steps, double* codec_ms, int64_t* codec_frames, int reset);
+/* Codec decoder (run_vocoder's graph, /root/reference/src/tts_onnx.cpp:759-776): how many of its conv / linear weight tensors are exact
+ * in fp16 after the power-of-two pre-scale (every bf16- or fp16-origin tensor) and therefore run two matrix-core products per fp32
+ * product, and how many keep a non-zero lo plane and run three.  Both 0 under Q3TTS_FLAG_FP32_CODEC. */
+int q3tts_codec_plane_stats(q3tts_engine* e, int* two_product, int* three_product);
 /* Per-stage device time of the decode step: runs n_steps EAGER steps of the armed slots (they advance like q3tts_decode_steps) with HIP
  * events at the stage boundaries.  out_ms[0] sampler (n_groups launches), [1] code predictor (layer passes + heads; predict_subcodes,
  * tts_onnx.cpp:851-872), [2] talker decode (layers + codec head; run_decode :667-732), [3] their sum — milliseconds per step. */

@@ -549,6 +549,12 @@ int q3tts_counters(q3tts_engine* h, double* dms, int64_t* dsteps, double* cms, i
     return 0;
     Q3_API_END(h)
 }
+int q3tts_codec_plane_stats(q3tts_engine* h, int* two_product, int* three_product) {
+    Q3_API_BEGIN(h)
+    h->e->codec_plane_stats(two_product, three_product);
+    return 0;
+    Q3_API_END(h)
+}
 int q3tts_stage_profile(q3tts_engine* h, int n_steps, double* out_ms) {
     Q3_API_BEGIN(h)
     if (!out_ms) throw q3::Error("stage_profile: null output");

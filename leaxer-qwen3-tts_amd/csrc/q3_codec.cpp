@@ -31,7 +31,8 @@ struct CodecW {
     SnakeP snake_out;
     std::vector<float*> packed; // owned
     // (hi, lo) bf16 planes of every conv / linear weight, keyed by the fp32 pointer the layer list holds (owned)
-    struct Planes { bf16_t* hi; bf16_t* lo; float scale_inv; };
+    struct Planes { bf16_t* hi; bf16_t* lo; float scale_inv; bool lo_zero; };   // lo_zero: the weight is exact in fp16 (bf16- / fp16-origin): two products instead of three
+    int n_lo_zero = 0, n_lo_used = 0;
     std::unordered_map<const float*, Planes> planes;
     // SnakeBeta constants [2][C] (exp(alpha) | 1 / (exp(beta) + 1e-9)) keyed by the alpha pointer (owned; split-precision path only)
     std::unordered_map<const float*, float*> snake_pre;
@@ -77,6 +78,11 @@ void Engine::codec_free() {
     if (codec->page_table) (void)hipFree(codec->page_table);
     delete codec;
     codec = nullptr;
+}
+
+void Engine::codec_plane_stats(int* two_product, int* three_product) const {
+    if (two_product) *two_product = codec ? codec->n_lo_zero : 0;
+    if (three_product) *three_product = codec ? codec->n_lo_used : 0;
 }
 
 void Engine::codec_finalize() {
@@ -149,7 +155,13 @@ void Engine::codec_finalize() {
             Q3_HIP_CHECK(hipMalloc((void**)&hi, 2 * np * sizeof(bf16_t)));
             lo = hi + np;
             launch_split_planes(w, hi, lo, n, ldexpf(1.0f, k), stream);
-            W.planes[w] = { hi, lo, ldexpf(1.0f, -k) };
+            unsigned lo_bits = 0;
+            Q3_HIP_CHECK(hipMemsetAsync(amax_d, 0, sizeof(unsigned), stream));
+            launch_or_mag16(lo, n, amax_d, stream);
+            Q3_HIP_CHECK(hipMemcpyAsync(&lo_bits, amax_d, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
+            sync();
+            W.planes[w] = { hi, lo, ldexpf(1.0f, -k), lo_bits == 0 };
+            (lo_bits == 0 ? W.n_lo_zero : W.n_lo_used) += 1;
         };
         const size_t FFn = (size_t)c.cd_ffn;
         for (const CodecW::Layer& L : W.layers) {
@@ -242,7 +254,7 @@ int64_t Engine::codec_run(const int32_t* codes_dev, int F, float** pcm_dev, int 
             if (plan) return;
             a.slab = kslab; a.slab_floats = kslab_floats; a.batch = nbatch;
             const auto it = W.planes.find(a.W);
-            if (it != W.planes.end()) { a.Wh = it->second.hi; a.Wl = it->second.lo; a.w_scale_inv = it->second.scale_inv; }
+            if (it != W.planes.end()) { a.Wh = it->second.hi; a.Wl = it->second.lo; a.w_scale_inv = it->second.scale_inv; a.w_lo_zero = it->second.lo_zero; }
             if (a.snake_alpha) { const auto sp = W.snake_pre.find(a.snake_alpha); if (sp != W.snake_pre.end()) a.snake_pre = sp->second; }
             if (a.mid_alpha) { const auto sp = W.snake_pre.find(a.mid_alpha); if (sp != W.snake_pre.end()) a.mid_pre = sp->second; }
             launch_conv(a, stream);
@@ -342,7 +354,7 @@ int64_t Engine::codec_run(const int32_t* codes_dev, int F, float** pcm_dev, int 
                 if (Co == 96 && p2 != W.planes.end() && W.planes.count(R.c1.w) && !getenv("Q3TTS_NO_FUSED_RES")) {
                     ConvArgs a; a.in = ns; a.T_in = To; a.C_in = Co; a.out = nx; a.T_out = To; a.C_out = Co; a.W = R.c1.w; a.bias = R.c1.b;
                     a.taps = 7; a.dil = dil[u]; a.mid_alpha = R.a2.alpha; a.mid_beta = R.a2.beta;
-                    a.W2 = R.c2.w; a.W2h = p2->second.hi; a.W2l = p2->second.lo; a.w2_scale_inv = p2->second.scale_inv; a.bias2 = R.c2.b;
+                    a.W2 = R.c2.w; a.W2h = p2->second.hi; a.W2l = p2->second.lo; a.w2_scale_inv = p2->second.scale_inv; a.w2_lo_zero = p2->second.lo_zero; a.bias2 = R.c2.b;
                     a.res = nx; a.out2 = nt; a.snake_alpha = nxt.alpha; a.snake_beta = nxt.beta;
                     a.in_planes = act_planes; a.out2_planes = nxt_planes;
                     conv(a);
@@ -434,7 +446,7 @@ const float* Engine::codec_pre_batch(const int32_t* codes_dev, int codes_stride_
     auto conv = [&](ConvArgs a) {
         a.slab = kslab; a.slab_floats = kslab_floats;
         const auto it = W.planes.find(a.W);
-        if (it != W.planes.end()) { a.Wh = it->second.hi; a.Wl = it->second.lo; a.w_scale_inv = it->second.scale_inv; }
+        if (it != W.planes.end()) { a.Wh = it->second.hi; a.Wl = it->second.lo; a.w_scale_inv = it->second.scale_inv; a.w_lo_zero = it->second.lo_zero; }
         if (a.snake_alpha) { const auto sp = W.snake_pre.find(a.snake_alpha); if (sp != W.snake_pre.end()) a.snake_pre = sp->second; }
         launch_conv(a, stream);
     };

@@ -97,6 +97,7 @@ struct ConvKArgs {
     size_t in_ustride;
     // fused residual unit (k_conv_split<..., F2 = true>): second (1x1) conv behind a SnakeBeta on the first conv's output
     const bf16_t* W2h; const bf16_t* W2l; float acc_scale2; const float* bias2; const float* s1_alpha; const float* s1_beta;
+    int wlo;                            // 0: every weight plane `lo` of this launch is identically zero (bf16- / fp16-origin weights) -> the WLO = false kernels
 };
 
 // batched launch: rebase the sequence-shaped pointers to this workgroup's sequence and return its row-tile index
@@ -424,7 +425,10 @@ static __device__ __forceinline__ void split_epilogue_block(const ConvKArgs& a, 
 // serially: a chunk costs one memory latency whatever its size, so 4x wider chunks are 4x fewer latencies); NBUF = weight-tile buffers.
 // PEEL: plain convs with >= 3 taps, next chunk's rows two iterations ahead (see the loop)
 // APL: the input is (hi, lo) fp16 planes (ConvKArgs::in_planes): staged without conversion
-template <int MB, int NB, int WM, int WN, int PA, int KC = 32, int NBUF = 2, bool F2 = false, bool PEEL = false, bool APL = false>
+// WLO: the weight has a non-zero lo plane.  false (weights that are exact in fp16 after the power-of-two pre-scale: every bf16-origin
+// tensor): w = hi exactly, so x . w = x_hi . w_hi + x_lo . w_hi — two products instead of three, exact, and the lo plane is neither
+// loaded nor staged
+template <int MB, int NB, int WM, int WN, int PA, int KC = 32, int NBUF = 2, bool F2 = false, bool PEEL = false, bool APL = false, bool WLO = true>
 // <= 96 accumulator registers and 32-column chunks: two workgroups per CU (256 registers each); otherwise ONE wave per SIMD with the
 // whole 512-register file — said explicitly, or hipcc still budgets 256 and spills the prefetch registers right behind their loads
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MB * NB <= 6 && KC == 32 ? 2 : 1), (MB * NB <= 6 && KC == 32 ? 2 : 1))))
@@ -435,7 +439,8 @@ void k_conv_split(ConvKArgs a0) {
     bx = conv_batch_rebase(a, bx);
     constexpr int TM = WM * MB * 32, TN = WN * NB * 32, AROWS = PA * 32;
     constexpr int CB = KC / 32, SEG = KC / 8, LD = KC + 8;       // 32-column blocks, 16-byte segments and padded halves per staged row
-    constexpr int PB = TN * SEG * 2 / 256;                       // 16-B segments per thread of one weight tile (2 planes x TN rows x SEG)
+    constexpr int BPL = WLO ? 2 : 1, PBT = TN * SEG * BPL;      // weight planes staged; their 16-B segments per tile
+    constexpr int PB = (PBT + 255) / 256;                        // segments per thread (a ragged last pass re-stages the tile's first segments: same bytes, same place)
     constexpr int A_BYTES = 2 * AROWS * LD * 2, B_BYTES = NBUF * 2 * TN * LD * 2;
     constexpr int E_BYTES = 4 * 32 * (NB * 32 + 8) * 4;          // epilogue staging: 32 rows per wave
     constexpr int SM_BYTES = A_BYTES + B_BYTES > E_BYTES ? A_BYTES + B_BYTES : E_BYTES;
@@ -488,7 +493,9 @@ void k_conv_split(ConvKArgs a0) {
     unsigned boff[PB];
 #pragma unroll
     for (int i = 0; i < PB; ++i) {
-        const int idx = tid + 256 * i, plane = idx / (TN * SEG), rem = idx % (TN * SEG), brow = rem / SEG, bseg = rem % SEG;
+        int idx = tid + 256 * i;
+        if (PBT % 256 != 0 && idx >= PBT) idx -= PBT;
+        const int plane = idx / (TN * SEG), rem = idx % (TN * SEG), brow = rem / SEG, bseg = rem % SEG;
         const int co = co0 + brow;
         const int cc = co < a.C_out ? co : a.C_out - 1;                   // rows past C_out repeat the last one; their columns are never stored
         boff[i] = (plane ? w_lo : 0u) + ((unsigned)cc * (unsigned)a.C_in + (unsigned)bseg * 8u) * 2u;
@@ -524,7 +531,9 @@ void k_conv_split(ConvKArgs a0) {
     auto storeB = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < PB; ++i) {
-            const int idx = tid + 256 * i, plane = idx / (TN * SEG), rem = idx % (TN * SEG), brow = rem / SEG, bseg = rem % SEG;
+            int idx = tid + 256 * i;
+            if (PBT % 256 != 0 && idx >= PBT) idx -= PBT;
+            const int plane = idx / (TN * SEG), rem = idx % (TN * SEG), brow = rem / SEG, bseg = rem % SEG;
             *reinterpret_cast<u32x4*>(&Bs[buf][plane][brow][bseg * 8]) = breg[i];
         }
     };
@@ -545,14 +554,14 @@ void k_conv_split(ConvKArgs a0) {
             for (int j = 0; j < NB; ++j) {
                 const int brow = wn * NB * 32 + j * 32 + (lane & 31);
                 bh[j] = *reinterpret_cast<const f16x8*>(&Bs[buf][0][brow][kof]);
-                bl[j] = *reinterpret_cast<const f16x8*>(&Bs[buf][1][brow][kof]);
+                if constexpr (WLO) bl[j] = *reinterpret_cast<const f16x8*>(&Bs[buf][1][brow][kof]);
             }
 #pragma unroll
             for (int i = 0; i < MB; ++i)
 #pragma unroll
                 for (int j = 0; j < NB; ++j) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    if constexpr (WLO) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
                 }
         }
@@ -674,7 +683,7 @@ void k_conv_split(ConvKArgs a0) {
                 for (int j = 0; j < NB; ++j) {
                     const size_t wo = (size_t)(j * 32 + col0) * C2 + st * 16 + 8 * rsel;   // weight row = output channel, [C_out][C_in] with C_in == C2
                     wbh[buf][j] = *reinterpret_cast<const f16x8*>(reinterpret_cast<const _Float16*>(a.W2h) + wo);
-                    wbl[buf][j] = *reinterpret_cast<const f16x8*>(reinterpret_cast<const _Float16*>(a.W2l) + wo);
+                    if constexpr (WLO) wbl[buf][j] = *reinterpret_cast<const f16x8*>(reinterpret_cast<const _Float16*>(a.W2l) + wo);
                 }
             };
             loadW(0, 0);
@@ -688,7 +697,7 @@ void k_conv_split(ConvKArgs a0) {
 #pragma unroll
                 for (int j = 0; j < NB; ++j) {
                     acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, wbh[st & 1][j], acc2[j], 0, 0, 0);
-                    acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wbl[st & 1][j], acc2[j], 0, 0, 0);
+                    if constexpr (WLO) acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wbl[st & 1][j], acc2[j], 0, 0, 0);
                     acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wbh[st & 1][j], acc2[j], 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -800,24 +809,37 @@ void launch_split_planes(const float* w, bf16_t* hi, bf16_t* lo, size_t n, float
     hipLaunchKernelGGL(k_split_planes, dim3((unsigned)std::min<size_t>((n + 255) / 256, 8192)), dim3(256), 0, s, w, hi, lo, n, scale);
     Q3_HIP_CHECK(hipGetLastError());
 }
+// OR of the magnitude bits of a 16-bit plane: 0 <=> every element is +-0 (is a weight's lo plane empty?)
+__global__ void k_or_mag16(const bf16_t* p, size_t n, unsigned* out) {
+    unsigned m = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) m |= (unsigned)(p[i] & 0x7FFFu);
+    if (m) atomicOr(out, m);
+}
+void launch_or_mag16(const bf16_t* p, size_t n, unsigned* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_or_mag16, dim3((unsigned)std::min<size_t>((n + 255) / 256, 1024)), dim3(256), 0, s, p, n, out);
+    Q3_HIP_CHECK(hipGetLastError());
+}
 void launch_absmax(const float* w, size_t n, unsigned* out, hipStream_t s) {
     hipLaunchKernelGGL(k_absmax, dim3((unsigned)std::min<size_t>((n + 255) / 256, 1024)), dim3(256), 0, s, w, n, out);
     Q3_HIP_CHECK(hipGetLastError());
 }
 
+// every k_conv_split launch: the WLO = false twin when the launch's weight planes `lo` are all zero (ConvKArgs::wlo == 0)
+#define Q3_CS(GRID, S, A, ...) do { if ((A).wlo) hipLaunchKernelGGL((k_conv_split<__VA_ARGS__, true>), GRID, dim3(256), 0, S, A); \
+                                     else hipLaunchKernelGGL((k_conv_split<__VA_ARGS__, false>), GRID, dim3(256), 0, S, A); } while (0)
 template <int MB, int NB, int WM, int WN, bool APL = false>
 static void launch_split_pa(const ConvKArgs& a, dim3 grid, int extra, hipStream_t s) {
     constexpr int P0 = WM * MB;
     if constexpr (MB == 2 && NB == 3) {   // the decoder's 7-tap convs on 256 x 96 tiles
         if (a.peel_taps && !a.transposed && a.taps >= 3 && extra >= 1) {
-            if (extra == 1) hipLaunchKernelGGL((k_conv_split<MB, NB, WM, WN, P0 + 1, 32, 2, false, true, APL>), grid, dim3(256), 0, s, a);
-            else hipLaunchKernelGGL((k_conv_split<MB, NB, WM, WN, P0 + 2, 32, 2, false, true, APL>), grid, dim3(256), 0, s, a);
+            if (extra == 1) Q3_CS(grid, s, a, MB, NB, WM, WN, P0 + 1, 32, 2, false, true, APL);
+            else Q3_CS(grid, s, a, MB, NB, WM, WN, P0 + 2, 32, 2, false, true, APL);
             return;
         }
     }
-    if (extra == 0) hipLaunchKernelGGL((k_conv_split<MB, NB, WM, WN, P0, 32, 2, false, false, APL>), grid, dim3(256), 0, s, a);
-    else if (extra == 1) hipLaunchKernelGGL((k_conv_split<MB, NB, WM, WN, P0 + 1, 32, 2, false, false, APL>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((k_conv_split<MB, NB, WM, WN, P0 + 2, 32, 2, false, false, APL>), grid, dim3(256), 0, s, a);
+    if (extra == 0) Q3_CS(grid, s, a, MB, NB, WM, WN, P0, 32, 2, false, false, APL);
+    else if (extra == 1) Q3_CS(grid, s, a, MB, NB, WM, WN, P0 + 1, 32, 2, false, false, APL);
+    else Q3_CS(grid, s, a, MB, NB, WM, WN, P0 + 2, 32, 2, false, false, APL);
 }
 // (hi, lo)-plane inputs exist for the tile shapes the decoder's convs use (96-multiples); anything else reads fp32
 template <int MB, int NB, int WM, int WN>
@@ -864,6 +886,8 @@ void launch_conv(const ConvArgs& c, hipStream_t s) {
     a.res = c.res; a.res_scale = c.res_scale; a.mul = c.mul; a.act = c.act; a.clamp = c.clamp;
     a.out2 = c.out2; a.s2_alpha = c.snake_alpha; a.s2_beta = c.snake_beta; a.s2_pre = c.snake_pre; a.s1_pre = nullptr;
     a.Wh = c.Wh; a.Wl = c.Wl;
+    static const bool force_wlo = getenv("Q3TTS_CONV_3PRODUCT") != nullptr;   // A/B knob: always the three-product kernels
+    a.wlo = (c.w_lo_zero && (c.W2h == nullptr || c.w2_lo_zero) && !force_wlo) ? 0 : 1;
     a.acc_scale = 1.0f;
     a.ksplit = 0; a.slab = nullptr; a.batch_tiles = 0;
     static const bool no_xcd_map = getenv("Q3TTS_CONV_NO_XCD_MAP") != nullptr;   // A/B switch
@@ -909,7 +933,7 @@ void launch_conv(const ConvArgs& c, hipStream_t s) {
         const int extra = (halo + 31) / 32, tiles = (rows + 255) / 256;
         if (nb > 1) a.batch_tiles = tiles;
         const dim3 g((unsigned)(tiles * nb), 1, 1);
-#define Q3_FUSED(PA_, PEEL_, APL_) hipLaunchKernelGGL((k_conv_split<2, 3, 4, 1, PA_, 32, 2, true, PEEL_, APL_>), g, dim3(256), 0, s, a)
+#define Q3_FUSED(PA_, PEEL_, APL_) Q3_CS(g, s, a, 2, 3, 4, 1, PA_, 32, 2, true, PEEL_, APL_)
         const bool peel = a.peel_taps && c.taps >= 3, wide = extra > 1;
         if (a.in_planes) { if (peel) { if (wide) Q3_FUSED(10, true, true); else Q3_FUSED(9, true, true); } else { if (wide) Q3_FUSED(10, false, true); else Q3_FUSED(9, false, true); } }
         else { if (peel) { if (wide) Q3_FUSED(10, true, false); else Q3_FUSED(9, true, false); } else { if (wide) Q3_FUSED(10, false, false); else Q3_FUSED(9, false, false); } }
@@ -940,8 +964,8 @@ void launch_conv(const ConvArgs& c, hipStream_t s) {
             }
             if (ks > 1) {
                 a.ksplit = ks; a.slab = c.slab;
-                if (a.in_planes) hipLaunchKernelGGL((k_conv_split<2, 1, 1, 4, 2, 128, 1, false, false, true>), dim3(g.x, g.y, ks), dim3(256), 0, s, a);
-                else hipLaunchKernelGGL((k_conv_split<2, 1, 1, 4, 2, 128, 1>), dim3(g.x, g.y, ks), dim3(256), 0, s, a);
+                if (a.in_planes) Q3_CS(dim3(g.x, g.y, ks), s, a, 2, 1, 1, 4, 2, 128, 1, false, false, true);
+                else Q3_CS(dim3(g.x, g.y, ks), s, a, 2, 1, 1, 4, 2, 128, 1, false, false, false);
                 const size_t n4 = (size_t)c.T_out * c.C_out / 4;
                 hipLaunchKernelGGL(k_conv_finish, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, a);
                 Q3_HIP_CHECK(hipGetLastError());
@@ -949,13 +973,13 @@ void launch_conv(const ConvArgs& c, hipStream_t s) {
             }
             if (c.C_in % 128 == 0) {
                 if (a.in_planes) {
-                    if (extra == 0) hipLaunchKernelGGL((k_conv_split<2, 1, 1, 4, 2, 128, 1, false, false, true>), g, dim3(256), 0, s, a);
-                    else if (extra == 1) hipLaunchKernelGGL((k_conv_split<2, 1, 1, 4, 3, 128, 1, false, false, true>), g, dim3(256), 0, s, a);
-                    else hipLaunchKernelGGL((k_conv_split<2, 1, 1, 4, 4, 128, 1, false, false, true>), g, dim3(256), 0, s, a);
+                    if (extra == 0) Q3_CS(g, s, a, 2, 1, 1, 4, 2, 128, 1, false, false, true);
+                    else if (extra == 1) Q3_CS(g, s, a, 2, 1, 1, 4, 3, 128, 1, false, false, true);
+                    else Q3_CS(g, s, a, 2, 1, 1, 4, 4, 128, 1, false, false, true);
                 }
-                else if (extra == 0) hipLaunchKernelGGL((k_conv_split<2, 1, 1, 4, 2, 128, 1>), g, dim3(256), 0, s, a);
-                else if (extra == 1) hipLaunchKernelGGL((k_conv_split<2, 1, 1, 4, 3, 128, 1>), g, dim3(256), 0, s, a);
-                else hipLaunchKernelGGL((k_conv_split<2, 1, 1, 4, 4, 128, 1>), g, dim3(256), 0, s, a);
+                else if (extra == 0) Q3_CS(g, s, a, 2, 1, 1, 4, 2, 128, 1, false, false, false);
+                else if (extra == 1) Q3_CS(g, s, a, 2, 1, 1, 4, 3, 128, 1, false, false, false);
+                else Q3_CS(g, s, a, 2, 1, 1, 4, 4, 128, 1, false, false, false);
             } else launch_split_in<2, 1, 1, 4>(a, g, extra, s);
         }
         else if (!deep || n_big < 1024) {

@@ -137,6 +137,7 @@ struct GemmArgs {
     bf16_t* oh = nullptr; bf16_t* ol = nullptr; int ldp = 0; // optional plane outputs (input of the next GEMM)
     int M = 0, N = 0, K = 0, epi = EPI_STORE;
     int slab_rows = 0;   // EPI_SLAB / EPI_SLAB2: rows per slab (0 = M); launch_gemm2 sets it when it cuts M into 128-row blocks
+    bool nt = false;     // non-temporal weight loads (weights this step reads once: the talker's)
 };
 void launch_gemm2(const GemmArgs& a, int ksplit, int nw, hipStream_t s); // EPI_SLAB: out = slabs [ksplit][M][ldo]
 void launch_finish(float* x, int ldx, const float* slab, int nslab, size_t slab_stride, int ld_slab, const float* gamma, float eps,
@@ -203,6 +204,7 @@ struct ConvArgs { // out[t][co] = epi(bias[co] + sum_{tap,ci} W[tap][co][ci] * i
     const float* W = nullptr;  // [taps][C_out][C_in] fp32
     const bf16_t* Wh = nullptr; const bf16_t* Wl = nullptr; // optional (hi, lo) fp16 planes of W * 2^k: selects the split-precision MFMA kernel
     float w_scale_inv = 1.0f;                                  // 2^-k
+    bool w_lo_zero = false, w2_lo_zero = false;                // the lo plane of W (W2) is identically zero: two matrix-core products instead of three, exact
     const float* bias = nullptr;
     int taps = 1, dil = 1;
     int transposed = 0, stride = 1, left = 0; // transposed: out index jo = m*stride + phase - left
@@ -228,6 +230,7 @@ void launch_conv(const ConvArgs& a, hipStream_t s);
 void launch_split_planes(const float* w, bf16_t* hi, bf16_t* lo, size_t n, float scale, hipStream_t s);
 void launch_snake_pre(const float* alpha, const float* beta, float* pre /* [2][C] */, int C, hipStream_t s);
 void launch_absmax(const float* w, size_t n, unsigned* out, hipStream_t s);
+void launch_or_mag16(const bf16_t* p, size_t n, unsigned* out /* |= magnitude bits */, hipStream_t s);
 void launch_repack_conv(const float* w, float* out, int cin, int cout, int k, int transposed, hipStream_t s);
 void launch_code_embed_mean(const float* table, const int32_t* codes, int F, int G, int codebook, int C, float* out, hipStream_t s,
                             int n_utt = 1, size_t codes_stride = 0, const int* perm = nullptr);

@@ -566,7 +566,8 @@ __global__ __launch_bounds__(256) void k_attn(const int* ppage_table, const int*
 
     auto cache_off = [&](int t) -> size_t {
         const int q = (t >> pshift) - pbase;
-        const int page = q <= 0 ? pg[0] : (q == 1 ? pg[1] : (q == 2 ? pg[2] : pg[3]));
+        // IDENT: the page id is arithmetic, so a split may span any number of pages (one split over the whole context at large batch)
+        const int page = IDENT ? slot * a.pages_per_slot + (t >> pshift) : (q <= 0 ? pg[0] : (q == 1 ? pg[1] : (q == 2 ? pg[2] : pg[3])));
         return ((((size_t)page * a.n_layers + a.layer) * a.nkv + kvh) * page_tokens + (t & (page_tokens - 1))) * D;
     };
 
@@ -971,6 +972,7 @@ void launch_attn(const AttnArgs& a, hipStream_t s) {
     if (a.n_splits < 1 || (a.n_splits > 1 && (a.po == nullptr || a.window > 0))) throw Error("attn: split mode needs partial buffers and no window");
     if ((size_t)a.n_new * a.n_splits > 65535) throw Error("attn: grid too large");
     if (a.n_splits > 1 && (a.chunk >> a.page_shift) + 1 > 4) throw Error("attn: a split may touch at most 4 KV pages");
+    if (a.n_splits == 1 && !a.identity_pages && a.pages_per_slot > 4 && a.window == 0) throw Error("attn: one split over more than 4 table-mapped KV pages");
     const bool tiny_ctx0 = a.n_splits == 1 && a.window == 0 && (a.pages_per_slot << a.page_shift) <= 32;
     static const bool no_tiny = getenv("Q3TTS_NO_ATTN_TINY") != nullptr;   // A/B switch
     if (!no_tiny && a.d == 128 && tiny_ctx0 && a.identity_pages && a.pages_per_slot == 1 && a.n_new >= 1 && a.n_new <= 2 && a.slot_map == nullptr &&

@@ -448,7 +448,7 @@ bool Engine::run_layers(const DecStack& W, float* x, int ldx, int nb, int n_new,
         const DecLayerW& w = W.layers[l];
         if (mfma) {
             GemmArgs g; // split-K slabs; the attention prologue sums them
-            g.W = w.qkv; g.xh = pl0h; g.xl = pl0l; g.ldx = ldp; g.out = qkv_slab_d; g.ldo = QKV; g.M = M; g.N = QKV; g.K = W.H; g.epi = EPI_SLAB;
+            g.W = w.qkv; g.xh = pl0h; g.xl = pl0l; g.ldx = ldp; g.out = qkv_slab_d; g.ldo = QKV; g.M = M; g.N = QKV; g.K = W.H; g.epi = EPI_SLAB; g.nt = W.nt;
             launch_gemm2(g, ks_q, 4, stream);
         } else {
             GemvArgs g;
@@ -486,9 +486,16 @@ bool Engine::run_layers(const DecStack& W, float* x, int ldx, int nb, int n_new,
         a.slot_offset = slot_offset; a.slot_map = slot_map; a.nb = nb; a.n_new = n_new; a.nq = W.nq; a.nkv = W.nkv; a.d = W.d;
         a.scale = 1.0f / sqrtf((float)W.d); a.window = 0; a.new_from_raw = 1;
         a.n_splits = W.n_splits; a.chunk = W.chunk; a.po = W.po; a.pm = W.pm; a.pl = W.pl;
-        const bool direct_planes = mfma && W.n_splits == 1;     // one split: the attention kernel normalises and writes the planes itself
+        // Split-T exists to fill the chip at small batch.  With >= 256 (row, kv head) workgroups already and a context of a few hundred
+        // tokens, one split walks the whole context (page ids are arithmetic with a fixed run of pages per slot) and writes the planes
+        // itself: no partials, no combine launch (28 launches per b=64 step).
+        static const bool keep_splits = getenv("Q3TTS_ATTN_KEEP_SPLITS") != nullptr;   // A/B knob
+        if (mfma && W.n_splits > 1 && W.identity_pages && !keep_splits && (size_t)nb * W.nkv >= 256 && (W.pages_per_slot << W.page_shift) <= 512) {
+            a.n_splits = 1; a.chunk = 1 << 30;
+        }
+        const bool direct_planes = mfma && a.n_splits == 1;     // one split: the attention kernel normalises and writes the planes itself
         if (direct_planes) { a.out = nullptr; a.po = nullptr; a.pm = nullptr; a.pl = nullptr; a.oh = pl1h; a.ol = pl1l; a.ldp = ldp; }
-        const bool direct_rows = !mfma && W.n_splits == 1;      // likewise for the GEMV family: normalised fp32 rows, nothing to combine
+        const bool direct_rows = !mfma && a.n_splits == 1;      // likewise for the GEMV family: normalised fp32 rows, nothing to combine
         if (direct_rows) { a.po = nullptr; a.pm = nullptr; a.pl = nullptr; }
         launch_attn(a, stream);
         if (mfma) {
@@ -498,17 +505,17 @@ bool Engine::run_layers(const DecStack& W, float* x, int ldx, int nb, int n_new,
             }
             const int ks_o = pick_ksplit(AO), ks_d = pick_ksplit(W.ffn);
             GemmArgs o;
-            o.W = w.o; o.xh = pl1h; o.xl = pl1l; o.ldx = ldp; o.out = slab_d; o.ldo = W.H; o.M = M; o.N = W.H; o.K = AO; o.epi = EPI_SLAB;
+            o.W = w.o; o.xh = pl1h; o.xl = pl1l; o.ldx = ldp; o.out = slab_d; o.ldo = W.H; o.M = M; o.N = W.H; o.K = AO; o.epi = EPI_SLAB; o.nt = W.nt;
             launch_gemm2(o, ks_o, 4, stream);
             // x += sum(slabs); planes0 = RMSNorm(post_norm)(x)
             launch_finish(x, ldx, slab_d, ks_o, (size_t)M * W.H, W.H, w.post_norm, W.eps, M, W.H, pl0h, pl0l, ldp, nullptr, 0, stream);
             GemmArgs f; // gate and up as split-K slab pairs, SwiGLU applied by the finish kernel
             f.W = w.gate; f.W2 = w.up; f.xh = pl0h; f.xl = pl0l; f.ldx = ldp; f.out = gu_slab_d; f.out2 = gu_slab_d + (size_t)4 * rows_max * W.ffn; f.ldo = W.ffn;
-            f.M = M; f.N = W.ffn; f.K = W.H; f.epi = EPI_SLAB2;
+            f.M = M; f.N = W.ffn; f.K = W.H; f.epi = EPI_SLAB2; f.nt = W.nt;
             launch_gemm2(f, ks_q, 4, stream);
             launch_finish_swiglu(gu_slab_d, gu_slab_d + (size_t)4 * rows_max * W.ffn, ks_q, (size_t)M * W.ffn, M, W.ffn, pl1h, pl1l, ldp, stream);
             GemmArgs d;
-            d.W = w.down; d.xh = pl1h; d.xl = pl1l; d.ldx = ldp; d.out = slab_d; d.ldo = W.H; d.M = M; d.N = W.H; d.K = W.ffn; d.epi = EPI_SLAB;
+            d.W = w.down; d.xh = pl1h; d.xl = pl1l; d.ldx = ldp; d.out = slab_d; d.ldo = W.H; d.M = M; d.N = W.H; d.K = W.ffn; d.epi = EPI_SLAB; d.nt = W.nt;
             launch_gemm2(d, ks_d, 4, stream);
             // x += sum(slabs); planes0 = RMSNorm(next layer's input norm | the stack's final norm)(x)
             const bool last = l + 1 == W.L;
@@ -550,7 +557,7 @@ int Engine::head_proj(const bf16_t* Wm, const float* x, int ldx, const float* ga
         }
         GemmArgs g;
         g.W = Wm; g.xh = pl0h + (size_t)plane_row0 * ldp; g.xl = pl0l + (size_t)plane_row0 * ldp; g.ldx = ldp * plane_row_stride;
-        g.out = out; g.ldo = ldo; g.M = M; g.N = N; g.K = K; g.epi = EPI_STORE;
+        g.out = out; g.ldo = ldo; g.M = M; g.N = N; g.K = K; g.epi = EPI_STORE; g.nt = nt;
         // a head of N columns is N / 64 workgroups walking all of K (32 for the predictor's 2048 columns: 14.8 us per launch at 64 rows);
         // with the consumer summing 4 K slices it is 4x the workgroups on a quarter of the bytes each
         if (slab_out != nullptr && M <= 128 && (K == 512 || K == 1024) && ldo % 4 == 0 && !getenv("Q3TTS_NO_HEAD_SLABS")) {

@@ -140,6 +140,7 @@ public:
     // ---- codec decoder (q3_codec.cpp) ----
     CodecW* codec = nullptr;
     void codec_finalize();
+    void codec_plane_stats(int* two_product, int* three_product) const;   // weight tensors on the 2-product (lo plane empty) / 3-product split path
     // returns the sample count; h_in: this utterance's rows from codec_pre_batch (h_stage 1: after the pre-transformer, 2: after the upsampling stages too)
     int64_t codec_run(const int32_t* codes_dev, int F, float** pcm_dev, int lane = 0, const float* h_in = nullptr, int h_stage = 1, int nbatch = 1, size_t h_ustride = 0);
     void codec_async_submit_group(const float* h_group, size_t h_ustride, int Fg, int g, const int* nf, float* const* user_pcm, int64_t cap, int64_t* const* len_out);

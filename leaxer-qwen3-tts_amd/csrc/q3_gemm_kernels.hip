@@ -222,7 +222,7 @@ void launch_gemm2(const GemmArgs& a0, int ksplit, int nw, hipStream_t s) {
 #define G3_LD (G3_CH + 16)
 #define G3_LDE 68
 
-template <int MTILES, int EPI, int NCH, int LA>
+template <int MTILES, int EPI, int NCH, int LA, bool NT>
 __global__ __launch_bounds__(256) void k_gemm3(const bf16_t* pW, const bf16_t* pW2, const bf16_t* pxh, const bf16_t* pxl, int pldx, int pM, int pN, int pK,
                                                 GemmArgs a) {   // leading scalars: kernarg-preloaded
     static_assert(EPI == EPI_SLAB || EPI == EPI_SLAB2, "k_gemm3 writes split-K slabs");
@@ -250,8 +250,15 @@ __global__ __launch_bounds__(256) void k_gemm3(const bf16_t* pW, const bf16_t* p
     for (int c = 0; c < NCH; ++c)
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
-            b[c][st] = *reinterpret_cast<const bf16x8*>(wp + c * G3_CH + st * 32);
-            if (DUAL) b2[DUAL ? c : 0][st] = *reinterpret_cast<const bf16x8*>(wp2 + c * G3_CH + st * 32);
+            // NT: weights one launch reads once per step (the talker's 887 MB) leave no footprint in L2 / the Infinity Cache, so the
+            // predictor's 161 MB, re-read 15 times per frame, stay resident there (MI355X guide, nt-weights)
+            if (NT) {
+                b[c][st] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp + c * G3_CH + st * 32));
+                if (DUAL) b2[DUAL ? c : 0][st] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp2 + c * G3_CH + st * 32));
+            } else {
+                b[c][st] = *reinterpret_cast<const bf16x8*>(wp + c * G3_CH + st * 32);
+                if (DUAL) b2[DUAL ? c : 0][st] = *reinterpret_cast<const bf16x8*>(wp2 + c * G3_CH + st * 32);
+            }
         }
     // 2. activation chunks: 8 threads per row (16 B each), 32 rows per pass; rows past M repeat row M - 1 (their products are never stored)
     const int srow = tid >> 3, scol = (tid & 7) * 8;
@@ -343,7 +350,7 @@ __global__ __launch_bounds__(256) void k_gemm3(const bf16_t* pW, const bf16_t* p
     }
 }
 
-template <int MTILES, int EPI>
+template <int MTILES, int EPI, bool NT>
 static void gemm3_go(const GemmArgs& a, int ksplit, hipStream_t s) {
     const dim3 grid((a.N + 63) / 64, ksplit), block(256);
     const int nch = a.K / ksplit / G3_CH;
@@ -351,9 +358,9 @@ static void gemm3_go(const GemmArgs& a, int ksplit, hipStream_t s) {
     // activation chunks two ahead (default) or all four at once (Q3TTS_GEMM3_LA=4, the A/B knob): issuing 24-32 loads per lane before the
     // first ds_write keeps the wave in its issue queue for ~2.5 us (the CU takes ~50 GB/s); two ahead measured 5.49 vs 5.63 ms per b=64 step
     static const bool la2 = !(getenv("Q3TTS_GEMM3_LA") && atoi(getenv("Q3TTS_GEMM3_LA")) == 4);
-    if (nch == 4 && la2) { hipLaunchKernelGGL((k_gemm3<MTILES, EPI, 4, 2>), grid, block, 0, s, a.W, a.W2, a.xh, a.xl, a.ldx, a.M, a.N, a.K, a); return; }
-    if (nch == 2) hipLaunchKernelGGL((k_gemm3<MTILES, EPI, 2, 2>), grid, block, 0, s, a.W, a.W2, a.xh, a.xl, a.ldx, a.M, a.N, a.K, a);
-    else hipLaunchKernelGGL((k_gemm3<MTILES, EPI, 4, LA4>), grid, block, 0, s, a.W, a.W2, a.xh, a.xl, a.ldx, a.M, a.N, a.K, a);
+    if (nch == 4 && la2) { hipLaunchKernelGGL((k_gemm3<MTILES, EPI, 4, 2, NT>), grid, block, 0, s, a.W, a.W2, a.xh, a.xl, a.ldx, a.M, a.N, a.K, a); return; }
+    if (nch == 2) hipLaunchKernelGGL((k_gemm3<MTILES, EPI, 2, 2, NT>), grid, block, 0, s, a.W, a.W2, a.xh, a.xl, a.ldx, a.M, a.N, a.K, a);
+    else hipLaunchKernelGGL((k_gemm3<MTILES, EPI, 4, LA4, NT>), grid, block, 0, s, a.W, a.W2, a.xh, a.xl, a.ldx, a.M, a.N, a.K, a);
 }
 // the shapes k_gemm3 is built for: slab epilogues, K slices of 128 or 256, 16-byte aligned slab rows
 static bool gemm3_ok(const GemmArgs& a, int ksplit) {
@@ -364,7 +371,13 @@ static bool gemm3_ok(const GemmArgs& a, int ksplit) {
 }
 static void launch_gemm3(const GemmArgs& a, int ksplit, hipStream_t s) {
     const bool dual = a.epi == EPI_SLAB2;
-#define Q3_G3(MT) do { if (dual) gemm3_go<MT, EPI_SLAB2>(a, ksplit, s); else gemm3_go<MT, EPI_SLAB>(a, ksplit, s); } while (0)
+    // nt weight loads measured on the b=64 step (graph replay, same box): 4.961 ms with, 4.917 ms without — the slab GEMM's launches are
+    // bound by their latency chain, not by where the weights come from, and a replayed GEMM body loses what default-policy loads leave in
+    // L2 / MALL (MI355X guide, nt-weights: "replayed back to back 0-34 % longer").  Off by default; Q3TTS_GEMM_NT=1 is the A/B knob.
+    static const bool want_nt = getenv("Q3TTS_GEMM_NT") != nullptr;
+    const bool nt = a.nt && want_nt;
+#define Q3_G3(MT) do { if (dual) { if (nt) gemm3_go<MT, EPI_SLAB2, true>(a, ksplit, s); else gemm3_go<MT, EPI_SLAB2, false>(a, ksplit, s); } \
+                       else { if (nt) gemm3_go<MT, EPI_SLAB, true>(a, ksplit, s); else gemm3_go<MT, EPI_SLAB, false>(a, ksplit, s); } } while (0)
     if (a.M <= 16) Q3_G3(1); else if (a.M <= 32) Q3_G3(2); else if (a.M <= 64) Q3_G3(4); else Q3_G3(8);
 #undef Q3_G3
 }
