@@ -147,10 +147,10 @@ def stage_report(eng, cfg, toks, sp, B, F, ctr):
     }
 
 
-def roofline_record(cfg, B, F, step_ms, model):
+def roofline_record(cfg, B, F, step_ms, model, kv_bf16=False):
     abytes = algorithmic_step_bytes(cfg, B, 8 + F / 2.0)
     achieved = abytes / (step_ms * 1e-3) / 1e9 if step_ms > 0 else 0.0
-    traffic, note = measured_traffic(B, model)
+    traffic, note = measured_traffic(B, model) if not kv_bf16 else (None, "no PMC pass in bf16-KV mode")
     return {"bound": "hbm", "kernel": "decode step = one hipGraph replay per frame ("
             + ("q3::k_gemv1 (QKV / o_proj / gate-up / down / heads), k_cp_attn_oproj x75, k_attn x28, k_sample x16" if B <= 2 else
                ("q3::k_gemv16 family" if B <= 16 else "q3::k_gemm3 (+ split-K k_finish*) + k_attn + k_sample")) + ")",
@@ -158,9 +158,12 @@ def roofline_record(cfg, B, F, step_ms, model):
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_note": note,
             "algorithmic_bytes_per_launch": int(abytes), "launch_ms": round(step_ms, 4),
             "kv_bytes_bf16_equivalent": int(kv_step_bytes(cfg, B, 8 + F / 2.0, 2.0)),
-            "kv_bytes_actual": int(kv_step_bytes(cfg, B, 8 + F / 2.0, 4.0)),
-            "kv_note": "the KV cache is fp32 (bit-exact code parity with the fp32 oracle): the hardware moves kv_bytes_actual per step, "
-                       "the numerator counts the bf16-equivalent SURVEY.md 8d budgets, so frac under-reports the bytes moved"}
+            "kv_bytes_actual": int(kv_step_bytes(cfg, B, 8 + F / 2.0, 2.0 if kv_bf16 else 4.0)),
+            "kv_dtype": "bf16" if kv_bf16 else "fp32",
+            "kv_note": ("bf16 KV cache (Q3TTS_FLAG_KV_BF16): K / V rounded to bf16 on append, fp32 attention math; the oracle rounds at the same point "
+                        "and codes are bit-exact against it in this mode (tests/test_gpu_full.py, tests/test_gpu_b64.py)") if kv_bf16 else
+                       ("the default KV cache is fp32 (bit-exact code parity with the fp32 oracle): the hardware moves kv_bytes_actual per step, "
+                        "the numerator counts the bf16-equivalent SURVEY.md 8d budgets, so frac under-reports the bytes moved")}
 
 
 # ------------------------------------------------------------------------------------------------
@@ -281,9 +284,11 @@ def self_launch(args, argv):
     sys.exit(0)
 
 
-def run_workload(q3tts, cfg, local_rank, B, F, sp_kwargs, steps, warmup, rank, no_graph, dist=None, torch=None, world=1, backend=None):
+def run_workload(q3tts, cfg, local_rank, B, F, sp_kwargs, steps, warmup, rank, no_graph, dist=None, torch=None, world=1, backend=None, kv_bf16=False,
+                 warm_frames=0):
     """W untimed warmup steps, then exactly K timed steps bracketed by barrier + synchronize; returns the engine and the raw measurements."""
-    eng = q3tts.Engine(cfg, device=local_rank, max_batch=B, max_ctx=F + 32, flags=q3tts.FLAG_NO_GRAPH if no_graph else 0)
+    eng = q3tts.Engine(cfg, device=local_rank, max_batch=B, max_ctx=F + 32,
+                       flags=(q3tts.FLAG_NO_GRAPH if no_graph else 0) | (q3tts.FLAG_KV_BF16 if kv_bf16 else 0))
     eng.fill_synthetic(seed=0)
     sp = q3tts.Sampling(max_new_tokens=F, **sp_kwargs)
     rng = np.random.default_rng(1 + rank)
@@ -307,8 +312,14 @@ def run_workload(q3tts, cfg, local_rank, B, F, sp_kwargs, steps, warmup, rank, n
             gathered["pcm_samples"] = int(sum(alln))
         return int(nfr.sum()), sum(len(p) for p in pcm)
 
-    for i in range(warmup):
-        step(-1 - i)
+    if warm_frames and warm_frames < F:   # the long sub-records warm up (graph capture, lazy allocations, caches) on a short utterance of the same batch
+        sp_full, sp = sp, q3tts.Sampling(max_new_tokens=warm_frames, **sp_kwargs)
+        for i in range(warmup):
+            step(-1 - i)
+        sp = sp_full
+    else:
+        for i in range(warmup):
+            step(-1 - i)
     eng.counters(reset=True)
     barrier()
     t0 = time.perf_counter()
@@ -356,6 +367,8 @@ def main():
     ap.add_argument("--model", default="0.6b", choices=["0.6b", "1.7b"], help="model dims (the headline is 0.6b; 1.7b = configs[4] dims)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-b64", action="store_true", help="skip the configs[2] sub-record (64 utterances x 256 frames) of the default line")
+    ap.add_argument("--kv-bf16", action="store_true", help="talker KV cache in bf16 (Q3TTS_FLAG_KV_BF16) for the headline run; the default line's "
+                                                            "b64_f2048 sub-record is reported in BOTH modes either way")
     ap.add_argument("--no-long", action="store_true", help="skip the b64_f2048 sub-record (64 utterances x 2048 frames, ~45 s)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay (rocprofv3 kernel tracing "
                                                              "crashes inside hipGraphLaunch on this ROCm; same kernels either way)")
@@ -394,7 +407,7 @@ def main():
     sp_kwargs = dict(temperature=1.0, top_p=1.0, top_k=1) if args.greedy else dict(temperature=0.8, top_p=0.95, top_k=50)
     sampling_txt = "greedy top_k=1" if args.greedy else "sampled temp=0.8 top-k=50 top-p=0.95"
     eng, toks, sp, dt, frames, samples, ctr, gathered = run_workload(q3tts, cfg, local_rank, B, F, sp_kwargs, args.steps, args.warmup, rank,
-                                                                     args.no_graph, dist, torch, world, backend)
+                                                                     args.no_graph, dist, torch, world, backend, kv_bf16=args.kv_bf16)
 
     if dist is not None:
         v = torch.tensor([dt, float(frames), float(samples)], dtype=torch.float64, device="cuda")
@@ -444,7 +457,7 @@ def main():
             "decode_ms_per_frame_step": round(step_ms, 4),
             "codec_decode_ms_per_frame": round(ctr["codec_ms"] / max(ctr["codec_frames"], 1), 5),
             "first_2s_audio_latency_ms": first_audio,
-            "roofline": roofline_record(cfg, B, F, step_ms, args.model),
+            "roofline": roofline_record(cfg, B, F, step_ms, args.model, args.kv_bf16),
         }
         if dist is not None:
             out["multi_gpu"] = {"backend": "nccl (RCCL)", "world_size": world, "gathered_utterances": gathered["utterances"],
@@ -460,16 +473,18 @@ def main():
             #   b64       configs[2], 64 utterances in one batch x 256 frames, 5 timed steps
             #   b64_f2048 the same batch at the length configs[1] and the reference default (tts_onnx.h:65) state: 64 x 2048 frames, 1 timed step
             #   b8        8 utterances x 256 frames
-            def sub_record(B2, F2, steps2, warm2, with_stages):
-                e2, toks2, sp2, dt2, fr2, smp2, ctr2, _ = run_workload(q3tts, cfg, local_rank, B2, F2, sp_kwargs, steps2, warm2, rank, False)
+            def sub_record(B2, F2, steps2, warm2, with_stages, kvb=False):
+                e2, toks2, sp2, dt2, fr2, smp2, ctr2, _ = run_workload(q3tts, cfg, local_rank, B2, F2, sp_kwargs, steps2, warm2, rank, False, kv_bf16=kvb,
+                                                                       warm_frames=64 if F2 > 256 else 0)
                 sm2 = ctr2["decode_ms"] / max(ctr2["decode_steps"], 1)
                 rec = {"config": {"workload": f"{MODEL}, batch={B2}/GPU, 16-token prompt, {sampling_txt}, max-tokens={F2} (EOS suppressed), "
                                               "hipGraph decode loop, synthetic seeded weights", "batch_per_gpu": B2, "frames_per_utterance": F2},
                        "value": round(fr2 * FRAME_SECONDS / dt2, 3), "unit": "x real-time (audio s / wall s)", "steps": steps2, "warmup": warm2,
+                       "warmup_frames": 64 if F2 > 256 else F2,
                        "ms_per_step": round(dt2 / steps2 * 1e3, 3), "codec_frames_per_s": round(fr2 / dt2, 2),
                        "decode_ms_per_frame_step": round(sm2, 4),
                        "codec_decode_ms_per_frame": round(ctr2["codec_ms"] / max(ctr2["codec_frames"], 1), 5),
-                       "roofline": roofline_record(cfg, B2, F2, sm2, args.model)}
+                       "roofline": roofline_record(cfg, B2, F2, sm2, args.model, kvb)}
                 if with_stages:
                     try:
                         rec["stages"] = stage_report(e2, cfg, toks2, sp2, B2, F2, ctr2)
@@ -477,12 +492,15 @@ def main():
                         rec["stages"] = {"error": str(ex)}
                 e2.close()
                 return rec
-            for key, (B2, F2, steps2, warm2, with_stages) in (("b64", (64, 256, 5, 1, True)), ("b8", (8, 256, 5, 1, True)),
-                                                              ("b64_f2048", (64, 2048, 1, 1, False))):
-                if key == "b64_f2048" and args.no_long:
+            #   *_kv_bf16 the same workloads with the talker KV cache in bf16 (the mode SURVEY.md 8d's KV budget describes)
+            for key, (B2, F2, steps2, warm2, with_stages, kvb) in (("b64", (64, 256, 5, 1, True, False)), ("b8", (8, 256, 5, 1, True, False)),
+                                                                   ("b64_f2048", (64, 2048, 1, 1, False, False)),
+                                                                   ("b64_f2048_kv_bf16", (64, 2048, 1, 1, False, True)),
+                                                                   ("b1_f2048_kv_bf16", (1, 2048, 2, 1, False, True))):
+                if key.startswith("b64_f2048") and args.no_long:
                     continue
                 try:
-                    out[key] = sub_record(B2, F2, steps2, warm2, with_stages)
+                    out[key] = sub_record(B2, F2, steps2, warm2, with_stages, kvb)
                 except Exception as ex:
                     out[key] = {"error": str(ex)}
         if world == 1 and dist is None and not args.no_cpu_baseline:

@@ -60,6 +60,12 @@ typedef struct q3tts_engine q3tts_engine;
 /* flags for q3tts_create */
 #define Q3TTS_FLAG_NO_GRAPH 1u   /* launch the decode step eagerly instead of replaying a hipGraph */
 #define Q3TTS_FLAG_NO_FUSED_CP 2u /* b = 1: keep code-predictor attention and o_proj as separate launches (A/B testing) */
+#define Q3TTS_FLAG_KV_BF16 8u     /* talker KV cache in bf16: K / V rows rounded to bf16 (round-to-nearest-even) where they enter the cache, fp32 attention
+                                   * math on the rounded rows — half the cache bytes of the default fp32 cache (which mirrors the reference's fp32
+                                   * KVCache, src/tts_onnx.h:108-115).  The CPU oracle has the same switch; rounding being a discontinuity, two implementations
+                                   * agree to ~4e-3 on logits in this mode (2e-5 with fp32 caches), ids to the first sub-noise decision. */
+#define Q3TTS_FLAG_KV_ROUND_BF16 16u /* test aid: fp32 KV storage holding the bf16-ROUNDED rows — the arithmetic of Q3TTS_FLAG_KV_BF16 without its 16-bit storage;
+                                     * the two modes must agree bit for bit (tests/test_gpu_full.py), which pins the bf16 load / store / convert path */
 #define Q3TTS_FLAG_FP32_CODEC 4u  /* codec decoder on the exact-fp32 matrix-core path instead of the bf16 hi/lo split path */
 
 /* ---- lifecycle (replaces TTSEngine ctor / load_model, tts_onnx.cpp:84-232) ---- */

@@ -81,6 +81,8 @@ struct AttnArgs {
     int ld_out = 0;
     float* kcache = nullptr;    // [page][layer][kvh][page_tokens][d]
     float* vcache = nullptr;
+    bool kv_bf16 = false;       // the caches hold bf16 (2 bytes per element, same element layout); rounded on append, fp32 math
+    bool kv_round = false;      // fp32 caches holding bf16-ROUNDED values (Q3TTS_FLAG_KV_ROUND_BF16): what kv_bf16 computes, without the 16-bit storage
     const int* page_table = nullptr; // [slot][pages_per_slot]
     int pages_per_slot = 0, page_shift = 0;
     bool identity_pages = false;     // page_table[slot][i] == slot * pages_per_slot + i by construction (code predictor): kernels may skip the table

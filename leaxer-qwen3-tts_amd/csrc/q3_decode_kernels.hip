@@ -516,7 +516,14 @@ void launch_gemv(const GemvArgs& a0, hipStream_t s) {
 #define ATT_MAX_NEW 16
 #define ATT_MAX_GRP 4
 
-template <int D, int U, int G, bool IDENT = false>
+// KVB: the cache holds bf16 (Q3TTS_FLAG_KV_BF16).  K / V rows are rounded to bf16 (RNE) where they enter the cache AND where this step
+// uses them itself (the LDS copies of the new tokens), so every reader sees the same values — the oracle rounds at the same point
+// (oracle/q3_oracle.c dec_forward, kv_bf16) and codes stay bit-exact against it in this mode.  Math stays fp32.
+static __device__ __forceinline__ float bf16_round_f(float f) {
+    uint32_t u = __float_as_uint(f);
+    return __uint_as_float((u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u);
+}
+template <int D, int U, int G, bool IDENT = false, bool KVB = false>
 __global__ __launch_bounds__(256) void k_attn(const int* ppage_table, const int* ppos_dev, const float* pqkv, const float* pkcache, const float* pvcache,
                                                const float* pcos, const float* psin, int ppos_scalar, int pn_splits, AttnArgs a) {
     // leading scalars: preloaded into SGPRs, so the first memory round (page ids, position) leaves at once (see k_gemv1)
@@ -581,6 +588,25 @@ __global__ __launch_bounds__(256) void k_attn(const int* ppage_table, const int*
             t = t < cend ? t : cend - 1;
             t = t > 0 ? t : 0;
             const size_t off = cache_off(t) + sub * EPL;
+            if (KVB) {   // EPL bf16 values per lane: one 16-byte (EPL 8), 8-byte (4) or 2-byte (1) load per row
+                const uint16_t* kc16 = reinterpret_cast<const uint16_t*>(pkcache) + off;
+                const uint16_t* vc16 = reinterpret_cast<const uint16_t*>(pvcache) + off;
+                if (EPL == 8) {
+                    const u32x4 k4 = *reinterpret_cast<const u32x4*>(kc16), v4 = *reinterpret_cast<const u32x4*>(vc16);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        kr[u][2 * e] = bf_lo(k4[e]); kr[u][2 * e + 1] = bf_hi(k4[e]);
+                        vr[u][2 * e] = bf_lo(v4[e]); vr[u][2 * e + 1] = bf_hi(v4[e]);
+                    }
+                } else if (EPL == 4) {
+                    const uint2 k2 = *reinterpret_cast<const uint2*>(kc16), v2 = *reinterpret_cast<const uint2*>(vc16);
+                    kr[u][0] = bf_lo(k2.x); kr[u][1] = bf_hi(k2.x); kr[u][2] = bf_lo(k2.y); kr[u][3] = bf_hi(k2.y);
+                    vr[u][0] = bf_lo(v2.x); vr[u][1] = bf_hi(v2.x); vr[u][2] = bf_lo(v2.y); vr[u][3] = bf_hi(v2.y);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < EPL; ++e) { kr[u][e] = bf_lo(kc16[e]); vr[u][e] = bf_lo(vc16[e]); }
+                }
+            } else
             if (EPL >= 4) {
 #pragma unroll
                 for (int e = 0; e < EPL; e += 4) {
@@ -648,16 +674,24 @@ __global__ __launch_bounds__(256) void k_attn(const int* ppage_table, const int*
             x0 = r.n0 * (x0 * rr); x1 = r.n1 * (x1 * rr);
         }
         if (lane < HALF) {
-            const float y0 = x0 * r.cs + (-x1) * r.sn;
-            const float y1 = x1 * r.cs + x0 * r.sn;
+            float y0 = x0 * r.cs + (-x1) * r.sn;
+            float y1 = x1 * r.cs + x0 * r.sn;
             if (is_q) { q_s[v][lane] = y0; q_s[v][lane + HALF] = y1; }
             else {
+                float v0 = r.v0, v1 = r.v1;
+                if (KVB || a.kv_round) { y0 = bf16_round_f(y0); y1 = bf16_round_f(y1); v0 = bf16_round_f(v0); v1 = bf16_round_f(v1); }
                 knew[j][lane] = y0; knew[j][lane + HALF] = y1;
-                vnew[j][lane] = r.v0; vnew[j][lane + HALF] = r.v1;
+                vnew[j][lane] = v0; vnew[j][lane + HALF] = v1;
                 if (j == inew) { // this workgroup owns position `pos`
                     const size_t off = cache_off(p);
-                    a.kcache[off + lane] = y0; a.kcache[off + lane + HALF] = y1;
-                    a.vcache[off + lane] = r.v0; a.vcache[off + lane + HALF] = r.v1;
+                    if (KVB) {
+                        uint16_t* kc16 = reinterpret_cast<uint16_t*>(a.kcache); uint16_t* vc16 = reinterpret_cast<uint16_t*>(a.vcache);
+                        kc16[off + lane] = (uint16_t)(__float_as_uint(y0) >> 16); kc16[off + lane + HALF] = (uint16_t)(__float_as_uint(y1) >> 16);
+                        vc16[off + lane] = (uint16_t)(__float_as_uint(v0) >> 16); vc16[off + lane + HALF] = (uint16_t)(__float_as_uint(v1) >> 16);
+                    } else {
+                        a.kcache[off + lane] = y0; a.kcache[off + lane + HALF] = y1;
+                        a.vcache[off + lane] = v0; a.vcache[off + lane + HALF] = v1;
+                    }
                 }
             }
         }
@@ -992,10 +1026,21 @@ generic:;
 #define Q3_ATT_I(D, U, I) do { if (grp == 1) hipLaunchKernelGGL((k_attn<D, U, 1, I>), grid, dim3(256), 0, s, Q3_ATT_ARGS); \
         else if (grp == 2) hipLaunchKernelGGL((k_attn<D, U, 2, I>), grid, dim3(256), 0, s, Q3_ATT_ARGS); \
         else hipLaunchKernelGGL((k_attn<D, U, 4, I>), grid, dim3(256), 0, s, Q3_ATT_ARGS); } while (0)
+#define Q3_ATT_B(D, U, I) do { if (grp == 1) hipLaunchKernelGGL((k_attn<D, U, 1, I, true>), grid, dim3(256), 0, s, Q3_ATT_ARGS); \
+        else if (grp == 2) hipLaunchKernelGGL((k_attn<D, U, 2, I, true>), grid, dim3(256), 0, s, Q3_ATT_ARGS); \
+        else hipLaunchKernelGGL((k_attn<D, U, 4, I, true>), grid, dim3(256), 0, s, Q3_ATT_ARGS); } while (0)
 #define Q3_ATT(D, U) Q3_ATT_I(D, U, false)
     const bool tiny_ctx = a.n_splits == 1 && a.window == 0 && (a.pages_per_slot << a.page_shift) <= 32; // code predictor
     // identity_pages: the decode stacks with a fixed run of pages per slot (slot_map == null: slot ids are computed too)
-    if (a.d == 128 && tiny_ctx && a.identity_pages) Q3_ATT_I(128, 2, true);
+    if (a.kv_bf16) {   // the talker's cache under Q3TTS_FLAG_KV_BF16
+        if (!a.new_from_raw || tiny_ctx) throw Error("attn: the bf16 cache is the talker's (raw new tokens, paged context)");
+        if (a.d == 128 && a.identity_pages) Q3_ATT_B(128, 8, true);
+        else if (a.d == 128) Q3_ATT_B(128, 8, false);
+        else if (a.d == 64) Q3_ATT_B(64, 8, false);
+        else if (a.d == 16) Q3_ATT_B(16, 4, false);
+        else throw Error("attn: head_dim must be 16, 64 or 128");
+    }
+    else if (a.d == 128 && tiny_ctx && a.identity_pages) Q3_ATT_I(128, 2, true);
     else if (a.d == 128 && a.identity_pages) Q3_ATT_I(128, 8, true);
     else if (a.d == 128 && tiny_ctx) Q3_ATT(128, 2);
     else if (a.d == 128) Q3_ATT(128, 8);
@@ -1003,6 +1048,7 @@ generic:;
     else if (a.d == 16) Q3_ATT(16, 4);
     else throw Error("attn: head_dim must be 16, 64 or 128");
 #undef Q3_ATT_I
+#undef Q3_ATT_B
 #undef Q3_ATT
 }
 
@@ -1157,6 +1203,7 @@ __global__ __launch_bounds__(1024) void k_cp_attn_oproj(const bf16_t* pW, const 
     for (int j = 0; j < NEW; ++j)
 #pragma unroll
         for (int e = 0; e < EPL; ++e) { kn[j][e] = knew[head][j][sub * EPL + e]; vn[j][e] = vnew[head][j][sub * EPL + e]; }
+    KP_MARK(19);
 #pragma unroll
     for (int inew = 0; inew < NEW; ++inew) {
         float qr[EPL];
@@ -1216,6 +1263,7 @@ __global__ __launch_bounds__(1024) void k_cp_attn_oproj(const bf16_t* pW, const 
             *reinterpret_cast<float4*>(dst + 4) = make_float4(o[4] * il, o[5] * il, o[6] * il, o[7] * il);
         }
     }
+    KP_MARK(22);
     __syncthreads();
     KP_MARK(20);
     // ---- 3. o_proj: wave (row = wave & 3, K quarter = wave >> 2), residual add ----
@@ -1304,7 +1352,7 @@ static __device__ __forceinline__ float wave_scan_f(float v, int lane) {
 // scaling); the file is built with -ffp-contract=off.  Within 1 ulp of expf.
 static __device__ __forceinline__ float q3_expf(float x) {
     if (!(x > -103.0f)) return 0.0f;
-    x = x > 88.0f ? 88.0f : x;
+    x = x > 43.0f ? 43.0f : x;   // domain x <= 43 (callers pass x - max <= 0): the 2^(n+64) scale factor below holds n <= 63; same clamp as q3o_expf
     const float n = __builtin_rintf(x * 1.44269504088896341f);
     float r = __builtin_fmaf(n, -0.693359375f, x);
     r = __builtin_fmaf(n, 2.12194440e-4f, r);

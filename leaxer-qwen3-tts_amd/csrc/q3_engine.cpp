@@ -286,16 +286,18 @@ Engine::Engine(const q3tts_config& cfg, int device_, int max_batch, int max_ctx_
             n_pages = (size_t)kv.device_pages();
         }
         S.identity_pages = !pooled;
-        const size_t page_elems = (size_t)L * nkv * ptok * d;
-        S.kc = (float*)dmalloc(n_pages * page_elems * sizeof(float));
-        S.vc = (float*)dmalloc(n_pages * page_elems * sizeof(float));
+        S.kv_bf16 = talker_stack && (flags & Q3TTS_FLAG_KV_BF16);
+        S.kv_round = talker_stack && !S.kv_bf16 && (flags & Q3TTS_FLAG_KV_ROUND_BF16);
+        const size_t page_elems = (size_t)L * nkv * ptok * d, esz = S.kv_bf16 ? 2 : sizeof(float);
+        S.kc = (float*)dmalloc(n_pages * page_elems * esz);
+        S.vc = (float*)dmalloc(n_pages * page_elems * esz);
         std::vector<int> pt((size_t)B * S.pages_per_slot);
         for (size_t i = 0; i < pt.size(); ++i) pt[i] = talker_stack ? kv.table[i] : (int)i;
         S.page_table = (int*)dmalloc(pt.size() * sizeof(int));
         Q3_HIP_CHECK(hipMemcpy(S.page_table, pt.data(), pt.size() * sizeof(int), hipMemcpyHostToDevice));
         if (pooled) {   // the scratch page
-            Q3_HIP_CHECK(hipMemsetAsync(S.kc, 0, page_elems * sizeof(float), stream));
-            Q3_HIP_CHECK(hipMemsetAsync(S.vc, 0, page_elems * sizeof(float), stream));
+            Q3_HIP_CHECK(hipMemsetAsync(S.kc, 0, page_elems * esz, stream));
+            Q3_HIP_CHECK(hipMemsetAsync(S.vc, 0, page_elems * esz, stream));
         }
         // RoPE tables with the oracle's formula (fp32 libm): inv = 1/powf(theta, 2i/d); ang = pos*inv
         const int half = d / 2, npos = S.pages_per_slot * ptok;
@@ -478,7 +480,7 @@ bool Engine::run_layers(const DecStack& W, float* x, int ldx, int nb, int n_new,
             }
         }
         AttnArgs a;
-        a.qkv = qkv; a.ld_qkv = QKV; a.out = attn; a.ld_out = AO; a.kcache = W.kc; a.vcache = W.vc;
+        a.qkv = qkv; a.ld_qkv = QKV; a.out = attn; a.ld_out = AO; a.kcache = W.kc; a.vcache = W.vc; a.kv_bf16 = W.kv_bf16; a.kv_round = W.kv_round;
         if (mfma) { a.qkv = qkv_slab_d; a.qkv_nslab = ks_q; a.qkv_slab_stride = (size_t)M * QKV; }
         a.page_table = W.page_table; a.pages_per_slot = W.pages_per_slot; a.page_shift = W.page_shift; a.identity_pages = W.identity_pages;
         a.layer = l; a.n_layers = W.L; a.q_norm = w.q_norm; a.k_norm = w.k_norm; a.eps = W.eps;
@@ -1188,7 +1190,7 @@ void Engine::step_bytes(double* wbytes, double* kvbytes) {
         int nf = 0;
         slot_status(b, &nf, nullptr);
         const double Tt = st_h[b].prompt_len + nf;
-        kv += Tt * c.n_layers * 2.0 * c.n_kv_heads * c.head_dim * 4.0;       // fp32 cache
+        kv += Tt * c.n_layers * 2.0 * c.n_kv_heads * c.head_dim * (talker.kv_bf16 ? 2.0 : 4.0);   // fp32 cache, bf16 under Q3TTS_FLAG_KV_BF16
         double tp = 0;
         for (int j = 0; j < P; ++j) tp += j + 2;
         kv += tp * c.cp_layers * 2.0 * c.cp_kv_heads * c.cp_head_dim * 4.0;

@@ -41,7 +41,8 @@ struct DecStack {
     int H = 0, L = 0, nq = 0, nkv = 0, d = 0, ffn = 0;
     float eps = 0.f;
     std::vector<DecLayerW> layers;
-    float *kc = nullptr, *vc = nullptr; // paged cache
+    float *kc = nullptr, *vc = nullptr; // paged cache (fp32, or bf16 behind the same pointers when kv_bf16)
+    bool kv_bf16 = false, kv_round = false;
     int* page_table = nullptr;
     int pages_per_slot = 0, page_shift = 0;
     bool identity_pages = false;

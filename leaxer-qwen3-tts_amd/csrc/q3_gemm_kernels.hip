@@ -235,6 +235,7 @@ __global__ __launch_bounds__(256) void k_gemm3(const bf16_t* pW, const bf16_t* p
     const int n0 = (blockIdx.x * 4 + wave) * 16;
     const int K = pK, M = pM;
     const int kbeg = blockIdx.y * (NCH * G3_CH);
+    const int m0 = blockIdx.z * (MTILES * 16);   // row block (grid z): the rows may be cut over workgroups to halve each one's activation ingest
     // ring of two chunk buffers [plane][row][k]; the epilogue reuses the same bytes as a [row][64 + 4] fp32 tile (x 2 for the dual product)
     constexpr int XS_BYTES = 2 * 2 * ROWS * G3_LD * 2, EP_BYTES = (DUAL ? 2 : 1) * ROWS * G3_LDE * 4;
     __shared__ __attribute__((aligned(16))) unsigned char smem[XS_BYTES > EP_BYTES ? XS_BYTES : EP_BYTES];
@@ -266,7 +267,7 @@ __global__ __launch_bounds__(256) void k_gemm3(const bf16_t* pW, const bf16_t* p
     auto issue = [&](int c) {
 #pragma unroll
         for (int p = 0; p < PASSES; ++p) {
-            int row = srow + p * RPP;
+            int row = m0 + srow + p * RPP;
             row = row < M ? row : M - 1;
             sh[c][p] = *reinterpret_cast<const u32x4*>(pxh + (size_t)row * pldx + kbeg + c * G3_CH + scol);
             sl[c][p] = *reinterpret_cast<const u32x4*>(pxl + (size_t)row * pldx + kbeg + c * G3_CH + scol);
@@ -334,14 +335,14 @@ __global__ __launch_bounds__(256) void k_gemm3(const bf16_t* pW, const bf16_t* p
     const size_t sbase = (size_t)blockIdx.y * a.slab_rows;
 #pragma unroll
     for (int p = 0; p < ROWS / 16; ++p) {
-        const int m = erow + p * 16;
+        const int ml = erow + p * 16, m = m0 + ml;
         if (m < M && ng < a.N) {
-            const float4 v = *reinterpret_cast<const float4*>(&ep[0][m][ecol]);
+            const float4 v = *reinterpret_cast<const float4*>(&ep[0][ml][ecol]);
             float* dst = a.out + (sbase + m) * a.ldo + ng;
             if (ng + 3 < a.N) *reinterpret_cast<float4*>(dst) = v;
             else { dst[0] = v.x; if (ng + 1 < a.N) dst[1] = v.y; if (ng + 2 < a.N) dst[2] = v.z; }
             if (DUAL) {
-                const float4 v2 = *reinterpret_cast<const float4*>(&ep[DUAL ? 1 : 0][m][ecol]);
+                const float4 v2 = *reinterpret_cast<const float4*>(&ep[DUAL ? 1 : 0][ml][ecol]);
                 float* dst2 = a.out2 + (sbase + m) * a.ldo + ng;
                 if (ng + 3 < a.N) *reinterpret_cast<float4*>(dst2) = v2;
                 else { dst2[0] = v2.x; if (ng + 1 < a.N) dst2[1] = v2.y; if (ng + 2 < a.N) dst2[2] = v2.z; }
@@ -352,7 +353,7 @@ __global__ __launch_bounds__(256) void k_gemm3(const bf16_t* pW, const bf16_t* p
 
 template <int MTILES, int EPI, bool NT>
 static void gemm3_go(const GemmArgs& a, int ksplit, hipStream_t s) {
-    const dim3 grid((a.N + 63) / 64, ksplit), block(256);
+    const dim3 grid((a.N + 63) / 64, ksplit, (a.M + MTILES * 16 - 1) / (MTILES * 16)), block(256);
     const int nch = a.K / ksplit / G3_CH;
     constexpr int LA4 = MTILES <= 4 ? 4 : 2;
     // activation chunks two ahead (default) or all four at once (Q3TTS_GEMM3_LA=4, the A/B knob): issuing 24-32 loads per lane before the
@@ -378,6 +379,11 @@ static void launch_gemm3(const GemmArgs& a, int ksplit, hipStream_t s) {
     const bool nt = a.nt && want_nt;
 #define Q3_G3(MT) do { if (dual) { if (nt) gemm3_go<MT, EPI_SLAB2, true>(a, ksplit, s); else gemm3_go<MT, EPI_SLAB2, false>(a, ksplit, s); } \
                        else { if (nt) gemm3_go<MT, EPI_SLAB, true>(a, ksplit, s); else gemm3_go<MT, EPI_SLAB, false>(a, ksplit, s); } } while (0)
+    // rows over workgroups (grid z): a 64-row workgroup ingests 32 KB of weights + 64 KB of planes; two 32-row workgroups ingest 32 + 32 KB
+    // each (the second one's weights are L2 hits: same XCD under round-robin placement since N / 64 is a multiple of 8) and there are
+    // twice as many of them.  Q3TTS_GEMM_ROWSPLIT=0 keeps one workgroup per column tile and K slice (the A/B knob).
+    static const int rowsplit = getenv("Q3TTS_GEMM_ROWSPLIT") ? atoi(getenv("Q3TTS_GEMM_ROWSPLIT")) : 1;
+    if (rowsplit && a.M > 32) { if (a.M <= 64) Q3_G3(2); else Q3_G3(4); return; }
     if (a.M <= 16) Q3_G3(1); else if (a.M <= 32) Q3_G3(2); else if (a.M <= 64) Q3_G3(4); else Q3_G3(8);
 #undef Q3_G3
 }

@@ -70,6 +70,8 @@ class Sampling(C.Structure):
 FLAG_NO_GRAPH = 1
 FLAG_NO_FUSED_CP = 2
 FLAG_FP32_CODEC = 4
+FLAG_KV_ROUND_BF16 = 16   # test aid: fp32 KV storage of the bf16-rounded rows (must equal FLAG_KV_BF16 bit for bit)
+FLAG_KV_BF16 = 8   # talker KV cache in bf16 (rounded on append, fp32 math); the oracle has the same switch (Oracle(kv_bf16=True))
 
 # every symbol include/q3tts.h declares
 EXPORTS = [
@@ -211,6 +213,7 @@ class Engine:
         self.cfg = cfg
         self.max_batch = max_batch
         self.max_ctx = max_ctx
+        self.flags = flags
         self.h = self.L.q3tts_create_pooled(C.byref(cfg), device, max_batch, max_ctx, kv_pool_tokens, flags)
         if not self.h:
             raise RuntimeError("q3tts_create failed: " + self.L.q3tts_last_error(None).decode())

@@ -95,6 +95,7 @@ typedef struct {
     int window;   /* 0 = full causal */
     int qk_norm;  /* per-head q/k RMSNorm (talker, predictor) */
     int lscale;   /* LayerScale on both residual branches (codec pre-transformer) */
+    int kv_bf16;  /* K / V rows rounded to bf16 (RNE) as they enter the cache; attention runs in fp32 on the rounded rows (talker only) */
 } dec_dims;
 
 typedef struct { float *alpha, *beta; } snake_w;
@@ -112,6 +113,7 @@ struct q3o_model {
     float *text_embed, *fc1_w, *fc1_b, *fc2_w, *fc2_b;
     float *kc, *vc; /* [L][nkv][max_ctx][d] */
     int pos;        /* tokens in the talker KV cache */
+    int kv_bf16;    /* q3o_set_kv_bf16: talker K / V rows rounded to bf16 on append */
     /* predictor */
     layer_w* pl;
     float* p_norm;
@@ -419,6 +421,18 @@ int q3o_set_tensor(q3o_model* m, const char* name, const float* data, int64_t n)
 /* :3267-3450].  x: [M][H] rows at absolute positions pos0..pos0+M-1; K/V appended to kc/vc.   */
 /* ------------------------------------------------------------------------------------------ */
 
+/* bf16 KV-cache mode of the product (Q3TTS_FLAG_KV_BF16): the talker's K / V rows are rounded to bf16 (RNE) where they enter the cache,
+ * replacing the reference's fp32 std::vector KVCache (src/tts_onnx.h:108-115) by half the bytes; fp32 attention math on the rounded rows. */
+void q3o_set_kv_bf16(q3o_model* m, int on) { if (m) m->kv_bf16 = on ? 1 : 0; }
+
+static float bf16_round(float f) {   /* round-to-nearest-even to 8 significant bits (finite inputs), result still an fp32 */
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    u = (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
 static void rope_row(float* v, int d, int pos, float theta) {
     int half = d / 2;
     for (int i = 0; i < half; ++i) {
@@ -461,8 +475,13 @@ static void dec_forward(const dec_dims* D, const layer_w* Ls, float* kc, float* 
                 float* kh = k + ((size_t)m * nkv + hh) * d;
                 if (D->qk_norm) rmsnorm(kh, W->k_norm, d, D->eps, kh);
                 rope_row(kh, d, p, D->theta);
-                memcpy(kc + (((size_t)l * nkv + hh) * Tmax + p) * d, kh, d * sizeof(float));
-                memcpy(vc + (((size_t)l * nkv + hh) * Tmax + p) * d, v + ((size_t)m * nkv + hh) * d, d * sizeof(float));
+                float* kdst = kc + (((size_t)l * nkv + hh) * Tmax + p) * d;
+                float* vdst = vc + (((size_t)l * nkv + hh) * Tmax + p) * d;
+                memcpy(kdst, kh, d * sizeof(float));
+                memcpy(vdst, v + ((size_t)m * nkv + hh) * d, d * sizeof(float));
+                /* bf16 KV mode (the product's q3tts KV_BF16 flag rounds at the same point): every reader, this token's own step
+                 * included, sees the rounded rows */
+                if (D->kv_bf16) for (int e = 0; e < d; ++e) { kdst[e] = bf16_round(kdst[e]); vdst[e] = bf16_round(vdst[e]); }
             }
         }
 #pragma omp parallel for collapse(2) schedule(static)
@@ -501,15 +520,15 @@ static void dec_forward(const dec_dims* D, const layer_w* Ls, float* kc, float* 
 }
 
 static dec_dims talker_dims(const q3o_config* c) {
-    dec_dims D = { c->hidden, c->n_layers, c->n_heads, c->n_kv_heads, c->head_dim, c->ffn, c->rope_theta, c->rms_eps, 0, 1, 0 };
+    dec_dims D = { c->hidden, c->n_layers, c->n_heads, c->n_kv_heads, c->head_dim, c->ffn, c->rope_theta, c->rms_eps, 0, 1, 0, 0 };
     return D;
 }
 static dec_dims cp_dims(const q3o_config* c) {
-    dec_dims D = { cp_width(c), c->cp_layers, c->cp_heads, c->cp_kv_heads, c->cp_head_dim, c->cp_ffn, c->cp_rope_theta, c->cp_rms_eps, 0, 1, 0 };
+    dec_dims D = { cp_width(c), c->cp_layers, c->cp_heads, c->cp_kv_heads, c->cp_head_dim, c->cp_ffn, c->cp_rope_theta, c->cp_rms_eps, 0, 1, 0, 0 };
     return D;
 }
 static dec_dims cd_dims(const q3o_config* c) {
-    dec_dims D = { c->cd_hidden, c->cd_layers, c->cd_heads, c->cd_heads, c->cd_head_dim, c->cd_ffn, c->cd_rope_theta, c->cd_rms_eps, c->cd_window, 0, 1 };
+    dec_dims D = { c->cd_hidden, c->cd_layers, c->cd_heads, c->cd_heads, c->cd_head_dim, c->cd_ffn, c->cd_rope_theta, c->cd_rms_eps, c->cd_window, 0, 1, 0 };
     return D;
 }
 
@@ -559,6 +578,7 @@ int q3o_prefill(q3o_model* m, const float* embeds, int S, float* logits, float* 
     int H = c->hidden;
     if (S <= 0 || S > m->max_ctx) FAIL("prefill length %d out of range", S);
     dec_dims D = talker_dims(c);
+    D.kv_bf16 = m->kv_bf16;
     float* x = zalloc((size_t)S * H);
     memcpy(x, embeds, (size_t)S * H * sizeof(float));
     dec_forward(&D, m->tl, m->kc, m->vc, m->max_ctx, x, S, 0);
@@ -578,6 +598,7 @@ int q3o_decode(q3o_model* m, const float* embed, float* logits, float* last_hidd
     int H = c->hidden;
     if (m->pos >= m->max_ctx) FAIL("KV cache full (%d)", m->max_ctx);
     dec_dims D = talker_dims(c);
+    D.kv_bf16 = m->kv_bf16;
     float* x = zalloc(H);
     memcpy(x, embed, H * sizeof(float));
     dec_forward(&D, m->tl, m->kc, m->vc, m->max_ctx, x, 1, m->pos);
@@ -655,7 +676,9 @@ float q3o_rng_uniform(uint64_t seed, uint32_t stream, uint32_t frame, uint32_t g
  * libm's expf (the reference uses std::exp, tts_onnx.cpp:912). */
 float q3o_expf(float x) {
     if (!(x > -103.0f)) return 0.0f;                    /* underflows past the smallest subnormal; also -inf */
-    if (x > 88.0f) x = 88.0f;
+    /* domain: x <= 43 (every caller passes x - max <= 0).  The scale below is built as 2^(n+64) * 2^-64, whose exponent field holds
+     * n <= 63, i.e. x <= 43.6: larger arguments are clamped here (the result is then a finite lower bound, never inf / a sign flip) */
+    if (x > 43.0f) x = 43.0f;
     const float n = rintf(x * 1.44269504088896341f);
     float r = fmaf(n, -0.693359375f, x);
     r = fmaf(n, 2.12194440e-4f, r);
@@ -675,12 +698,18 @@ float q3o_expf(float x) {
     return (y * s1.f) * s2.f;
 }
 
+/* Diagnostic switch (tests/test_cpu_host.py): evaluate the sampler's softmax with libm's expf — what the reference's std::exp
+ * (tts_onnx.cpp:912) is on the host — instead of the fully specified q3o_expf the HIP sampler shares.  Off by default; process-global. */
+static int g_sampler_exp_libm = 0;
+void q3o_set_sampler_exp_libm(int on) { g_sampler_exp_libm = on ? 1 : 0; }
+
 /* :907-915 */
 void q3o_softmax(float* x, int n) {
     float mx = x[0];
     for (int i = 1; i < n; ++i) if (x[i] > mx) mx = x[i];
     float sum = 0.f;
-    for (int i = 0; i < n; ++i) { x[i] = q3o_expf(x[i] - mx); sum += x[i]; }
+    if (g_sampler_exp_libm) for (int i = 0; i < n; ++i) { x[i] = expf(x[i] - mx); sum += x[i]; }
+    else for (int i = 0; i < n; ++i) { x[i] = q3o_expf(x[i] - mx); sum += x[i]; }
     for (int i = 0; i < n; ++i) x[i] /= sum;
 }
 static void softmax_libm(float* x, int n) {

@@ -71,6 +71,10 @@ typedef struct q3o_sampling {
 typedef struct q3o_model q3o_model;
 
 q3o_model* q3o_create(const q3o_config* cfg, int max_ctx);
+/* talker K / V rows rounded to bf16 (round-to-nearest-even) on append, like the product under Q3TTS_FLAG_KV_BF16; off by default (fp32 cache) */
+void q3o_set_kv_bf16(q3o_model* m, int on);
+/* diagnostic: the sampler's softmax with libm expf (the reference's std::exp, tts_onnx.cpp:912) instead of q3o_expf; process-global, off by default */
+void q3o_set_sampler_exp_libm(int on);
 void q3o_destroy(q3o_model* m);
 const char* q3o_last_error(void);
 /* copies n floats; returns 0 ok, <0 unknown name / wrong element count */

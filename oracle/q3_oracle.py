@@ -307,6 +307,8 @@ def lib():
         L.q3o_tensor_numel.restype = C.c_int64
         L.q3o_tensor_numel.argtypes = [C.c_void_p, C.c_char_p]
         L.q3o_set_threads.argtypes = [C.c_int]
+        L.q3o_set_kv_bf16.argtypes = [C.c_void_p, C.c_int]
+        L.q3o_set_sampler_exp_libm.argtypes = [C.c_int]
         L.q3o_text_project.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.q3o_codec_embed.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.q3o_cp_embed.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
@@ -351,11 +353,13 @@ def _p(a):
 
 
 class Oracle:
-    def __init__(self, cfg, max_ctx=256, weights=None):
+    def __init__(self, cfg, max_ctx=256, weights=None, kv_bf16=False):
         self.L = lib()
         self.cfg = cfg
         self.max_ctx = max_ctx
         self.h = self.L.q3o_create(C.byref(cfg), max_ctx)
+        if kv_bf16:   # the product's Q3TTS_FLAG_KV_BF16: talker K / V rounded to bf16 on append
+            self.L.q3o_set_kv_bf16(self.h, 1)
         self.threads = default_threads(cfg)
         self.L.q3o_set_threads(self.threads)
         if weights is not None:

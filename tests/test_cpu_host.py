@@ -1,6 +1,7 @@
 """CPU-only tests: oracle host logic (sampler, prompt layout, generation loop), C-ABI surface.
 Expected values are derived by hand from the reference source (file:line cited inline)."""
 import ctypes
+import ctypes as C
 import os
 import re
 
@@ -183,6 +184,58 @@ def test_sampler_exp_is_within_one_ulp_and_fully_specified():
     assert (np.abs(got[normal] - ref[normal]) / ulp).max() < 1.0
     assert np.abs(got[~normal] - ref[~normal]).max() < 3e-45
     assert L.q3o_expf(0.0) == 1.0 and L.q3o_expf(-104.0) == 0.0 and L.q3o_expf(float("-inf")) == 0.0
+
+
+def test_sampler_exp_stays_finite_past_its_domain():
+    """The scale factor of q3o_expf holds exponents up to 2^63: arguments past 43 (never produced by the sampler, which passes
+    x - max <= 0) are clamped instead of overflowing the exponent field into inf or the sign bit (round-2 advisor finding)."""
+    L = qo.lib()
+    for x in (43.0, 44.0, 60.0, 88.0, 1000.0):
+        v = L.q3o_expf(x)
+        assert np.isfinite(v) and v > 0 and abs(v / np.exp(43.0) - 1.0) < 1e-6, (x, v)
+    assert abs(L.q3o_expf(42.5) / np.exp(42.5) - 1.0) < 1e-6
+
+
+SAMPLER_SETTINGS = [dict(temperature=0.8, top_p=0.95, top_k=50), dict(temperature=1.0, top_p=1.0, top_k=1), dict(temperature=0.0, top_p=1.0, top_k=0),
+                    dict(temperature=1.3, top_p=0.5, top_k=10), dict(temperature=0.7, top_p=0.9, top_k=0), dict(temperature=0.8, top_p=1.0, top_k=200),
+                    dict(temperature=0.9, top_p=0.9, top_k=64), dict(temperature=0.9, top_p=0.9, top_k=65), dict(temperature=1.0, top_p=0.8, top_k=2)]
+
+
+def test_shared_exp_vs_libm_exp_decisions():
+    """What sharing one fully specified exp with the HIP sampler changed relative to the reference's std::exp
+    (/root/reference/src/tts_onnx.cpp:907-915): q3o_sample with q3o_expf beside q3o_sample with libm's expf on 10^4 random logit rows under
+    each of the nine sampler settings of tests/test_gpu_decode.py.  The two exps agree to 1 ulp, so the decisions can only part where a
+    running probability sum sits within a few ulps of top_p or of u * total: the fraction is reported per setting and asserted < 1 %,
+    and every differing decision must be a boundary case — the shared-exp oracle's own decision margin there is < 1e-5."""
+    import q3_oracle as q
+    L = q.lib()
+    rng = np.random.default_rng(11)
+    rows = 10000
+    worst_frac, report = 0.0, []
+    try:
+        for params in SAMPLER_SETTINGS:
+            sp = q.Sampling(max_new_tokens=1, repetition_penalty=1.0, **params)
+            n = 2048
+            diff, worst_margin = 0, 0.0
+            for t in range(rows):
+                lg = (rng.standard_normal(n) * 2.0).astype(np.float32)
+                u = float(rng.random())
+                m = C.c_float(0)
+                L.q3o_set_sampler_exp_libm(0)
+                a = L.q3o_sample_margin(q._p(lg), n, C.byref(sp), u, C.byref(m))
+                L.q3o_set_sampler_exp_libm(1)
+                b = L.q3o_sample(q._p(lg), n, C.byref(sp), u)
+                if a != b:
+                    diff += 1
+                    worst_margin = max(worst_margin, float(m.value))
+            report.append((params, diff, worst_margin))
+            worst_frac = max(worst_frac, diff / rows)
+            assert worst_margin < 1e-5, (params, worst_margin)
+    finally:
+        L.q3o_set_sampler_exp_libm(0)
+    for params, diff, wm in report:
+        print("libm exp vs shared exp, %s: %d of %d decisions differ (largest shared-exp margin among them %.2g)" % (params, diff, rows, wm))
+    assert worst_frac < 0.01, report
 
 
 def test_sample_margin_reports_how_close_a_decision_was():

@@ -14,13 +14,17 @@ pytestmark = pytest.mark.gpu
 CHECK = (0, 16, 17, 31, 63)     # oracle cost: a spread of utterances, both sides of the 16/17-row kernel switch
 
 
-@pytest.fixture(scope="module")
-def wide():
+@pytest.fixture(scope="module", params=["fp32kv", "bf16kv"])
+def wide(request):
+    """64 slots at 0.6B dims; second round with the talker KV cache in bf16 (Q3TTS_FLAG_KV_BF16) and the oracle in the same mode."""
     import q3tts
     cfg = q3tts.default_config("0.6b")
-    eng = q3tts.Engine(cfg, device=0, max_batch=64, max_ctx=64)
+    bf = request.param == "bf16kv"
+    eng = q3tts.Engine(cfg, device=0, max_batch=64, max_ctx=64, flags=q3tts.FLAG_KV_BF16 if bf else 0)
     eng.fill_synthetic(seed=0)
-    orc = qo.Oracle(to_ocfg(cfg), max_ctx=48)
+    eng.margin_noise = 2e-2 if bf else 2e-4     # tests/test_gpu_full.py, bf16 KV note: what logit agreement this cache mode can honour
+    eng.logit_bound = 2e-2 if bf else 2e-4
+    orc = qo.Oracle(to_ocfg(cfg), max_ctx=48, kv_bf16=bf)
     for name, shape in eng.tensor_infos():
         if not name.startswith(("cd.", "spk.")):
             orc.set_tensor(name, eng.get_tensor(name, shape))
@@ -44,9 +48,12 @@ def test_batched_generation_full_size(wide, nb, sampled):
     assert all(int(n) == 8 for n in nfr)
     bad = []
     for u in [u for u in CHECK if u < nb] + [nb - 1]:
-        ref = orc.generate(orc.build_prompt(toks[u], 0), to_osampling(sp), seed=77, stream=u, cp_cached=True, ignore_eos=True)
-        if not np.array_equal(codes[u], ref):
-            bad.append((u, np.argwhere(codes[u] != ref)[:3].tolist()))
+        ref, mg = orc.generate_margins(orc.build_prompt(toks[u], 0), to_osampling(sp), seed=77, stream=u, cp_cached=True, ignore_eos=True)
+        if not np.array_equal(codes[u], ref):   # margin-aware verdict (tests/test_gpu_full.py check_free_running): one decision to explain
+            f, g = [int(v) for v in np.argwhere(codes[u] != ref)[0]]
+            print("utterance %d parts from the oracle at frame %d group %d, oracle decision margin %.3g" % (u, f, g, float(mg[f, 2 + g])))
+            if not (float(mg[f, 2 + g]) < eng.margin_noise and np.array_equal(codes[u][:f], ref[:f]) and np.array_equal(codes[u][f, :g], ref[f, :g])):
+                bad.append((u, f, g, float(mg[f, 2 + g])))
         assert np.isfinite(pcm[u]).all() and len(pcm[u]) == eng.codec_decode_len(8)
     assert not bad, bad
     # the batch is deterministic and every utterance independent of its neighbours: the first 24 of a 64-batch == the 24-batch
@@ -54,6 +61,28 @@ def test_batched_generation_full_size(wide, nb, sampled):
         _, codes64, _ = eng.synthesize_batch(toks, sp, lang=0, seed=77, ignore_eos=True)
         for u in range(24):
             assert np.array_equal(codes64[u], codes[u]), u
+
+
+def test_batched_greedy_32_frames_margin_aware(wide):
+    """64 utterances x 32 free-running greedy frames in one batch (the split-K slab GEMM path for every projection, 32 hipGraph replays):
+    a spread of utterances against their own single-utterance oracle runs.  Margin-aware: a divergence is a failure unless the oracle's
+    top-2 logit gap at that decision is below the logit-noise bound (then it is printed and everything before it must match)."""
+    import q3tts
+    eng, orc, toks = wide
+    F = 32
+    sp = q3tts.Sampling(max_new_tokens=F, temperature=1.0, top_p=1.0, top_k=1)
+    _, codes, nfr = eng.synthesize_batch(toks, sp, lang=0, seed=9, ignore_eos=True)
+    assert all(int(n) == F for n in nfr)
+    for u in (0, 17, 63):
+        ref, mg = orc.generate_margins(orc.build_prompt(toks[u], 0), to_osampling(sp), seed=9, stream=u, cp_cached=True, ignore_eos=True)
+        bad = np.argwhere(codes[u] != ref)
+        if bad.size == 0:
+            print("b=64 greedy, utterance %d: %d frames bit-exact, smallest top-2 margin %.3g" % (u, F, float(mg[:, 2:].min())))
+            continue
+        f, g = int(bad[0][0]), int(bad[0][1])
+        print("b=64 greedy, utterance %d: first divergence at frame %d group %d, oracle margin %.3g" % (u, f, g, float(mg[f, 2 + g])))
+        assert float(mg[f, 2 + g]) < eng.margin_noise, (u, f, g, float(mg[f, 2 + g]))
+        assert np.array_equal(codes[u][:f], ref[:f]) and np.array_equal(codes[u][f, :g], ref[f, :g])
 
 
 def test_teacher_forced_logits_64_rows_full_size(wide):
@@ -70,7 +99,9 @@ def test_teacher_forced_logits_64_rows_full_size(wide):
     for u in CHECK:
         po = orc.build_prompt(toks[u], 0)
         ref = orc.generate(po, to_osampling(sp), seed=5, stream=u, cp_cached=True, ignore_eos=True)
-        assert np.array_equal(codes[u], ref), u
+        if not np.array_equal(codes[u], ref):   # bf16 KV mode: the frame may already hold a sub-noise decision; teacher-force what the ENGINE emitted
+            assert eng.margin_noise > 1e-3, u
+            ref = codes[u]
         # teacher forcing: frame 0's embedding sum (tts_onnx.cpp:824-842) into the oracle's run_decode
         tro, _ = orc.trailing()
         orc.prefill(po)
@@ -81,8 +112,8 @@ def test_teacher_forced_logits_64_rows_full_size(wide):
         lo, ho = orc.decode(x)
         lg, lh = eng.slot_logits(u)
         worst = max(worst, float(np.abs(lg - lo).max()), float(np.abs(lh - ho).max()))
-    print("teacher-forced 64-row step: max |logit / hidden error| %.3g" % worst)
-    assert worst < 2e-4, worst
+    print("teacher-forced 64-row step: max |logit / hidden error| %.3g (bound %.0e)" % (worst, eng.logit_bound))
+    assert worst < eng.logit_bound, worst
 
 
 def test_gemm3_slabs_are_bit_identical_to_gemm2(wide):
@@ -97,7 +128,7 @@ def test_gemm3_slabs_are_bit_identical_to_gemm2(wide):
     lg3 = [eng.slot_logits(u) for u in (0, 17, 63)]
     os.environ["Q3TTS_GEMM2"] = "1"
     try:
-        e2 = q3tts.Engine(eng.cfg, device=0, max_batch=64, max_ctx=64)     # a fresh engine: its step graph is captured with the old kernel
+        e2 = q3tts.Engine(eng.cfg, device=0, max_batch=64, max_ctx=64, flags=eng.flags)     # a fresh engine: its step graph is captured with the old kernel
         e2.fill_synthetic(seed=0)
         _, codes2, _ = e2.synthesize_batch(toks, sp, seed=21, ignore_eos=True)
         lg2 = [e2.slot_logits(u) for u in (0, 17, 63)]

@@ -67,62 +67,154 @@ def test_greedy_generation_full_size(full):
     assert np.array_equal(codes, again)            # deterministic, slot-independent
 
 
-def test_free_running_160_frames_greedy_full_size(full):
-    """0.6B dims, 160 FREE-RUNNING greedy frames (configs[0] sampling: top_k = 1) = 2560 codec decisions on one utterance: ids bit-exact
-    vs the oracle (KV-cached predictor), with the talker context growing from 8 to 168 tokens — across the first 128-token attention
-    split of the fused step.  Reports what SURVEY.md section 7 asks for: the first divergence index (none expected) and the smallest
-    top-2 logit margins the run came across (how close parity came to flipping; the HIP logits sit within ~3e-5 of the oracle's).
+NOISE = 2e-4    # bound asserted on |HIP logit - oracle logit| by the teacher-forced tests (measured: 2-3e-5)
+
+
+def check_free_running(eng, orc, sp, ids, seed, label, stream=2, noise=None):
+    """Free-running generation against the oracle with a margin-aware verdict.  Up to the first differing code both
+    sides are in the same state, so exactly one decision has to be explained: a divergence is a FAILURE unless the ORACLE's margin of
+    that decision (q3o_sample_margin: greedy = the top-2 logit gap; sampled = top-k gap, top-p cut, distance of u * total from the drawn
+    interval's edges) is below NOISE, the asserted bound on the logit difference between two correct fp32 implementations — and then it
+    is printed, with everything before it required bit-exact.  Returns the number of bit-exact frames."""
+    F = sp.max_new_tokens
+    noise = NOISE if noise is None else noise
+    p, t = eng.build_prompt(ids, 0)
+    codes = eng.generate(p, t, sp, seed=seed, stream_id=stream, ignore_eos=True)
+    ref, mg = orc.generate_margins(orc.build_prompt(ids, 0), to_osampling(sp), seed=seed, stream=stream, cp_cached=True, ignore_eos=True)
+    assert codes.shape == ref.shape == (F, 16)
+    dm = mg[:, 2:]                                   # [F][16] decision margins
+    bad = np.argwhere(codes != ref)
+    if bad.size == 0:
+        print("free-running %s: %d frames bit-exact (%d decisions); smallest decision margin %.3g; min top-2 logit margin code0 %.3g, "
+              "sub-codes %.3g; frames past the 128-token attention split: %d"
+              % (label, F, F * 16, float(dm.min()), float(mg[:, 0].min()), float(mg[:, 1].min()), max(0, F - (128 - 8))))
+        return F
+    f, g = int(bad[0][0]), int(bad[0][1])
+    before = np.concatenate([dm[:f].ravel(), dm[f, :g]])
+    print("free-running %s: %d frames + %d decisions bit-exact, first divergence at frame %d group %d where the oracle's decision margin "
+          "is %.3g (noise bound %.0e); smallest margin of the matching decisions before it %.3g"
+          % (label, f, g, f, g, float(dm[f, g]), noise, float(before.min()) if before.size else float("nan")))
+    assert float(dm[f, g]) < noise, "%s: ids differ at frame %d group %d although the oracle's decision margin there is %g" % (label, f, g, float(dm[f, g]))
+    assert np.array_equal(codes[:f], ref[:f]) and np.array_equal(codes[f, :g], ref[f, :g])
+    return f
+
+
+@pytest.mark.parametrize("prompt_seed", [4, 11, 12, 13])
+def test_free_running_160_frames_greedy_full_size(full, prompt_seed):
+    """0.6B dims, 160 FREE-RUNNING greedy frames (configs[0] sampling: top_k = 1) = 2560 codec decisions per utterance, four prompts: ids
+    bit-exact vs the oracle (KV-cached predictor), with the talker context growing from 8 to 168 tokens — across the first 128-token
+    attention split of the fused step.  Margin-aware like the sampled test: the day a top-2 logit gap below the logit noise flips an
+    argmax, the run is accepted up to that decision and the margin is printed; a flip at a comfortable margin fails.
     Reference loop: /root/reference/src/tts_onnx.cpp:782-872, sampler :878-950."""
     import q3tts
     eng, orc = full
-    F = 160
-    ids = frame_tokens(np.random.default_rng(4).integers(0, 151643, 16))
-    sp = q3tts.Sampling(max_new_tokens=F, temperature=1.0, top_p=1.0, top_k=1)
-    p, t = eng.build_prompt(ids, 0)
-    codes = eng.generate(p, t, sp, seed=5, stream_id=2, ignore_eos=True)
-    ref, mg = orc.generate_margins(orc.build_prompt(ids, 0), to_osampling(sp), seed=5, stream=2, cp_cached=True, ignore_eos=True)
-    assert codes.shape == ref.shape == (F, 16)
-    bad = np.argwhere(codes != ref)
-    first = "none" if bad.size == 0 else "frame %d group %d" % (bad[0][0], bad[0][1])
-    print("free-running greedy, %d frames: first divergence %s; min top-2 margin code0 %.3g (frame %d), sub-codes %.3g (frame %d); "
-          "frames past the 128-token split: %d"
-          % (F, first, float(mg[:, 0].min()), int(mg[:, 0].argmin()), float(mg[:, 1].min()), int(mg[:, 1].argmin()), F - (128 - 8)))
-    assert bad.size == 0, (first, bad[:4].tolist())
-
-
-NOISE = 2e-4    # bound asserted on |HIP logit - oracle logit| by the teacher-forced tests (measured: 2-3e-5)
+    ids = frame_tokens(np.random.default_rng(prompt_seed).integers(0, 151643, 16))
+    sp = q3tts.Sampling(max_new_tokens=160, temperature=1.0, top_p=1.0, top_k=1)
+    check_free_running(eng, orc, sp, ids, 5, "greedy, prompt seed %d" % prompt_seed)
 
 
 @pytest.mark.parametrize("seed", [5, 6, 7])
 def test_free_running_sampled_margin_aware_full_size(full, seed):
     """0.6B dims, configs[1] sampling (temp 0.8 / top-k 50 / top-p 0.95), 160 free-running frames.  A sampled decision compares running
     probability sums with u and top_p; two correct fp32 implementations whose logits differ in the 5th digit legitimately part at a
-    decision whose margin is below that noise — and from then on the streams are different utterances.  Up to the first differing code
-    both sides are in the same state, so exactly one decision has to be explained: the test requires the ORACLE's margin of that
-    decision (q3o_sample_margin: top-k gap, top-p cut, distance of u * total from the drawn interval's edges) to be under NOISE; a
-    divergence at a comfortable margin is a bug.  The sampler itself is exact by construction (test_sampler_vs_oracle,
-    test_sampler_on_decision_boundaries) and greedy runs never part (test_free_running_160_frames_greedy_full_size).
-    SURVEY.md section 7: margin-aware comparison, first-divergence report."""
+    decision whose margin is below that noise — and from then on the streams are different utterances (check_free_running has the
+    verdict).  The sampler itself is exact by construction (test_sampler_vs_oracle, test_sampler_on_decision_boundaries)."""
     import q3tts
     eng, orc = full
-    F = 160
     ids = frame_tokens(np.random.default_rng(4).integers(0, 151643, 16))
-    sp = q3tts.Sampling(max_new_tokens=F, temperature=0.8, top_p=0.95, top_k=50)
+    sp = q3tts.Sampling(max_new_tokens=160, temperature=0.8, top_p=0.95, top_k=50)
+    check_free_running(eng, orc, sp, ids, seed, "sampled seed %d" % seed)
+
+
+# ---- bf16 KV cache (Q3TTS_FLAG_KV_BF16) ----
+# K / V rows are rounded to bf16 where they enter the cache; the oracle has the same switch.  What parity can mean in this mode: rounding
+# is a discontinuity.  Two fp32 implementations agree to ~1e-6..1e-5 relative on the rows BEFORE rounding, a bf16 ulp is 2^-8, so a few
+# elements per thousand land on the other side of a rounding boundary and differ by a whole ulp (0.4 %); those flips move the next
+# layers' rows by ~1e-4, which flips percents of THEIR elements — within a few layers the two implementations' rounding errors are
+# largely uncorrelated.  Measured: logits 3.9e-3 from the same-mode oracle, 5.8e-3 from the fp32-cache engine (the full effect of the
+# rounding), against 2e-5 between engine and oracle with fp32 caches.  Bit-exact ids against an independent implementation are therefore
+# not a property of this mode; the tests pin (1) the bf16 DATA PATH exactly: 16-bit storage must equal fp32 storage of the same rounded
+# rows (Q3TTS_FLAG_KV_ROUND_BF16) bit for bit — same rows before rounding, same rounding, same math — and (2) the SEMANTICS against the
+# oracle in the same mode, with the logit bound this mode can honour and the margin-aware verdict (ids equal up to the first decision
+# whose top-2 gap is under that bound).
+NOISE_BF16KV = 2e-2
+
+
+@pytest.fixture(scope="module")
+def full_bf16kv():
+    import q3tts
+    cfg = q3tts.default_config("0.6b")
+    eng = q3tts.Engine(cfg, device=0, max_batch=2, max_ctx=512, flags=q3tts.FLAG_KV_BF16)
+    eng.fill_synthetic(seed=0)
+    orc = qo.Oracle(to_ocfg(cfg), max_ctx=192, kv_bf16=True)
+    for name, shape in eng.tensor_infos():
+        if not name.startswith(("cd.", "spk.")):
+            orc.set_tensor(name, eng.get_tensor(name, shape))
+    yield eng, orc
+    eng.close()
+    orc.close()
+
+
+def test_bf16_kv_storage_equals_rounded_fp32_storage(full_bf16kv):
+    """The 16-bit cache against an fp32 cache holding the same bf16-rounded rows: bit-identical logits through a prefill and 140 decode
+    steps (context 8 -> 148, across the 128-token attention split) and identical sampled codes over 160 free-running frames."""
+    import q3tts
+    eng, _ = full_bf16kv
+    rnd = q3tts.Engine(eng.cfg, device=0, max_batch=2, max_ctx=512, flags=q3tts.FLAG_KV_ROUND_BF16)
+    rnd.fill_synthetic(seed=0)
+    rng = np.random.default_rng(9)
+    x = (rng.standard_normal((8, 1024)) * 0.05).astype(np.float32)
+    a, ah = eng.prefill(x)
+    b, bh = rnd.prefill(x)
+    assert np.array_equal(a, b) and np.array_equal(ah, bh)
+    for i in range(140):
+        e = (rng.standard_normal(1024) * 0.05).astype(np.float32)
+        a, ah = eng.decode(e)
+        b, bh = rnd.decode(e)
+        assert np.array_equal(a, b) and np.array_equal(ah, bh), i
+    ids = frame_tokens(np.random.default_rng(4).integers(0, 151643, 16))
+    sp = q3tts.Sampling(max_new_tokens=160, temperature=0.8, top_p=0.95, top_k=50)
     p, t = eng.build_prompt(ids, 0)
-    codes = eng.generate(p, t, sp, seed=seed, stream_id=2, ignore_eos=True)
-    ref, mg = orc.generate_margins(orc.build_prompt(ids, 0), to_osampling(sp), seed=seed, stream=2, cp_cached=True, ignore_eos=True)
-    assert codes.shape == ref.shape == (F, 16)
-    dm = mg[:, 2:]                                   # [F][16] decision margins
-    bad = np.argwhere(codes != ref)
-    if bad.size == 0:
-        print("free-running sampled seed %d: %d frames bit-exact (%d decisions; smallest decision margin %.3g)" % (seed, F, F * 16, float(dm.min())))
-        return
-    f, g = int(bad[0][0]), int(bad[0][1])
-    print("free-running sampled seed %d: %d frames + %d decisions bit-exact, first divergence at frame %d group %d where the oracle's "
-          "decision margin is %.3g (noise bound %.0e); smallest margin of the matching decisions before it %.3g"
-          % (seed, f, g, f, g, float(dm[f, g]), NOISE, float(np.concatenate([dm[:f].ravel(), dm[f, :g]]).min()) if f + g else float("nan")))
-    assert float(dm[f, g]) < NOISE, "ids differ at frame %d group %d although the oracle's decision margin there is %g" % (f, g, float(dm[f, g]))
-    assert np.array_equal(codes[:f], ref[:f]) and np.array_equal(codes[f, :g], ref[f, :g])
+    ca = eng.generate(p, t, sp, seed=5, stream_id=2, ignore_eos=True)
+    cb = rnd.generate(p, t, sp, seed=5, stream_id=2, ignore_eos=True)
+    rnd.close()
+    assert np.array_equal(ca, cb)
+
+
+def test_bf16_kv_session_ops_full_size(full, full_bf16kv):
+    """Q3TTS_FLAG_KV_BF16 against the oracle in the same mode: prefill + decode logits within the bound this mode can honour (see the
+    note above), and the mode is visibly on (the logits move by ~6e-3 against the fp32-cache engine).  Replaces the reference's fp32
+    KVCache (/root/reference/src/tts_onnx.h:108-115) by half the bytes."""
+    eng, orc = full_bf16kv
+    eng32, _ = full
+    ids = frame_tokens(np.random.default_rng(1).integers(0, 151643, 16))
+    p, t = eng.build_prompt(ids, 0)
+    lg, lh = eng.prefill(p)
+    lo, ho = orc.prefill(orc.build_prompt(ids, 0))
+    eng32.prefill(p)
+    worst = max(float(np.abs(lg - lo).max()), float(np.abs(lh - ho).max()))
+    mode = 0.0
+    rng = np.random.default_rng(3)
+    for i in range(12):
+        x = t[i] + eng.codec_embed([int(rng.integers(0, 2048))])[0]
+        lg, lh = eng.decode(x)
+        lo, ho = orc.decode(x)
+        l32, _ = eng32.decode(x)
+        worst = max(worst, float(np.abs(lg - lo).max()), float(np.abs(lh - ho).max()))
+        mode = max(mode, float(np.abs(lg - l32).max()))
+    print("bf16 KV: max |logit - same-mode oracle| %.3g; max |logit - fp32-cache engine| %.3g" % (worst, mode))
+    assert worst < NOISE_BF16KV, worst
+    assert mode > 1e-4            # bf16 rounding of K / V is visible in the logits
+
+
+@pytest.mark.parametrize("prompt_seed", [4, 11])
+def test_free_running_160_frames_greedy_bf16_kv(full_bf16kv, prompt_seed):
+    """160 free-running greedy frames with the bf16 KV cache against the oracle in the same mode, margin-aware with this mode's bound."""
+    import q3tts
+    eng, orc = full_bf16kv
+    ids = frame_tokens(np.random.default_rng(prompt_seed).integers(0, 151643, 16))
+    sp = q3tts.Sampling(max_new_tokens=160, temperature=1.0, top_p=1.0, top_k=1)
+    check_free_running(eng, orc, sp, ids, 5, "greedy, bf16 KV, prompt seed %d" % prompt_seed, noise=NOISE_BF16KV)
 
 
 def test_fused_predictor_attention_matches_separate_launches(full):

@@ -49,17 +49,18 @@ ids = frame_tokens(rng.integers(0, 151643, 16))
 p, tr = eng.build_prompt(ids, 0)
 eng.slot_begin(0, p, tr, q3tts.Sampling(max_new_tokens=200), seed=1, ignore_eos=True)
 eng.decode_steps(150)   # context ~160: two attention splits
-acc_g, acc_c, acc_a, n = np.zeros(4), np.zeros(6), np.zeros(6), 0
+acc_g, acc_c, acc_a, n = np.zeros(4), np.zeros(7), np.zeros(6), 0
 for i in range(40):
     eng.decode_steps(1)
     t = marks()
     acc_g += t[8:12] - t[8]
-    acc_c += t[16:22] - t[16]
+    acc_c += t[16:23] - t[16]
     acc_a += t[24:30] - t[24]
     n += 1
 g, c = acc_g / n, acc_c / n
 print(f"{'k_gemv1 (last = codec head)':28s} issue_loads={g[1]:.0f}ns norm+wait={g[2] - g[1]:.0f}ns dot+reduce={g[3] - g[2]:.0f}ns total={g[3]:.0f}ns")
-print(f"{'k_cp_attn_oproj (last layer)':28s} issue_loads={c[1]:.0f}ns norm+rope={c[2] - c[1]:.0f}ns scores+merge={c[4] - c[2]:.0f}ns gemv={c[5] - c[4]:.0f}ns total={c[5]:.0f}ns")
+print(f"{'k_cp_attn_oproj (last layer)':28s} issue_loads={c[1]:.0f}ns norm+rope={c[2] - c[1]:.0f}ns lds_fragments={c[3] - c[2]:.0f}ns scores+merge(wave 0)={c[6] - c[3]:.0f}ns "
+      f"block_barrier={c[4] - c[6]:.0f}ns gemv={c[5] - c[4]:.0f}ns total={c[5]:.0f}ns")
 a = acc_a / n
 print(f"{'k_attn talker (split 0)':28s} round1_issue={a[1]:.0f}ns wait+range={a[2] - a[1]:.0f}ns issue2+norm/rope+sync={a[3] - a[2]:.0f}ns softmax_loop={a[4] - a[3]:.0f}ns combine={a[5] - a[4]:.0f}ns total={a[5]:.0f}ns")
 print("cost of one mark:", marks()[31] - marks()[30], "ns")
