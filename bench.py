@@ -272,8 +272,32 @@ def self_launch(args, argv):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out0, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    # poll every child: if any rank dies (bad GPU index, import error) before or inside the rendezvous, the others would sit in
+    # init_process_group / a barrier until the store or NCCL timeout — terminate them instead and fail at once
+    import threading
+    buf = []
+    rd = threading.Thread(target=lambda: buf.append(procs[0].stdout.read()), daemon=True)
+    rd.start()
+    rcs = [None] * len(procs)
+    while any(rc is None for rc in rcs):
+        for i, p in enumerate(procs):
+            if rcs[i] is None:
+                rcs[i] = p.poll()
+        if any(rc not in (None, 0) for rc in rcs):
+            for i, p in enumerate(procs):
+                if rcs[i] is None:
+                    p.terminate()
+            for i, p in enumerate(procs):
+                if rcs[i] is None:
+                    try:
+                        rcs[i] = p.wait(timeout=20)
+                    except subprocess.TimeoutExpired:
+                        p.kill()
+                        rcs[i] = p.wait()
+            break
+        time.sleep(0.2)
+    rd.join(timeout=10)
+    out0 = buf[0] if buf else ""
     if out0:
         sys.stdout.write(out0)
         sys.stdout.flush()
@@ -398,7 +422,9 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         backend = "nccl"
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))  # RCCL on ROCm
+        import datetime
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank),   # RCCL on ROCm
+                                timeout=datetime.timedelta(seconds=300))
 
     import q3tts
     cfg = q3tts.default_config(args.model)

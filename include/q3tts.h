@@ -66,7 +66,8 @@ typedef struct q3tts_engine q3tts_engine;
                                    * agree to ~4e-3 on logits in this mode (2e-5 with fp32 caches), ids to the first sub-noise decision. */
 #define Q3TTS_FLAG_KV_ROUND_BF16 16u /* test aid: fp32 KV storage holding the bf16-ROUNDED rows — the arithmetic of Q3TTS_FLAG_KV_BF16 without its 16-bit storage;
                                      * the two modes must agree bit for bit (tests/test_gpu_full.py), which pins the bf16 load / store / convert path */
-#define Q3TTS_FLAG_FP32_CODEC 4u  /* codec decoder on the exact-fp32 matrix-core path instead of the bf16 hi/lo split path */
+#define Q3TTS_FLAG_TEST_HOOKS 32u  /* honour the fault-injection environment hooks of the test suite (Q3TTS_TEST_FAIL_VOCODER_SUBMIT); without it they are ignored */
+#define Q3TTS_FLAG_FP32_CODEC 4u  /* codec decoder on the exact-fp32 matrix-core path instead of the fp16 (hi, lo) split-operand path */
 
 /* ---- lifecycle (replaces TTSEngine ctor / load_model, tts_onnx.cpp:84-232) ---- */
 int q3tts_default_config(const char* name /* "0.6b" | "1.7b" */, q3tts_config* out);

@@ -326,6 +326,12 @@ int q3tts_synthesize_schedule_host(q3tts_engine* h, int n_utt, const int64_t* id
     const bool reserve_all = ignore_eos != 0;
     const int first_look = 8;
     int live = 0;
+    // A preempted utterance is not re-admitted on the pages it just gave back: it waits until a live utterance has retired or the pool
+    // holds what it owned when it was preempted plus one page of head-room — otherwise a pool just above one utterance's cap re-admits
+    // and preempts the same utterance look after look, paying a prefill and discarding its frames each time.
+    std::vector<int> hold_pages((size_t)n_utt, 0);
+    std::vector<int64_t> hold_mark((size_t)n_utt, 0);
+    int64_t n_retired = 0;
     e.sched_admitted = e.sched_preempted = 0; e.sched_peak_live = 0;
     try {
         while (!pending.empty() || live > 0) {
@@ -335,7 +341,9 @@ int q3tts_synthesize_schedule_host(q3tts_engine* h, int n_utt, const int64_t* id
                 for (int b = 0; b < B; ++b) if (slot_utt[(size_t)b] < 0) free_slots.push_back(b);
                 for (size_t i = 0; i < pending.size() && i < free_slots.size(); ++i) {
                     const int u = pending[i], all = prep[(size_t)u].S + cap_of(u);
-                    need.push_back(e.kv_pages_for(reserve_all ? all : std::min(all, prep[(size_t)u].S + first_look)));
+                    int pages = e.kv_pages_for(reserve_all ? all : std::min(all, prep[(size_t)u].S + first_look));
+                    if (hold_pages[(size_t)u] > 0 && n_retired == hold_mark[(size_t)u] && live > 0) pages = std::max(pages, std::min(hold_pages[(size_t)u], e.kv_total_pages()));
+                    need.push_back(pages);
                 }
                 const int n_adm = q3::sched_admit_count(e.kv, need, (int)free_slots.size(), live, reserve_all);
                 for (int i = 0; i < n_adm; ++i) { slot_utt[(size_t)free_slots[(size_t)i]] = pending.front(); pending.pop_front(); fresh.push_back(free_slots[(size_t)i]); }
@@ -382,6 +390,8 @@ int q3tts_synthesize_schedule_host(q3tts_engine* h, int n_utt, const int64_t* id
                 const std::vector<int> victims = q3::sched_grow(e.kv, order, want, &changed);
                 for (int vb : victims) {          // youngest first: pushed to the front one by one, the oldest of them ends up first in the queue
                     const int vu = slot_utt[(size_t)vb];
+                    hold_pages[(size_t)vu] = e.kv_pages_for(prep[(size_t)vu].S + done_frames[(size_t)vb]) + 1;
+                    hold_mark[(size_t)vu] = n_retired;
                     e.slot_release(vb);           // deactivates the slot (its pages are already back in the pool)
                     pending.push_front(vu);
                     slot_utt[(size_t)vb] = -1; done_frames[(size_t)vb] = 0;
@@ -408,7 +418,7 @@ int q3tts_synthesize_schedule_host(q3tts_engine* h, int n_utt, const int64_t* id
                 if (codes_out) e.slot_codes(b, codes_out + (size_t)u * p->max_new_tokens * G, p->max_new_tokens);
                 e.slot_release(b);
                 slot_utt[(size_t)b] = -1; done_frames[(size_t)b] = 0;
-                --live;
+                --live; ++n_retired;
             }
         }
     } catch (...) {
@@ -435,10 +445,16 @@ int q3tts_synthesize_schedule_host(q3tts_engine* h, int n_utt, const int64_t* id
         const int F0 = got_frames[(size_t)order[(size_t)y0]];
         if (F0 <= 0) break;                                            // sorted: the rest of the job produced no frame
         int y1 = y0 + 1;
-        // a block is a batch dimension of the batched kernels (gridDim.y / .z <= 65535): at most 4096 sequences and 2^16 padded frames
-        while (y1 < n_utt && y1 - y0 < 4096 && (int64_t)(y1 - y0 + 1) * F0 <= (int64_t)1 << 16 && got_frames[(size_t)order[(size_t)y1]] * 2 >= F0) ++y1;
+        // a block is a batch dimension of the batched kernels (gridDim.y / .z <= 65535): at most 4096 sequences and 2^16 padded frames, and
+        // no activation matrix of its batched front may reach 4 GB (k_conv_split addresses rows with 32-bit byte offsets): the widest is
+        // the ConvNeXt hidden [frames x upsampling][4 x cd_hidden] — at 0.6B dims exactly 4 GB at 2^16 frames, hence the strict bound
+        int64_t up_front = 1;
+        for (int i = 0; i < e.c.cd_n_up; ++i) up_front *= e.c.cd_up_ratios[i];
+        const int64_t widest = std::max<int64_t>((int64_t)4 * e.c.cd_hidden * up_front, std::max<int64_t>(e.c.cd_ffn, (int64_t)3 * e.c.cd_hidden));
+        const int64_t frame_cap = std::min<int64_t>((int64_t)1 << 16, (((int64_t)1 << 32) - 1) / ((int64_t)sizeof(float) * widest));
+        while (y1 < n_utt && y1 - y0 < 4096 && (int64_t)(y1 - y0 + 1) * F0 <= frame_cap && got_frames[(size_t)order[(size_t)y1]] * 2 >= F0) ++y1;
         const int nblk = y1 - y0;
-        if (nblk >= 2 && batchable && F0 <= ((int64_t)1 << 16) / 2) {
+        if (nblk >= 2 && batchable && F0 <= frame_cap / 2) {
             int rows = 0;
             e.codec_lanes_join();                                      // the previous block's groups still read the batched buffers
             const float* hb = e.codec_pre_batch(e.codec_job_codes(0, row_frames), row_frames, nblk, F0, true, &rows, order.data() + y0);

@@ -526,7 +526,10 @@ void Engine::codec_async_prepare(int max_frames, int n_utt) {
     if (!codec) throw Error("codec decoder not finalized");
     CodecW& W = *codec;
     codec_async_abort();   // a previous job that failed mid-way must not leak its pending items into this one
-    if (const char* fv = getenv("Q3TTS_TEST_FAIL_VOCODER_SUBMIT")) W.fail_at_submit = atoi(fv); else W.fail_at_submit = 0;   // test hook (tests/test_gpu_edges.py)
+    // fault injection for the tests (tests/test_gpu_edges.py): only an engine created with Q3TTS_FLAG_TEST_HOOKS reads the variable, so a
+    // stray environment setting cannot fail a production job
+    const char* fv = (flags & Q3TTS_FLAG_TEST_HOOKS) ? getenv("Q3TTS_TEST_FAIL_VOCODER_SUBMIT") : nullptr;
+    W.fail_at_submit = fv ? atoi(fv) : 0;
     int P = 1;
     while (P < max_frames) P <<= 1;
     if (W.rope_P < P) {   // grow the shared RoPE tables before any lane is in flight

@@ -2,12 +2,13 @@
 // tokenizer12hz_decode.onnx session, src/tts_onnx.cpp:759-776): codebook-embedding mean,
 // sliding-window pre-transformer, ConvNeXt upsampling and the SnakeBeta transposed-conv decoder.
 //
-// Every convolution / linear layer is one implicit GEMM on the fp32-input matrix cores
-// (v_mfma_f32_32x32x2_f32: exact fp32 fmaf chains, 155 TF peak on MI355X), so the PCM matches the
-// fp32 oracle to rounding.  Activations are time-major [T][C]; a k-tap causal conv is k shifted
-// GEMMs accumulated in registers; a stride-s transposed conv is s phase GEMMs (blockIdx.z).
-// SnakeBeta is applied in the PRODUCER's epilogue (second output), never on the k-times-re-read
-// operand loads.
+// Every convolution / linear layer is one implicit GEMM on the matrix cores.  Default path, k_conv_split: both operands as fp16
+// (hi, lo) planes on v_mfma_f32_32x32x16_f16 with fp32 accumulate — three products per fp32 product (lo.hi + hi.lo + hi.hi), two when
+// the weight is exact in fp16 (every bf16-origin tensor: its lo plane is empty) — PCM within 2e-7 RMS of the fp32 oracle.  k_conv_mfma,
+// the exact-fp32 path (v_mfma_f32_32x32x2_f32: fp32 fmaf chains, 155 TF peak on MI355X), serves Q3TTS_FLAG_FP32_CODEC and channel
+// counts that are not multiples of 32.  Activations are time-major [T][C]; a k-tap causal conv is k shifted GEMMs accumulated in
+// registers; a stride-s transposed conv is s phase GEMMs (blockIdx.z).  SnakeBeta is applied in the PRODUCER's epilogue (second
+// output), never on the k-times-re-read operand loads.
 #include <cstdlib>
 #include <type_traits>
 #include <utility>

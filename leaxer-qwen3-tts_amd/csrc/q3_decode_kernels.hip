@@ -1041,6 +1041,7 @@ generic:;
         else throw Error("attn: head_dim must be 16, 64 or 128");
     }
     else if (a.d == 128 && tiny_ctx && a.identity_pages) Q3_ATT_I(128, 2, true);
+    else if (a.d == 128 && a.identity_pages && a.n_splits > 1 && a.chunk <= 64) Q3_ATT_I(128, 4, true);   // 64-token splits: 4 tokens per lane group in flight
     else if (a.d == 128 && a.identity_pages) Q3_ATT_I(128, 8, true);
     else if (a.d == 128 && tiny_ctx) Q3_ATT(128, 2);
     else if (a.d == 128) Q3_ATT(128, 8);

@@ -181,6 +181,7 @@ Engine::Engine(const q3tts_config& cfg, int device_, int max_batch, int max_ctx_
     if (null_stream) { stream = nullptr; flags |= Q3TTS_FLAG_NO_GRAPH; }
     else if (const char* cm = getenv("Q3TTS_STREAM_CU_MASK")) {   // experiment aid (tools/overlap_probe.py): this engine's stream on a subset of the CUs;
         const uint32_t pat = (uint32_t)strtoul(cm, nullptr, 16);    // the 32-bit pattern is repeated over the 256-CU mask
+        if (pat == 0) throw Error("Q3TTS_STREAM_CU_MASK must be a non-zero hexadecimal CU pattern (a stream with no CU never runs)");
         uint32_t mask[8];
         for (int i = 0; i < 8; ++i) mask[i] = pat;
         Q3_HIP_CHECK(hipExtStreamCreateWithCUMask(&stream, 8, mask));
@@ -317,8 +318,11 @@ Engine::Engine(const q3tts_config& cfg, int device_, int max_batch, int max_ctx_
     setup_stack(talker, H, c.n_layers, c.n_heads, c.n_kv_heads, c.head_dim, c.ffn, c.rms_eps, 6, max_ctx, c.rope_theta, true, kv_pool_tokens, true);
     setup_stack(cp, Hc, c.cp_layers, c.cp_heads, c.cp_kv_heads, c.cp_head_dim, c.cp_ffn, c.cp_rms_eps, 5, 32, c.cp_rope_theta, false, 0, false);
     // split-T attention: 128 cache tokens per workgroup (16 lane groups x 8 tokens in flight)
-    talker.chunk = 128;
-    talker.n_splits = (max_ctx + 127) / 128;
+    // 128 cache tokens per workgroup; 64 for engines of one or two slots, where the attention launch is 72 workgroups at a 1041-token context
+    // and each one's K/V ingest (128 KB) and softmax loop set its length: b=1 step 2.178 -> 2.156 ms.  Q3TTS_ATTN_CHUNK is the A/B knob.
+    talker.chunk = B <= 2 ? 64 : 128;
+    if (const char* ck = getenv("Q3TTS_ATTN_CHUNK")) talker.chunk = atoi(ck) == 64 ? 64 : 128;
+    talker.n_splits = (max_ctx + talker.chunk - 1) / talker.chunk;
     if (talker.n_splits > 64) { talker.n_splits = 64; talker.chunk = ((max_ctx + 63) / 64 + 127) / 128 * 128; }
     for (DecStack* S : { &talker, &cp }) {
         S->po = fm((size_t)rows_max * S->nq * S->n_splits * S->d);
@@ -809,13 +813,11 @@ void Engine::record_step(int nb) {
         if (j == 0) pr = run_layers(cp, xin, Hc, nb, 2, 0, nullptr, 0, cp_norm, c.cp_rms_eps);
         else pr = run_layers(cp, xin, Hc, nb, 1, 0, nullptr, j + 1, cp_norm, c.cp_rms_eps);
         // head j on the last row of every utterance (pass 0 holds two rows per utterance: planes row b*2+1)
+        // a traced step (step_logits) keeps plain logits rows: the head then takes the unsplit GEMM at any batch
         const int nsl = head_proj(cp_head[j], j == 0 ? xin + Hc : xin, j == 0 ? 2 * Hc : Hc, cp_norm, c.cp_rms_eps, nullptr, 0, logits_cp, SV, nb, SV, Hc, false,
-                                  pr, j == 0 ? 1 : 0, j == 0 ? 2 : 1, cp_logit_slab_d);
+                                  pr, j == 0 ? 1 : 0, j == 0 ? 2 : 1, trace_d ? nullptr : cp_logit_slab_d);
         mark();
-        if (trace_d) {
-            if (nsl > 1) throw Error("step_logits: run it on a batch below the split-K head threshold");
-            launch_copy_rows(logits_cp + (size_t)trace_slot * SV, SV, trace_d + (size_t)(j + 1) * trace_cols, trace_cols, 1, SV, stream);
-        }
+        if (trace_d) launch_copy_rows(logits_cp + (size_t)trace_slot * SV, SV, trace_d + (size_t)(j + 1) * trace_cols, trace_cols, 1, SV, stream);
         SampleArgs s = s0;
         s.logits = nsl > 1 ? cp_logit_slab_d : logits_cp; s.nslab = nsl; s.slab_stride = (size_t)nb * SV;
         s.ld = SV; s.V = SV; s.group = j + 1; s.embed = cp_embed_w[j];

@@ -71,6 +71,7 @@ FLAG_NO_GRAPH = 1
 FLAG_NO_FUSED_CP = 2
 FLAG_FP32_CODEC = 4
 FLAG_KV_ROUND_BF16 = 16   # test aid: fp32 KV storage of the bf16-rounded rows (must equal FLAG_KV_BF16 bit for bit)
+FLAG_TEST_HOOKS = 32   # the engine honours the test suite's fault-injection environment hooks
 FLAG_KV_BF16 = 8   # talker KV cache in bf16 (rounded on append, fp32 math); the oracle has the same switch (Oracle(kv_bf16=True))
 
 # every symbol include/q3tts.h declares

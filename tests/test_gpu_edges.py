@@ -125,7 +125,7 @@ def test_vocoder_phase_error_leaves_the_engine_usable(fail_at, caps):
     import gc
     import os
     import q3tts
-    eng, orc, _ = tiny_pair(seed=33, max_batch=3, max_ctx=64)
+    eng, orc, _ = tiny_pair(seed=33, max_batch=3, max_ctx=64, flags=q3tts.FLAG_TEST_HOOKS)   # only such an engine reads the injection variable
     sp = q3tts.Sampling(temperature=0.8, top_p=0.95, top_k=50, max_new_tokens=9)
     rng = np.random.default_rng(41)
     toks = [frame_tokens(rng.integers(0, 151643, int(n))) for n in (3, 5, 2, 7, 4)]

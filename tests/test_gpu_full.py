@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 def full():
     import q3tts
     cfg = q3tts.default_config("0.6b")
-    eng = q3tts.Engine(cfg, device=0, max_batch=2, max_ctx=512)
+    eng = q3tts.Engine(cfg, device=0, max_batch=2, max_ctx=512, flags=q3tts.FLAG_TEST_HOOKS)   # the fault-injection test below needs the hooks
     eng.fill_synthetic(seed=0)
     orc = qo.Oracle(to_ocfg(cfg), max_ctx=192)
     for name, shape in eng.tensor_infos():
@@ -253,8 +253,9 @@ def test_codec_full_size(full):
 
 
 def test_codec_split_precision_matrix_path_full_size(full):
-    """24 frames at 0.6B dims reach the 256-row tiles of k_conv_bf3 (bf16 hi/lo split, 3 products per fp32 product):
-    PCM against the fp32 oracle within the north_star tolerance, and against the exact-fp32 MFMA path."""
+    """24 frames at 0.6B dims reach the 256-row tiles of k_conv_split (fp16 hi/lo split operands: 2 matrix-core products per fp32
+    product when the weight is exact in fp16 — these bf16-origin weights — else 3): PCM against the fp32 oracle within the north_star
+    tolerance, and against the exact-fp32 MFMA path."""
     import q3tts
     eng, orc = full
     codes = np.random.default_rng(4).integers(0, 2048, (24, 16)).astype(np.int64)
@@ -270,7 +271,7 @@ def test_codec_split_precision_matrix_path_full_size(full):
     exact.close()
     err32 = float(np.sqrt(np.mean((pcm32 - ref) ** 2)))
     assert err32 < 1e-4 and float(np.sqrt(np.mean((pcm - pcm32) ** 2))) < 1e-4
-    print("codec rms error vs oracle: split-bf16 %.3g, fp32-mfma %.3g, signal rms %.3g" % (err, err32, rms_ref))
+    print("codec rms error vs oracle: split-fp16 %.3g, fp32-mfma %.3g, signal rms %.3g; weight tensors on 2 / 3 products: %s" % (err, err32, rms_ref, eng.codec_plane_stats()))
 
 
 def test_chunked_codec_full_size(full):
@@ -371,6 +372,25 @@ def test_vocoder_blocks_of_mixed_lengths_full_size(full):
     for u in range(6):
         single = eng.codec_decode(codes[u])
         assert pcm[u].shape == single.shape and float(np.sqrt(np.mean((pcm[u] - single) ** 2))) < 1e-5, u
+
+
+def test_fault_injection_variable_is_ignored_without_the_flag():
+    """Q3TTS_TEST_FAIL_VOCODER_SUBMIT in the environment of an engine created WITHOUT Q3TTS_FLAG_TEST_HOOKS changes nothing (round-2
+    advisor finding: the production library used to read the hook on every job)."""
+    import os
+    import q3tts
+    cfg = q3tts.default_config("0.6b")
+    eng = q3tts.Engine(cfg, device=0, max_batch=2, max_ctx=64)
+    eng.fill_synthetic(seed=0)
+    sp = q3tts.Sampling(temperature=0.8, top_p=0.95, top_k=50, max_new_tokens=4)
+    toks = [frame_tokens([11, 22, 33]), frame_tokens([5, 6, 7, 8])]
+    os.environ["Q3TTS_TEST_FAIL_VOCODER_SUBMIT"] = "1"
+    try:
+        pcm, codes, nfr = eng.synthesize_batch(toks, sp, seed=9, ignore_eos=True)
+    finally:
+        del os.environ["Q3TTS_TEST_FAIL_VOCODER_SUBMIT"]
+    eng.close()
+    assert all(int(n) == 4 for n in nfr) and all(np.isfinite(p).all() for p in pcm)
 
 
 def test_vocoder_group_failure_leaves_the_engine_usable(full):

@@ -170,3 +170,48 @@ def test_pack_refuses_an_incomplete_tensor_set(tmp_path):
     write_q3w(str(tmp_path / "e.q3w"), cfg, w)
     back = q3tts.Config()
     assert q3tts.lib().q3tts_read_weights_config(os.fsencode(str(tmp_path / "e.q3w")), back) == 0 and back.cd_tconv_trim == 1
+
+
+def _pb_varint(v):
+    out = bytearray()
+    while True:
+        b = v & 0x7F
+        v >>= 7
+        out.append(b | (0x80 if v else 0))
+        if not v:
+            return bytes(out)
+
+
+def _pb_field(no, wt, payload):
+    return _pb_varint(no << 3 | wt) + (_pb_varint(len(payload)) + payload if wt == 2 else payload)
+
+
+def test_onnx_initializer_lister_reads_its_wire_format(tmp_path):
+    """tools/list_onnx_initializers.py (the artefacts the reference's users hold are .onnx graphs, /root/reference/src/tts_onnx.cpp:91-107):
+    the dependency-free protobuf reader finds every initialiser of a ModelProto.  NOT a reference fixture — no .onnx file, ONNX Runtime
+    or `onnx` package exists in the image — the file is written here, field by field, from the published schema (ModelProto.graph = 7,
+    GraphProto.initializer = 5, TensorProto dims = 1 / data_type = 2 / name = 8 / raw_data = 9 / float_data = 4 / external_data = 13),
+    with both dims encodings (packed and one varint per field) and a node field in front that must be skipped."""
+    from tools.list_onnx_initializers import initializers
+    w = np.arange(12, dtype=np.float32).reshape(3, 4)
+    t_raw = (_pb_field(1, 2, _pb_varint(3) + _pb_varint(4)) + _pb_field(2, 0, _pb_varint(1)) + _pb_field(8, 2, b"onnx::MatMul_1234") + _pb_field(9, 2, w.tobytes()))
+    t_typed = (_pb_field(1, 0, _pb_varint(5)) + _pb_field(2, 0, _pb_varint(1)) + _pb_field(4, 2, np.ones(5, np.float32).tobytes()) + _pb_field(8, 2, b"talker.norm.weight"))
+    t_ext = (_pb_field(1, 2, _pb_varint(2048) + _pb_varint(1024)) + _pb_field(2, 0, _pb_varint(16)) + _pb_field(8, 2, b"big")
+             + _pb_field(13, 2, _pb_field(1, 2, b"location") + _pb_field(2, 2, b"weights.bin")) + _pb_field(14, 0, _pb_varint(1)))
+    node = _pb_field(1, 2, _pb_field(4, 2, b"MatMul"))                       # GraphProto.node = 1: skipped
+    graph = node + _pb_field(2, 2, b"main_graph") + b"".join(_pb_field(5, 2, t) for t in (t_raw, t_typed, t_ext))
+    model = _pb_field(1, 0, _pb_varint(8)) + _pb_field(2, 2, b"pytorch") + _pb_field(7, 2, graph) + _pb_field(8, 2, _pb_field(2, 0, _pb_varint(17)))
+    path = tmp_path / "toy.onnx"
+    path.write_bytes(model)
+    ts = initializers(str(path))
+    assert [t["name"] for t in ts] == ["onnx::MatMul_1234", "talker.norm.weight", "big"]
+    assert ts[0]["dims"] == [3, 4] and ts[0]["data_type"] == 1 and ts[0]["raw_bytes"] == 48 and not ts[0]["external"]
+    assert ts[1]["dims"] == [5] and ts[1]["n_typed"] == 5
+    assert ts[2]["dims"] == [2048, 1024] and ts[2]["data_type"] == 16 and ts[2]["external"]
+    # truncated files are reported, not mis-read
+    (tmp_path / "cut.onnx").write_bytes(model[: len(model) - 7])
+    try:
+        initializers(str(tmp_path / "cut.onnx"))
+        assert False, "a truncated file must raise"
+    except ValueError:
+        pass
