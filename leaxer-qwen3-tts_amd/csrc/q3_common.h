@@ -76,6 +76,9 @@ void launch_gemv16(const GemvArgs& a, hipStream_t s);
 struct AttnArgs {
     const float* qkv = nullptr; // [nb*n_new][ld_qkv]: q heads | k heads | v heads (raw projections)
     int ld_qkv = 0;
+    // deferred RMSNorm of the projection's input (split-K seam, GemmArgs::seam): the raw q / k / v sums are scaled by
+    // 1 / sqrt(sum_t ssq_in[row][t] / ssq_K + ssq_eps) before anything else.  Null: the input planes were normalised.
+    const float* ssq_in = nullptr; int ssq_nt = 0, ssq_K = 0; float ssq_eps = 0.f;
     int qkv_nslab = 1; size_t qkv_slab_stride = 0; // > 1: qkv is the sum of that many split-K partial slabs
     float* out = nullptr;       // [nb*n_new][nq*d]
     int ld_out = 0;
@@ -140,8 +143,20 @@ struct GemmArgs {
     int M = 0, N = 0, K = 0, epi = EPI_STORE;
     int slab_rows = 0;   // EPI_SLAB / EPI_SLAB2: rows per slab (0 = M); launch_gemm2 sets it when it cuts M into 128-row blocks
     bool nt = false;     // non-temporal weight loads (weights this step reads once: the talker's)
+    // ---- split-K seam (k_gemm3 only): the slabs are reduced INSIDE the launch by the K-slice workgroups of a column tile themselves
+    // (sc1 slab stores, arrival ticket, the arrivers that see the tile complete claim 16-row chunks), instead of by a k_finish* launch.
+    // seam 1: x += sum(slabs); planes = split(gamma * x) — NOT normalised: the consumer applies 1/rms from the per-(row, tile) sums of
+    //         squares written to ssq_out (deferred RMSNorm, as k_gemv16 does);
+    // seam 2: planes = split(silu(r * sum(gate slabs)) * (r * sum(up slabs))), r = 1/rms of the INPUT planes' rows from ssq_in.
+    int seam = 0;
+    unsigned* seam_cnt = nullptr;                    // 4 words per (column tile, row block): arrivals, chunk claims; zeroed before the launch
+    float* sx = nullptr; int sldx = 0;               // seam 1: residual stream rows, updated in place
+    const float* sgamma = nullptr;                   // seam 1: the consumer's RMSNorm gain
+    float* ssq_out = nullptr; int ssq_nt = 0;        // seam 1: [M][ssq_nt] partial sums of squares, one per 64-column tile
+    const float* ssq_in = nullptr; int ssq_in_nt = 0; float seps = 0.f;   // seam 2 (K = this GEMM's K): the input rows' partial sums of squares
 };
 void launch_gemm2(const GemmArgs& a, int ksplit, int nw, hipStream_t s); // EPI_SLAB: out = slabs [ksplit][M][ldo]
+bool gemm_seam_ok(const GemmArgs& a, int ksplit);                        // the in-launch split-K reduction (GemmArgs::seam) covers this launch
 void launch_finish(float* x, int ldx, const float* slab, int nslab, size_t slab_stride, int ld_slab, const float* gamma, float eps,
                    int rows, int K, bf16_t* oh, bf16_t* ol, int ldp, float* xn_out, int ld_xn, hipStream_t s);
 void launch_finish_swiglu(const float* gs, const float* us, int nslab, size_t slab_stride, int rows, int N,

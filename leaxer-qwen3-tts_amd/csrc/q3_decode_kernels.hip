@@ -523,6 +523,15 @@ static __device__ __forceinline__ float bf16_round_f(float f) {
     uint32_t u = __float_as_uint(f);
     return __uint_as_float((u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u);
 }
+// Deferred RMSNorm (split-K seam, GemmArgs::seam): the projection's input planes were gamma * x, NOT normalised; the row's 1 / rms comes
+// from the producer's per-(row, 64-column tile) sums of squares.  Lane t holds partial t (loaded with the kernel's other operands);
+// the sum runs in tile order through readlanes (wave-uniform, deterministic).  `have` false: 1.0f (the product is then exact).
+static __device__ __forceinline__ float ssq_row_scale(float part, int nt, int K, float eps, bool have) {
+    float tot = 0.f;
+    for (int t = 0; t < nt; ++t) tot += lane_bcast(part, t);
+    const float r = 1.0f / sqrtf(tot / (float)K + eps);
+    return have ? r : 1.0f;
+}
 template <int D, int U, int G, bool IDENT = false, bool KVB = false>
 __global__ __launch_bounds__(256) void k_attn(const int* ppage_table, const int* ppos_dev, const float* pqkv, const float* pkcache, const float* pvcache,
                                                const float* pcos, const float* psin, int ppos_scalar, int pn_splits, AttnArgs a) {
@@ -646,10 +655,16 @@ __global__ __launch_bounds__(256) void k_attn(const int* ppage_table, const int*
             px0[sb] = src[so + hl]; px1[sb] = src[so + hl + HALF];
             pv0[sb] = vs[so + hl]; pv1[sb] = vs[so + hl + HALF];
         }
+        // deferred RMSNorm of the projection's input rows (address select: the load stays unconditional)
+        const bool have_ssq = a.ssq_in != nullptr;
+        const int snt = have_ssq ? a.ssq_nt : 1;
+        const float spart = (have_ssq ? a.ssq_in + (size_t)(bi * a.n_new + j) * a.ssq_nt : src)[lane < snt ? lane : 0];   // fallback address: the row itself (rope tables may be null: codec)
         r.x0 = px0[0]; r.x1 = px1[0]; r.v0 = pv0[0]; r.v1 = pv1[0];
 #pragma unroll
         for (int sb = 1; sb < 4; ++sb)
             if (sb < a.qkv_nslab) { r.x0 += px0[sb]; r.x1 += px1[sb]; r.v0 += pv0[sb]; r.v1 += pv1[sb]; }
+        const float rsc = ssq_row_scale(spart, snt, a.ssq_K, a.ssq_eps, have_ssq);
+        r.x0 *= rsc; r.x1 *= rsc; r.v0 *= rsc; r.v1 *= rsc;
         const float* nw = is_q ? a.q_norm : a.k_norm;
         r.n0 = 1.f; r.n1 = 1.f; r.cs = 1.f; r.sn = 0.f;
         if (a.new_from_raw) {
@@ -866,6 +881,12 @@ __global__ __launch_bounds__(128) void k_attn_tiny(const float* pqkv, const floa
         }
         cs[j] = pcos[(size_t)(base + j) * HALF + lane]; sn[j] = psin[(size_t)(base + j) * HALF + lane];
     }
+    // deferred RMSNorm of the projection's input rows (split-K seam): per-tile partial sums of squares of each new row, one per lane
+    const bool have_ssq = a.ssq_in != nullptr;
+    const int snt = have_ssq ? a.ssq_nt : 1;
+    float spart[NN];
+#pragma unroll
+    for (int j = 0; j < NN; ++j) spart[j] = (have_ssq ? a.ssq_in + (size_t)(bi * NN + j) * a.ssq_nt : pqkv + (size_t)(bi * NN + j) * a.ld_qkv)[lane < snt ? lane : 0];
     const float* qnw = a.q_norm ? a.q_norm : pcos;      // address select: the loads stay unconditional, the values are replaced below
     const float* knw = a.k_norm ? a.k_norm : pcos;
     const float qn0 = qnw[lane], qn1 = qnw[lane + HALF], kn0 = knw[lane], kn1 = knw[lane + HALF];
@@ -892,10 +913,11 @@ __global__ __launch_bounds__(128) void k_attn_tiny(const float* pqkv, const floa
     float ky0[NN], ky1[NN], vn0[NN], vn1[NN], qy0[NN][G], qy1[NN][G];
 #pragma unroll
     for (int j = 0; j < NN; ++j) {
+        const float rsc = ssq_row_scale(spart[j], snt, a.ssq_K, a.ssq_eps, have_ssq);
         auto slabsum = [&](const float (&p)[4]) { float t = p[0];
 #pragma unroll
             for (int sb = 1; sb < 4; ++sb) if (sb < a.qkv_nslab) t += p[sb];
-            return t; };
+            return t * rsc; };
         float k0 = slabsum(kx0[j]), k1 = slabsum(kx1[j]);
         vn0[j] = slabsum(vx0[j]); vn1[j] = slabsum(vx1[j]);
         if (a.k_norm != nullptr) {

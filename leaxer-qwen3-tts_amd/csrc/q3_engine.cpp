@@ -255,6 +255,15 @@ Engine::Engine(const q3tts_config& cfg, int device_, int max_batch, int max_ctx_
     pl1h = (bf16_t*)dmalloc((size_t)rows_max * ldp * 2); pl1l = (bf16_t*)dmalloc((size_t)rows_max * ldp * 2);
     slab_d = fm((size_t)16 * rows_max * H);
     qkv_slab_d = fm((size_t)4 * rows_max * std::max(QKV, QKVp));
+    {   // seam counters: <= 3 seam launches per layer pass, <= (ffn / 64) x 2 row blocks units of 4 words each
+        const size_t per_launch = (size_t)(std::max(std::max(c.ffn, c.cp_ffn), H) / 64 + 1) * 2 * 4;
+        const size_t launches = (size_t)3 * ((size_t)c.n_layers + (size_t)(c.n_groups - 1) * c.cp_layers) + 8;
+        seam_cnt_words = per_launch * launches;
+        seam_cnt_d = (unsigned*)dmalloc(seam_cnt_words * sizeof(unsigned));
+        Q3_HIP_CHECK(hipMemsetAsync(seam_cnt_d, 0, seam_cnt_words * sizeof(unsigned), stream));
+        ssq_a_d = fm((size_t)rows_max * 64);
+        ssq_b_d = fm((size_t)rows_max * 64);
+    }
     gu_slab_d = fm((size_t)2 * 4 * rows_max * std::max(c.ffn, c.cp_ffn));
     ids_d = (int64_t*)dmalloc(64 * sizeof(int64_t));
     tok_d = (int64_t*)dmalloc(sizeof(int64_t));
@@ -448,6 +457,31 @@ bool Engine::run_layers(const DecStack& W, float* x, int ldx, int nb, int n_new,
     // M >= mfma_min_rows: bf16-MFMA skinny GEMM over (hi, lo) activation planes; below it the single-pass GEMV family
     const bool mfma = M >= mfma_min_rows && W.H % 128 == 0 && AO % 128 == 0 && W.ffn % 128 == 0 && W.H <= 4096;
     const int ks_q = mfma ? std::min(4, pick_ksplit(W.H)) : 1;
+    // Split-K seam (decode step only): the three finish launches of a layer pass fold into their GEMMs — o_proj and down reduce their
+    // slabs in-launch and leave gamma * x planes plus per-tile sums of squares (the consumer applies 1 / rms: deferred RMSNorm), gate/up
+    // reduces and applies SwiGLU.  The last layer's down projection keeps the finish launch (it also applies the stack's final norm).
+    // Measured (profiles/r03_negative_results.txt item 1): the b=64 step takes 5.57 ms with the seam against 4.99 ms without — a seam is four
+    // dependent memory round trips (drain, ticket, claim, slab loads: 3.5-6 us after the GEMM body) against a 4.8 us finish launch.  Off by
+    // default; Q3TTS_SEAM=1 turns it on (the A/B knob, and the path tests/test_gpu_b64.py runs in its seam round).
+    static const bool no_seam = !(getenv("Q3TTS_SEAM") && atoi(getenv("Q3TTS_SEAM")) != 0);
+    bool seam = false;
+    const int NTH = W.H / 64;
+    if (mfma && seam_step && !no_seam && slot_map == nullptr && M <= 128 && NTH <= 64 && NTH % 4 == 0) {
+        GemmArgs t1, t2, t3;
+        t1.seam = 1; t1.epi = EPI_SLAB; t1.M = M; t1.N = W.H; t1.K = AO; t1.ldo = W.H; t1.ldx = ldp; t1.sx = x; t1.sldx = ldx; t1.sgamma = W.layers[0].post_norm;
+        t1.ssq_out = ssq_a_d; t1.ssq_nt = NTH; t1.seam_cnt = seam_cnt_d; t1.oh = pl0h; t1.ol = pl0l; t1.ldp = ldp;
+        t3 = t1; t3.K = W.ffn;
+        t2.seam = 2; t2.epi = EPI_SLAB2; t2.M = M; t2.N = W.ffn; t2.K = W.H; t2.ldo = W.ffn; t2.ldx = ldp; t2.ssq_in = ssq_a_d; t2.ssq_in_nt = NTH;
+        t2.seam_cnt = seam_cnt_d; t2.oh = pl1h; t2.ol = pl1l; t2.ldp = ldp;
+        seam = gemm_seam_ok(t1, pick_ksplit(AO)) && gemm_seam_ok(t2, ks_q) && gemm_seam_ok(t3, pick_ksplit(W.ffn));
+    }
+    auto seam_counters = [&](int n_tiles) -> unsigned* {   // this launch's counter region
+        const size_t need = (size_t)n_tiles * 2 * 4;
+        if (seam_cnt_used + need > seam_cnt_words) throw Error("split-K seam: counter buffer too small for this step");
+        unsigned* p = seam_cnt_d + seam_cnt_used;
+        seam_cnt_used += need;
+        return p;
+    };
     if (mfma) // planes0 = RMSNorm(in_norm[0])(x)
         launch_finish(x, ldx, nullptr, 0, 0, 0, W.layers[0].in_norm, W.eps, M, W.H, pl0h, pl0l, ldp, nullptr, 0, stream);
     for (int l = 0; l < W.L; ++l) {
@@ -486,6 +520,7 @@ bool Engine::run_layers(const DecStack& W, float* x, int ldx, int nb, int n_new,
         AttnArgs a;
         a.qkv = qkv; a.ld_qkv = QKV; a.out = attn; a.ld_out = AO; a.kcache = W.kc; a.vcache = W.vc; a.kv_bf16 = W.kv_bf16; a.kv_round = W.kv_round;
         if (mfma) { a.qkv = qkv_slab_d; a.qkv_nslab = ks_q; a.qkv_slab_stride = (size_t)M * QKV; }
+        if (seam && l > 0) { a.ssq_in = ssq_b_d; a.ssq_nt = NTH; a.ssq_K = W.H; a.ssq_eps = W.eps; }   // planes0 came from the previous layer's down seam: gamma * x, 1 / rms deferred
         a.page_table = W.page_table; a.pages_per_slot = W.pages_per_slot; a.page_shift = W.page_shift; a.identity_pages = W.identity_pages;
         a.layer = l; a.n_layers = W.L; a.q_norm = w.q_norm; a.k_norm = w.k_norm; a.eps = W.eps;
         a.rope_cos = W.rope_cos; a.rope_sin = W.rope_sin; a.pos_dev = pos_dev; a.pos_scalar = pos_scalar;
@@ -512,16 +547,30 @@ bool Engine::run_layers(const DecStack& W, float* x, int ldx, int nb, int n_new,
             const int ks_o = pick_ksplit(AO), ks_d = pick_ksplit(W.ffn);
             GemmArgs o;
             o.W = w.o; o.xh = pl1h; o.xl = pl1l; o.ldx = ldp; o.out = slab_d; o.ldo = W.H; o.M = M; o.N = W.H; o.K = AO; o.epi = EPI_SLAB; o.nt = W.nt;
+            if (seam) {   // x += sum(slabs); planes0 = gamma(post_norm) * x; ssq_a = per-tile sums of squares of x
+                o.seam = 1; o.seam_cnt = seam_counters(W.H / 64); o.sx = x; o.sldx = ldx; o.sgamma = w.post_norm;
+                o.oh = pl0h; o.ol = pl0l; o.ldp = ldp; o.ssq_out = ssq_a_d; o.ssq_nt = NTH;
+            }
             launch_gemm2(o, ks_o, 4, stream);
             // x += sum(slabs); planes0 = RMSNorm(post_norm)(x)
-            launch_finish(x, ldx, slab_d, ks_o, (size_t)M * W.H, W.H, w.post_norm, W.eps, M, W.H, pl0h, pl0l, ldp, nullptr, 0, stream);
+            if (!seam) launch_finish(x, ldx, slab_d, ks_o, (size_t)M * W.H, W.H, w.post_norm, W.eps, M, W.H, pl0h, pl0l, ldp, nullptr, 0, stream);
             GemmArgs f; // gate and up as split-K slab pairs, SwiGLU applied by the finish kernel
             f.W = w.gate; f.W2 = w.up; f.xh = pl0h; f.xl = pl0l; f.ldx = ldp; f.out = gu_slab_d; f.out2 = gu_slab_d + (size_t)4 * rows_max * W.ffn; f.ldo = W.ffn;
             f.M = M; f.N = W.ffn; f.K = W.H; f.epi = EPI_SLAB2; f.nt = W.nt;
+            if (seam) {   // planes1 = SwiGLU of the slab sums scaled by 1 / rms(x) (from ssq_a)
+                f.seam = 2; f.seam_cnt = seam_counters(W.ffn / 64); f.oh = pl1h; f.ol = pl1l; f.ldp = ldp;
+                f.ssq_in = ssq_a_d; f.ssq_in_nt = NTH; f.seps = W.eps;
+            }
             launch_gemm2(f, ks_q, 4, stream);
-            launch_finish_swiglu(gu_slab_d, gu_slab_d + (size_t)4 * rows_max * W.ffn, ks_q, (size_t)M * W.ffn, M, W.ffn, pl1h, pl1l, ldp, stream);
+            if (!seam) launch_finish_swiglu(gu_slab_d, gu_slab_d + (size_t)4 * rows_max * W.ffn, ks_q, (size_t)M * W.ffn, M, W.ffn, pl1h, pl1l, ldp, stream);
             GemmArgs d;
             d.W = w.down; d.xh = pl1h; d.xl = pl1l; d.ldx = ldp; d.out = slab_d; d.ldo = W.H; d.M = M; d.N = W.H; d.K = W.ffn; d.epi = EPI_SLAB; d.nt = W.nt;
+            if (seam && l + 1 < W.L) {   // x += sum(slabs); planes0 = gamma(next input norm) * x; ssq_b for the next layer's attention
+                d.seam = 1; d.seam_cnt = seam_counters(W.H / 64); d.sx = x; d.sldx = ldx; d.sgamma = W.layers[l + 1].in_norm;
+                d.oh = pl0h; d.ol = pl0l; d.ldp = ldp; d.ssq_out = ssq_b_d; d.ssq_nt = NTH;
+                launch_gemm2(d, ks_d, 4, stream);
+                continue;
+            }
             launch_gemm2(d, ks_d, 4, stream);
             // x += sum(slabs); planes0 = RMSNorm(next layer's input norm | the stack's final norm)(x)
             const bool last = l + 1 == W.L;
@@ -802,6 +851,10 @@ void Engine::record_step(int nb) {
     // stage_profile(): events between the stages of the step (eager launches only)
     size_t mk = 0;
     auto mark = [&]() { if (!stage_ev.empty()) Q3_HIP_CHECK(hipEventRecord(stage_ev[mk++], stream)); };
+    // split-K seam counters of this step's GEMM launches: zeroed at the head of the step (a memset node of the captured graph)
+    struct SeamScope { Engine& e; explicit SeamScope(Engine& en) : e(en) { e.seam_step = true; e.seam_cnt_used = 0; } ~SeamScope() { e.seam_step = false; } } seam_scope(*this);
+    if (2 * nb >= mfma_min_rows && getenv("Q3TTS_SEAM") && atoi(getenv("Q3TTS_SEAM")) != 0)   // predictor pass 0 runs 2 nb rows: it may take the slab GEMMs from nb = 9 on
+        Q3_HIP_CHECK(hipMemsetAsync(seam_cnt_d, 0, seam_cnt_words * sizeof(unsigned), stream));
     mark();
     if (trace_d) launch_copy_rows(logits_t + (size_t)trace_slot * V, V, trace_d, trace_cols, 1, V, stream);
     launch_sample(s0, stream);                                  // code0 (tts_onnx.cpp:803-812)

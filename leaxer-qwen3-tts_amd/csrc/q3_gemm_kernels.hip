@@ -24,8 +24,13 @@ namespace q3 {
 __device__ long long g_gemm_prof[32];
 void gemm_prof_read(long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gemm_prof), sizeof(long long) * 32); }
 #define GP_MARK(cond, k) do { if ((cond) && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_gemm_prof[k] = wall_clock64(); } while (0)
+// split-K seam: every K-slice workgroup of column tile 0 / row block 0 stamps its own row [kind = 0 o_proj, 1 gate/up, 2 down][slice][mark]
+__device__ long long g_seam_prof[3][16][8];
+void seam_prof_read(long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_seam_prof), sizeof(long long) * 3 * 16 * 8); }
+#define SP_SEAM(k) do { if (blockIdx.x == 0 && blockIdx.z == 0 && threadIdx.x == 0) g_seam_prof[SEAM == 2 ? 1 : (gridDim.y > 8 ? 2 : 0)][blockIdx.y & 15][k] = wall_clock64(); } while (0)
 #else
 #define GP_MARK(cond, k) do { } while (0)
+#define SP_SEAM(k) do { } while (0)
 #endif
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -42,6 +47,13 @@ static __device__ __forceinline__ void split_store(float v, bf16_t* hi, bf16_t* 
     *lo = bf16_rne(v - __uint_as_float((uint32_t)h << 16)); // v - hi is exact in fp32
 }
 
+static __device__ __forceinline__ void split_store4(const float (&y)[4], bf16_t* hi, bf16_t* lo) {   // 4 values -> one 8-byte store per plane
+    bf16_t h[4], l[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { h[j] = bf16_rne(y[j]); l[j] = bf16_rne(y[j] - __uint_as_float((uint32_t)h[j] << 16)); }
+    *reinterpret_cast<uint2*>(hi) = make_uint2((uint32_t)h[0] | (uint32_t)h[1] << 16, (uint32_t)h[2] | (uint32_t)h[3] << 16);
+    *reinterpret_cast<uint2*>(lo) = make_uint2((uint32_t)l[0] | (uint32_t)l[1] << 16, (uint32_t)l[2] | (uint32_t)l[3] << 16);
+}
 // ================================================================================================
 // k_gemm2 — second-generation batched-decode GEMM.  Workgroup = (n-group of NW*16 columns, K slice):
 // its NW waves each own one 16-column tile and SHARE the activation slice, staged once per 128-wide
@@ -174,6 +186,7 @@ static void gemm2_epi(const GemmArgs& a, int ksplit, hipStream_t s) {
 }
 static bool gemm3_ok(const GemmArgs& a, int ksplit);                       // third generation of the slab GEMM, below
 static void launch_gemm3(const GemmArgs& a, int ksplit, hipStream_t s);
+static void launch_gemm3_seam(const GemmArgs& a, int ksplit, hipStream_t s);
 template <int MTILES>
 static void gemm2_nw(const GemmArgs& a, int ksplit, int nw, hipStream_t s) {
     if (nw == 2) gemm2_epi<MTILES, 2>(a, ksplit, s); else gemm2_epi<MTILES, 4>(a, ksplit, s);
@@ -193,6 +206,11 @@ void launch_gemm2(const GemmArgs& a0, int ksplit, int nw, hipStream_t s) {
         if (a0.out2) a.out2 = a0.out2 + (size_t)m0 * a0.ldo;
         if (a0.oh) { a.oh = a0.oh + (size_t)m0 * a0.ldp; a.ol = a0.ol + (size_t)m0 * a0.ldp; }
         if (a0.res) a.res = a0.res + (size_t)m0 * a0.ldres;
+        if (a.seam != 0) {   // the caller checked gemm_seam_ok: there is no finish launch behind this GEMM
+            if (a0.M > 128 || nw != 4 || !gemm_seam_ok(a, ksplit)) throw Error("gemm: split-K seam requested for a shape it does not cover");
+            launch_gemm3_seam(a, ksplit, s);
+            continue;
+        }
         if (nw == 4 && gemm3_ok(a, ksplit)) { launch_gemm3(a, ksplit, s); continue; }
         if (a.M <= 16) gemm2_nw<1>(a, ksplit, nw, s);
         else if (a.M <= 32) gemm2_nw<2>(a, ksplit, nw, s);
@@ -222,7 +240,10 @@ void launch_gemm2(const GemmArgs& a0, int ksplit, int nw, hipStream_t s) {
 #define G3_LD (G3_CH + 16)
 #define G3_LDE 68
 
-template <int MTILES, int EPI, int NCH, int LA, bool NT>
+#define G3_AUX_SC1 16      // raw-buffer cache policy: sc1 (agent scope: write-through stores, L1-bypassing loads)
+#define G3_SEAM_SPIN 256   // bounded wait of an early arriver for its tile's last slice (~30 us at worst; it then simply leaves)
+// SEAM / NS: the split-K seam (GemmArgs::seam), NS = slab registers of the reducer (>= the launch's K slices)
+template <int MTILES, int EPI, int NCH, int LA, bool NT, int SEAM = 0, int NS = 1>
 __global__ __launch_bounds__(256) void k_gemm3(const bf16_t* pW, const bf16_t* pW2, const bf16_t* pxh, const bf16_t* pxl, int pldx, int pM, int pN, int pK,
                                                 GemmArgs a) {   // leading scalars: kernarg-preloaded
     static_assert(EPI == EPI_SLAB || EPI == EPI_SLAB2, "k_gemm3 writes split-K slabs");
@@ -235,6 +256,7 @@ __global__ __launch_bounds__(256) void k_gemm3(const bf16_t* pW, const bf16_t* p
     const int n0 = (blockIdx.x * 4 + wave) * 16;
     const int K = pK, M = pM;
     const int kbeg = blockIdx.y * (NCH * G3_CH);
+    if constexpr (SEAM != 0) SP_SEAM(0);
     const int m0 = blockIdx.z * (MTILES * 16);   // row block (grid z): the rows may be cut over workgroups to halve each one's activation ingest
     // ring of two chunk buffers [plane][row][k]; the epilogue reuses the same bytes as a [row][64 + 4] fp32 tile (x 2 for the dual product)
     constexpr int XS_BYTES = 2 * 2 * ROWS * G3_LD * 2, EP_BYTES = (DUAL ? 2 : 1) * ROWS * G3_LDE * 4;
@@ -333,6 +355,100 @@ __global__ __launch_bounds__(256) void k_gemm3(const bf16_t* pW, const bf16_t* p
     __syncthreads();
     const int erow = tid >> 4, ecol = (tid & 15) * 4, ng = blockIdx.x * 64 + ecol;
     const size_t sbase = (size_t)blockIdx.y * a.slab_rows;
+    if constexpr (SEAM != 0) {
+        // ---- split-K seam (tools/microbench_seam.hip, variant C; MI355X guide, hand-off table row 1).  Slab tiles leave write-through
+        // (sc1), every wave drains its stores, the workgroup meets, ONE lane takes a ticket on the tile's counter.  Whoever finds the tile
+        // complete — the last arriver at once, an earlier one within a bounded wait — claims 16-row chunks of the reduction and sums the
+        // K slices in slab order (bit-reproducible) with sc1 loads.  An arriver whose wait runs out just leaves: the last arriver claims
+        // whatever is left, so every chunk is reduced exactly once whatever the placement or residency of the workgroups.
+        __shared__ unsigned seam_flag;
+        SP_SEAM(1);   // body done, tile in LDS
+        const size_t slab_bytes = (size_t)gridDim.y * a.slab_rows * a.ldo * sizeof(float);
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (int)slab_bytes, 0x00020000);
+        __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc(DUAL ? a.out2 : a.out, 0, (int)slab_bytes, 0x00020000);
+#pragma unroll
+        for (int p = 0; p < ROWS / 16; ++p) {
+            const int ml = erow + p * 16, m = m0 + ml;
+            const unsigned off = (unsigned)(((sbase + (m < M ? m : M - 1)) * a.ldo + ng) * sizeof(float));   // rows past M rewrite row M - 1 of this slice with its own value
+            const int mls = m < M ? ml : M - 1 - m0;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, *reinterpret_cast<const f32x4*>(&ep[0][mls][ecol])), rs, off, 0, G3_AUX_SC1);
+            if (DUAL) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, *reinterpret_cast<const f32x4*>(&ep[DUAL ? 1 : 0][mls][ecol])), rs2, off, 0, G3_AUX_SC1);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        SP_SEAM(2);   // slab tile written through and drained
+        const unsigned KS = gridDim.y;
+        unsigned* cnt = a.seam_cnt + ((size_t)blockIdx.z * gridDim.x + blockIdx.x) * 4;
+        if (tid == 0) {
+            const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned f = old + 1 == KS ? 1u : 0u;
+            if (!f)
+                for (int i = 0; i < G3_SEAM_SPIN; ++i) {
+                    if (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= KS) { f = 2u; break; }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+            seam_flag = f;
+        }
+        __syncthreads();
+        SP_SEAM(3);   // ticket taken, tile seen complete (or the wait ran out)
+        if (seam_flag == 0) return;
+        constexpr int NCHK = ROWS / 16;
+        const size_t slab_stride = (size_t)a.slab_rows * a.ldo * sizeof(float);
+        for (;;) {
+            __syncthreads();
+            if (tid == 0) seam_flag = __hip_atomic_fetch_add(cnt + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            const int chunk = (int)seam_flag;
+            SP_SEAM(4 + (chunk >= NCHK ? 2 : 0));   // 4: a chunk claimed (last one wins the stamp), 6: nothing left
+            if (chunk >= NCHK) return;
+            const int mr = m0 + chunk * 16 + erow;
+            const bool live = mr < M;
+            const int m = live ? mr : M - 1;                       // clamped: loads stay unconditional, stores are skipped
+            const unsigned off0 = (unsigned)(((size_t)m * a.ldo + ng) * sizeof(float));
+            u32x4 pp[NS], qq[DUAL ? NS : 1];
+#pragma unroll
+            for (int sidx = 0; sidx < NS; ++sidx) {
+                const unsigned so = off0 + (unsigned)((sidx < (int)KS ? sidx : (int)KS - 1) * slab_stride);
+                pp[sidx] = __builtin_amdgcn_raw_buffer_load_b128(rs, so, 0, G3_AUX_SC1);
+                if (DUAL) qq[DUAL ? sidx : 0] = __builtin_amdgcn_raw_buffer_load_b128(rs2, so, 0, G3_AUX_SC1);
+            }
+            if constexpr (SEAM == 1) {
+                float* xr = a.sx + (size_t)m * a.sldx + ng;
+                f32x4 t = *reinterpret_cast<const f32x4*>(xr);
+                const f32x4 g = *reinterpret_cast<const f32x4*>(a.sgamma + ng);
+#pragma unroll
+                for (int sidx = 0; sidx < NS; ++sidx) if (sidx < (int)KS) t += __builtin_bit_cast(f32x4, pp[sidx]);
+                float ss = 0.f;
+                ss = fmaf(t.x, t.x, ss); ss = fmaf(t.y, t.y, ss); ss = fmaf(t.z, t.z, ss); ss = fmaf(t.w, t.w, ss);
+                // the row's 16 lanes (64 columns) in a fixed butterfly order: deterministic
+                ss += __shfl_xor(ss, 1, 16); ss += __shfl_xor(ss, 2, 16); ss += __shfl_xor(ss, 4, 16); ss += __shfl_xor(ss, 8, 16);
+                if (live) {
+                    *reinterpret_cast<f32x4*>(xr) = t;
+                    const float y[4] = { g.x * t.x, g.y * t.y, g.z * t.z, g.w * t.w };
+                    split_store4(y, a.oh + (size_t)m * a.ldp + ng, a.ol + (size_t)m * a.ldp + ng);
+                    if ((tid & 15) == 0) a.ssq_out[(size_t)m * a.ssq_nt + blockIdx.x] = ss;
+                }
+            } else {
+                // row scale of the input planes: 1 / rms from the producer's per-tile partials, summed in tile order
+                float rsc = 1.0f;
+                if (a.ssq_in != nullptr) {
+                    const float* sq = a.ssq_in + (size_t)m * a.ssq_in_nt;
+                    float tot = 0.f;
+                    for (int t4 = 0; t4 < a.ssq_in_nt; t4 += 4) { const f32x4 v = *reinterpret_cast<const f32x4*>(sq + t4); tot += v.x; tot += v.y; tot += v.z; tot += v.w; }
+                    rsc = 1.0f / sqrtf(tot / (float)K + a.seps);
+                }
+                f32x4 gs = { 0.f, 0.f, 0.f, 0.f }, us = { 0.f, 0.f, 0.f, 0.f };
+#pragma unroll
+                for (int sidx = 0; sidx < NS; ++sidx) if (sidx < (int)KS) { gs += __builtin_bit_cast(f32x4, pp[sidx]); us += __builtin_bit_cast(f32x4, qq[DUAL ? sidx : 0]); }
+                gs *= rsc; us *= rsc;
+                if (live) {
+                    const float o[4] = { silu_g(gs.x) * us.x, silu_g(gs.y) * us.y, silu_g(gs.z) * us.z, silu_g(gs.w) * us.w };
+                    split_store4(o, a.oh + (size_t)m * a.ldp + ng, a.ol + (size_t)m * a.ldp + ng);
+                }
+            }
+            SP_SEAM(5);   // the chunk's sums are stored
+        }
+    }
 #pragma unroll
     for (int p = 0; p < ROWS / 16; ++p) {
         const int ml = erow + p * 16, m = m0 + ml;
@@ -348,6 +464,33 @@ __global__ __launch_bounds__(256) void k_gemm3(const bf16_t* pW, const bf16_t* p
                 else { dst2[0] = v2.x; if (ng + 1 < a.N) dst2[1] = v2.y; if (ng + 2 < a.N) dst2[2] = v2.z; }
             }
         }
+    }
+}
+
+// seam launches: the shapes the batched decode step produces (64 / 128 rows -> 32- / 64-row blocks, K slices of 256, N a multiple of 64)
+template <int MTILES, int EPI, int SEAM, int NS>
+static void gemm3_seam_go(const GemmArgs& a, int ksplit, hipStream_t s) {
+    const dim3 grid(a.N / 64, ksplit, (a.M + MTILES * 16 - 1) / (MTILES * 16)), block(256);
+    const int nch = a.K / ksplit / G3_CH;
+    if (nch == 4) hipLaunchKernelGGL((k_gemm3<MTILES, EPI, 4, 2, false, SEAM, NS>), grid, block, 0, s, a.W, a.W2, a.xh, a.xl, a.ldx, a.M, a.N, a.K, a);
+    else hipLaunchKernelGGL((k_gemm3<MTILES, EPI, 2, 2, false, SEAM, NS>), grid, block, 0, s, a.W, a.W2, a.xh, a.xl, a.ldx, a.M, a.N, a.K, a);
+}
+bool gemm_seam_ok(const GemmArgs& a, int ksplit) {
+    if (a.seam != 1 && a.seam != 2) return false;
+    if ((a.seam == 1) != (a.epi == EPI_SLAB) || (a.seam == 2) != (a.epi == EPI_SLAB2)) return false;
+    const int ksl = ksplit > 0 && a.K % ksplit == 0 ? a.K / ksplit : 0;
+    if (!(ksl == 128 || ksl == 256) || a.N % 64 != 0 || a.ldo % 4 != 0 || a.ldx % 8 != 0 || a.M < 17 || a.M > 128) return false;
+    if (a.seam == 1 && (ksplit > 12 || !a.sx || !a.sgamma || !a.ssq_out || a.ssq_nt != a.N / 64 || a.sldx % 4 != 0)) return false;
+    if (a.seam == 2 && (ksplit > 4 || (a.ssq_in && a.ssq_in_nt % 4 != 0))) return false;
+    return a.seam_cnt != nullptr && a.oh != nullptr && a.ol != nullptr && a.ldp % 4 == 0 && (a.slab_rows == 0 || a.slab_rows == a.M);
+}
+static void launch_gemm3_seam(const GemmArgs& a, int ksplit, hipStream_t s) {
+    const bool big = a.M > 64;   // 32-row blocks up to 64 rows, 64-row blocks beyond
+    if (a.seam == 1) {
+        if (ksplit <= 8) { if (big) gemm3_seam_go<4, EPI_SLAB, 1, 8>(a, ksplit, s); else gemm3_seam_go<2, EPI_SLAB, 1, 8>(a, ksplit, s); }
+        else { if (big) gemm3_seam_go<4, EPI_SLAB, 1, 12>(a, ksplit, s); else gemm3_seam_go<2, EPI_SLAB, 1, 12>(a, ksplit, s); }
+    } else {
+        if (big) gemm3_seam_go<4, EPI_SLAB2, 2, 4>(a, ksplit, s); else gemm3_seam_go<2, EPI_SLAB2, 2, 4>(a, ksplit, s);
     }
 }
 
@@ -598,13 +741,6 @@ void launch_gemv16(const GemvArgs& a, hipStream_t s) {
 
 // x[m][:] += sum_ks slab[ks][m][:] (fixed order), then RMSNorm(gamma) -> (hi, lo) planes (+ optional fp32 rows).
 // One workgroup per row.  nslab == 0: plain RMSNorm + split.  gamma == null: residual update only.
-static __device__ __forceinline__ void split_store4(const float (&y)[4], bf16_t* hi, bf16_t* lo) {   // 4 values -> one 8-byte store per plane
-    bf16_t h[4], l[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { h[j] = bf16_rne(y[j]); l[j] = bf16_rne(y[j] - __uint_as_float((uint32_t)h[j] << 16)); }
-    *reinterpret_cast<uint2*>(hi) = make_uint2((uint32_t)h[0] | (uint32_t)h[1] << 16, (uint32_t)h[2] | (uint32_t)h[3] << 16);
-    *reinterpret_cast<uint2*>(lo) = make_uint2((uint32_t)l[0] | (uint32_t)l[1] << 16, (uint32_t)l[2] | (uint32_t)l[3] << 16);
-}
 static __device__ __forceinline__ float wave_sum_dpp(float v) {   // DPP path (see q3_decode_kernels.hip); __shfl_xor costs an LDS round trip per step
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));

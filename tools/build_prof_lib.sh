@@ -19,7 +19,8 @@ hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -DQ3_SAMPLE_P
 fi
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -DQ3_SAMPLE_PROF -mllvm -amdgpu-kernarg-preload-count=16 -x hip -c "$ROOT/leaxer-qwen3-tts_amd/csrc/q3_gemm_kernels.hip" -o gk_prof.o
 cat > prof_api.cpp <<'EOC'
-namespace q3 { void sample_prof_read(long long* out); void conv_prof_read(long long* out); void gemm_prof_read(long long* out); }
+namespace q3 { void sample_prof_read(long long* out); void conv_prof_read(long long* out); void gemm_prof_read(long long* out); void seam_prof_read(long long* out); }
+extern "C" void q3_seam_prof(long long* out) { q3::seam_prof_read(out); }
 extern "C" void q3_kernel_prof(long long* out) { q3::sample_prof_read(out); }
 extern "C" void q3_conv_prof(long long* out) { q3::conv_prof_read(out); }
 extern "C" void q3_gemm_prof(long long* out) { q3::gemm_prof_read(out); }
