@@ -144,12 +144,13 @@ struct GemmArgs {
     int slab_rows = 0;   // EPI_SLAB / EPI_SLAB2: rows per slab (0 = M); launch_gemm2 sets it when it cuts M into 128-row blocks
     bool nt = false;     // non-temporal weight loads (weights this step reads once: the talker's)
     // ---- split-K seam (k_gemm3 only): the slabs are reduced INSIDE the launch by the K-slice workgroups of a column tile themselves
-    // (sc1 slab stores, arrival ticket, the arrivers that see the tile complete claim 16-row chunks), instead of by a k_finish* launch.
+    // (sc1 slab stores, a flag per slice, slice s < 16-row-chunk count owns chunk s once every flag is set), instead of by a k_finish* launch.
     // seam 1: x += sum(slabs); planes = split(gamma * x) — NOT normalised: the consumer applies 1/rms from the per-(row, tile) sums of
     //         squares written to ssq_out (deferred RMSNorm, as k_gemv16 does);
     // seam 2: planes = split(silu(r * sum(gate slabs)) * (r * sum(up slabs))), r = 1/rms of the INPUT planes' rows from ssq_in.
     int seam = 0;
-    unsigned* seam_cnt = nullptr;                    // 4 words per (column tile, row block): arrivals, chunk claims; zeroed before the launch
+    unsigned* seam_cnt = nullptr;                    // one 64-byte line per (column tile, row block): words 0..11 slice flags, 12..15 abandoned-chunk marks; zeroed before the launch
+    int seam_spin = 4096;                            // polls an owner makes before it abandons its chunk (~0.7 us each)
     float* sx = nullptr; int sldx = 0;               // seam 1: residual stream rows, updated in place
     const float* sgamma = nullptr;                   // seam 1: the consumer's RMSNorm gain
     float* ssq_out = nullptr; int ssq_nt = 0;        // seam 1: [M][ssq_nt] partial sums of squares, one per 64-column tile

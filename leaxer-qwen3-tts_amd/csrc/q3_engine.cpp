@@ -177,6 +177,8 @@ Engine::Engine(const q3tts_config& cfg, int device_, int max_batch, int max_ctx_
     // Q3TTS_NULL_STREAM=1 (profiling aid): rocprofv3 --pmc crashes on user-created streams on this ROCm; run on the
     // default stream instead (forces eager launches: the default stream cannot be captured)
     if (const char* mr = getenv("Q3TTS_MFMA_MIN_ROWS")) mfma_min_rows = std::max(3, atoi(mr));   // A/B knob for the GEMV <-> GEMM crossover
+    if (const char* sv = getenv("Q3TTS_SEAM")) seam_on = atoi(sv) != 0;
+    if (const char* sv = getenv("Q3TTS_SEAM_SPIN")) seam_spin = std::max(1, atoi(sv));
     null_stream = getenv("Q3TTS_NULL_STREAM") && getenv("Q3TTS_NULL_STREAM")[0] == '1';
     if (null_stream) { stream = nullptr; flags |= Q3TTS_FLAG_NO_GRAPH; }
     else if (const char* cm = getenv("Q3TTS_STREAM_CU_MASK")) {   // experiment aid (tools/overlap_probe.py): this engine's stream on a subset of the CUs;
@@ -255,8 +257,8 @@ Engine::Engine(const q3tts_config& cfg, int device_, int max_batch, int max_ctx_
     pl1h = (bf16_t*)dmalloc((size_t)rows_max * ldp * 2); pl1l = (bf16_t*)dmalloc((size_t)rows_max * ldp * 2);
     slab_d = fm((size_t)16 * rows_max * H);
     qkv_slab_d = fm((size_t)4 * rows_max * std::max(QKV, QKVp));
-    {   // seam counters: <= 3 seam launches per layer pass, <= (ffn / 64) x 2 row blocks units of 4 words each
-        const size_t per_launch = (size_t)(std::max(std::max(c.ffn, c.cp_ffn), H) / 64 + 1) * 2 * 4;
+    {   // seam flag lines: <= 3 seam launches per layer pass, <= (ffn / 64) x 2 row blocks units of 16 words (one 64-byte line) each
+        const size_t per_launch = (size_t)(std::max(std::max(c.ffn, c.cp_ffn), H) / 64 + 1) * 2 * 16;
         const size_t launches = (size_t)3 * ((size_t)c.n_layers + (size_t)(c.n_groups - 1) * c.cp_layers) + 8;
         seam_cnt_words = per_launch * launches;
         seam_cnt_d = (unsigned*)dmalloc(seam_cnt_words * sizeof(unsigned));
@@ -460,10 +462,9 @@ bool Engine::run_layers(const DecStack& W, float* x, int ldx, int nb, int n_new,
     // Split-K seam (decode step only): the three finish launches of a layer pass fold into their GEMMs — o_proj and down reduce their
     // slabs in-launch and leave gamma * x planes plus per-tile sums of squares (the consumer applies 1 / rms: deferred RMSNorm), gate/up
     // reduces and applies SwiGLU.  The last layer's down projection keeps the finish launch (it also applies the stack's final norm).
-    // Measured (profiles/r03_negative_results.txt item 1): the b=64 step takes 5.57 ms with the seam against 4.99 ms without — a seam is four
-    // dependent memory round trips (drain, ticket, claim, slab loads: 3.5-6 us after the GEMM body) against a 4.8 us finish launch.  Off by
-    // default; Q3TTS_SEAM=1 turns it on (the A/B knob, and the path tests/test_gpu_b64.py runs in its seam round).
-    static const bool no_seam = !(getenv("Q3TTS_SEAM") && atoi(getenv("Q3TTS_SEAM")) != 0);
+    // Measured, b=64 step: 4.97 ms with the finish launches, 4.77 ms with this seam (flag line + static chunk owners); a first protocol with
+    // an arrival ticket and a claim counter — two returning atomics on the critical path — took 5.57 ms (profiles/r03_negative_results.txt).
+    const bool no_seam = !seam_on;
     bool seam = false;
     const int NTH = W.H / 64;
     if (mfma && seam_step && !no_seam && slot_map == nullptr && M <= 128 && NTH <= 64 && NTH % 4 == 0) {
@@ -476,7 +477,7 @@ bool Engine::run_layers(const DecStack& W, float* x, int ldx, int nb, int n_new,
         seam = gemm_seam_ok(t1, pick_ksplit(AO)) && gemm_seam_ok(t2, ks_q) && gemm_seam_ok(t3, pick_ksplit(W.ffn));
     }
     auto seam_counters = [&](int n_tiles) -> unsigned* {   // this launch's counter region
-        const size_t need = (size_t)n_tiles * 2 * 4;
+        const size_t need = (size_t)n_tiles * 2 * 16;
         if (seam_cnt_used + need > seam_cnt_words) throw Error("split-K seam: counter buffer too small for this step");
         unsigned* p = seam_cnt_d + seam_cnt_used;
         seam_cnt_used += need;
@@ -548,7 +549,7 @@ bool Engine::run_layers(const DecStack& W, float* x, int ldx, int nb, int n_new,
             GemmArgs o;
             o.W = w.o; o.xh = pl1h; o.xl = pl1l; o.ldx = ldp; o.out = slab_d; o.ldo = W.H; o.M = M; o.N = W.H; o.K = AO; o.epi = EPI_SLAB; o.nt = W.nt;
             if (seam) {   // x += sum(slabs); planes0 = gamma(post_norm) * x; ssq_a = per-tile sums of squares of x
-                o.seam = 1; o.seam_cnt = seam_counters(W.H / 64); o.sx = x; o.sldx = ldx; o.sgamma = w.post_norm;
+                o.seam = 1; o.seam_spin = seam_spin; o.seam_cnt = seam_counters(W.H / 64); o.sx = x; o.sldx = ldx; o.sgamma = w.post_norm;
                 o.oh = pl0h; o.ol = pl0l; o.ldp = ldp; o.ssq_out = ssq_a_d; o.ssq_nt = NTH;
             }
             launch_gemm2(o, ks_o, 4, stream);
@@ -558,7 +559,7 @@ bool Engine::run_layers(const DecStack& W, float* x, int ldx, int nb, int n_new,
             f.W = w.gate; f.W2 = w.up; f.xh = pl0h; f.xl = pl0l; f.ldx = ldp; f.out = gu_slab_d; f.out2 = gu_slab_d + (size_t)4 * rows_max * W.ffn; f.ldo = W.ffn;
             f.M = M; f.N = W.ffn; f.K = W.H; f.epi = EPI_SLAB2; f.nt = W.nt;
             if (seam) {   // planes1 = SwiGLU of the slab sums scaled by 1 / rms(x) (from ssq_a)
-                f.seam = 2; f.seam_cnt = seam_counters(W.ffn / 64); f.oh = pl1h; f.ol = pl1l; f.ldp = ldp;
+                f.seam = 2; f.seam_spin = seam_spin; f.seam_cnt = seam_counters(W.ffn / 64); f.oh = pl1h; f.ol = pl1l; f.ldp = ldp;
                 f.ssq_in = ssq_a_d; f.ssq_in_nt = NTH; f.seps = W.eps;
             }
             launch_gemm2(f, ks_q, 4, stream);
@@ -566,7 +567,7 @@ bool Engine::run_layers(const DecStack& W, float* x, int ldx, int nb, int n_new,
             GemmArgs d;
             d.W = w.down; d.xh = pl1h; d.xl = pl1l; d.ldx = ldp; d.out = slab_d; d.ldo = W.H; d.M = M; d.N = W.H; d.K = W.ffn; d.epi = EPI_SLAB; d.nt = W.nt;
             if (seam && l + 1 < W.L) {   // x += sum(slabs); planes0 = gamma(next input norm) * x; ssq_b for the next layer's attention
-                d.seam = 1; d.seam_cnt = seam_counters(W.H / 64); d.sx = x; d.sldx = ldx; d.sgamma = W.layers[l + 1].in_norm;
+                d.seam = 1; d.seam_spin = seam_spin; d.seam_cnt = seam_counters(W.H / 64); d.sx = x; d.sldx = ldx; d.sgamma = W.layers[l + 1].in_norm;
                 d.oh = pl0h; d.ol = pl0l; d.ldp = ldp; d.ssq_out = ssq_b_d; d.ssq_nt = NTH;
                 launch_gemm2(d, ks_d, 4, stream);
                 continue;
@@ -853,7 +854,7 @@ void Engine::record_step(int nb) {
     auto mark = [&]() { if (!stage_ev.empty()) Q3_HIP_CHECK(hipEventRecord(stage_ev[mk++], stream)); };
     // split-K seam counters of this step's GEMM launches: zeroed at the head of the step (a memset node of the captured graph)
     struct SeamScope { Engine& e; explicit SeamScope(Engine& en) : e(en) { e.seam_step = true; e.seam_cnt_used = 0; } ~SeamScope() { e.seam_step = false; } } seam_scope(*this);
-    if (2 * nb >= mfma_min_rows && getenv("Q3TTS_SEAM") && atoi(getenv("Q3TTS_SEAM")) != 0)   // predictor pass 0 runs 2 nb rows: it may take the slab GEMMs from nb = 9 on
+    if (2 * nb >= mfma_min_rows && seam_on)   // predictor pass 0 runs 2 nb rows: it may take the slab GEMMs from nb = 9 on
         Q3_HIP_CHECK(hipMemsetAsync(seam_cnt_d, 0, seam_cnt_words * sizeof(unsigned), stream));
     mark();
     if (trace_d) launch_copy_rows(logits_t + (size_t)trace_slot * V, V, trace_d, trace_cols, 1, V, stream);

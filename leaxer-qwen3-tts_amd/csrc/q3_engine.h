@@ -199,6 +199,8 @@ public:
     unsigned* seam_cnt_d = nullptr; size_t seam_cnt_words = 0, seam_cnt_used = 0;
     float *ssq_a_d = nullptr, *ssq_b_d = nullptr;
     bool seam_step = false;      // inside record_step: run_layers may fold the finish launches into the GEMMs
+    bool seam_on = true;         // Q3TTS_SEAM=0 at engine creation keeps the finish launches (the A/B knob and the tests' second path)
+    int seam_spin = 4096;        // Q3TTS_SEAM_SPIN: polls before an owner abandons its chunk (1 forces the rescue path in the tests)
     int32_t* codes_d = nullptr;
     int32_t* codes_scratch_d = nullptr;
     int32_t* talker_pos_d = nullptr;

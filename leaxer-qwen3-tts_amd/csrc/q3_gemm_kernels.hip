@@ -241,7 +241,6 @@ void launch_gemm2(const GemmArgs& a0, int ksplit, int nw, hipStream_t s) {
 #define G3_LDE 68
 
 #define G3_AUX_SC1 16      // raw-buffer cache policy: sc1 (agent scope: write-through stores, L1-bypassing loads)
-#define G3_SEAM_SPIN 256   // bounded wait of an early arriver for its tile's last slice (~30 us at worst; it then simply leaves)
 // SEAM / NS: the split-K seam (GemmArgs::seam), NS = slab registers of the reducer (>= the launch's K slices)
 template <int MTILES, int EPI, int NCH, int LA, bool NT, int SEAM = 0, int NS = 1>
 __global__ __launch_bounds__(256) void k_gemm3(const bf16_t* pW, const bf16_t* pW2, const bf16_t* pxh, const bf16_t* pxl, int pldx, int pM, int pN, int pK,
@@ -377,30 +376,60 @@ __global__ __launch_bounds__(256) void k_gemm3(const bf16_t* pW, const bf16_t* p
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         SP_SEAM(2);   // slab tile written through and drained
+        // Second protocol (the first one — arrival ticket + claim counter, two RETURNING atomics of 0.7-2 us each on the critical path —
+        // lost to the finish launch: profiles/r03_negative_results.txt item 1).  No returning atomic on the fast path: every slice sets its
+        // word of the unit's 64-byte line (sc1 store behind the drain); slice s < NCHK OWNS chunk s and polls the line (one sc1 load per
+        // poll) until all KS words are set, then reduces.  Liveness does not rest on co-residency: an owner whose bounded wait runs out
+        // marks its chunk abandoned (words 12..15) and leaves; whoever later observes the line complete — the late slice itself, after
+        // its own flag store — takes abandoned chunks by compare-and-swap (1 -> 2), the owner included after one last look (the two
+        // orders of {mark, last flag} are both covered because each side's store is acknowledged before its load is issued).
         const unsigned KS = gridDim.y;
-        unsigned* cnt = a.seam_cnt + ((size_t)blockIdx.z * gridDim.x + blockIdx.x) * 4;
-        if (tid == 0) {
-            const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            unsigned f = old + 1 == KS ? 1u : 0u;
-            if (!f)
-                for (int i = 0; i < G3_SEAM_SPIN; ++i) {
-                    if (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= KS) { f = 2u; break; }
-                    __builtin_amdgcn_s_sleep(2);
+        constexpr int NCHK = ROWS / 16;
+        unsigned* line = a.seam_cnt + ((size_t)blockIdx.z * gridDim.x + blockIdx.x) * 16;
+        const int mine = (int)blockIdx.y < NCHK ? (int)blockIdx.y : -1;
+        if (wave == 0) {
+            if (lane == 0) __hip_atomic_store(line + blockIdx.y, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // an owner polls at once (its own word counts as set: only the others' are awaited); everybody else looks once, AFTER its flag
+            // store is acknowledged (the rescue protocol's store -> load order)
+            if (mine < 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            auto look = [&](unsigned& marks) -> bool {   // one sc1 load of the line: all slices in? which chunks are abandoned?
+                const unsigned v = __hip_atomic_load(line + (lane & 15), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long in = __ballot((lane < (int)KS && lane != (int)blockIdx.y) ? v != 0u : true);
+                const unsigned long long ab = __ballot(lane >= 12 && lane < 16 && v == 1u);
+                marks = (unsigned)(ab >> 12) & 0xFu;
+                return in == ~0ull;
+            };
+            unsigned take = 0, marks = 0;     // bit c: this workgroup reduces chunk c
+            bool complete = false;
+            const int spins = mine >= 0 ? a.seam_spin : 1;
+            for (int i = 0; i < spins && !complete; ++i) complete = look(marks);
+            if (mine >= 0) {
+                if (complete) take |= 1u << mine;
+                else {
+                    if (lane == 0) __hip_atomic_exchange(line + 12 + mine, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    complete = look(marks);
                 }
-            seam_flag = f;
+            }
+            if (complete && marks) {          // rescue abandoned chunks (never on a chip that runs the whole grid at once)
+                for (int c = 0; c < NCHK; ++c)
+                    if (marks >> c & 1u) {
+                        unsigned won = 0;
+                        if (lane == 0) { unsigned expect = 1u; won = __hip_atomic_compare_exchange_strong(line + 12 + c, &expect, 2u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1u : 0u; }
+                        won = __builtin_amdgcn_readfirstlane(won);
+                        if (won) take |= 1u << c;
+                    }
+            }
+            if (lane == 0) seam_flag = take;
         }
         __syncthreads();
-        SP_SEAM(3);   // ticket taken, tile seen complete (or the wait ran out)
-        if (seam_flag == 0) return;
-        constexpr int NCHK = ROWS / 16;
+        SP_SEAM(3);   // tile seen complete (or the wait ran out)
+        const unsigned take_all = seam_flag;
+        if (take_all == 0) return;
         const size_t slab_stride = (size_t)a.slab_rows * a.ldo * sizeof(float);
-        for (;;) {
-            __syncthreads();
-            if (tid == 0) seam_flag = __hip_atomic_fetch_add(cnt + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __syncthreads();
-            const int chunk = (int)seam_flag;
-            SP_SEAM(4 + (chunk >= NCHK ? 2 : 0));   // 4: a chunk claimed (last one wins the stamp), 6: nothing left
-            if (chunk >= NCHK) return;
+        for (int chunk = 0; chunk < NCHK; ++chunk) {
+            if (!(take_all >> chunk & 1u)) continue;
+            SP_SEAM(4);
             const int mr = m0 + chunk * 16 + erow;
             const bool live = mr < M;
             const int m = live ? mr : M - 1;                       // clamped: loads stay unconditional, stores are skipped
@@ -448,6 +477,7 @@ __global__ __launch_bounds__(256) void k_gemm3(const bf16_t* pW, const bf16_t* p
             }
             SP_SEAM(5);   // the chunk's sums are stored
         }
+        return;
     }
 #pragma unroll
     for (int p = 0; p < ROWS / 16; ++p) {

@@ -14,13 +14,24 @@ pytestmark = pytest.mark.gpu
 CHECK = (0, 16, 17, 31, 63)     # oracle cost: a spread of utterances, both sides of the 16/17-row kernel switch
 
 
-@pytest.fixture(scope="module", params=["fp32kv", "bf16kv"])
+@pytest.fixture(scope="module", params=["fp32kv", "bf16kv", "finish-launches", "seam-rescue"])
 def wide(request):
-    """64 slots at 0.6B dims; second round with the talker KV cache in bf16 (Q3TTS_FLAG_KV_BF16) and the oracle in the same mode."""
+    """64 slots at 0.6B dims.  Rounds: the default engine (split-K seam inside k_gemm3: the slab GEMMs reduce their own slabs, deferred
+    RMSNorm); the talker KV cache in bf16 (Q3TTS_FLAG_KV_BF16, oracle in the same mode); Q3TTS_SEAM=0, the k_finish* launches the seam
+    replaces; Q3TTS_SEAM_SPIN=1, every chunk owner gives up after one look, so the abandon / compare-and-swap rescue path of the seam
+    produces the planes (a path a chip that runs the whole grid at once never takes)."""
+    import os
     import q3tts
     cfg = q3tts.default_config("0.6b")
     bf = request.param == "bf16kv"
-    eng = q3tts.Engine(cfg, device=0, max_batch=64, max_ctx=64, flags=q3tts.FLAG_KV_BF16 if bf else 0)
+    env = {"finish-launches": {"Q3TTS_SEAM": "0"}, "seam-rescue": {"Q3TTS_SEAM_SPIN": "1"}}.get(request.param, {})
+    os.environ.update(env)             # read at engine creation
+    try:
+        eng = q3tts.Engine(cfg, device=0, max_batch=64, max_ctx=64, flags=q3tts.FLAG_KV_BF16 if bf else 0)
+    finally:
+        for k in env:
+            del os.environ[k]
+    eng.creation_env = env
     eng.fill_synthetic(seed=0)
     eng.margin_noise = 2e-2 if bf else 2e-4     # tests/test_gpu_full.py, bf16 KV note: what logit agreement this cache mode can honour
     eng.logit_bound = 2e-2 if bf else 2e-4
@@ -127,6 +138,7 @@ def test_gemm3_slabs_are_bit_identical_to_gemm2(wide):
     _, codes3, _ = eng.synthesize_batch(toks, sp, seed=21, ignore_eos=True)
     lg3 = [eng.slot_logits(u) for u in (0, 17, 63)]
     os.environ["Q3TTS_GEMM2"] = "1"
+    os.environ.update(eng.creation_env)     # the twin engine runs the same round (seam / finish launches) as the fixture's
     try:
         e2 = q3tts.Engine(eng.cfg, device=0, max_batch=64, max_ctx=64, flags=eng.flags)     # a fresh engine: its step graph is captured with the old kernel
         e2.fill_synthetic(seed=0)
@@ -135,6 +147,8 @@ def test_gemm3_slabs_are_bit_identical_to_gemm2(wide):
         e2.close()
     finally:
         del os.environ["Q3TTS_GEMM2"]
+        for k in eng.creation_env:
+            del os.environ[k]
     for u in range(64):
         assert np.array_equal(codes3[u], codes2[u]), u
     for (a, ah), (b, bh) in zip(lg3, lg2):
