@@ -1561,13 +1561,14 @@ static __device__ __forceinline__ float kth_largest_of_lanes(float v, int k) {
 // Four waves per utterance: wave w owns the 64-element slices j = w, w+4, ... of the logits row (registers),
 // the few cross-wave hand-offs go through LDS; the serial tail (threshold rounds, top-p, draw) runs on wave 0
 // only, the embedding epilogue on all 256 threads.
-#define SAMP_PERW (SAMP_MAXV / 256)
+// PW = 64-element slices per wave: 16 covers 4096 logits; 8 (vocabularies up to 2048: fifteen of a frame's sixteen samplers) and 12 (up to
+// 3072: the code0 sampler) halve / trim every per-element loop — loads, suppression, the temperature division, survivor scans
 #ifdef Q3_SAMPLE_PROF
 #define SP_MARK(k) do { if (threadIdx.x == 0) g_kernel_prof[k] = wall_clock64(); } while (0)
 #else
 #define SP_MARK(k) do { } while (0)
 #endif
-template <bool SLABS>   // SLABS: the logits row is the ordered sum of a.nslab (<= 4) split-K partial slabs of the head projection
+template <bool SLABS, int PW>   // SLABS: the logits row is the ordered sum of a.nslab (<= 4) split-K partial slabs of the head projection
 __global__ __launch_bounds__(256) void k_sample(const float* plogits, SlotState* pst, int pld, int pV, SampleArgs a) {   // leading scalars: preloaded (see k_gemv1)
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1599,18 +1600,18 @@ __global__ __launch_bounds__(256) void k_sample(const float* plogits, SlotState*
     }
     const float* lg = plogits + (size_t)b * pld;
     const int PER = (V + 63) / 64;               // 64-element slices in the row
-    float x[SAMP_PERW];
+    float x[PW];
     if (SLABS) {   // every load first (clamped slab index: a load under a runtime condition is a serial round trip), then the sums in slab order
-        float xp[SAMP_PERW][4];
+        float xp[PW][4];
 #pragma unroll
-        for (int jj = 0; jj < SAMP_PERW; ++jj) {
+        for (int jj = 0; jj < PW; ++jj) {
             const int i = (jj * 4 + wave) * 64 + lane;
 #pragma unroll
             for (int sb = 0; sb < 4; ++sb) xp[jj][sb] = lg[(size_t)(sb < a.nslab ? sb : 0) * a.slab_stride + (i < V ? i : V - 1)];
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int jj = 0; jj < SAMP_PERW; ++jj) {
+        for (int jj = 0; jj < PW; ++jj) {
             float t = xp[jj][0];
 #pragma unroll
             for (int sb = 1; sb < 4; ++sb) t = sb < a.nslab ? t + xp[jj][sb] : t;
@@ -1618,7 +1619,7 @@ __global__ __launch_bounds__(256) void k_sample(const float* plogits, SlotState*
         }
     } else {
 #pragma unroll
-        for (int jj = 0; jj < SAMP_PERW; ++jj) {
+        for (int jj = 0; jj < PW; ++jj) {
             const int i = (jj * 4 + wave) * 64 + lane;
             x[jj] = lg[i < V ? i : V - 1];           // clamped, unconditional
         }
@@ -1640,7 +1641,7 @@ __global__ __launch_bounds__(256) void k_sample(const float* plogits, SlotState*
     const bool use_temp = temperature > 0.0f && temperature != 1.0f;
     float lmax = -INFINITY;
 #pragma unroll
-    for (int jj = 0; jj < SAMP_PERW; ++jj) {
+    for (int jj = 0; jj < PW; ++jj) {
         const int i = (jj * 4 + wave) * 64 + lane;
         float v = x[jj];
         const bool sup = suppress && i >= a.sup_begin && i < a.sup_end && !(i == a.eos_id && keep_eos);
@@ -1667,7 +1668,7 @@ __global__ __launch_bounds__(256) void k_sample(const float* plogits, SlotState*
         SP_MARK(3);
         int nw = 0;
 #pragma unroll
-        for (int jj = 0; jj < SAMP_PERW; ++jj) {
+        for (int jj = 0; jj < PW; ++jj) {
             const bool sv = x[jj] >= B && x[jj] != -INFINITY;
             const unsigned long long m = __ballot(sv);
             const int ppos = nw + __popcll(m & lt_mask);
@@ -1722,7 +1723,7 @@ __global__ __launch_bounds__(256) void k_sample(const float* plogits, SlotState*
                 SP_MARK(3);
                 int nw = 0;
     #pragma unroll
-                for (int jj = 0; jj < SAMP_PERW; ++jj) {
+                for (int jj = 0; jj < PW; ++jj) {
                     const bool sv = x[jj] >= L1 && x[jj] != -INFINITY;
                     const unsigned long long m = __ballot(sv);
                     const int ppos = nw + __popcll(m & lt_mask);
@@ -1779,7 +1780,7 @@ __global__ __launch_bounds__(256) void k_sample(const float* plogits, SlotState*
                     const uint32_t cand = prefix | (1u << bit);
                     int c = 0;
     #pragma unroll
-                    for (int jj = 0; jj < SAMP_PERW; ++jj) c += ((jj * 4 + wave) * 64 + lane < V && fkey(x[jj]) >= cand) ? 1 : 0;
+                    for (int jj = 0; jj < PW; ++jj) c += ((jj * 4 + wave) * 64 + lane < V && fkey(x[jj]) >= cand) ? 1 : 0;
                     c = wave_sum_i(c);
                     __syncthreads();
                     if (lane == 0) svn[wave] = c;
@@ -1792,9 +1793,9 @@ __global__ __launch_bounds__(256) void k_sample(const float* plogits, SlotState*
         }
 
         // ---- index-ordered compaction of the kept entries; softmax numerators exp(x - max) (:907-915) ----
-        unsigned long long km[SAMP_PERW];
+        unsigned long long km[PW];
     #pragma unroll
-        for (int jj = 0; jj < SAMP_PERW; ++jj) {
+        for (int jj = 0; jj < PW; ++jj) {
             const bool keep = x[jj] >= thr && x[jj] != -INFINITY;
             km[jj] = __ballot(keep);
             const int j = jj * 4 + wave;
@@ -1806,7 +1807,7 @@ __global__ __launch_bounds__(256) void k_sample(const float* plogits, SlotState*
         const int cincl = wave_scan_incl_i(cmine);
         const int n_kept = lane_bcast_i(cincl, 63);
     #pragma unroll
-        for (int jj = 0; jj < SAMP_PERW; ++jj) {
+        for (int jj = 0; jj < PW; ++jj) {
             const int j = jj * 4 + wave;
             if (km[jj]) { // wave-uniform: most slices hold no survivor
                 const int base = lane_bcast_i(cincl, j) - lane_bcast_i(cmine, j);
@@ -1922,8 +1923,10 @@ __global__ __launch_bounds__(256) void k_sample(const float* plogits, SlotState*
 void launch_sample(const SampleArgs& a, hipStream_t s) {
     if (a.V > SAMP_MAXV) throw Error("sample: vocabulary larger than 4096");
     if (a.nslab < 1 || a.nslab > 4) throw Error("sample: 1..4 logits slabs");
-    if (a.nslab > 1) hipLaunchKernelGGL(k_sample<true>, dim3(a.nb), dim3(256), 0, s, a.logits, a.st, a.ld, a.V, a);
-    else hipLaunchKernelGGL(k_sample<false>, dim3(a.nb), dim3(256), 0, s, a.logits, a.st, a.ld, a.V, a);
+#define Q3_SAMP(SL, PW_) hipLaunchKernelGGL((k_sample<SL, PW_>), dim3(a.nb), dim3(256), 0, s, a.logits, a.st, a.ld, a.V, a)
+    if (a.nslab > 1) { if (a.V <= 2048) Q3_SAMP(true, 8); else if (a.V <= 3072) Q3_SAMP(true, 12); else Q3_SAMP(true, 16); }
+    else { if (a.V <= 2048) Q3_SAMP(false, 8); else if (a.V <= 3072) Q3_SAMP(false, 12); else Q3_SAMP(false, 16); }
+#undef Q3_SAMP
 }
 
 // ================================================================================================
