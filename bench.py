@@ -9,9 +9,12 @@ talker prefill, F frames of [sampler + 15 code-predictor passes + talker decode]
 hipGraph, then the 12 Hz codec decode to 24 kHz PCM.  Default workload = BASELINE.json configs[1]:
 0.6B, batch 1, sampled (temp 0.8 / top-k 50 / top-p 0.95), max-tokens 2048, 16-token prompt; weights
 are seeded synthetic (no checkpoint in the image), EOS is suppressed so every utterance runs the full
-2048 frames (random weights never learnt to stop).  The default line also carries the other half of
-the metric as the sub-record "b64": configs[2] (64 utterances in one batch, 256 frames each), run in
-the same process after the timed region of `value`.
+2048 frames (random weights never learnt to stop).  The default line also carries the rest of the
+metric ("0.6B @ b1/b64", north_star "batch 1/8/64") as sub-records run in the same process after the
+timed region of `value`: "b64" = configs[2] (64 utterances in one batch x 256 frames, 5 timed steps),
+"b8", "b64_f2048" (64 x 2048 frames: the length configs[1] and the reference default state), and the
+same long workloads with the talker KV cache in bf16 ("b64_f2048_kv_bf16", "b1_f2048_kv_bf16"), each
+with its own `roofline`.
 
 Multi-GPU (configs[3]): utterances are independent, each rank runs its own batch on its own GPU
 (weak scaling); RCCL carries only the final gather of codes + PCM lengths.  `--gpus N` with
@@ -102,7 +105,7 @@ def measured_traffic(batch, model):
     return rec, "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over eager decode steps of this build (tools/pmc_traffic.py); FETCH_SIZE x2 (gfx950)"
 
 
-def stage_report(eng, cfg, toks, sp, B, F, ctr):
+def stage_report(eng, cfg, toks, sp, B, F, ctr, kv_bf16=False):
     """north_star: achieved fraction of the HBM / MFMA roofline per stage.  Arms the B slots again, advances them to mid-utterance with
     graph replays, then runs 16 EAGER steps with HIP events at the stage boundaries (q3tts_stage_profile); eager launches carry a
     little more launch gap than the graph replay the headline times.  Codec numbers come from the timed region's counters."""
@@ -132,8 +135,8 @@ def stage_report(eng, cfg, toks, sp, B, F, ctr):
     tf = CODEC_GFLOP_PER_FRAME * 1e9 / (codec_ms * 1e-3) / 1e12 if codec_ms > 0 else 0.0
     two, three = eng.codec_plane_stats()
     return {
-        "talker_decode": dict(hbm(st["talker_decode_ms"], talker_bytes), context=ctx,
-                              kv_bytes_actual_fp32=int(kv_step_bytes(cfg, B, ctx, 4.0))),
+        "talker_decode": dict(hbm(st["talker_decode_ms"], talker_bytes), context=ctx, kv_dtype="bf16" if kv_bf16 else "fp32",
+                              kv_bytes_actual=int(kv_step_bytes(cfg, B, ctx, 2.0 if kv_bf16 else 4.0))),
         "code_predictor": hbm(st["code_predictor_ms"], pred_bytes),
         "sampler": {"ms_per_step": round(st["sampler_ms"], 4), "launches_per_step": cfg.n_groups, "bound": "latency"},
         "codec_decode": {"ms_per_frame": round(codec_ms, 5), "GFLOP_per_frame": CODEC_GFLOP_PER_FRAME, "TFLOP/s": round(tf, 1),
@@ -153,7 +156,7 @@ def roofline_record(cfg, B, F, step_ms, model, kv_bf16=False):
     traffic, note = measured_traffic(B, model) if not kv_bf16 else (None, "no PMC pass in bf16-KV mode")
     return {"bound": "hbm", "kernel": "decode step = one hipGraph replay per frame ("
             + ("q3::k_gemv1 (QKV / o_proj / gate-up / down / heads), k_cp_attn_oproj x75, k_attn x28, k_sample x16" if B <= 2 else
-               ("q3::k_gemv16 family" if B <= 16 else "q3::k_gemm3 (+ split-K k_finish*) + k_attn + k_sample")) + ")",
+               ("q3::k_gemv16 family" if B <= 16 else "q3::k_gemm3 (split-K slabs reduced in-launch: seam) + k_attn / k_attn_tiny + k_sample")) + ")",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_note": note,
             "algorithmic_bytes_per_launch": int(abytes), "launch_ms": round(step_ms, 4),
@@ -461,7 +464,7 @@ def main():
     stages = None
     if world == 1 and dist is None and not args.no_graph:
         try:
-            stages = stage_report(eng, cfg, toks, sp, B, F, ctr)
+            stages = stage_report(eng, cfg, toks, sp, B, F, ctr, args.kv_bf16)
         except Exception as ex:   # a reported extra, never the measurement
             stages = {"error": str(ex)}
 
@@ -513,7 +516,7 @@ def main():
                        "roofline": roofline_record(cfg, B2, F2, sm2, args.model, kvb)}
                 if with_stages:
                     try:
-                        rec["stages"] = stage_report(e2, cfg, toks2, sp2, B2, F2, ctr2)
+                        rec["stages"] = stage_report(e2, cfg, toks2, sp2, B2, F2, ctr2, kvb)
                     except Exception as ex:
                         rec["stages"] = {"error": str(ex)}
                 e2.close()

@@ -4,7 +4,7 @@ set -e
 # Modes (second argument): main = tests, bench lines, kernel traces, codec; pmc = the rocprofv3 --pmc passes + the default bench line that quotes
 # them.  The counter passes run LAST and in a call of their own: rocprofv3 --pmc has hung on this image (a WRITE_SIZE pass over 24 eager
 # steps sat in hipStreamSynchronize until its timeout), and after a killed GPU step nothing else should run in the same call.
-TAG=${1:-r02}
+TAG=${1:-r03}
 MODE=${2:-main}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && mkdir -p gpurun_out/$TAG
 O=gpurun_out/$TAG
@@ -31,11 +31,10 @@ fi
 if [ "$3" != "--skip-tests" ]; then timeout -k 10 1000 python -m pytest tests -m gpu -x -q --timeout 600 -s > $O/gpu_tests.log 2>&1 || true; grep -E "passed|failed|free-running|teacher" $O/gpu_tests.log | tail -8; fi
 # 2. headline bench (configs[1] + the b64 sub-record + cpu baseline), then b=8 and 1.7B b=8
 timeout -k 10 600 python bench.py > $O/bench_default.json 2> $O/bench_default.err
-python -c "import json;j=json.load(open('$O/bench_default.json'));print('b1', j['value'], j['decode_ms_per_frame_step'], j['roofline']['frac'], '| b64', j['b64']['value'], j['b64']['decode_ms_per_frame_step'], j['b64']['roofline']['frac'], '| cpu', j['cpu_baseline']['value'])"
-timeout -k 10 600 python bench.py --batch 8 --frames 256 --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_b8.json 2> $O/bench_b8.err
+python -c "import json;j=json.load(open('$O/bench_default.json'));print('b1', j['value'], j['decode_ms_per_frame_step'], j['roofline']['frac'], *[(k, j[k].get('value'), j[k].get('decode_ms_per_frame_step'), (j[k].get('roofline') or {}).get('frac')) for k in ('b64','b8','b64_f2048','b64_f2048_kv_bf16','b1_f2048_kv_bf16') if k in j], '| cpu', j['cpu_baseline']['value'])"
 timeout -k 10 600 python bench.py --model 1.7b --batch 8 --frames 256 --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_1p7b_b8.json 2> $O/bench_1p7b_b8.err
 timeout -k 10 600 python bench.py --batch 128 --frames 256 --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_b128.json 2> $O/bench_b128.err
-python -c "import json;print(*[(t, json.load(open('$O/bench_%s.json' % t))['value']) for t in ('b8','1p7b_b8','b128')])"
+python -c "import json;print(*[(t, json.load(open('$O/bench_%s.json' % t))['value']) for t in ('1p7b_b8','b128')])"
 # 3. kernel traces (eager launches: rocprofv3 cannot trace hipGraphLaunch on this ROCm): b=1 x 1024 frames, b=8 / b=64 x 48 frames
 rocprofv3 --kernel-trace --stats -d $O/trace_b1 -o b1 -- python bench.py --frames 1024 --steps 1 --warmup 0 --no-cpu-baseline --no-graph --no-b64 > $O/trace_b1.log 2>&1
 python tools/rocpd_summary.py $O/trace_b1/b1_results.db 40 > $O/decode_b1_f1024_eager_by_grid.txt
