@@ -205,6 +205,15 @@ struct SampleArgs {
     int32_t* codes = nullptr;      // [nb][max_frames_cap][n_groups]
     int max_frames_cap = 0;
     int32_t* talker_pos = nullptr; // [nb], last group only: position of the token the talker decodes next
+    // optional (batched step with the split-K seam): the sampler also prepares the NEXT predictor pass's input planes, so that the pass
+    // needs no RMSNorm launch in front of its first projection — (hi, lo) planes of gamma0 * row (NOT normalised: deferred RMSNorm) and
+    // the row's sum of squares in ssq_out[row * ssq_nt + 0] (the other ssq_nt - 1 partials zero).  Row of utterance b: b * pl_row_mul +
+    // pl_row_add.  lh (group 0 only): the talker's last_hidden rows [nb][ld_lh], which pass 0 takes as row b * 2.
+    bf16_t* pl_h = nullptr; bf16_t* pl_l = nullptr; int pl_ldp = 0;
+    const float* gamma0 = nullptr;
+    float* ssq_out = nullptr; int ssq_nt = 0;
+    int pl_row_mul = 1, pl_row_add = 0;
+    const float* lh = nullptr; int ld_lh = 0;
 };
 void launch_sample(const SampleArgs& a, hipStream_t s);
 

@@ -1885,8 +1885,11 @@ __global__ __launch_bounds__(256) void k_sample(const float* plogits, SlotState*
     if (last_group) text = frame < sl.trailing_len ? a.trailing + ((size_t)b * a.max_trailing + frame) * a.H : a.tts_pad; // :833-842
     const float* sum_r = a.group != 0 ? a.sum + (size_t)b * a.H : nullptr;
     constexpr int EP_MAX = 2; // H <= 2048: 256 threads x 4 floats x 2
+    const bool planes = a.pl_h != nullptr && a.x_next != nullptr;   // uniform: the next pass's input planes are made here (launcher: H <= 2048)
+    const float* lh_r = planes && a.lh ? a.lh + (size_t)b * a.ld_lh : nullptr;
+    float ss_e = 0.f, ss_l = 0.f;
     for (int h0 = 0; h0 < a.H; h0 += 1024 * EP_MAX) {
-        float e[EP_MAX][4], sm[EP_MAX][4], tx[EP_MAX][4];
+        float e[EP_MAX][4], sm[EP_MAX][4], tx[EP_MAX][4], g0[EP_MAX][4], lhv[EP_MAX][4];
 #pragma unroll
         for (int it = 0; it < EP_MAX; ++it) { // every load first (clamped, unconditional), stores below
             int h = h0 + (it * 256 + tid) * 4;
@@ -1896,6 +1899,8 @@ __global__ __launch_bounds__(256) void k_sample(const float* plogits, SlotState*
             e[it][2] = __uint_as_float(raw.y << 16); e[it][3] = __uint_as_float(raw.y & 0xFFFF0000u);
             if (sum_r) { const float4 v = *reinterpret_cast<const float4*>(sum_r + h); sm[it][0] = v.x; sm[it][1] = v.y; sm[it][2] = v.z; sm[it][3] = v.w; }
             if (last_group) { const float4 v = *reinterpret_cast<const float4*>(text + h); tx[it][0] = v.x; tx[it][1] = v.y; tx[it][2] = v.z; tx[it][3] = v.w; }
+            if (planes) { const float4 v = *reinterpret_cast<const float4*>(a.gamma0 + h); g0[it][0] = v.x; g0[it][1] = v.y; g0[it][2] = v.z; g0[it][3] = v.w; }
+            if (lh_r) { const float4 v = *reinterpret_cast<const float4*>(lh_r + h); lhv[it][0] = v.x; lhv[it][1] = v.y; lhv[it][2] = v.z; lhv[it][3] = v.w; }
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1909,9 +1914,48 @@ __global__ __launch_bounds__(256) void k_sample(const float* plogits, SlotState*
                     o[q] = last_group ? sacc + tx[it][q] : sacc;
                 }
                 if (a.x_next) *reinterpret_cast<float4*>(a.x_next + (size_t)b * a.ld_xnext + h) = make_float4(e[it][0], e[it][1], e[it][2], e[it][3]);
+                if (planes) {   // gamma0 * row as (hi, lo) bf16 planes; 1 / rms is the consumer's (deferred RMSNorm)
+                    const size_t prow = (size_t)b * a.pl_row_mul + a.pl_row_add;
+                    uint32_t hh[4], ll[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float y = g0[it][q] * e[it][q];
+                        ss_e = fmaf(e[it][q], e[it][q], ss_e);
+                        const uint32_t u = __float_as_uint(y);
+                        hh[q] = (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+                        const uint32_t v = __float_as_uint(y - __uint_as_float(hh[q] << 16));
+                        ll[q] = (v + 0x7FFFu + ((v >> 16) & 1u)) >> 16;
+                    }
+                    *reinterpret_cast<uint2*>(a.pl_h + prow * a.pl_ldp + h) = make_uint2(hh[0] | hh[1] << 16, hh[2] | hh[3] << 16);
+                    *reinterpret_cast<uint2*>(a.pl_l + prow * a.pl_ldp + h) = make_uint2(ll[0] | ll[1] << 16, ll[2] | ll[3] << 16);
+                    if (lh_r) {   // pass 0's first row: the talker's last_hidden of this utterance
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float y = g0[it][q] * lhv[it][q];
+                            ss_l = fmaf(lhv[it][q], lhv[it][q], ss_l);
+                            const uint32_t u = __float_as_uint(y);
+                            hh[q] = (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+                            const uint32_t v = __float_as_uint(y - __uint_as_float(hh[q] << 16));
+                            ll[q] = (v + 0x7FFFu + ((v >> 16) & 1u)) >> 16;
+                        }
+                        *reinterpret_cast<uint2*>(a.pl_h + (prow - 1) * a.pl_ldp + h) = make_uint2(hh[0] | hh[1] << 16, hh[2] | hh[3] << 16);
+                        *reinterpret_cast<uint2*>(a.pl_l + (prow - 1) * a.pl_ldp + h) = make_uint2(ll[0] | ll[1] << 16, ll[2] | ll[3] << 16);
+                    }
+                }
                 if (last_group) *reinterpret_cast<float4*>(a.x_talk + (size_t)b * a.H + h) = make_float4(o[0], o[1], o[2], o[3]);
                 else *reinterpret_cast<float4*>(a.sum + (size_t)b * a.H + h) = make_float4(o[0], o[1], o[2], o[3]);
             }
+        }
+    }
+    if (planes) {   // the rows' sums of squares: waves in order, then one partial per row (the consumer sums ssq_nt partials: the rest are zero)
+        ss_e = wave_sum(ss_e); ss_l = wave_sum(ss_l);
+        __syncthreads();                       // sh_f is free again (the token has been read)
+        if (lane == 0) { sh_f[wave] = ss_e; gmax[0][wave] = ss_l; }
+        __syncthreads();
+        const size_t prow = (size_t)b * a.pl_row_mul + a.pl_row_add;
+        if (tid < a.ssq_nt) {
+            a.ssq_out[prow * a.ssq_nt + tid] = tid == 0 ? ((sh_f[0] + sh_f[1]) + sh_f[2]) + sh_f[3] : 0.f;
+            if (lh_r) a.ssq_out[(prow - 1) * a.ssq_nt + tid] = tid == 0 ? ((gmax[0][0] + gmax[0][1]) + gmax[0][2]) + gmax[0][3] : 0.f;
         }
     }
     if (last_group && tid == 0) {
@@ -1923,6 +1967,8 @@ __global__ __launch_bounds__(256) void k_sample(const float* plogits, SlotState*
 void launch_sample(const SampleArgs& a, hipStream_t s) {
     if (a.V > SAMP_MAXV) throw Error("sample: vocabulary larger than 4096");
     if (a.nslab < 1 || a.nslab > 4) throw Error("sample: 1..4 logits slabs");
+    if (a.pl_h && (a.H > 2048 || a.H % 4 || !a.pl_l || !a.gamma0 || !a.ssq_out || a.ssq_nt < 1 || a.ssq_nt > 256 || a.pl_ldp % 4 || (a.lh && a.pl_row_add < 1)))
+        throw Error("sample: bad plane-output arguments");
 #define Q3_SAMP(SL, PW_) hipLaunchKernelGGL((k_sample<SL, PW_>), dim3(a.nb), dim3(256), 0, s, a.logits, a.st, a.ld, a.V, a)
     if (a.nslab > 1) { if (a.V <= 2048) Q3_SAMP(true, 8); else if (a.V <= 3072) Q3_SAMP(true, 12); else Q3_SAMP(true, 16); }
     else { if (a.V <= 2048) Q3_SAMP(false, 8); else if (a.V <= 3072) Q3_SAMP(false, 12); else Q3_SAMP(false, 16); }

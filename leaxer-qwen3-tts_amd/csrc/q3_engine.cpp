@@ -453,6 +453,20 @@ static int pick_ksplit(int K) { // K slices per GEMM: 256 (two LDS chunks) per w
     return ks;
 }
 
+bool Engine::seam_applies(const DecStack& W, int M, float* x, int ldx, bool has_slot_map) const {
+    const int AO = W.nq * W.d, NTH = W.H / 64;
+    const bool mfma = M >= mfma_min_rows && W.H % 128 == 0 && AO % 128 == 0 && W.ffn % 128 == 0 && W.H <= 4096;
+    if (!mfma || !seam_step || !seam_on || has_slot_map || M > 128 || NTH > 64 || NTH % 4 != 0 || W.L < 1) return false;
+    const int ks_q = std::min(4, pick_ksplit(W.H));
+    GemmArgs t1, t2, t3;
+    t1.seam = 1; t1.epi = EPI_SLAB; t1.M = M; t1.N = W.H; t1.K = AO; t1.ldo = W.H; t1.ldx = ldp; t1.sx = x; t1.sldx = ldx; t1.sgamma = W.layers[0].post_norm;
+    t1.ssq_out = ssq_a_d; t1.ssq_nt = NTH; t1.seam_cnt = seam_cnt_d; t1.oh = pl0h; t1.ol = pl0l; t1.ldp = ldp;
+    t3 = t1; t3.K = W.ffn;
+    t2.seam = 2; t2.epi = EPI_SLAB2; t2.M = M; t2.N = W.ffn; t2.K = W.H; t2.ldo = W.ffn; t2.ldx = ldp; t2.ssq_in = ssq_a_d; t2.ssq_in_nt = NTH;
+    t2.seam_cnt = seam_cnt_d; t2.oh = pl1h; t2.ol = pl1l; t2.ldp = ldp;
+    return gemm_seam_ok(t1, pick_ksplit(AO)) && gemm_seam_ok(t2, ks_q) && gemm_seam_ok(t3, pick_ksplit(W.ffn));
+}
+
 bool Engine::run_layers(const DecStack& W, float* x, int ldx, int nb, int n_new, int slot_offset, const int* pos_dev, int pos_scalar,
                         const float* final_gamma, float final_eps, float* final_xn, int final_ld_xn, const int* slot_map) {
     const int M = nb * n_new, QKV = (W.nq + 2 * W.nkv) * W.d, AO = W.nq * W.d;
@@ -464,18 +478,11 @@ bool Engine::run_layers(const DecStack& W, float* x, int ldx, int nb, int n_new,
     // reduces and applies SwiGLU.  The last layer's down projection keeps the finish launch (it also applies the stack's final norm).
     // Measured, b=64 step: 4.97 ms with the finish launches, 4.77 ms with this seam (flag line + static chunk owners); a first protocol with
     // an arrival ticket and a claim counter — two returning atomics on the critical path — took 5.57 ms (profiles/r03_negative_results.txt).
-    const bool no_seam = !seam_on;
-    bool seam = false;
     const int NTH = W.H / 64;
-    if (mfma && seam_step && !no_seam && slot_map == nullptr && M <= 128 && NTH <= 64 && NTH % 4 == 0) {
-        GemmArgs t1, t2, t3;
-        t1.seam = 1; t1.epi = EPI_SLAB; t1.M = M; t1.N = W.H; t1.K = AO; t1.ldo = W.H; t1.ldx = ldp; t1.sx = x; t1.sldx = ldx; t1.sgamma = W.layers[0].post_norm;
-        t1.ssq_out = ssq_a_d; t1.ssq_nt = NTH; t1.seam_cnt = seam_cnt_d; t1.oh = pl0h; t1.ol = pl0l; t1.ldp = ldp;
-        t3 = t1; t3.K = W.ffn;
-        t2.seam = 2; t2.epi = EPI_SLAB2; t2.M = M; t2.N = W.ffn; t2.K = W.H; t2.ldo = W.ffn; t2.ldx = ldp; t2.ssq_in = ssq_a_d; t2.ssq_in_nt = NTH;
-        t2.seam_cnt = seam_cnt_d; t2.oh = pl1h; t2.ol = pl1l; t2.ldp = ldp;
-        seam = gemm_seam_ok(t1, pick_ksplit(AO)) && gemm_seam_ok(t2, ks_q) && gemm_seam_ok(t3, pick_ksplit(W.ffn));
-    }
+    const bool seam = mfma && seam_applies(W, M, x, ldx, slot_map != nullptr);
+    const bool planes_in = planes_in_ready;   // the sampler made planes0 + ssq_b (record_step checked seam_applies for this pass)
+    planes_in_ready = false;
+    if (planes_in && !seam) throw Error("run_layers: input planes announced without the seam");
     auto seam_counters = [&](int n_tiles) -> unsigned* {   // this launch's counter region
         const size_t need = (size_t)n_tiles * 2 * 16;
         if (seam_cnt_used + need > seam_cnt_words) throw Error("split-K seam: counter buffer too small for this step");
@@ -483,7 +490,7 @@ bool Engine::run_layers(const DecStack& W, float* x, int ldx, int nb, int n_new,
         seam_cnt_used += need;
         return p;
     };
-    if (mfma) // planes0 = RMSNorm(in_norm[0])(x)
+    if (mfma && !planes_in) // planes0 = RMSNorm(in_norm[0])(x)
         launch_finish(x, ldx, nullptr, 0, 0, 0, W.layers[0].in_norm, W.eps, M, W.H, pl0h, pl0l, ldp, nullptr, 0, stream);
     for (int l = 0; l < W.L; ++l) {
         const DecLayerW& w = W.layers[l];
@@ -521,7 +528,7 @@ bool Engine::run_layers(const DecStack& W, float* x, int ldx, int nb, int n_new,
         AttnArgs a;
         a.qkv = qkv; a.ld_qkv = QKV; a.out = attn; a.ld_out = AO; a.kcache = W.kc; a.vcache = W.vc; a.kv_bf16 = W.kv_bf16; a.kv_round = W.kv_round;
         if (mfma) { a.qkv = qkv_slab_d; a.qkv_nslab = ks_q; a.qkv_slab_stride = (size_t)M * QKV; }
-        if (seam && l > 0) { a.ssq_in = ssq_b_d; a.ssq_nt = NTH; a.ssq_K = W.H; a.ssq_eps = W.eps; }   // planes0 came from the previous layer's down seam: gamma * x, 1 / rms deferred
+        if (seam && (l > 0 || planes_in)) { a.ssq_in = ssq_b_d; a.ssq_nt = NTH; a.ssq_K = W.H; a.ssq_eps = W.eps; }   // planes0 came from the previous layer's down seam (or the sampler): gamma * x, 1 / rms deferred
         a.page_table = W.page_table; a.pages_per_slot = W.pages_per_slot; a.page_shift = W.page_shift; a.identity_pages = W.identity_pages;
         a.layer = l; a.n_layers = W.L; a.q_norm = w.q_norm; a.k_norm = w.k_norm; a.eps = W.eps;
         a.rope_cos = W.rope_cos; a.rope_sin = W.rope_sin; a.pos_dev = pos_dev; a.pos_scalar = pos_scalar;
@@ -858,12 +865,23 @@ void Engine::record_step(int nb) {
         Q3_HIP_CHECK(hipMemsetAsync(seam_cnt_d, 0, seam_cnt_words * sizeof(unsigned), stream));
     mark();
     if (trace_d) launch_copy_rows(logits_t + (size_t)trace_slot * V, V, trace_d, trace_cols, 1, V, stream);
+    // With the seam's deferred RMSNorm in place the sampler also writes the next predictor pass's input planes (gamma0 * row + the row's
+    // sum of squares): the pass then starts at its QKV projection, without an RMSNorm launch in front (15 launches per step).
+    static const bool no_sp = getenv("Q3TTS_NO_SAMPLER_PLANES") != nullptr;   // A/B knob
+    const bool sp_ok = !no_sp && !cp_projected() && H <= 2048 && H % 256 == 0;
+    const bool sp0 = sp_ok && seam_applies(cp, nb * 2, x_cp, Hc, false), spn = sp_ok && seam_applies(cp, nb, x_cp1, Hc, false);
+    auto with_planes = [&](SampleArgs& s, int mul, int add, const float* lh, int ld_lh) {
+        s.pl_h = pl0h; s.pl_l = pl0l; s.pl_ldp = ldp; s.gamma0 = cp.layers[0].in_norm; s.ssq_out = ssq_b_d; s.ssq_nt = Hc / 64;
+        s.pl_row_mul = mul; s.pl_row_add = add; s.lh = lh; s.ld_lh = ld_lh;
+    };
+    if (sp0) with_planes(s0, 2, 1, x_cp, 2 * H);
     launch_sample(s0, stream);                                  // code0 (tts_onnx.cpp:803-812)
     mark();
     for (int j = 0; j < G - 1; ++j) {                           // predict_subcodes (:851-872), KV-cached
         // pass 0: rows [last_hidden, embed(code0)] of every utterance; later passes: the embedding of the code just sampled
         float* xin = j == 0 ? cp_project(x_cp, H, nb * 2) : cp_project(x_cp1, H, nb);
         bool pr;
+        planes_in_ready = j == 0 ? sp0 : spn;                   // the sampler in front of this pass made its input planes
         if (j == 0) pr = run_layers(cp, xin, Hc, nb, 2, 0, nullptr, 0, cp_norm, c.cp_rms_eps);
         else pr = run_layers(cp, xin, Hc, nb, 1, 0, nullptr, j + 1, cp_norm, c.cp_rms_eps);
         // head j on the last row of every utterance (pass 0 holds two rows per utterance: planes row b*2+1)
@@ -876,6 +894,8 @@ void Engine::record_step(int nb) {
         s.logits = nsl > 1 ? cp_logit_slab_d : logits_cp; s.nslab = nsl; s.slab_stride = (size_t)nb * SV;
         s.ld = SV; s.V = SV; s.group = j + 1; s.embed = cp_embed_w[j];
         s.x_next = j + 1 < G - 1 ? x_cp1 : nullptr; s.ld_xnext = H;
+        s.pl_h = nullptr; s.lh = nullptr;
+        if (spn && s.x_next) with_planes(s, 1, 0, nullptr, 0);
         launch_sample(s, stream);
         mark();
     }

@@ -221,6 +221,8 @@ public:
                     const float* final_gamma = nullptr, float final_eps = 0.f, float* final_xn = nullptr, int final_ld_xn = 0,
                     const int* slot_map = nullptr);   // slot_map (device, nb ints): row group bi belongs to slot slot_map[bi]
     void record_step(int nb);
+    bool seam_applies(const DecStack& W, int M, float* x, int ldx, bool has_slot_map) const;   // run_layers folds the finish launches of this stack pass into its GEMMs
+    bool planes_in_ready = false;   // record_step -> run_layers: the sampler already wrote planes0 (gamma0 * rows) + their sums of squares (ssq_b_d)
     // returns the number of split-K slabs `out` was written as (1: plain rows).  slab_out non-null: the caller's consumer can sum slabs
     // ([nslab][M][ldo] at slab_out), which lets a 17..128-row head split K over 4x the workgroups
     int head_proj(const bf16_t* Wm, const float* x, int ldx, const float* gamma, float eps, float* xn_out, int ld_xn,
