@@ -149,7 +149,9 @@ struct GemmArgs {
     //         squares written to ssq_out (deferred RMSNorm, as k_gemv16 does);
     // seam 2: planes = split(silu(r * sum(gate slabs)) * (r * sum(up slabs))), r = 1/rms of the INPUT planes' rows from ssq_in.
     int seam = 0;
-    unsigned* seam_cnt = nullptr;                    // one 64-byte line per (column tile, row block): words 0..11 slice flags, 12..15 abandoned-chunk marks; zeroed before the launch
+    unsigned* seam_cnt = nullptr;                    // one 64-byte line per (column tile, row block): words 0..11 slice flags, 12..15 abandoned-chunk marks
+    const unsigned* seam_gen = nullptr;              // the step's generation (bumped once per step by the first sampler): every word a launch writes carries it,
+                                                     // so nothing is ever reset and a copy of the line left over from an earlier step can never read as set
     int seam_spin = 4096;                            // polls an owner makes before it abandons its chunk (~0.7 us each)
     float* sx = nullptr; int sldx = 0;               // seam 1: residual stream rows, updated in place
     const float* sgamma = nullptr;                   // seam 1: the consumer's RMSNorm gain
@@ -214,6 +216,7 @@ struct SampleArgs {
     float* ssq_out = nullptr; int ssq_nt = 0;
     int pl_row_mul = 1, pl_row_add = 0;
     const float* lh = nullptr; int ld_lh = 0;
+    unsigned* step_gen = nullptr;  // group 0 only: the step's generation counter (split-K seam flags), bumped by workgroup 0
 };
 void launch_sample(const SampleArgs& a, hipStream_t s);
 

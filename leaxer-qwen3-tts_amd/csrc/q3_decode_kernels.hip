@@ -1587,6 +1587,7 @@ __global__ __launch_bounds__(256) void k_sample(const float* plogits, SlotState*
     __shared__ int sh_i[4];
 
     SP_MARK(0);
+    if (a.step_gen != nullptr && b == 0 && tid == 0) *a.step_gen += 1u;   // first launch of a step: the generation its seam flags will carry
     // ---- round trip 1: slot state (one 64-byte struct) and this wave's logits slices, all in flight ----
     float temperature = a.temperature, top_p = a.top_p, u = a.u;
     int top_k = a.top_k, suppress = a.suppress, keep_eos = 1;

@@ -263,6 +263,8 @@ Engine::Engine(const q3tts_config& cfg, int device_, int max_batch, int max_ctx_
         seam_cnt_words = per_launch * launches;
         seam_cnt_d = (unsigned*)dmalloc(seam_cnt_words * sizeof(unsigned));
         Q3_HIP_CHECK(hipMemsetAsync(seam_cnt_d, 0, seam_cnt_words * sizeof(unsigned), stream));
+        seam_gen_d = (unsigned*)dmalloc(64);
+        Q3_HIP_CHECK(hipMemsetAsync(seam_gen_d, 0, 64, stream));
         ssq_a_d = fm((size_t)rows_max * 64);
         ssq_b_d = fm((size_t)rows_max * 64);
     }
@@ -460,10 +462,10 @@ bool Engine::seam_applies(const DecStack& W, int M, float* x, int ldx, bool has_
     const int ks_q = std::min(4, pick_ksplit(W.H));
     GemmArgs t1, t2, t3;
     t1.seam = 1; t1.epi = EPI_SLAB; t1.M = M; t1.N = W.H; t1.K = AO; t1.ldo = W.H; t1.ldx = ldp; t1.sx = x; t1.sldx = ldx; t1.sgamma = W.layers[0].post_norm;
-    t1.ssq_out = ssq_a_d; t1.ssq_nt = NTH; t1.seam_cnt = seam_cnt_d; t1.oh = pl0h; t1.ol = pl0l; t1.ldp = ldp;
+    t1.ssq_out = ssq_a_d; t1.ssq_nt = NTH; t1.seam_cnt = seam_cnt_d; t1.seam_gen = seam_gen_d; t1.oh = pl0h; t1.ol = pl0l; t1.ldp = ldp;
     t3 = t1; t3.K = W.ffn;
     t2.seam = 2; t2.epi = EPI_SLAB2; t2.M = M; t2.N = W.ffn; t2.K = W.H; t2.ldo = W.ffn; t2.ldx = ldp; t2.ssq_in = ssq_a_d; t2.ssq_in_nt = NTH;
-    t2.seam_cnt = seam_cnt_d; t2.oh = pl1h; t2.ol = pl1l; t2.ldp = ldp;
+    t2.seam_cnt = seam_cnt_d; t2.seam_gen = seam_gen_d; t2.oh = pl1h; t2.ol = pl1l; t2.ldp = ldp;
     return gemm_seam_ok(t1, pick_ksplit(AO)) && gemm_seam_ok(t2, ks_q) && gemm_seam_ok(t3, pick_ksplit(W.ffn));
 }
 
@@ -556,7 +558,7 @@ bool Engine::run_layers(const DecStack& W, float* x, int ldx, int nb, int n_new,
             GemmArgs o;
             o.W = w.o; o.xh = pl1h; o.xl = pl1l; o.ldx = ldp; o.out = slab_d; o.ldo = W.H; o.M = M; o.N = W.H; o.K = AO; o.epi = EPI_SLAB; o.nt = W.nt;
             if (seam) {   // x += sum(slabs); planes0 = gamma(post_norm) * x; ssq_a = per-tile sums of squares of x
-                o.seam = 1; o.seam_spin = seam_spin; o.seam_cnt = seam_counters(W.H / 64); o.sx = x; o.sldx = ldx; o.sgamma = w.post_norm;
+                o.seam = 1; o.seam_gen = seam_gen_d; o.seam_spin = seam_spin; o.seam_cnt = seam_counters(W.H / 64); o.sx = x; o.sldx = ldx; o.sgamma = w.post_norm;
                 o.oh = pl0h; o.ol = pl0l; o.ldp = ldp; o.ssq_out = ssq_a_d; o.ssq_nt = NTH;
             }
             launch_gemm2(o, ks_o, 4, stream);
@@ -566,7 +568,7 @@ bool Engine::run_layers(const DecStack& W, float* x, int ldx, int nb, int n_new,
             f.W = w.gate; f.W2 = w.up; f.xh = pl0h; f.xl = pl0l; f.ldx = ldp; f.out = gu_slab_d; f.out2 = gu_slab_d + (size_t)4 * rows_max * W.ffn; f.ldo = W.ffn;
             f.M = M; f.N = W.ffn; f.K = W.H; f.epi = EPI_SLAB2; f.nt = W.nt;
             if (seam) {   // planes1 = SwiGLU of the slab sums scaled by 1 / rms(x) (from ssq_a)
-                f.seam = 2; f.seam_spin = seam_spin; f.seam_cnt = seam_counters(W.ffn / 64); f.oh = pl1h; f.ol = pl1l; f.ldp = ldp;
+                f.seam = 2; f.seam_gen = seam_gen_d; f.seam_spin = seam_spin; f.seam_cnt = seam_counters(W.ffn / 64); f.oh = pl1h; f.ol = pl1l; f.ldp = ldp;
                 f.ssq_in = ssq_a_d; f.ssq_in_nt = NTH; f.seps = W.eps;
             }
             launch_gemm2(f, ks_q, 4, stream);
@@ -574,7 +576,7 @@ bool Engine::run_layers(const DecStack& W, float* x, int ldx, int nb, int n_new,
             GemmArgs d;
             d.W = w.down; d.xh = pl1h; d.xl = pl1l; d.ldx = ldp; d.out = slab_d; d.ldo = W.H; d.M = M; d.N = W.H; d.K = W.ffn; d.epi = EPI_SLAB; d.nt = W.nt;
             if (seam && l + 1 < W.L) {   // x += sum(slabs); planes0 = gamma(next input norm) * x; ssq_b for the next layer's attention
-                d.seam = 1; d.seam_spin = seam_spin; d.seam_cnt = seam_counters(W.H / 64); d.sx = x; d.sldx = ldx; d.sgamma = W.layers[l + 1].in_norm;
+                d.seam = 1; d.seam_gen = seam_gen_d; d.seam_spin = seam_spin; d.seam_cnt = seam_counters(W.H / 64); d.sx = x; d.sldx = ldx; d.sgamma = W.layers[l + 1].in_norm;
                 d.oh = pl0h; d.ol = pl0l; d.ldp = ldp; d.ssq_out = ssq_b_d; d.ssq_nt = NTH;
                 launch_gemm2(d, ks_d, 4, stream);
                 continue;
@@ -859,10 +861,10 @@ void Engine::record_step(int nb) {
     // stage_profile(): events between the stages of the step (eager launches only)
     size_t mk = 0;
     auto mark = [&]() { if (!stage_ev.empty()) Q3_HIP_CHECK(hipEventRecord(stage_ev[mk++], stream)); };
-    // split-K seam counters of this step's GEMM launches: zeroed at the head of the step (a memset node of the captured graph)
+    // split-K seam flag lines of this step's GEMM launches: one region per launch; their words carry the step's generation (s0.step_gen:
+    // the first sampler launch bumps it), so nothing has to be zeroed between steps
     struct SeamScope { Engine& e; explicit SeamScope(Engine& en) : e(en) { e.seam_step = true; e.seam_cnt_used = 0; } ~SeamScope() { e.seam_step = false; } } seam_scope(*this);
-    if (2 * nb >= mfma_min_rows && seam_on)   // predictor pass 0 runs 2 nb rows: it may take the slab GEMMs from nb = 9 on
-        Q3_HIP_CHECK(hipMemsetAsync(seam_cnt_d, 0, seam_cnt_words * sizeof(unsigned), stream));
+    s0.step_gen = seam_gen_d;
     mark();
     if (trace_d) launch_copy_rows(logits_t + (size_t)trace_slot * V, V, trace_d, trace_cols, 1, V, stream);
     // With the seam's deferred RMSNorm in place the sampler also writes the next predictor pass's input planes (gamma0 * row + the row's
@@ -894,7 +896,7 @@ void Engine::record_step(int nb) {
         s.logits = nsl > 1 ? cp_logit_slab_d : logits_cp; s.nslab = nsl; s.slab_stride = (size_t)nb * SV;
         s.ld = SV; s.V = SV; s.group = j + 1; s.embed = cp_embed_w[j];
         s.x_next = j + 1 < G - 1 ? x_cp1 : nullptr; s.ld_xnext = H;
-        s.pl_h = nullptr; s.lh = nullptr;
+        s.pl_h = nullptr; s.lh = nullptr; s.step_gen = nullptr;
         if (spn && s.x_next) with_planes(s, 1, 0, nullptr, 0);
         launch_sample(s, stream);
         mark();

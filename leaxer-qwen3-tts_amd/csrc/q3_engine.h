@@ -194,9 +194,10 @@ public:
     float* gu_slab_d = nullptr;  // gate | up split-K partial sums, 2 x [<=4][rows][ffn]
     float* cp_logit_slab_d = nullptr; // split-K partial sums of the batched predictor heads [4][B][sub_vocab]: the sampler sums them
     float* qkv_slab_d = nullptr; // split-K partial sums of the QKV projection [<=4][rows][QKV]
-    // split-K seam of the batched step (GemmArgs::seam): arrival / claim counters, one region per seam launch of the step (zeroed by a
-    // memset at the head of the step), and the per-(row, 64-column tile) sums of squares behind the two residual seams of a layer
+    // split-K seam of the batched step (GemmArgs::seam): arrival / claim counters, one region per seam launch of the step (generation-valued words:
+    // never reset), and the per-(row, 64-column tile) sums of squares behind the two residual seams of a layer
     unsigned* seam_cnt_d = nullptr; size_t seam_cnt_words = 0, seam_cnt_used = 0;
+    unsigned* seam_gen_d = nullptr;   // the step generation the flag words carry (bumped by the step's first sampler launch)
     float *ssq_a_d = nullptr, *ssq_b_d = nullptr;
     bool seam_step = false;      // inside record_step: run_layers may fold the finish launches into the GEMMs
     bool seam_on = true;         // Q3TTS_SEAM=0 at engine creation keeps the finish launches (the A/B knob and the tests' second path)

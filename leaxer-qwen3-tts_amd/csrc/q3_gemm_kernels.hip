@@ -387,15 +387,18 @@ __global__ __launch_bounds__(256) void k_gemm3(const bf16_t* pW, const bf16_t* p
         constexpr int NCHK = ROWS / 16;
         unsigned* line = a.seam_cnt + ((size_t)blockIdx.z * gridDim.x + blockIdx.x) * 16;
         const int mine = (int)blockIdx.y < NCHK ? (int)blockIdx.y : -1;
+        // every word carries the step's generation: flag set = 4 gen + 3, chunk abandoned = 4 gen + 1, taken = 4 gen + 2.  Nothing is reset
+        // between steps; whatever an earlier step (or the allocation) left in the line never equals this step's values.
+        const unsigned gbase = __builtin_amdgcn_readfirstlane(*a.seam_gen) << 2;
         if (wave == 0) {
-            if (lane == 0) __hip_atomic_store(line + blockIdx.y, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) __hip_atomic_store(line + blockIdx.y, gbase | 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             // an owner polls at once (its own word counts as set: only the others' are awaited); everybody else looks once, AFTER its flag
             // store is acknowledged (the rescue protocol's store -> load order)
             if (mine < 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             auto look = [&](unsigned& marks) -> bool {   // one sc1 load of the line: all slices in? which chunks are abandoned?
                 const unsigned v = __hip_atomic_load(line + (lane & 15), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const unsigned long long in = __ballot((lane < (int)KS && lane != (int)blockIdx.y) ? v != 0u : true);
-                const unsigned long long ab = __ballot(lane >= 12 && lane < 16 && v == 1u);
+                const unsigned long long in = __ballot((lane < (int)KS && lane != (int)blockIdx.y) ? v == (gbase | 3u) : true);
+                const unsigned long long ab = __ballot(lane >= 12 && lane < 16 && v == (gbase | 1u));
                 marks = (unsigned)(ab >> 12) & 0xFu;
                 return in == ~0ull;
             };
@@ -406,7 +409,7 @@ __global__ __launch_bounds__(256) void k_gemm3(const bf16_t* pW, const bf16_t* p
             if (mine >= 0) {
                 if (complete) take |= 1u << mine;
                 else {
-                    if (lane == 0) __hip_atomic_exchange(line + 12 + mine, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (lane == 0) __hip_atomic_exchange(line + 12 + mine, gbase | 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     complete = look(marks);
                 }
@@ -415,7 +418,7 @@ __global__ __launch_bounds__(256) void k_gemm3(const bf16_t* pW, const bf16_t* p
                 for (int c = 0; c < NCHK; ++c)
                     if (marks >> c & 1u) {
                         unsigned won = 0;
-                        if (lane == 0) { unsigned expect = 1u; won = __hip_atomic_compare_exchange_strong(line + 12 + c, &expect, 2u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1u : 0u; }
+                        if (lane == 0) { unsigned expect = gbase | 1u; won = __hip_atomic_compare_exchange_strong(line + 12 + c, &expect, gbase | 2u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1u : 0u; }
                         won = __builtin_amdgcn_readfirstlane(won);
                         if (won) take |= 1u << c;
                     }
@@ -512,7 +515,7 @@ bool gemm_seam_ok(const GemmArgs& a, int ksplit) {
     if (!(ksl == 128 || ksl == 256) || a.N % 64 != 0 || a.ldo % 4 != 0 || a.ldx % 8 != 0 || a.M < 17 || a.M > 128) return false;
     if (a.seam == 1 && (ksplit > 12 || !a.sx || !a.sgamma || !a.ssq_out || a.ssq_nt != a.N / 64 || a.sldx % 4 != 0)) return false;
     if (a.seam == 2 && (ksplit > 4 || (a.ssq_in && a.ssq_in_nt % 4 != 0))) return false;
-    return a.seam_cnt != nullptr && a.oh != nullptr && a.ol != nullptr && a.ldp % 4 == 0 && (a.slab_rows == 0 || a.slab_rows == a.M);
+    return a.seam_cnt != nullptr && a.seam_gen != nullptr && a.oh != nullptr && a.ol != nullptr && a.ldp % 4 == 0 && (a.slab_rows == 0 || a.slab_rows == a.M);
 }
 static void launch_gemm3_seam(const GemmArgs& a, int ksplit, hipStream_t s) {
     const bool big = a.M > 64;   // 32-row blocks up to 64 rows, 64-row blocks beyond
