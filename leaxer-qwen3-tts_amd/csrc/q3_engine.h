@@ -181,9 +181,11 @@ public:
     std::vector<const bf16_t*> cp_head, cp_embed_w;
 
     int rows_max = 0, max_trailing = 0, max_frames_cap = 0;
-    // rows from which a projection takes the split-K slab GEMM (k_gemm2 + finish kernels, 8 launches per layer).  Below it the GEMV-family
-    // contract holds (5 launches per layer): 1-2 rows single-pass GEMV, 3-16 rows k_gemv16 on the matrix cores.
-    int mfma_min_rows = 17;
+    // rows from which a projection takes the split-K slab GEMM (k_gemm3 with the in-launch seam, 5 launches per layer; k_gemm2 + finish
+    // kernels, 8 launches, where the seam does not apply).  Below it the GEMV-family contract holds (5 launches per layer): 1-2 rows
+    // single-pass GEMV, 3..11 rows k_gemv16 on the matrix cores.  Crossover measured with the seam (round 3): b=8 3.76 (gemv16) vs 3.87 ms,
+    // b=12 3.99 vs 3.89, b=16 4.22 vs 3.93; it was 17 rows with the finish launches.
+    int mfma_min_rows = 12;
     float *x_talk = nullptr, *qkv = nullptr, *attn = nullptr, *act = nullptr, *logits_t = nullptr, *logits_cp = nullptr;
     float *x_cp = nullptr, *x_cp1 = nullptr, *sum = nullptr, *xp = nullptr, *hn = nullptr, *logits_p = nullptr;
     float *trailing_d = nullptr, *tts_pad_d = nullptr, *text_tmp = nullptr, *text_tmp2 = nullptr;

@@ -512,7 +512,7 @@ bool gemm_seam_ok(const GemmArgs& a, int ksplit) {
     if (a.seam != 1 && a.seam != 2) return false;
     if ((a.seam == 1) != (a.epi == EPI_SLAB) || (a.seam == 2) != (a.epi == EPI_SLAB2)) return false;
     const int ksl = ksplit > 0 && a.K % ksplit == 0 ? a.K / ksplit : 0;
-    if (!(ksl == 128 || ksl == 256) || a.N % 64 != 0 || a.ldo % 4 != 0 || a.ldx % 8 != 0 || a.M < 17 || a.M > 128) return false;
+    if (!(ksl == 128 || ksl == 256) || a.N % 64 != 0 || a.ldo % 4 != 0 || a.ldx % 8 != 0 || a.M < 1 || a.M > 128) return false;
     if (a.seam == 1 && (ksplit > 12 || !a.sx || !a.sgamma || !a.ssq_out || a.ssq_nt != a.N / 64 || a.sldx % 4 != 0)) return false;
     if (a.seam == 2 && (ksplit > 4 || (a.ssq_in && a.ssq_in_nt % 4 != 0))) return false;
     return a.seam_cnt != nullptr && a.seam_gen != nullptr && a.oh != nullptr && a.ol != nullptr && a.ldp % 4 == 0 && (a.slab_rows == 0 || a.slab_rows == a.M);
