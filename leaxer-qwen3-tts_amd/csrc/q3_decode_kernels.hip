@@ -1522,15 +1522,175 @@ __global__ __launch_bounds__(1024) void k_cp_attn_oproj2(const bf16_t* pW, const
     }
 }
 
+// ================================================================================================
+// k_cp_attn_oproj3 (round 3, NOT the default: measured slower, see launch_cp_attn_oproj) — the fused launch with k_attn_tiny's attention layout.  The first version is bound by the vector-issue time of
+// the four waves that share a SIMD (r03_negative_results.txt item 6): per wave, every cached token costs a 16-lane dot product with a
+// four-step DPP reduction, and four partial softmaxes are merged through 18 cross-lane moves.  Here a wave (= query head) holds the cached
+// K rows as (token = lane / 4, 32-dim chunk = lane % 4): ALL 16 tokens' scores are 32 FMAs + two DPP steps; the V rows as (dim = lane,
+// lane + 64) per token; one softmax over the wave (DPP max / sum), p_t reaches the P.V loop through v_readlane; the output lands in
+// (lane, lane + 64) layout, exactly what the o_proj phase reads.  No partials, no merges, no knew / vnew staging.  base <= 16.
+// ================================================================================================
+template <int NEW>
+__global__ __launch_bounds__(1024) void k_cp_attn_oproj3(const bf16_t* pW, const float* pqkv, const float* pkc, const float* pvc, const float* px,
+                                                          const float* pcos, const float* psin, uint32_t pk0, uint32_t pk1, CpAttnOprojArgs a) {
+    const int pbase = (int)(pk0 & 0xFFFFu), ppage_tokens = (int)(pk0 >> 16), pN = (int)(pk1 & 0xFFFFu), pldx = (int)(pk1 >> 16);
+    constexpr int LDQ = 4096;
+    constexpr int D = 128, HALF = 64, NKV = 8, NQ = 16, K = 2048, G = 2;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // 16 waves: one query head each
+    const int head = wave, kvh = wave / G;
+    const int base = pbase;
+
+    __shared__ __attribute__((aligned(16))) float q_s[NQ][NEW][D];   // wave-private: (lane, lane + 64) layout -> 32-dim chunks
+    __shared__ float attn_s[NEW][K];
+    __shared__ float part[NEW][16];
+
+    KP_MARK(16);
+    // ---- the one memory round ----
+    const int orow = blockIdx.x * 4 + (wave & 3), kq = wave >> 2;
+    const int orow_c = orow < pN ? orow : pN - 1;
+    const uint4 w4 = ldw_rt(pW + (size_t)orow_c * K + kq * 512 + lane * 8, false);
+    float resid[NEW];
+#pragma unroll
+    for (int m = 0; m < NEW; ++m) resid[m] = px[(size_t)m * pldx + orow_c];
+    __builtin_amdgcn_sched_barrier(0);
+    float qx0[NEW], qx1[NEW], kx0[NEW], kx1[NEW], vn0[NEW], vn1[NEW], cs[NEW], sn[NEW];
+#pragma unroll
+    for (int j = 0; j < NEW; ++j) {
+        const float* rowp = pqkv + (size_t)j * LDQ;
+        qx0[j] = rowp[head * D + lane]; qx1[j] = rowp[head * D + lane + HALF];
+        kx0[j] = rowp[(NQ + kvh) * D + lane]; kx1[j] = rowp[(NQ + kvh) * D + lane + HALF];
+        vn0[j] = rowp[(NQ + NKV + kvh) * D + lane]; vn1[j] = rowp[(NQ + NKV + kvh) * D + lane + HALF];
+        cs[j] = pcos[(size_t)(base + j) * HALF + lane]; sn[j] = psin[(size_t)(base + j) * HALF + lane];
+    }
+    const float qn0 = a.q_norm[lane], qn1 = a.q_norm[lane + HALF], kn0 = a.k_norm[lane], kn1 = a.k_norm[lane + HALF];
+    // cached K as (token = lane / 4, 32-dim chunk = lane % 4), cached V as (dim = lane, lane + 64) per token; tokens past `base` repeat the last one
+    const float* kc = pkc + (size_t)kvh * ppage_tokens * D;
+    const float* vc = pvc + (size_t)kvh * ppage_tokens * D;
+    const int tk = lane >> 2, ch = lane & 3;
+    const int last = base > 0 ? base - 1 : 0;
+    float4 kr[8];
+    {
+        const int t = tk < base ? tk : last;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) kr[e] = *reinterpret_cast<const float4*>(kc + (size_t)t * D + ch * 32 + e * 4);
+    }
+    float vr0[16], vr1[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const int tt = t < base ? t : last;
+        vr0[t] = vc[(size_t)tt * D + lane]; vr1[t] = vc[(size_t)tt * D + lane + HALF];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < 16; ++t) { vr0[t] = t < base ? vr0[t] : 0.f; vr1[t] = t < base ? vr1[t] : 0.f; }   // never-written cache rows may hold anything: 0 x NaN
+
+    KP_MARK(17);
+    // ---- q / k RMSNorm + RoPE in (lane, lane + 64) layout; q to the wave's LDS slice; the even head of workgroup 0 appends K / V ----
+    float ky0[NEW], ky1[NEW], qy0[NEW], qy1[NEW];
+#pragma unroll
+    for (int j = 0; j < NEW; ++j) {
+        {
+            const float ss = wave_sum(kx0[j] * kx0[j] + kx1[j] * kx1[j]);
+            const float rr = 1.0f / sqrtf(ss / (float)D + a.eps);
+            const float x0 = kn0 * (kx0[j] * rr), x1 = kn1 * (kx1[j] * rr);
+            ky0[j] = x0 * cs[j] + (-x1) * sn[j];
+            ky1[j] = x1 * cs[j] + x0 * sn[j];
+            if (blockIdx.x == 0 && (head & 1) == 0) {
+                const size_t off = ((size_t)kvh * a.page_tokens + base + j) * D;
+                a.kc[off + lane] = ky0[j]; a.kc[off + lane + HALF] = ky1[j];
+                a.vc[off + lane] = vn0[j]; a.vc[off + lane + HALF] = vn1[j];
+            }
+        }
+        const float ss = wave_sum(qx0[j] * qx0[j] + qx1[j] * qx1[j]);
+        const float rr = 1.0f / sqrtf(ss / (float)D + a.eps);
+        const float x0 = qn0 * (qx0[j] * rr), x1 = qn1 * (qx1[j] * rr);
+        qy0[j] = x0 * cs[j] + (-x1) * sn[j];
+        qy1[j] = x1 * cs[j] + x0 * sn[j];
+        q_s[head][j][lane] = qy0[j]; q_s[head][j][lane + HALF] = qy1[j];
+    }
+    wave_lds_sync();
+
+    KP_MARK(18);
+    KP_MARK(19);
+    // ---- per new row: scores of all cached tokens at once, softmax over the wave, P.V ----
+#pragma unroll
+    for (int j = 0; j < NEW; ++j) {
+        float partk = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float4 q4 = *reinterpret_cast<const float4*>(&q_s[head][j][ch * 32 + e * 4]);
+            partk = fmaf(q4.x, kr[e].x, partk); partk = fmaf(q4.y, kr[e].y, partk); partk = fmaf(q4.z, kr[e].z, partk); partk = fmaf(q4.w, kr[e].w, partk);
+        }
+        partk += dpp_f<Q3_DPP_XOR1, 0xF>(0.f, partk);
+        partk += dpp_f<Q3_DPP_XOR2, 0xF>(0.f, partk);
+        const float sc = tk < base ? partk * a.scale : -INFINITY;            // all four lanes of a token hold its score
+        float sn_[NEW];
+#pragma unroll
+        for (int jn = 0; jn < NEW; ++jn) sn_[jn] = jn <= j ? wave_sum(qy0[j] * ky0[jn] + qy1[j] * ky1[jn]) * a.scale : -INFINITY;   // causal among the new rows
+        float m = wave_max(sc);
+#pragma unroll
+        for (int jn = 0; jn < NEW; ++jn) m = fmaxf(m, sn_[jn]);              // the token itself is always there: m is finite
+        const float pA = __expf(sc - m);                                     // exp(-inf) = 0
+        float l = wave_sum(ch == 0 ? pA : 0.f);
+        float pn[NEW];
+#pragma unroll
+        for (int jn = 0; jn < NEW; ++jn) { pn[jn] = __expf(sn_[jn] - m); l += pn[jn]; }
+        float o0 = 0.f, o1 = 0.f;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const float pt = lane_bcast(pA, 4 * t);
+            o0 = fmaf(pt, vr0[t], o0); o1 = fmaf(pt, vr1[t], o1);
+        }
+#pragma unroll
+        for (int jn = 0; jn < NEW; ++jn) { o0 = fmaf(pn[jn], vn0[jn], o0); o1 = fmaf(pn[jn], vn1[jn], o1); }
+        const float il = 1.0f / l;
+        attn_s[j][head * D + lane] = o0 * il;
+        attn_s[j][head * D + lane + HALF] = o1 * il;
+    }
+    KP_MARK(22);
+    __syncthreads();
+    KP_MARK(20);
+    // ---- o_proj: wave (row = wave & 3, K quarter = wave >> 2), residual add ----
+#pragma unroll
+    for (int m = 0; m < NEW; ++m) {
+        const float* xr = &attn_s[m][kq * 512 + lane * 8];
+        const float4 x0 = *reinterpret_cast<const float4*>(xr), x1 = *reinterpret_cast<const float4*>(xr + 4);
+        const float xv[8] = { x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w };
+        const uint32_t wu[4] = { w4.x, w4.y, w4.z, w4.w };
+        float s1 = 0.f;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) { s1 = fmaf(xv[2 * jj], bf_lo(wu[jj]), s1); s1 = fmaf(xv[2 * jj + 1], bf_hi(wu[jj]), s1); }
+        s1 = wave_sum(s1);
+        if (lane == 0) part[m][wave] = s1;
+    }
+    __syncthreads();
+    KP_MARK(21);
+    if (wave < 4 && lane < NEW && orow < a.N) {
+        float r = resid[0];
+        if (NEW > 1 && lane == 1) r = resid[NEW - 1];
+        a.x[(size_t)lane * a.ldx + orow] = r + (((part[lane][wave] + part[lane][wave + 4]) + part[lane][wave + 8]) + part[lane][wave + 12]);
+    }
+}
+
 void launch_cp_attn_oproj(const CpAttnOprojArgs& a, int n_new, hipStream_t s) {
     if (!cp_attn_oproj_ok(a, n_new)) throw Error("cp_attn_oproj: unsupported shape");
     const int U = a.base <= 4 ? 1 : (a.base <= 8 ? 2 : (a.base <= 12 ? 3 : 4));
     const dim3 grid((a.N + 3) / 4), block(1024);
-    // Q3TTS_CP_ATTN_V2=1 (A/B knob): the two waves of a kv group split the tokens, U2 cached tokens per (wave, lane group), 8 U2 >= base.
-    // Measured SLOWER (b=1 step 2.12 -> 2.29 ms, profiles/r03_negative_results.txt item 6): the launch is bound by the vector-issue time of
-    // the four waves that share a SIMD, and two heads per wave double each wave's score / softmax chain; the halved K / V requests buy nothing.
-    static const bool v2 = getenv("Q3TTS_CP_ATTN_V2") != nullptr;
-    if (v2) {
+    // Q3TTS_CP_ATTN = 2 | 3 (A/B knob): the two round-3 variants, both correct and both measured SLOWER than the first kernel (b=1 step 2.10 ms
+    // against 2.29 / 2.30 ms, profiles/r03_negative_results.txt item 6): the launch is bound by BOTH the CU's 64 B/clk vector-memory path
+    // (336 KB requested per workgroup = 2.5 us) and the vector-issue time of four waves per SIMD.  Variant 2 halves the requests and doubles
+    // each wave's softmax chain; variant 3 (k_attn_tiny's layout) trims the chain and needs 58 instead of 34 memory instructions per wave.
+    static const int ver = getenv("Q3TTS_CP_ATTN") ? atoi(getenv("Q3TTS_CP_ATTN")) : 1;
+    if (ver == 3) {
+#define Q3_CAO3(NEW) hipLaunchKernelGGL((k_cp_attn_oproj3<NEW>), grid, block, 0, s, a.W, a.qkv, (const float*)a.kc, (const float*)a.vc, (const float*)a.x, \
+        a.rope_cos, a.rope_sin, (uint32_t)a.base | (uint32_t)a.page_tokens << 16, (uint32_t)a.N | (uint32_t)a.ldx << 16, a)
+        if (n_new == 1) Q3_CAO3(1); else Q3_CAO3(2);
+#undef Q3_CAO3
+        Q3_HIP_CHECK(hipGetLastError());
+        return;
+    }
+    if (ver == 2) {
 #define Q3_CAO2(NEW, UU) hipLaunchKernelGGL((k_cp_attn_oproj2<NEW, UU>), grid, block, 0, s, a.W, a.qkv, (const float*)a.kc, (const float*)a.vc, (const float*)a.x, \
         a.rope_cos, a.rope_sin, (uint32_t)a.base | (uint32_t)a.page_tokens << 16, (uint32_t)a.N | (uint32_t)a.ldx << 16, a)
         if (n_new == 1) { if (a.base <= 8) Q3_CAO2(1, 1); else Q3_CAO2(1, 2); }
