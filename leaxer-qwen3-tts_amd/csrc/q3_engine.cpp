@@ -268,7 +268,7 @@ Engine::Engine(const q3tts_config& cfg, int device_, int max_batch, int max_ctx_
         ssq_a_d = fm((size_t)rows_max * 64);
         ssq_b_d = fm((size_t)rows_max * 64);
     }
-    gu_slab_d = fm((size_t)2 * 4 * rows_max * std::max(c.ffn, c.cp_ffn));
+    gu_slab_d = fm((size_t)2 * 8 * rows_max * std::max(c.ffn, c.cp_ffn));   // gate | up halves of up to 8 K slices each
     ids_d = (int64_t*)dmalloc(64 * sizeof(int64_t));
     tok_d = (int64_t*)dmalloc(sizeof(int64_t));
     codes_d = (int32_t*)dmalloc((size_t)B * max_frames_cap * c.n_groups * sizeof(int32_t));
@@ -455,11 +455,19 @@ static int pick_ksplit(int K) { // K slices per GEMM: 256 (two LDS chunks) per w
     return ks;
 }
 
+// K slices of the gate/up GEMM under the seam: 4 (256-wide at K = 1024).  Q3TTS_SEAM_GU_KS=8 is the A/B knob for 128-wide slices (twice the
+// workgroups, half the body each, 8 slab pairs per seam): measured slower, 4.90 vs 4.78 ms per b=64 step (profiles/r03_negative_results.txt).
+static int seam_gu_ksplit(int K) {
+    static const int forced = getenv("Q3TTS_SEAM_GU_KS") ? atoi(getenv("Q3TTS_SEAM_GU_KS")) : 0;
+    const int ks4 = std::min(4, pick_ksplit(K));
+    return forced == 8 && K % (128 * 8) == 0 && K / 8 == 128 ? 8 : ks4;
+}
+
 bool Engine::seam_applies(const DecStack& W, int M, float* x, int ldx, bool has_slot_map) const {
     const int AO = W.nq * W.d, NTH = W.H / 64;
     const bool mfma = M >= mfma_min_rows && W.H % 128 == 0 && AO % 128 == 0 && W.ffn % 128 == 0 && W.H <= 4096;
     if (!mfma || !seam_step || !seam_on || has_slot_map || M > 128 || NTH > 64 || NTH % 4 != 0 || W.L < 1) return false;
-    const int ks_q = std::min(4, pick_ksplit(W.H));
+    const int ks_q = seam_gu_ksplit(W.H);
     GemmArgs t1, t2, t3;
     t1.seam = 1; t1.epi = EPI_SLAB; t1.M = M; t1.N = W.H; t1.K = AO; t1.ldo = W.H; t1.ldx = ldp; t1.sx = x; t1.sldx = ldx; t1.sgamma = W.layers[0].post_norm;
     t1.ssq_out = ssq_a_d; t1.ssq_nt = NTH; t1.seam_cnt = seam_cnt_d; t1.seam_gen = seam_gen_d; t1.oh = pl0h; t1.ol = pl0l; t1.ldp = ldp;
@@ -567,12 +575,14 @@ bool Engine::run_layers(const DecStack& W, float* x, int ldx, int nb, int n_new,
             GemmArgs f; // gate and up as split-K slab pairs, SwiGLU applied by the finish kernel
             f.W = w.gate; f.W2 = w.up; f.xh = pl0h; f.xl = pl0l; f.ldx = ldp; f.out = gu_slab_d; f.out2 = gu_slab_d + (size_t)4 * rows_max * W.ffn; f.ldo = W.ffn;
             f.M = M; f.N = W.ffn; f.K = W.H; f.epi = EPI_SLAB2; f.nt = W.nt;
+            const int ks_gu = seam ? seam_gu_ksplit(W.H) : ks_q;
+            f.out2 = gu_slab_d + (size_t)ks_gu * rows_max * W.ffn;
             if (seam) {   // planes1 = SwiGLU of the slab sums scaled by 1 / rms(x) (from ssq_a)
                 f.seam = 2; f.seam_gen = seam_gen_d; f.seam_spin = seam_spin; f.seam_cnt = seam_counters(W.ffn / 64); f.oh = pl1h; f.ol = pl1l; f.ldp = ldp;
                 f.ssq_in = ssq_a_d; f.ssq_in_nt = NTH; f.seps = W.eps;
             }
-            launch_gemm2(f, ks_q, 4, stream);
-            if (!seam) launch_finish_swiglu(gu_slab_d, gu_slab_d + (size_t)4 * rows_max * W.ffn, ks_q, (size_t)M * W.ffn, M, W.ffn, pl1h, pl1l, ldp, stream);
+            launch_gemm2(f, ks_gu, 4, stream);
+            if (!seam) launch_finish_swiglu(gu_slab_d, gu_slab_d + (size_t)ks_gu * rows_max * W.ffn, ks_q, (size_t)M * W.ffn, M, W.ffn, pl1h, pl1l, ldp, stream);
             GemmArgs d;
             d.W = w.down; d.xh = pl1h; d.xl = pl1l; d.ldx = ldp; d.out = slab_d; d.ldo = W.H; d.M = M; d.N = W.H; d.K = W.ffn; d.epi = EPI_SLAB; d.nt = W.nt;
             if (seam && l + 1 < W.L) {   // x += sum(slabs); planes0 = gamma(next input norm) * x; ssq_b for the next layer's attention

@@ -514,7 +514,7 @@ bool gemm_seam_ok(const GemmArgs& a, int ksplit) {
     const int ksl = ksplit > 0 && a.K % ksplit == 0 ? a.K / ksplit : 0;
     if (!(ksl == 128 || ksl == 256) || a.N % 64 != 0 || a.ldo % 4 != 0 || a.ldx % 8 != 0 || a.M < 1 || a.M > 128) return false;
     if (a.seam == 1 && (ksplit > 12 || !a.sx || !a.sgamma || !a.ssq_out || a.ssq_nt != a.N / 64 || a.sldx % 4 != 0)) return false;
-    if (a.seam == 2 && (ksplit > 4 || (a.ssq_in && a.ssq_in_nt % 4 != 0))) return false;
+    if (a.seam == 2 && (ksplit > 8 || (a.ssq_in && a.ssq_in_nt % 4 != 0))) return false;
     return a.seam_cnt != nullptr && a.seam_gen != nullptr && a.oh != nullptr && a.ol != nullptr && a.ldp % 4 == 0 && (a.slab_rows == 0 || a.slab_rows == a.M);
 }
 static void launch_gemm3_seam(const GemmArgs& a, int ksplit, hipStream_t s) {
@@ -523,7 +523,8 @@ static void launch_gemm3_seam(const GemmArgs& a, int ksplit, hipStream_t s) {
         if (ksplit <= 8) { if (big) gemm3_seam_go<4, EPI_SLAB, 1, 8>(a, ksplit, s); else gemm3_seam_go<2, EPI_SLAB, 1, 8>(a, ksplit, s); }
         else { if (big) gemm3_seam_go<4, EPI_SLAB, 1, 12>(a, ksplit, s); else gemm3_seam_go<2, EPI_SLAB, 1, 12>(a, ksplit, s); }
     } else {
-        if (big) gemm3_seam_go<4, EPI_SLAB2, 2, 4>(a, ksplit, s); else gemm3_seam_go<2, EPI_SLAB2, 2, 4>(a, ksplit, s);
+        if (ksplit <= 4) { if (big) gemm3_seam_go<4, EPI_SLAB2, 2, 4>(a, ksplit, s); else gemm3_seam_go<2, EPI_SLAB2, 2, 4>(a, ksplit, s); }
+        else { if (big) gemm3_seam_go<4, EPI_SLAB2, 2, 8>(a, ksplit, s); else gemm3_seam_go<2, EPI_SLAB2, 2, 8>(a, ksplit, s); }
     }
 }
 
