@@ -14,17 +14,18 @@ pytestmark = pytest.mark.gpu
 CHECK = (0, 16, 17, 31, 63)     # oracle cost: a spread of utterances, both sides of the 16/17-row kernel switch
 
 
-@pytest.fixture(scope="module", params=["fp32kv", "bf16kv", "finish-launches", "seam-rescue"])
+@pytest.fixture(scope="module", params=["fp32kv", "bf16kv", "finish-launches", "seam-rescue", "seam-inband"])
 def wide(request):
     """64 slots at 0.6B dims.  Rounds: the default engine (split-K seam inside k_gemm3: the slab GEMMs reduce their own slabs, deferred
     RMSNorm); the talker KV cache in bf16 (Q3TTS_FLAG_KV_BF16, oracle in the same mode); Q3TTS_SEAM=0, the k_finish* launches the seam
     replaces; Q3TTS_SEAM_SPIN=1, every chunk owner gives up after one look, so the abandon / compare-and-swap rescue path of the seam
-    produces the planes (a path a chip that runs the whole grid at once never takes)."""
+    produces the planes (a path a chip that runs the whole grid at once never takes); Q3TTS_SEAM_INBAND=1, the third seam protocol (a slice's
+    arrival is detected in the partial sums themselves, which rest at a sentinel between launches; kept as a measured negative result)."""
     import os
     import q3tts
     cfg = q3tts.default_config("0.6b")
     bf = request.param == "bf16kv"
-    env = {"finish-launches": {"Q3TTS_SEAM": "0"}, "seam-rescue": {"Q3TTS_SEAM_SPIN": "1"}}.get(request.param, {})
+    env = {"finish-launches": {"Q3TTS_SEAM": "0"}, "seam-rescue": {"Q3TTS_SEAM_SPIN": "1"}, "seam-inband": {"Q3TTS_SEAM_INBAND": "1"}}.get(request.param, {})
     os.environ.update(env)             # read at engine creation
     try:
         eng = q3tts.Engine(cfg, device=0, max_batch=64, max_ctx=64, flags=q3tts.FLAG_KV_BF16 if bf else 0)
@@ -67,6 +68,7 @@ def test_batched_generation_full_size(wide, nb, sampled):
                 bad.append((u, f, g, float(mg[f, 2 + g])))
         assert np.isfinite(pcm[u]).all() and len(pcm[u]) == eng.codec_decode_len(8)
     assert not bad, bad
+    assert eng.seam_residue() == 0      # the in-launch reduction left every partial-sum word at rest (q3tts_seam_residue)
     # the batch is deterministic and every utterance independent of its neighbours: the first 24 of a 64-batch == the 24-batch
     if nb == 24:
         _, codes64, _ = eng.synthesize_batch(toks, sp, lang=0, seed=77, ignore_eos=True)
@@ -84,6 +86,7 @@ def test_batched_greedy_32_frames_margin_aware(wide):
     sp = q3tts.Sampling(max_new_tokens=F, temperature=1.0, top_p=1.0, top_k=1)
     _, codes, nfr = eng.synthesize_batch(toks, sp, lang=0, seed=9, ignore_eos=True)
     assert all(int(n) == F for n in nfr)
+    assert eng.seam_residue() == 0
     for u in (0, 17, 63):
         ref, mg = orc.generate_margins(orc.build_prompt(toks[u], 0), to_osampling(sp), seed=9, stream=u, cp_cached=True, ignore_eos=True)
         bad = np.argwhere(codes[u] != ref)

@@ -34,5 +34,5 @@ for rep in range(3):
         print(f"{nm} (tile 0, row block 0), ns from the first workgroup's entry; columns: entry body drain ticket+wait claim reduce none-left")
         for s in range(ks):
             r = t[kind, s]
-            print("  slice %2d: " % s + " ".join("%7.0f" % (v - t0) if v >= t0 else "      -" for v in r[:7]))
+            print("  slice %2d: " % s + " ".join("%7.0f" % (v - t0) if v >= t0 else "      -" for v in r[:6]) + ("   poll rounds %d" % int(r[6] / 10.0) if 0 < r[6] < 1e6 else ""))
 eng.close()
