@@ -809,6 +809,12 @@ __global__ __launch_bounds__(NWV * 64) void k_gemv16(const bf16_t* pW, const bf1
     const bool nt = (pKnt >> 31) != 0;
     const int kslice = K / NWV, kw = kslice >> 5;   // k-steps of 32 this wave owns (1..KWMAX)
     const int kbeg = wave * kslice;
+#ifdef Q3_SAMPLE_PROF
+#define G16_MARK(k) do { if (KWMAX == 12 && EPI == EPI_RESIDUAL && blockIdx.x == 0 && (tid == 0 || tid == NWV * 64 - 64)) g_gemm_prof[(tid == 0 ? 16 : 24) + (k)] = wall_clock64(); } while (0)
+#else
+#define G16_MARK(k) do { } while (0)
+#endif
+    G16_MARK(0);
     __shared__ float red[DUAL ? 2 : 1][NWV][16][17];
     __shared__ float ssq[NWV][16];
 
@@ -856,11 +862,13 @@ __global__ __launch_bounds__(NWV * 64) void k_gemv16(const bf16_t* pW, const bf1
         if (tid < 256 && em < M && en < N) epi_in = EPI == EPI_RESIDUAL ? pepi[(size_t)em * pldepi + en] : pepi[en];
     }
     __builtin_amdgcn_sched_barrier(0);
+    G16_MARK(1);   // every load issued
 
     f32x4 acc = { 0.f, 0.f, 0.f, 0.f }, acc2 = { 0.f, 0.f, 0.f, 0.f };
     float ss = 0.f;
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
+        if (g == 1) G16_MARK(2);   // first group's activations and weights arrived, its MFMAs issued
 #pragma unroll
         for (int j = 0; j < G16_AB; ++j) {
             const int ks = g * G16_AB + j;
@@ -890,6 +898,7 @@ __global__ __launch_bounds__(NWV * 64) void k_gemv16(const bf16_t* pW, const bf1
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+    G16_MARK(3);   // all MFMAs issued
     // meet in LDS: D layout col = lane & 15 (n), row = q * 4 + reg (m)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -902,6 +911,7 @@ __global__ __launch_bounds__(NWV * 64) void k_gemv16(const bf16_t* pW, const bf1
         if (q == 0) ssq[wave][r16] = ss;
     }
     __syncthreads();
+    G16_MARK(4);   // all waves met
     if (tid < 256) {
         float v = 0.f, v2 = 0.f;
 #pragma unroll
@@ -923,6 +933,7 @@ __global__ __launch_bounds__(NWV * 64) void k_gemv16(const bf16_t* pW, const bf1
             a.out[(size_t)em * a.ldo + en] = o;
         }
     }
+    G16_MARK(5);   // outputs stored
     // optional fp32 copy of the normalised rows (the talker head keeps them as the predictor's first input row)
     if (NORM && a.xn_out != nullptr && blockIdx.x == 0) {
         for (int m = 0; m < M; ++m) {
