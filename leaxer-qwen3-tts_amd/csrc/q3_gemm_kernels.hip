@@ -794,8 +794,16 @@ static __device__ __forceinline__ void g16_split8(const float (&y)[8], bf16x8& h
     lo = __builtin_bit_cast(bf16x8, l);
 }
 
+// R8 (M <= 8): the activation rows arrive as 8 rows x 128 bytes per load instruction — lane (r8 = lane & 7, c = lane >> 3) takes floats
+// [4c, 4c + 4) of row r8's 32-float k-step — instead of 16 rows x 2 x 64 bytes with the lanes of rows 8..15 switched off.  The
+// launch is bound by the ISSUE of its loads (3-5 us of 6.8: profiles/r03_gemv16_phase_stamps.txt; the CU's address path takes one
+// 128-byte line per clock and the operand layout made every instruction touch 8-16 lines half used): one instruction per k-step
+// instead of two, every lane active, every line touched once.  Lane (r16 < 8, q) of the MFMA layout already holds its floats
+// [8q, 8q + 4) (its own load: c = 2q) and takes [8q + 4, 8q + 8) from lane + 8 with one row_ror:8 DPP move per dword; lanes of
+// rows 8..15 carry other rows' chunks into the product, which only reaches output rows 8..15 (never stored).  The values each
+// product sees and their order are unchanged: results are bit-identical to the R8 = false kernel.
 #define G16_AB 4
-template <int KWMAX, int NWV, int EPI, bool NORM>
+template <int KWMAX, int NWV, int EPI, bool NORM, bool R8 = false>
 __global__ __launch_bounds__(NWV * 64) void k_gemv16(const bf16_t* pW, const bf16_t* pW2, const float* px, const float* pgamma, const float* pepi,
                                                       int pN, int pM, int pldx, int pldepi, uint32_t pKnt /* K | nt << 31 */, GemvArgs a) {   // leading scalars: kernarg-preloaded
     constexpr bool DUAL = EPI == EPI_SWIGLU;
@@ -820,20 +828,22 @@ __global__ __launch_bounds__(NWV * 64) void k_gemv16(const bf16_t* pW, const bf1
 
     // Loads return in issue order, so what is issued before the weight stream can be converted while the weights are in flight:
     // the first PREG groups of activation k-steps go first, the rest follow the weights one group at a time into a freed buffer.
-    const float* xr = px + (size_t)(r16 < M ? r16 : M - 1) * pldx + kbeg + q * 8;   // lane (r16, q): row r16, 8 consecutive k per k-step
+    const int r8 = lane & 7, c8 = lane >> 3;
+    const float* xr = R8 ? px + (size_t)(r8 < M ? r8 : M - 1) * pldx + kbeg + c8 * 4     // lane (r8, c): row r8, floats [4c, 4c + 4) of each k-step
+                         : px + (size_t)(r16 < M ? r16 : M - 1) * pldx + kbeg + q * 8;   // lane (r16, q): row r16, 8 consecutive k per k-step
     const float* gr = NORM ? pgamma + kbeg + q * 8 : nullptr;
-    g16_f32x4 xa[PREG][G16_AB][2], ga[NORM ? PREG : 1][G16_AB][2];
-    const bool row_live = r16 < M;   // lanes of rows past M issue no activation loads (their outputs are never stored)
+    g16_f32x4 xa[PREG][G16_AB][R8 ? 1 : 2], ga[NORM ? PREG : 1][G16_AB][2];
+    const bool row_live = R8 ? r8 < M : r16 < M;   // lanes of rows past M issue no activation loads (their outputs are never stored)
     auto issue = [&](int buf, int g) {
 #pragma unroll
         for (int j = 0; j < G16_AB; ++j) {
             const int ks = g * G16_AB + j;
             const int kk = ks < kw ? ks : kw - 1;   // k-steps past kw repeat the last one; their fragment is zeroed below
             xa[buf][j][0] = g16_f32x4{ 0.f, 0.f, 0.f, 0.f };
-            xa[buf][j][1] = g16_f32x4{ 0.f, 0.f, 0.f, 0.f };
+            if (!R8) xa[buf][j][R8 ? 0 : 1] = g16_f32x4{ 0.f, 0.f, 0.f, 0.f };
             if (row_live) {
                 xa[buf][j][0] = *reinterpret_cast<const g16_f32x4*>(xr + kk * 32);
-                xa[buf][j][1] = *reinterpret_cast<const g16_f32x4*>(xr + kk * 32 + 4);
+                if (!R8) xa[buf][j][R8 ? 0 : 1] = *reinterpret_cast<const g16_f32x4*>(xr + kk * 32 + 4);
             }
             if (NORM) {
                 ga[buf][j][0] = *reinterpret_cast<const g16_f32x4*>(gr + kk * 32);
@@ -874,10 +884,16 @@ __global__ __launch_bounds__(NWV * 64) void k_gemv16(const bf16_t* pW, const bf1
             const int ks = g * G16_AB + j;
             if (ks >= KWMAX) continue;
             const float live = ks < kw ? 1.0f : 0.0f;
-            float y[8];
+            float y[8], xin[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                xin[e] = xa[g % PREG][j][0][e];
+                if (R8) xin[4 + e] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, xin[e]), 0x128 /* row_ror:8 */, 0xF, 0xF, false));
+                else xin[4 + e] = xa[g % PREG][j][R8 ? 0 : 1][e];
+            }
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const float xv = xa[g % PREG][j][e >> 2][e & 3] * live;
+                const float xv = (R8 && r16 >= 8 ? 0.f : xin[e]) * live;   // R8: the lanes of rows 8..15 hold other rows' chunks: zero, as the R8 = false kernel has there
                 if (NORM) { ss = fmaf(xv, xv, ss); y[e] = xv * ga[g % PREG][j][e >> 2][e & 3]; }
                 else y[e] = xv;
             }
@@ -958,8 +974,11 @@ template <int KWMAX, int NWV>
 static void gemv16_epi(const GemvArgs& a, hipStream_t s) {
     const dim3 grid((a.N + 15) / 16), block(NWV * 64);
     const bool norm = a.gamma != nullptr;
-#define Q3_G16(EPI, NORM) hipLaunchKernelGGL((k_gemv16<KWMAX, NWV, EPI, NORM>), grid, block, 0, s, a.W, a.W2, a.x, a.gamma, \
+    static const bool no_r8 = getenv("Q3TTS_GEMV16_R8") && atoi(getenv("Q3TTS_GEMV16_R8")) == 0;   // A/B knob
+    const bool r8 = a.M <= 8 && !no_r8;
+#define Q3_G16_(EPI, NORM, R8_) hipLaunchKernelGGL((k_gemv16<KWMAX, NWV, EPI, NORM, R8_>), grid, block, 0, s, a.W, a.W2, a.x, a.gamma, \
         (a.epi == EPI_RESIDUAL ? a.res : a.bias), a.N, a.M, a.ldx, a.ldres, (uint32_t)a.K | (a.nt ? 0x80000000u : 0u), a)
+#define Q3_G16(EPI, NORM) do { if (r8) Q3_G16_(EPI, NORM, true); else Q3_G16_(EPI, NORM, false); } while (0)
     switch (a.epi) {
     case EPI_STORE: if (norm) Q3_G16(EPI_STORE, true); else Q3_G16(EPI_STORE, false); break;
     case EPI_SWIGLU: if (norm) Q3_G16(EPI_SWIGLU, true); else Q3_G16(EPI_SWIGLU, false); break;
@@ -969,6 +988,7 @@ static void gemv16_epi(const GemvArgs& a, hipStream_t s) {
     default: throw Error("gemv16: bad epilogue");
     }
 #undef Q3_G16
+#undef Q3_G16_
 }
 void launch_gemv16(const GemvArgs& a, hipStream_t s) {
     if (!gemv16_ok(a)) throw Error("gemv16: unsupported shape");

@@ -414,3 +414,42 @@ def test_vocoder_group_failure_leaves_the_engine_usable(full):
     for u in range(3):
         single = eng.codec_decode(codes[u])
         assert pcm[u].shape == single.shape and float(np.sqrt(np.mean((pcm[u] - single) ** 2))) < 1e-5, u
+
+
+def test_gemv16_row8_layout_is_bit_identical():
+    """k_gemv16 at <= 8 rows asks for its activation rows as 8 rows x 128 bytes per load (every lane active, one DPP move per dword
+    to reach the matrix-core operand layout) instead of 16 rows x 64 bytes with half the lanes off; the values each product sees and
+    their order do not change, so an engine created with Q3TTS_GEMV16_R8=0 (the older layout) must produce the same codes and PCM bit
+    for bit: 8 and 5 utterances x 12 sampled frames at 0.6B dims (rows 5 and 8 of the 3..11-row kernel family; predictor pass 0 at
+    5 utterances runs 10 rows: the older layout on both engines)."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    script = r'''
+import sys, numpy as np
+sys.path.insert(0, %r)
+import q3tts
+cfg = q3tts.default_config("0.6b")
+rng = np.random.default_rng(88)
+toks = [np.array([151644, 77091, 151672] + list(rng.integers(0, 151643, int(n))) + [151673, 151645], np.int64) for n in rng.integers(3, 16, 8)]
+sp = q3tts.Sampling(max_new_tokens=12, temperature=0.8, top_p=0.95, top_k=50)
+eng = q3tts.Engine(cfg, device=0, max_batch=8, max_ctx=64)
+eng.fill_synthetic(seed=0)
+res = {}
+for nb in (8, 5):
+    pcm, codes, nfr = eng.synthesize_batch(toks[:nb], sp, lang=0, seed=3, ignore_eos=True)
+    res["codes%%d" %% nb] = np.stack(codes); res["pcm%%d" %% nb] = np.stack(pcm)
+np.savez(sys.argv[1], **res)
+''' % os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "leaxer-qwen3-tts_amd")
+    out = {}
+    with tempfile.TemporaryDirectory() as td:
+        for mode in ("1", "0"):      # the knob is read once per process (first k_gemv16 launch): each layout runs in a child of its own
+            env = dict(os.environ, Q3TTS_GEMV16_R8=mode)
+            path = os.path.join(td, "m%s.npz" % mode)
+            r = subprocess.run([sys.executable, "-c", script, path], env=env, capture_output=True, text=True, timeout=500)
+            assert r.returncode == 0, r.stderr[-2000:]
+            out[mode] = dict(np.load(path))
+    for k in out["1"]:
+        assert np.array_equal(out["1"][k], out["0"][k]), k
+    assert np.isfinite(out["1"]["pcm8"]).all()
