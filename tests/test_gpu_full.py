@@ -416,7 +416,7 @@ def test_vocoder_group_failure_leaves_the_engine_usable(full):
         assert pcm[u].shape == single.shape and float(np.sqrt(np.mean((pcm[u] - single) ** 2))) < 1e-5, u
 
 
-def test_gemv16_row8_layout_is_bit_identical():
+def test_gemv16_load_layouts_are_bit_identical():
     """k_gemv16 at <= 8 rows asks for its activation rows as 8 rows x 128 bytes per load (every lane active, one DPP move per dword
     to reach the matrix-core operand layout) instead of 16 rows x 64 bytes with half the lanes off; the values each product sees and
     their order do not change, so an engine created with Q3TTS_GEMV16_R8=0 (the older layout) must produce the same codes and PCM bit
