@@ -453,3 +453,35 @@ np.savez(sys.argv[1], **res)
     for k in out["1"]:
         assert np.array_equal(out["1"][k], out["0"][k]), k
     assert np.isfinite(out["1"]["pcm8"]).all()
+
+
+@pytest.mark.parametrize("nb", [8, 5])
+def test_batch8_greedy_24_frames_full_size(full, nb):
+    """north_star's batch 8 at 0.6B dims: nb utterances x 24 free-running greedy frames in one batch — every projection of the step on the
+    3..11-row matrix-core GEMV (k_gemv16: 8 rows on the 8-row activation loads, 5 rows too; predictor pass 0 runs 2 nb = 16 / 10 rows) —
+    each checked utterance against its own single-utterance oracle run, margin-aware like the b=1 and b=64 tests.
+    Reference loop: /root/reference/src/tts_onnx.cpp:782-872 (one utterance at a time; batching is this build's)."""
+    import q3tts
+    _, orc = full
+    cfg = q3tts.default_config("0.6b")
+    eng = q3tts.Engine(cfg, device=0, max_batch=8, max_ctx=64)
+    try:
+        eng.fill_synthetic(seed=0)
+        rng = np.random.default_rng(808)
+        toks = [frame_tokens(rng.integers(0, 151643, int(n))) for n in rng.integers(3, 20, 8)]
+        F = 24
+        sp = q3tts.Sampling(max_new_tokens=F, temperature=1.0, top_p=1.0, top_k=1)
+        _, codes, nfr = eng.synthesize_batch(toks[:nb], sp, lang=0, seed=21, ignore_eos=True)
+        assert all(int(n) == F for n in nfr)
+        for u in (0, nb - 1):
+            ref, mg = orc.generate_margins(orc.build_prompt(toks[u], 0), to_osampling(sp), seed=21, stream=u, cp_cached=True, ignore_eos=True)
+            bad = np.argwhere(codes[u] != ref)
+            if bad.size == 0:
+                print("b=%d greedy, utterance %d: %d frames bit-exact, smallest top-2 margin %.3g" % (nb, u, F, float(mg[:, 2:].min())))
+                continue
+            f, g = int(bad[0][0]), int(bad[0][1])
+            print("b=%d greedy, utterance %d: first divergence at frame %d group %d, oracle margin %.3g" % (nb, u, f, g, float(mg[f, 2 + g])))
+            assert float(mg[f, 2 + g]) < NOISE, (u, f, g, float(mg[f, 2 + g]))
+            assert np.array_equal(codes[u][:f], ref[:f]) and np.array_equal(codes[u][f, :g], ref[f, :g])
+    finally:
+        eng.close()
