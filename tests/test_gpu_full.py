@@ -485,3 +485,40 @@ def test_batch8_greedy_24_frames_full_size(full, nb):
             assert np.array_equal(codes[u][:f], ref[:f]) and np.array_equal(codes[u][f, :g], ref[f, :g])
     finally:
         eng.close()
+
+
+def test_talker_decode_at_context_2048_full_size(full):
+    """The talker at the depth BASELINE's 2048-frame run reaches: a 2044-token cache (32 KV pages of 64 tokens; 8 prefill rows + 2036 decode
+    steps on the engine, one 2044-row prefill on the oracle) and then 8 decode steps — across the 2048-token page boundary — whose
+    attention runs as 32-33 splits of 64 tokens merged by the o_proj prologue — logits and hidden rows against the oracle (its own
+    fp32 loops over one long cache).  The free-running tests stop at 170 tokens because the CPU oracle makes ~7 frames per second; the
+    long cache itself is cheap for it to BUILD with a prefill.  Reference: run_prefill / run_decode, /root/reference/src/tts_onnx.cpp:600-732."""
+    import q3tts
+    _, orc = full
+    cfg = q3tts.default_config("0.6b")
+    S = 2044
+    eng = q3tts.Engine(cfg, device=0, max_batch=1, max_ctx=S + 64)
+    big = qo.Oracle(orc.cfg, max_ctx=S + 16)
+    try:
+        eng.fill_synthetic(seed=0)
+        for name, shape in eng.tensor_infos():
+            if name.startswith("talker."):
+                big.set_tensor(name, eng.get_tensor(name, shape))
+        rng = np.random.default_rng(2048)
+        x = (rng.standard_normal((S, 1024)) * 0.05).astype(np.float32)
+        eng.prefill(x[:8])                               # the session-shaped prefill takes <= 16 rows: the rest of the cache grows by decode steps
+        for i in range(8, S):
+            lg, lh = eng.decode(x[i])
+        lo_all, ho = big.prefill(x)                      # the oracle builds the same cache in one pass (rows 8.. as prefill rows)
+        lo = lo_all[-1] if lo_all.ndim == 2 else lo_all
+        worst = max(float(np.abs(lg - lo).max()), float(np.abs(lh - ho).max()))
+        for _ in range(8):
+            e = (rng.standard_normal(1024) * 0.05).astype(np.float32)
+            lg, lh = eng.decode(e)
+            lo, ho = big.decode(e)
+            worst = max(worst, float(np.abs(lg - lo).max()), float(np.abs(lh - ho).max()))
+        print("talker at context %d..%d: worst |logit / hidden difference| vs the oracle %.3g" % (S, S + 8, worst))
+        assert worst < 3e-4, worst
+    finally:
+        eng.close()
+        big.close()
