@@ -522,3 +522,30 @@ def test_talker_decode_at_context_2048_full_size(full):
     finally:
         eng.close()
         big.close()
+
+
+@pytest.mark.parametrize("F", [300, 2048])
+def test_codec_long_utterances_full_size(full, F):
+    """300 and 2048 frames (BASELINE configs[1]'s length: 3.9 M samples) at 0.6B dims — 300 is four times the pre-transformer's 72-frame attention window (the sliding-window mask is active on most rows),
+    more than 256 row tiles per conv (the large-F tile shapes and XCD-aware tile ids of k_conv_split; 24 frames take the small-grid
+    shapes), 576 000 samples — against the fp32 oracle at the north_star tolerance.  Reference: run_vocoder, /root/reference/src/tts_onnx.cpp:759-776."""
+    import q3tts
+    eng, orc = full
+    codes = np.random.default_rng(F).integers(0, 2048, (F, 16)).astype(np.int64)
+    if F <= 512:
+        pcm = eng.codec_decode(codes)
+    else:                                              # the module's engine holds 512 frames: a second one of the same seeded weights
+        long_eng = q3tts.Engine(eng.cfg, device=0, max_batch=1, max_ctx=F + 32)
+        try:
+            long_eng.fill_synthetic(seed=0)
+            pcm = long_eng.codec_decode(codes)
+        finally:
+            long_eng.close()
+    ref = orc.vocoder(codes)
+    assert pcm.shape == ref.shape == (eng.codec_decode_len(F),)
+    sig = float(np.sqrt(np.mean(ref ** 2)))
+    err = float(np.sqrt(np.mean((pcm - ref) ** 2)))
+    tail = slice(-1920 * 8, None)                      # the last 8 frames alone (rows whose window dropped > 200 earlier frames)
+    err_tail = float(np.sqrt(np.mean((pcm[tail] - ref[tail]) ** 2)))
+    print("codec, %d frames: rms error vs oracle %.3g (last 8 frames %.3g), signal rms %.3g, max abs error %.3g" % (F, err, err_tail, sig, float(np.abs(pcm - ref).max())))
+    assert sig > 1e-3 and err < 1e-4 and err < 2e-3 * sig and err_tail < 1e-4, (err, err_tail, sig)
