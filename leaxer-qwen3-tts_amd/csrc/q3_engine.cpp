@@ -180,6 +180,7 @@ Engine::Engine(const q3tts_config& cfg, int device_, int max_batch, int max_ctx_
     if (const char* sv = getenv("Q3TTS_SEAM")) seam_on = atoi(sv) != 0;
     if (const char* sv = getenv("Q3TTS_SEAM_SPIN")) seam_spin = std::max(1, atoi(sv));
     if (const char* sv = getenv("Q3TTS_SEAM_INBAND")) seam_inband = atoi(sv) != 0;
+    attn_keep_splits = getenv("Q3TTS_ATTN_KEEP_SPLITS") != nullptr;
     null_stream = getenv("Q3TTS_NULL_STREAM") && getenv("Q3TTS_NULL_STREAM")[0] == '1';
     if (null_stream) { stream = nullptr; flags |= Q3TTS_FLAG_NO_GRAPH; }
     else if (const char* cm = getenv("Q3TTS_STREAM_CU_MASK")) {   // experiment aid (tools/overlap_probe.py): this engine's stream on a subset of the CUs;
@@ -572,8 +573,7 @@ bool Engine::run_layers(const DecStack& W, float* x, int ldx, int nb, int n_new,
         // Split-T exists to fill the chip at small batch.  With >= 256 (row, kv head) workgroups already and a context of a few hundred
         // tokens, one split walks the whole context (page ids are arithmetic with a fixed run of pages per slot) and writes the planes
         // itself: no partials, no combine launch (28 launches per b=64 step).
-        static const bool keep_splits = getenv("Q3TTS_ATTN_KEEP_SPLITS") != nullptr;   // A/B knob
-        if (mfma && W.n_splits > 1 && W.identity_pages && !keep_splits && (size_t)nb * W.nkv >= 256 && (W.pages_per_slot << W.page_shift) <= 512) {
+        if (mfma && W.n_splits > 1 && W.identity_pages && !attn_keep_splits && (size_t)nb * W.nkv >= 256 && (W.pages_per_slot << W.page_shift) <= 512) {
             a.n_splits = 1; a.chunk = 1 << 30;
         }
         const bool direct_planes = mfma && a.n_splits == 1;     // one split: the attention kernel normalises and writes the planes itself

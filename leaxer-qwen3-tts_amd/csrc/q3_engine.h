@@ -209,6 +209,7 @@ public:
     float* seam_gu_slab_d = nullptr;   // 2 x [<= 8][rows][ffn]
     size_t seam_slab_words = 0, seam_gu_slab_words = 0;
     size_t seam_residue();       // test hook: words of the two buffers that are not the sentinel (0 between steps)
+    bool attn_keep_splits = false;   // Q3TTS_ATTN_KEEP_SPLITS at engine creation: the batched step keeps split-T attention + the combine launch (A/B knob, tests' second path)
     int seam_spin = 4096;        // Q3TTS_SEAM_SPIN: polls before an owner abandons its chunk (1 forces the rescue path in the tests)
     int32_t* codes_d = nullptr;
     int32_t* codes_scratch_d = nullptr;

@@ -14,21 +14,24 @@ pytestmark = pytest.mark.gpu
 CHECK = (0, 16, 17, 31, 63)     # oracle cost: a spread of utterances, both sides of the 16/17-row kernel switch
 
 
-@pytest.fixture(scope="module", params=["fp32kv", "bf16kv", "finish-launches", "seam-rescue", "seam-inband"])
+@pytest.fixture(scope="module", params=["fp32kv", "bf16kv", "finish-launches", "seam-rescue", "seam-inband", "attn-splits"])
 def wide(request):
     """64 slots at 0.6B dims.  Rounds: the default engine (split-K seam inside k_gemm3: the slab GEMMs reduce their own slabs, deferred
     RMSNorm); the talker KV cache in bf16 (Q3TTS_FLAG_KV_BF16, oracle in the same mode); Q3TTS_SEAM=0, the k_finish* launches the seam
     replaces; Q3TTS_SEAM_SPIN=1, every chunk owner gives up after one look, so the abandon / compare-and-swap rescue path of the seam
     produces the planes (a path a chip that runs the whole grid at once never takes); Q3TTS_SEAM_INBAND=1, the third seam protocol (a slice's
-    arrival is detected in the partial sums themselves, which rest at a sentinel between launches; kept as a measured negative result)."""
+    arrival is detected in the partial sums themselves, which rest at a sentinel between launches; kept as a measured negative result);
+    Q3TTS_ATTN_KEEP_SPLITS + 64-token splits on a 192-token cache: the talker's attention as split-T partials + the combine launch (what a
+    64-utterance batch runs beyond 512 tokens of context — the b64_f2048 bench — and never at the 64-token contexts of the other rounds)."""
     import os
     import q3tts
     cfg = q3tts.default_config("0.6b")
     bf = request.param == "bf16kv"
-    env = {"finish-launches": {"Q3TTS_SEAM": "0"}, "seam-rescue": {"Q3TTS_SEAM_SPIN": "1"}, "seam-inband": {"Q3TTS_SEAM_INBAND": "1"}}.get(request.param, {})
+    env = {"finish-launches": {"Q3TTS_SEAM": "0"}, "seam-rescue": {"Q3TTS_SEAM_SPIN": "1"}, "seam-inband": {"Q3TTS_SEAM_INBAND": "1"},
+           "attn-splits": {"Q3TTS_ATTN_KEEP_SPLITS": "1", "Q3TTS_ATTN_CHUNK": "64"}}.get(request.param, {})
     os.environ.update(env)             # read at engine creation
     try:
-        eng = q3tts.Engine(cfg, device=0, max_batch=64, max_ctx=64, flags=q3tts.FLAG_KV_BF16 if bf else 0)
+        eng = q3tts.Engine(cfg, device=0, max_batch=64, max_ctx=192 if request.param == "attn-splits" else 64, flags=q3tts.FLAG_KV_BF16 if bf else 0)
     finally:
         for k in env:
             del os.environ[k]
@@ -36,7 +39,8 @@ def wide(request):
     eng.fill_synthetic(seed=0)
     eng.margin_noise = 2e-2 if bf else 2e-4     # tests/test_gpu_full.py, bf16 KV note: what logit agreement this cache mode can honour
     eng.logit_bound = 2e-2 if bf else 2e-4
-    orc = qo.Oracle(to_ocfg(cfg), max_ctx=48, kv_bf16=bf)
+    eng.long_run = request.param == "attn-splits"     # the 32-frame greedy test runs 56 frames there: contexts cross the 64-token split
+    orc = qo.Oracle(to_ocfg(cfg), max_ctx=96 if eng.long_run else 48, kv_bf16=bf)
     for name, shape in eng.tensor_infos():
         if not name.startswith(("cd.", "spk.")):
             orc.set_tensor(name, eng.get_tensor(name, shape))
@@ -82,7 +86,7 @@ def test_batched_greedy_32_frames_margin_aware(wide):
     top-2 logit gap at that decision is below the logit-noise bound (then it is printed and everything before it must match)."""
     import q3tts
     eng, orc, toks = wide
-    F = 32
+    F = 56 if eng.long_run else 32
     sp = q3tts.Sampling(max_new_tokens=F, temperature=1.0, top_p=1.0, top_k=1)
     _, codes, nfr = eng.synthesize_batch(toks, sp, lang=0, seed=9, ignore_eos=True)
     assert all(int(n) == F for n in nfr)
