@@ -160,3 +160,36 @@ def test_gemm3_slabs_are_bit_identical_to_gemm2(wide):
         assert np.array_equal(codes3[u], codes2[u]), u
     for (a, ah), (b, bh) in zip(lg3, lg2):
         assert np.array_equal(a, b) and np.array_equal(ah, bh)
+
+
+def test_batch_of_80_crosses_the_128_row_block():
+    """80 utterances in one batch at 0.6B dims: the talker's projections run 80 rows (64-row blocks of the split-K seam GEMM), predictor
+    pass 0 runs 160 rows — past the 128 rows one GEMM block and the seam cover, so those launches walk 128-row blocks and keep the
+    finish launches — and the later passes 80.  Sampled, 8 frames; a spread of utterances against their single-utterance oracle runs."""
+    import q3tts
+    cfg = q3tts.default_config("0.6b")
+    eng = q3tts.Engine(cfg, device=0, max_batch=80, max_ctx=64)
+    orc = qo.Oracle(to_ocfg(cfg), max_ctx=48)
+    try:
+        eng.fill_synthetic(seed=0)
+        for name, shape in eng.tensor_infos():
+            if not name.startswith(("cd.", "spk.")):
+                orc.set_tensor(name, eng.get_tensor(name, shape))
+        rng = np.random.default_rng(80)
+        toks = [frame_tokens(rng.integers(0, 151643, int(n))) for n in rng.integers(3, 20, 80)]
+        sp = q3tts.Sampling(max_new_tokens=8, temperature=0.8, top_p=0.95, top_k=50)
+        pcm, codes, nfr = eng.synthesize_batch(toks, sp, lang=0, seed=5, ignore_eos=True)
+        assert all(int(n) == 8 for n in nfr) and eng.seam_residue() == 0
+        bad = []
+        for u in (0, 63, 64, 79):
+            ref, mg = orc.generate_margins(orc.build_prompt(toks[u], 0), to_osampling(sp), seed=5, stream=u, cp_cached=True, ignore_eos=True)
+            if not np.array_equal(codes[u], ref):
+                f, g = [int(v) for v in np.argwhere(codes[u] != ref)[0]]
+                print("b=80, utterance %d parts from the oracle at frame %d group %d, oracle decision margin %.3g" % (u, f, g, float(mg[f, 2 + g])))
+                if not (float(mg[f, 2 + g]) < 2e-4 and np.array_equal(codes[u][:f], ref[:f]) and np.array_equal(codes[u][f, :g], ref[f, :g])):
+                    bad.append((u, f, g, float(mg[f, 2 + g])))
+            assert np.isfinite(pcm[u]).all()
+        assert not bad, bad
+    finally:
+        eng.close()
+        orc.close()
