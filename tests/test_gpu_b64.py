@@ -193,3 +193,39 @@ def test_batch_of_80_crosses_the_128_row_block():
     finally:
         eng.close()
         orc.close()
+
+
+def test_batch_of_32_with_long_prompts_one_split_attention_walks_several_batches():
+    """32 utterances with 100..150-token prompts, 12 greedy frames, at 0.6B dims.  With >= 256 (utterance, kv head) pairs the batched step
+    runs the talker's attention as ONE split per pair that walks the whole context in batches of 128 tokens with an online softmax across
+    batches — the b=64 x 256-frame bench spends most of its steps there (contexts 130-280), while the other batched tests stop at 60 tokens
+    and the b=1 tests take 64-token splits of one batch each.  Also: the scheduler's batched prefill over ~4000 prompt rows (128-row GEMM
+    blocks, prompts longer than one 64-token KV page).  A spread of utterances against their single-utterance oracle runs, margin-aware."""
+    import q3tts
+    cfg = q3tts.default_config("0.6b")
+    eng = q3tts.Engine(cfg, device=0, max_batch=32, max_ctx=192)
+    orc = qo.Oracle(to_ocfg(cfg), max_ctx=192)
+    try:
+        eng.fill_synthetic(seed=0)
+        for name, shape in eng.tensor_infos():
+            if not name.startswith(("cd.", "spk.")):
+                orc.set_tensor(name, eng.get_tensor(name, shape))
+        rng = np.random.default_rng(32)
+        toks = [frame_tokens(rng.integers(0, 151643, int(n))) for n in rng.integers(100, 150, 32)]
+        F = 12
+        sp = q3tts.Sampling(max_new_tokens=F, temperature=1.0, top_p=1.0, top_k=1)
+        _, codes, nfr = eng.synthesize_batch(toks, sp, lang=0, seed=3, ignore_eos=True)
+        assert all(int(n) == F for n in nfr) and eng.seam_residue() == 0
+        for u in (0, 15, 31):
+            ref, mg = orc.generate_margins(orc.build_prompt(toks[u], 0), to_osampling(sp), seed=3, stream=u, cp_cached=True, ignore_eos=True)
+            bad = np.argwhere(codes[u] != ref)
+            if bad.size == 0:
+                print("b=32, %d-token prompt, utterance %d: %d frames bit-exact, smallest top-2 margin %.3g" % (len(toks[u]), u, F, float(mg[:, 2:].min())))
+                continue
+            f, g = int(bad[0][0]), int(bad[0][1])
+            print("b=32, utterance %d: first divergence at frame %d group %d, oracle margin %.3g" % (u, f, g, float(mg[f, 2 + g])))
+            assert float(mg[f, 2 + g]) < 2e-4, (u, f, g, float(mg[f, 2 + g]))
+            assert np.array_equal(codes[u][:f], ref[:f]) and np.array_equal(codes[u][f, :g], ref[f, :g])
+    finally:
+        eng.close()
+        orc.close()
