@@ -857,6 +857,7 @@ __global__ __launch_bounds__(128) void k_attn_tiny(const float* pqkv, const floa
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int pair = blockIdx.x * 2 + wave;
     if (pair >= a.nb * a.nkv) return;                                   // wave-uniform
+    KP_MARK(12);
     const int bi = pair / a.nkv, kvh = pair - bi * a.nkv;
     const int slot = a.slot_offset + bi, base = pbase;
     const int PT = 1 << a.page_shift;
@@ -906,8 +907,10 @@ __global__ __launch_bounds__(128) void k_attn_tiny(const float* pqkv, const floa
         vr0[t] = vc[(size_t)tt * D + lane]; vr1[t] = vc[(size_t)tt * D + lane + HALF];
     }
     __builtin_amdgcn_sched_barrier(0);
+    KP_MARK(13);   // every load issued
 #pragma unroll
     for (int t = 0; t < 16; ++t) { vr0[t] = t < base ? vr0[t] : 0.f; vr1[t] = t < base ? vr1[t] : 0.f; }   // never-written cache rows may hold anything: 0 x NaN
+    KP_MARK(14);   // the cached K / V rows have arrived (the selects above wait for the last V row)
 
     // ---- new tokens: slab sums (slab order), RMSNorm, RoPE; K / V appended to the cache; q to LDS ----
     float ky0[NN], ky1[NN], vn0[NN], vn1[NN], qy0[NN][G], qy1[NN][G];
@@ -944,6 +947,7 @@ __global__ __launch_bounds__(128) void k_attn_tiny(const float* pqkv, const floa
         }
     }
     wave_lds_sync();
+    KP_MARK(15);   // slab sums, norms, RoPE done; q in LDS
 
     // ---- per new token: scores, softmax, P.V, output ----
 #pragma unroll
@@ -1019,6 +1023,7 @@ __global__ __launch_bounds__(128) void k_attn_tiny(const float* pqkv, const floa
             }
         }
     }
+    KP_MARK(23);
 }
 
 void launch_attn(const AttnArgs& a, hipStream_t s) {
