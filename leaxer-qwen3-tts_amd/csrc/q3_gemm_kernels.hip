@@ -803,7 +803,10 @@ static __device__ __forceinline__ void g16_split8(const float (&y)[8], bf16x8& h
 // rows 8..15 carry other rows' chunks into the product, which only reaches output rows 8..15 (never stored).  The values each
 // product sees and their order are unchanged: results are bit-identical to the R8 = false kernel.
 #define G16_AB 4
-template <int KWMAX, int NWV, int EPI, bool NORM, bool R8 = false>
+// GL (NORM kernels): the RMSNorm gains of a wave's K slice arrive as ONE (or two) whole-line load instructions into the wave's own LDS
+// slice and reach the lanes through ds_read (broadcast over the 16 rows) instead of two 16-byte global loads per k-step and lane — 16
+// of a K = 1024 wave's 40 load instructions were gains, every row's lanes asking for the same bytes.  Same values: bit-identical.
+template <int KWMAX, int NWV, int EPI, bool NORM, bool R8 = false, bool GL = false>
 __global__ __launch_bounds__(NWV * 64) void k_gemv16(const bf16_t* pW, const bf16_t* pW2, const float* px, const float* pgamma, const float* pepi,
                                                       int pN, int pM, int pldx, int pldepi, uint32_t pKnt /* K | nt << 31 */, GemvArgs a) {   // leading scalars: kernarg-preloaded
     constexpr bool DUAL = EPI == EPI_SWIGLU;
@@ -825,6 +828,7 @@ __global__ __launch_bounds__(NWV * 64) void k_gemv16(const bf16_t* pW, const bf1
     G16_MARK(0);
     __shared__ float red[DUAL ? 2 : 1][NWV][16][17];
     __shared__ float ssq[NWV][16];
+    __shared__ __attribute__((aligned(16))) float gam_s[(NORM && GL) ? NWV : 1][(NORM && GL) ? KWMAX * 32 : 4];
 
     // Loads return in issue order, so what is issued before the weight stream can be converted while the weights are in flight:
     // the first PREG groups of activation k-steps go first, the rest follow the weights one group at a time into a freed buffer.
@@ -832,7 +836,17 @@ __global__ __launch_bounds__(NWV * 64) void k_gemv16(const bf16_t* pW, const bf1
     const float* xr = R8 ? px + (size_t)(r8 < M ? r8 : M - 1) * pldx + kbeg + c8 * 4     // lane (r8, c): row r8, floats [4c, 4c + 4) of each k-step
                          : px + (size_t)(r16 < M ? r16 : M - 1) * pldx + kbeg + q * 8;   // lane (r16, q): row r16, 8 consecutive k per k-step
     const float* gr = NORM ? pgamma + kbeg + q * 8 : nullptr;
-    g16_f32x4 xa[PREG][G16_AB][R8 ? 1 : 2], ga[NORM ? PREG : 1][G16_AB][2];
+    g16_f32x4 xa[PREG][G16_AB][R8 ? 1 : 2], ga[(NORM && !GL) ? PREG : 1][G16_AB][2];
+    // GL: the slice's gains, 4 floats per lane and pass (a pass = 256 floats = one 1 KB load instruction), requested before everything else
+    constexpr int GPASS = (KWMAX * 32 + 255) / 256;
+    g16_f32x4 gq[(NORM && GL) ? GPASS : 1];
+    if constexpr (NORM && GL) {
+#pragma unroll
+        for (int gp = 0; gp < GPASS; ++gp) {
+            const int o = gp * 256 + lane * 4;
+            gq[gp] = *reinterpret_cast<const g16_f32x4*>(pgamma + kbeg + (o < kslice ? o : kslice - 4));
+        }
+    }
     const bool row_live = R8 ? r8 < M : r16 < M;   // lanes of rows past M issue no activation loads (their outputs are never stored)
     auto issue = [&](int buf, int g) {
 #pragma unroll
@@ -845,9 +859,9 @@ __global__ __launch_bounds__(NWV * 64) void k_gemv16(const bf16_t* pW, const bf1
                 xa[buf][j][0] = *reinterpret_cast<const g16_f32x4*>(xr + kk * 32);
                 if (!R8) xa[buf][j][R8 ? 0 : 1] = *reinterpret_cast<const g16_f32x4*>(xr + kk * 32 + 4);
             }
-            if (NORM) {
-                ga[buf][j][0] = *reinterpret_cast<const g16_f32x4*>(gr + kk * 32);
-                ga[buf][j][1] = *reinterpret_cast<const g16_f32x4*>(gr + kk * 32 + 4);
+            if (NORM && !GL) {
+                ga[GL ? 0 : buf][j][0] = *reinterpret_cast<const g16_f32x4*>(gr + kk * 32);
+                ga[GL ? 0 : buf][j][1] = *reinterpret_cast<const g16_f32x4*>(gr + kk * 32 + 4);
             }
         }
     };
@@ -874,6 +888,16 @@ __global__ __launch_bounds__(NWV * 64) void k_gemv16(const bf16_t* pW, const bf1
     __builtin_amdgcn_sched_barrier(0);
     G16_MARK(1);   // every load issued
 
+    if constexpr (NORM && GL) {   // gains into the wave's LDS slice (wave-private: the wave's in-order LDS queue is the synchronisation)
+#pragma unroll
+        for (int gp = 0; gp < GPASS; ++gp) {
+            const int o = gp * 256 + lane * 4;
+            if (o < KWMAX * 32) *reinterpret_cast<g16_f32x4*>(&gam_s[wave][o]) = gq[gp];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
     f32x4 acc = { 0.f, 0.f, 0.f, 0.f }, acc2 = { 0.f, 0.f, 0.f, 0.f };
     float ss = 0.f;
 #pragma unroll
@@ -891,10 +915,19 @@ __global__ __launch_bounds__(NWV * 64) void k_gemv16(const bf16_t* pW, const bf1
                 if (R8) xin[4 + e] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, xin[e]), 0x128 /* row_ror:8 */, 0xF, 0xF, false));
                 else xin[4 + e] = xa[g % PREG][j][R8 ? 0 : 1][e];
             }
+            g16_f32x4 gl0 = { 0.f, 0.f, 0.f, 0.f }, gl1 = { 0.f, 0.f, 0.f, 0.f };
+            if constexpr (NORM && GL) {
+                const int kk = ks < kw ? ks : kw - 1;
+                gl0 = *reinterpret_cast<const g16_f32x4*>(&gam_s[wave][kk * 32 + q * 8]);
+                gl1 = *reinterpret_cast<const g16_f32x4*>(&gam_s[wave][kk * 32 + q * 8 + 4]);
+            }
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float xv = (R8 && r16 >= 8 ? 0.f : xin[e]) * live;   // R8: the lanes of rows 8..15 hold other rows' chunks: zero, as the R8 = false kernel has there
-                if (NORM) { ss = fmaf(xv, xv, ss); y[e] = xv * ga[g % PREG][j][e >> 2][e & 3]; }
+                if (NORM) {
+                    ss = fmaf(xv, xv, ss);
+                    y[e] = xv * (GL ? (e < 4 ? gl0[e & 3] : gl1[e & 3]) : ga[GL ? 0 : g % PREG][j][e >> 2][e & 3]);
+                }
                 else y[e] = xv;
             }
             bf16x8 ah, al;
@@ -976,9 +1009,12 @@ static void gemv16_epi(const GemvArgs& a, hipStream_t s) {
     const bool norm = a.gamma != nullptr;
     static const bool no_r8 = getenv("Q3TTS_GEMV16_R8") && atoi(getenv("Q3TTS_GEMV16_R8")) == 0;   // A/B knob
     const bool r8 = a.M <= 8 && !no_r8;
-#define Q3_G16_(EPI, NORM, R8_) hipLaunchKernelGGL((k_gemv16<KWMAX, NWV, EPI, NORM, R8_>), grid, block, 0, s, a.W, a.W2, a.x, a.gamma, \
+    static const bool no_gl = getenv("Q3TTS_GEMV16_GL") && atoi(getenv("Q3TTS_GEMV16_GL")) == 0;
+    const bool gl = norm && !no_gl && (a.K / NWV) % 4 == 0;
+#define Q3_G16_(EPI, NORM, R8_, GL_) hipLaunchKernelGGL((k_gemv16<KWMAX, NWV, EPI, NORM, R8_, GL_>), grid, block, 0, s, a.W, a.W2, a.x, a.gamma, \
         (a.epi == EPI_RESIDUAL ? a.res : a.bias), a.N, a.M, a.ldx, a.ldres, (uint32_t)a.K | (a.nt ? 0x80000000u : 0u), a)
-#define Q3_G16(EPI, NORM) do { if (r8) Q3_G16_(EPI, NORM, true); else Q3_G16_(EPI, NORM, false); } while (0)
+#define Q3_G16(EPI, NORM) do { if (NORM && gl) { if (r8) Q3_G16_(EPI, NORM, true, NORM); else Q3_G16_(EPI, NORM, false, NORM); } \
+                               else { if (r8) Q3_G16_(EPI, NORM, true, false); else Q3_G16_(EPI, NORM, false, false); } } while (0)
     switch (a.epi) {
     case EPI_STORE: if (norm) Q3_G16(EPI_STORE, true); else Q3_G16(EPI_STORE, false); break;
     case EPI_SWIGLU: if (norm) Q3_G16(EPI_SWIGLU, true); else Q3_G16(EPI_SWIGLU, false); break;

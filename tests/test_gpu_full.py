@@ -444,15 +444,19 @@ np.savez(sys.argv[1], **res)
 ''' % os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "leaxer-qwen3-tts_amd")
     out = {}
     with tempfile.TemporaryDirectory() as td:
-        for mode in ("1", "0"):      # the knob is read once per process (first k_gemv16 launch): each layout runs in a child of its own
-            env = dict(os.environ, Q3TTS_GEMV16_R8=mode)
+        # the knobs are read once per process (first k_gemv16 launch): each variant runs in a child of its own.  Q3TTS_GEMV16_GL=0: the RMSNorm
+        # gains as two global loads per k-step and lane (the default brings a wave's gains in with one load and reads them from its LDS slice)
+        for mode, knobs in (("new", {}), ("old_rows", {"Q3TTS_GEMV16_R8": "0"}), ("old_gains", {"Q3TTS_GEMV16_GL": "0"}),
+                            ("old_both", {"Q3TTS_GEMV16_R8": "0", "Q3TTS_GEMV16_GL": "0"})):
+            env = dict(os.environ, **knobs)
             path = os.path.join(td, "m%s.npz" % mode)
             r = subprocess.run([sys.executable, "-c", script, path], env=env, capture_output=True, text=True, timeout=500)
             assert r.returncode == 0, r.stderr[-2000:]
             out[mode] = dict(np.load(path))
-    for k in out["1"]:
-        assert np.array_equal(out["1"][k], out["0"][k]), k
-    assert np.isfinite(out["1"]["pcm8"]).all()
+    for mode in ("old_rows", "old_gains", "old_both"):
+        for k in out["new"]:
+            assert np.array_equal(out["new"][k], out[mode][k]), (mode, k)
+    assert np.isfinite(out["new"]["pcm8"]).all()
 
 
 @pytest.mark.parametrize("nb", [8, 5])
