@@ -237,11 +237,6 @@ int q3tts_counters(q3tts_engine* e, double* decode_ms, int64_t* decode_steps, do
  * in fp16 after the power-of-two pre-scale (every bf16- or fp16-origin tensor) and therefore run two matrix-core products per fp32
  * product, and how many keep a non-zero lo plane and run three.  Both 0 under Q3TTS_FLAG_FP32_CODEC. */
 int q3tts_codec_plane_stats(q3tts_engine* e, int* two_product, int* three_product);
-/* Test hook for the batched step's in-launch split-K reduction (no reference counterpart: the reference has no batched path): the
- * partial-sum buffers of that reduction rest at an all-ones word pattern between steps — a K slice's words are their own ready flags —
- * and *words is the number of words that do not (0 whenever no step is in flight; anything else would make a later step read a stale
- * partial sum as fresh).  Synchronises the engine's stream. */
-int q3tts_seam_residue(q3tts_engine* e, int64_t* words);
 /* Per-stage device time of the decode step: runs n_steps EAGER steps of the armed slots (they advance like q3tts_decode_steps) with HIP
  * events at the stage boundaries.  out_ms[0] sampler (n_groups launches), [1] code predictor (layer passes + heads; predict_subcodes,
  * tts_onnx.cpp:851-872), [2] talker decode (layers + codec head; run_decode :667-732), [3] their sum — milliseconds per step. */

@@ -571,13 +571,6 @@ int q3tts_codec_plane_stats(q3tts_engine* h, int* two_product, int* three_produc
     return 0;
     Q3_API_END(h)
 }
-int q3tts_seam_residue(q3tts_engine* h, int64_t* words) {
-    Q3_API_BEGIN(h)
-    if (!words) throw q3::Error("q3tts_seam_residue: null output");
-    *words = (int64_t)h->e->seam_residue();
-    return 0;
-    Q3_API_END(h)
-}
 int q3tts_stage_profile(q3tts_engine* h, int n_steps, double* out_ms) {
     Q3_API_BEGIN(h)
     if (!out_ms) throw q3::Error("stage_profile: null output");

@@ -152,8 +152,6 @@ struct GemmArgs {
     unsigned* seam_cnt = nullptr;                    // one 64-byte line per (column tile, row block): words 0..11 slice flags, 12..15 abandoned-chunk marks
     const unsigned* seam_gen = nullptr;              // the step's generation (bumped once per step by the first sampler): every word a launch writes carries it,
                                                      // so nothing is ever reset and a copy of the line left over from an earlier step can never read as set
-    int seam_inband = 0;                             // third protocol: slab words are their own ready flags (slabs rest at SEAM_SENTINEL between launches; out / out2
-                                                     // must be buffers only seam launches touch); the flag line then only carries the abandoned-chunk hand-off
     int seam_spin = 4096;                            // polls an owner makes before it abandons its chunk (~0.7 us each)
     float* sx = nullptr; int sldx = 0;               // seam 1: residual stream rows, updated in place
     const float* sgamma = nullptr;                   // seam 1: the consumer's RMSNorm gain

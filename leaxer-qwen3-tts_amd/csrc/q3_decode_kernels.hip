@@ -518,7 +518,9 @@ void launch_gemv(const GemvArgs& a0, hipStream_t s) {
 
 // KVB: the cache holds bf16 (Q3TTS_FLAG_KV_BF16).  K / V rows are rounded to bf16 (RNE) where they enter the cache AND where this step
 // uses them itself (the LDS copies of the new tokens), so every reader sees the same values — the oracle rounds at the same point
-// (oracle/q3_oracle.c dec_forward, kv_bf16) and codes stay bit-exact against it in this mode.  Math stays fp32.
+// (oracle/q3_oracle.c dec_forward, kv_bf16).  Ids are NOT bit-exact against the oracle in this mode: rounding is a discontinuity, the two
+// implementations' logits sit ~4e-3 apart and the ids agree up to the first decision whose margin is below that noise; what IS bit-exact
+// is this 16-bit storage path against fp32 storage of the same rounded rows (Q3TTS_FLAG_KV_ROUND_BF16).  Math stays fp32.
 static __device__ __forceinline__ float bf16_round_f(float f) {
     uint32_t u = __float_as_uint(f);
     return __uint_as_float((u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u);
@@ -1316,394 +1318,12 @@ __global__ __launch_bounds__(1024) void k_cp_attn_oproj(const bf16_t* pW, const 
     }
 }
 
-// ================================================================================================
-// k_cp_attn_oproj2 (round 3, NOT the default: measured slower, see launch_cp_attn_oproj) — the same launch with the K/V requests halved.
-// Stamps of the first version (profiles/r03_kernel_phases.txt):
-// wave 0 is done with its scores at 2.6 us and then waits 2.3 us at the block barrier for the other waves' K/V rows — every workgroup
-// requests 336 KB (the layer's whole fp32 K/V TWICE, once per query head of a kv group, + q / k / v / norm rows + weights) at the CU's
-// ~64 B/clk L1 rate.  Here the two waves of a kv group split the TOKENS instead of the heads: wave parity p takes cached tokens
-// 2 (tg + 4 u) + p for BOTH query heads (each K / V row is requested once per workgroup), the partial softmaxes (m, l, o) of the two
-// waves meet in LDS.  Same arithmetic per token; the softmax sums associate differently (fp32, ~1e-7).
-// ================================================================================================
-template <int NEW, int U2>
-__global__ __launch_bounds__(1024) void k_cp_attn_oproj2(const bf16_t* pW, const float* pqkv, const float* pkc, const float* pvc, const float* px,
-                                                          const float* pcos, const float* psin, uint32_t pk0, uint32_t pk1, CpAttnOprojArgs a) {
-    const int pbase = (int)(pk0 & 0xFFFFu), ppage_tokens = (int)(pk0 >> 16), pN = (int)(pk1 & 0xFFFFu), pldx = (int)(pk1 >> 16);
-    constexpr int LDQ = 4096;
-    constexpr int D = 128, HALF = 64, EPL = 8, NKV = 8, NQ = 16, K = 2048;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // 16 waves: kv head = wave / 2, token parity = wave & 1
-    const int kvh = wave >> 1, par = wave & 1;
-    const int base = pbase;
-
-    __shared__ float q_s[16][2][NEW][D];   // wave-private staging: both query heads of the wave's kv group
-    __shared__ float knew[16][NEW][D];
-    __shared__ float vnew[16][NEW][D];
-    __shared__ float xch[16][NEW][D + 4];  // partial (o, m, l) of the head the PARTNER wave finishes
-    __shared__ float attn_s[NEW][K];
-    __shared__ float part[NEW][16];
-
-    // ---- the one memory round: o_proj weights, residual, q (two heads) / k / v rows + norm / RoPE operands, this wave's half of the cached K / V ----
-    const int orow = blockIdx.x * 4 + (wave & 3), kq = wave >> 2;
-    const int orow_c = orow < pN ? orow : pN - 1;
-    const uint4 w4 = ldw_rt(pW + (size_t)orow_c * K + kq * 512 + lane * 8, false);
-    float resid[NEW];
-#pragma unroll
-    for (int m = 0; m < NEW; ++m) resid[m] = px[(size_t)m * pldx + orow_c];
-    __builtin_amdgcn_sched_barrier(0);
-    float qx0[NEW][2], qx1[NEW][2], kx0[NEW], kx1[NEW], vx0[NEW], vx1[NEW], cs[NEW], sn[NEW];
-#pragma unroll
-    for (int j = 0; j < NEW; ++j) {
-        const float* rowp = pqkv + (size_t)j * LDQ;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) { qx0[j][h] = rowp[(kvh * 2 + h) * D + lane]; qx1[j][h] = rowp[(kvh * 2 + h) * D + lane + HALF]; }
-        kx0[j] = rowp[(NQ + kvh) * D + lane]; kx1[j] = rowp[(NQ + kvh) * D + lane + HALF];
-        vx0[j] = rowp[(NQ + NKV + kvh) * D + lane]; vx1[j] = rowp[(NQ + NKV + kvh) * D + lane + HALF];
-        cs[j] = pcos[(size_t)(base + j) * HALF + lane]; sn[j] = psin[(size_t)(base + j) * HALF + lane];
-    }
-    const float qn0 = a.q_norm[lane], qn1 = a.q_norm[lane + HALF], kn0 = a.k_norm[lane], kn1 = a.k_norm[lane + HALF];
-    const int tg = lane >> 4, sub = lane & 15;
-    float kr[U2][EPL], vr[U2][EPL];
-#pragma unroll
-    for (int u = 0; u < U2; ++u) {
-        int t = 2 * (tg + 4 * u) + par;          // clamped, unconditional (a conditional load is a serial round trip)
-        t = t < base ? t : base - 1;
-        t = t > 0 ? t : 0;
-        const size_t off = ((size_t)kvh * ppage_tokens + t) * D + sub * EPL;
-        const float4 k0 = *reinterpret_cast<const float4*>(pkc + off), k1 = *reinterpret_cast<const float4*>(pkc + off + 4);
-        const float4 v0 = *reinterpret_cast<const float4*>(pvc + off), v1 = *reinterpret_cast<const float4*>(pvc + off + 4);
-        kr[u][0] = k0.x; kr[u][1] = k0.y; kr[u][2] = k0.z; kr[u][3] = k0.w; kr[u][4] = k1.x; kr[u][5] = k1.y; kr[u][6] = k1.z; kr[u][7] = k1.w;
-        vr[u][0] = v0.x; vr[u][1] = v0.y; vr[u][2] = v0.z; vr[u][3] = v0.w; vr[u][4] = v1.x; vr[u][5] = v1.y; vr[u][6] = v1.z; vr[u][7] = v1.w;
-    }
-    __builtin_amdgcn_sched_barrier(0);
-
-    // ---- 1. q / k RMSNorm + RoPE; the parity-0 wave of workgroup 0 appends K / V to the cache ----
-#pragma unroll
-    for (int j = 0; j < NEW; ++j) {
-        {
-            const float ss = wave_sum(kx0[j] * kx0[j] + kx1[j] * kx1[j]);
-            const float rr = 1.0f / sqrtf(ss / (float)D + a.eps);
-            const float x0 = kn0 * (kx0[j] * rr), x1 = kn1 * (kx1[j] * rr);
-            const float y0 = x0 * cs[j] + (-x1) * sn[j], y1 = x1 * cs[j] + x0 * sn[j];
-            knew[wave][j][lane] = y0; knew[wave][j][lane + HALF] = y1;
-            vnew[wave][j][lane] = vx0[j]; vnew[wave][j][lane + HALF] = vx1[j];
-            if (blockIdx.x == 0 && par == 0) {
-                const size_t off = ((size_t)kvh * a.page_tokens + base + j) * D;
-                a.kc[off + lane] = y0; a.kc[off + lane + HALF] = y1;
-                a.vc[off + lane] = vx0[j]; a.vc[off + lane + HALF] = vx1[j];
-            }
-        }
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const float ss = wave_sum(qx0[j][h] * qx0[j][h] + qx1[j][h] * qx1[j][h]);
-            const float rr = 1.0f / sqrtf(ss / (float)D + a.eps);
-            const float x0 = qn0 * (qx0[j][h] * rr), x1 = qn1 * (qx1[j][h] * rr);
-            q_s[wave][h][j][lane] = x0 * cs[j] + (-x1) * sn[j];
-            q_s[wave][h][j][lane + HALF] = x1 * cs[j] + x0 * sn[j];
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-    // ---- 2. this wave's tokens for both heads: cached tokens 2 (tg + 4 u) + par; new token j belongs to wave parity (j & 1), group (j >> 1) & 3 ----
-    float kn[NEW][EPL], vn[NEW][EPL];
-#pragma unroll
-    for (int j = 0; j < NEW; ++j)
-#pragma unroll
-        for (int e = 0; e < EPL; ++e) { kn[j][e] = knew[wave][j][sub * EPL + e]; vn[j][e] = vnew[wave][j][sub * EPL + e]; }
-#pragma unroll
-    for (int inew = 0; inew < NEW; ++inew) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            float qr[EPL];
-#pragma unroll
-            for (int e = 0; e < EPL; ++e) qr[e] = q_s[wave][h][inew][sub * EPL + e];
-            float sc[U2 + NEW];
-#pragma unroll
-            for (int u = 0; u < U2; ++u) {
-                float sdot = 0.f;
-#pragma unroll
-                for (int e = 0; e < EPL; ++e) sdot = fmaf(qr[e], kr[u][e], sdot);
-                sdot = row_sum16(sdot) * a.scale;
-                sc[u] = 2 * (tg + 4 * u) + par < base ? sdot : -INFINITY;
-            }
-#pragma unroll
-            for (int j = 0; j < NEW; ++j) {
-                float sdot = 0.f;
-#pragma unroll
-                for (int e = 0; e < EPL; ++e) sdot = fmaf(qr[e], kn[j][e], sdot);
-                sdot = row_sum16(sdot) * a.scale;
-                sc[U2 + j] = (j <= inew && (j & 1) == par && ((j >> 1) & 3) == tg) ? sdot : -INFINITY;   // causal among the new rows
-            }
-            float mx = -INFINITY;
-#pragma unroll
-            for (int i = 0; i < U2 + NEW; ++i) mx = fmaxf(mx, sc[i]);
-            float l = 0.f, o[EPL];
-#pragma unroll
-            for (int e = 0; e < EPL; ++e) o[e] = 0.f;
-#pragma unroll
-            for (int u = 0; u < U2; ++u) {
-                const float pw = mx == -INFINITY ? 0.f : __expf(sc[u] - mx);
-                l += pw;
-#pragma unroll
-                for (int e = 0; e < EPL; ++e) o[e] = fmaf(pw, 2 * (tg + 4 * u) + par < base ? vr[u][e] : 0.f, o[e]);   // never-written cache rows may hold NaN
-            }
-#pragma unroll
-            for (int j = 0; j < NEW; ++j) {
-                const float pw = mx == -INFINITY ? 0.f : __expf(sc[U2 + j] - mx);
-                l += pw;
-#pragma unroll
-                for (int e = 0; e < EPL; ++e) o[e] = fmaf(pw, vn[j][e], o[e]);
-            }
-            // the wave's 4 token groups meet in registers (lanes {sub, sub + 16, sub + 32, sub + 48} hold the same 8 dims)
-            const float mall = wave_max(mx);
-            const float wgt = mx == -INFINITY ? 0.f : __expf(mx - mall);
-            l *= wgt;
-#pragma unroll
-            for (int e = 0; e < EPL; ++e) o[e] *= wgt;
-            l += wave_xor_lane_f<16>(l, lane);
-            l += wave_xor_lane_f<32>(l, lane);
-#pragma unroll
-            for (int e = 0; e < EPL; ++e) { o[e] += wave_xor_lane_f<16>(o[e], lane); o[e] += wave_xor_lane_f<32>(o[e], lane); }
-            // head h is FINISHED by the wave of parity h: the other wave parks its partial in LDS, the finisher keeps its own in registers
-            if (h != par) {
-                if (tg == 0) {
-                    float* dst = &xch[wave][inew][sub * EPL];
-                    *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
-                    *reinterpret_cast<float4*>(dst + 4) = make_float4(o[4], o[5], o[6], o[7]);
-                    if (sub == 0) { xch[wave][inew][D] = mall; xch[wave][inew][D + 1] = l; }
-                }
-            } else {
-                // keep (mall, l, o) of the own head in the staging slot of q (its q row is not needed any more): registers would do, but
-                // the two heads are produced in one unrolled loop and the finisher's head index differs per wave
-                if (tg == 0) {
-                    float* dst = &q_s[wave][h][inew][sub * EPL];
-                    *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
-                    *reinterpret_cast<float4*>(dst + 4) = make_float4(o[4], o[5], o[6], o[7]);
-                    if (sub == 0) { knew[wave][inew][0] = mall; knew[wave][inew][1] = l; }   // knew / vnew fragments are in registers already
-                }
-            }
-        }
-    }
-    __syncthreads();
-    // ---- 2b. merge with the partner's partial of the head this wave finishes (head = kv head * 2 + parity) ----
-    if (tg == 0) {
-#pragma unroll
-        for (int inew = 0; inew < NEW; ++inew) {
-            const int pw_ = wave ^ 1;
-            const float ma = knew[wave][inew][0], la = knew[wave][inew][1], mb = xch[pw_][inew][D], lb = xch[pw_][inew][D + 1];
-            const float mm = fmaxf(ma, mb);
-            const float wa = ma == -INFINITY ? 0.f : __expf(ma - mm), wb = mb == -INFINITY ? 0.f : __expf(mb - mm);
-            const float il = 1.0f / (la * wa + lb * wb);
-            const float* oa = &q_s[wave][par][inew][sub * EPL];
-            const float* ob = &xch[pw_][inew][sub * EPL];
-            const float4 a0 = *reinterpret_cast<const float4*>(oa), a1 = *reinterpret_cast<const float4*>(oa + 4);
-            const float4 b0 = *reinterpret_cast<const float4*>(ob), b1 = *reinterpret_cast<const float4*>(ob + 4);
-            float* dst = &attn_s[inew][(kvh * 2 + par) * D + sub * EPL];
-            *reinterpret_cast<float4*>(dst) = make_float4((a0.x * wa + b0.x * wb) * il, (a0.y * wa + b0.y * wb) * il, (a0.z * wa + b0.z * wb) * il, (a0.w * wa + b0.w * wb) * il);
-            *reinterpret_cast<float4*>(dst + 4) = make_float4((a1.x * wa + b1.x * wb) * il, (a1.y * wa + b1.y * wb) * il, (a1.z * wa + b1.z * wb) * il, (a1.w * wa + b1.w * wb) * il);
-        }
-    }
-    __syncthreads();
-    // ---- 3. o_proj: wave (row = wave & 3, K quarter = wave >> 2), residual add ----
-#pragma unroll
-    for (int m = 0; m < NEW; ++m) {
-        const float* xr = &attn_s[m][kq * 512 + lane * 8];
-        const float4 x0 = *reinterpret_cast<const float4*>(xr), x1 = *reinterpret_cast<const float4*>(xr + 4);
-        const float xv[8] = { x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w };
-        const uint32_t wu[4] = { w4.x, w4.y, w4.z, w4.w };
-        float s1 = 0.f;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { s1 = fmaf(xv[2 * j], bf_lo(wu[j]), s1); s1 = fmaf(xv[2 * j + 1], bf_hi(wu[j]), s1); }
-        s1 = wave_sum(s1);
-        if (lane == 0) part[m][wave] = s1;
-    }
-    __syncthreads();
-    if (wave < 4 && lane < NEW && orow < a.N) {
-        float r = resid[0];
-        if (NEW > 1 && lane == 1) r = resid[NEW - 1];
-        a.x[(size_t)lane * a.ldx + orow] = r + (((part[lane][wave] + part[lane][wave + 4]) + part[lane][wave + 8]) + part[lane][wave + 12]);
-    }
-}
-
-// ================================================================================================
-// k_cp_attn_oproj3 (round 3, NOT the default: measured slower, see launch_cp_attn_oproj) — the fused launch with k_attn_tiny's attention layout.  The first version is bound by the vector-issue time of
-// the four waves that share a SIMD (r03_negative_results.txt item 6): per wave, every cached token costs a 16-lane dot product with a
-// four-step DPP reduction, and four partial softmaxes are merged through 18 cross-lane moves.  Here a wave (= query head) holds the cached
-// K rows as (token = lane / 4, 32-dim chunk = lane % 4): ALL 16 tokens' scores are 32 FMAs + two DPP steps; the V rows as (dim = lane,
-// lane + 64) per token; one softmax over the wave (DPP max / sum), p_t reaches the P.V loop through v_readlane; the output lands in
-// (lane, lane + 64) layout, exactly what the o_proj phase reads.  No partials, no merges, no knew / vnew staging.  base <= 16.
-// ================================================================================================
-template <int NEW>
-__global__ __launch_bounds__(1024) void k_cp_attn_oproj3(const bf16_t* pW, const float* pqkv, const float* pkc, const float* pvc, const float* px,
-                                                          const float* pcos, const float* psin, uint32_t pk0, uint32_t pk1, CpAttnOprojArgs a) {
-    const int pbase = (int)(pk0 & 0xFFFFu), ppage_tokens = (int)(pk0 >> 16), pN = (int)(pk1 & 0xFFFFu), pldx = (int)(pk1 >> 16);
-    constexpr int LDQ = 4096;
-    constexpr int D = 128, HALF = 64, NKV = 8, NQ = 16, K = 2048, G = 2;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // 16 waves: one query head each
-    const int head = wave, kvh = wave / G;
-    const int base = pbase;
-
-    __shared__ __attribute__((aligned(16))) float q_s[NQ][NEW][D];   // wave-private: (lane, lane + 64) layout -> 32-dim chunks
-    __shared__ float attn_s[NEW][K];
-    __shared__ float part[NEW][16];
-
-    KP_MARK(16);
-    // ---- the one memory round ----
-    const int orow = blockIdx.x * 4 + (wave & 3), kq = wave >> 2;
-    const int orow_c = orow < pN ? orow : pN - 1;
-    const uint4 w4 = ldw_rt(pW + (size_t)orow_c * K + kq * 512 + lane * 8, false);
-    float resid[NEW];
-#pragma unroll
-    for (int m = 0; m < NEW; ++m) resid[m] = px[(size_t)m * pldx + orow_c];
-    __builtin_amdgcn_sched_barrier(0);
-    float qx0[NEW], qx1[NEW], kx0[NEW], kx1[NEW], vn0[NEW], vn1[NEW], cs[NEW], sn[NEW];
-#pragma unroll
-    for (int j = 0; j < NEW; ++j) {
-        const float* rowp = pqkv + (size_t)j * LDQ;
-        qx0[j] = rowp[head * D + lane]; qx1[j] = rowp[head * D + lane + HALF];
-        kx0[j] = rowp[(NQ + kvh) * D + lane]; kx1[j] = rowp[(NQ + kvh) * D + lane + HALF];
-        vn0[j] = rowp[(NQ + NKV + kvh) * D + lane]; vn1[j] = rowp[(NQ + NKV + kvh) * D + lane + HALF];
-        cs[j] = pcos[(size_t)(base + j) * HALF + lane]; sn[j] = psin[(size_t)(base + j) * HALF + lane];
-    }
-    const float qn0 = a.q_norm[lane], qn1 = a.q_norm[lane + HALF], kn0 = a.k_norm[lane], kn1 = a.k_norm[lane + HALF];
-    // cached K as (token = lane / 4, 32-dim chunk = lane % 4), cached V as (dim = lane, lane + 64) per token; tokens past `base` repeat the last one
-    const float* kc = pkc + (size_t)kvh * ppage_tokens * D;
-    const float* vc = pvc + (size_t)kvh * ppage_tokens * D;
-    const int tk = lane >> 2, ch = lane & 3;
-    const int last = base > 0 ? base - 1 : 0;
-    float4 kr[8];
-    {
-        const int t = tk < base ? tk : last;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) kr[e] = *reinterpret_cast<const float4*>(kc + (size_t)t * D + ch * 32 + e * 4);
-    }
-    float vr0[16], vr1[16];
-#pragma unroll
-    for (int t = 0; t < 16; ++t) {
-        const int tt = t < base ? t : last;
-        vr0[t] = vc[(size_t)tt * D + lane]; vr1[t] = vc[(size_t)tt * D + lane + HALF];
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int t = 0; t < 16; ++t) { vr0[t] = t < base ? vr0[t] : 0.f; vr1[t] = t < base ? vr1[t] : 0.f; }   // never-written cache rows may hold anything: 0 x NaN
-
-    KP_MARK(17);
-    // ---- q / k RMSNorm + RoPE in (lane, lane + 64) layout; q to the wave's LDS slice; the even head of workgroup 0 appends K / V ----
-    float ky0[NEW], ky1[NEW], qy0[NEW], qy1[NEW];
-#pragma unroll
-    for (int j = 0; j < NEW; ++j) {
-        {
-            const float ss = wave_sum(kx0[j] * kx0[j] + kx1[j] * kx1[j]);
-            const float rr = 1.0f / sqrtf(ss / (float)D + a.eps);
-            const float x0 = kn0 * (kx0[j] * rr), x1 = kn1 * (kx1[j] * rr);
-            ky0[j] = x0 * cs[j] + (-x1) * sn[j];
-            ky1[j] = x1 * cs[j] + x0 * sn[j];
-            if (blockIdx.x == 0 && (head & 1) == 0) {
-                const size_t off = ((size_t)kvh * a.page_tokens + base + j) * D;
-                a.kc[off + lane] = ky0[j]; a.kc[off + lane + HALF] = ky1[j];
-                a.vc[off + lane] = vn0[j]; a.vc[off + lane + HALF] = vn1[j];
-            }
-        }
-        const float ss = wave_sum(qx0[j] * qx0[j] + qx1[j] * qx1[j]);
-        const float rr = 1.0f / sqrtf(ss / (float)D + a.eps);
-        const float x0 = qn0 * (qx0[j] * rr), x1 = qn1 * (qx1[j] * rr);
-        qy0[j] = x0 * cs[j] + (-x1) * sn[j];
-        qy1[j] = x1 * cs[j] + x0 * sn[j];
-        q_s[head][j][lane] = qy0[j]; q_s[head][j][lane + HALF] = qy1[j];
-    }
-    wave_lds_sync();
-
-    KP_MARK(18);
-    KP_MARK(19);
-    // ---- per new row: scores of all cached tokens at once, softmax over the wave, P.V ----
-#pragma unroll
-    for (int j = 0; j < NEW; ++j) {
-        float partk = 0.f;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float4 q4 = *reinterpret_cast<const float4*>(&q_s[head][j][ch * 32 + e * 4]);
-            partk = fmaf(q4.x, kr[e].x, partk); partk = fmaf(q4.y, kr[e].y, partk); partk = fmaf(q4.z, kr[e].z, partk); partk = fmaf(q4.w, kr[e].w, partk);
-        }
-        partk += dpp_f<Q3_DPP_XOR1, 0xF>(0.f, partk);
-        partk += dpp_f<Q3_DPP_XOR2, 0xF>(0.f, partk);
-        const float sc = tk < base ? partk * a.scale : -INFINITY;            // all four lanes of a token hold its score
-        float sn_[NEW];
-#pragma unroll
-        for (int jn = 0; jn < NEW; ++jn) sn_[jn] = jn <= j ? wave_sum(qy0[j] * ky0[jn] + qy1[j] * ky1[jn]) * a.scale : -INFINITY;   // causal among the new rows
-        float m = wave_max(sc);
-#pragma unroll
-        for (int jn = 0; jn < NEW; ++jn) m = fmaxf(m, sn_[jn]);              // the token itself is always there: m is finite
-        const float pA = __expf(sc - m);                                     // exp(-inf) = 0
-        float l = wave_sum(ch == 0 ? pA : 0.f);
-        float pn[NEW];
-#pragma unroll
-        for (int jn = 0; jn < NEW; ++jn) { pn[jn] = __expf(sn_[jn] - m); l += pn[jn]; }
-        float o0 = 0.f, o1 = 0.f;
-#pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            const float pt = lane_bcast(pA, 4 * t);
-            o0 = fmaf(pt, vr0[t], o0); o1 = fmaf(pt, vr1[t], o1);
-        }
-#pragma unroll
-        for (int jn = 0; jn < NEW; ++jn) { o0 = fmaf(pn[jn], vn0[jn], o0); o1 = fmaf(pn[jn], vn1[jn], o1); }
-        const float il = 1.0f / l;
-        attn_s[j][head * D + lane] = o0 * il;
-        attn_s[j][head * D + lane + HALF] = o1 * il;
-    }
-    KP_MARK(22);
-    __syncthreads();
-    KP_MARK(20);
-    // ---- o_proj: wave (row = wave & 3, K quarter = wave >> 2), residual add ----
-#pragma unroll
-    for (int m = 0; m < NEW; ++m) {
-        const float* xr = &attn_s[m][kq * 512 + lane * 8];
-        const float4 x0 = *reinterpret_cast<const float4*>(xr), x1 = *reinterpret_cast<const float4*>(xr + 4);
-        const float xv[8] = { x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w };
-        const uint32_t wu[4] = { w4.x, w4.y, w4.z, w4.w };
-        float s1 = 0.f;
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) { s1 = fmaf(xv[2 * jj], bf_lo(wu[jj]), s1); s1 = fmaf(xv[2 * jj + 1], bf_hi(wu[jj]), s1); }
-        s1 = wave_sum(s1);
-        if (lane == 0) part[m][wave] = s1;
-    }
-    __syncthreads();
-    KP_MARK(21);
-    if (wave < 4 && lane < NEW && orow < a.N) {
-        float r = resid[0];
-        if (NEW > 1 && lane == 1) r = resid[NEW - 1];
-        a.x[(size_t)lane * a.ldx + orow] = r + (((part[lane][wave] + part[lane][wave + 4]) + part[lane][wave + 8]) + part[lane][wave + 12]);
-    }
-}
-
 void launch_cp_attn_oproj(const CpAttnOprojArgs& a, int n_new, hipStream_t s) {
     if (!cp_attn_oproj_ok(a, n_new)) throw Error("cp_attn_oproj: unsupported shape");
     const int U = a.base <= 4 ? 1 : (a.base <= 8 ? 2 : (a.base <= 12 ? 3 : 4));
     const dim3 grid((a.N + 3) / 4), block(1024);
-    // Q3TTS_CP_ATTN = 2 | 3 (A/B knob): the two round-3 variants, both correct and both measured SLOWER than the first kernel (b=1 step 2.10 ms
-    // against 2.29 / 2.30 ms, profiles/r03_negative_results.txt item 6): the launch is bound by BOTH the CU's 64 B/clk vector-memory path
-    // (336 KB requested per workgroup = 2.5 us) and the vector-issue time of four waves per SIMD.  Variant 2 halves the requests and doubles
-    // each wave's softmax chain; variant 3 (k_attn_tiny's layout) trims the chain and needs 58 instead of 34 memory instructions per wave.
-    static const int ver = getenv("Q3TTS_CP_ATTN") ? atoi(getenv("Q3TTS_CP_ATTN")) : 1;
-    if (ver == 3) {
-#define Q3_CAO3(NEW) hipLaunchKernelGGL((k_cp_attn_oproj3<NEW>), grid, block, 0, s, a.W, a.qkv, (const float*)a.kc, (const float*)a.vc, (const float*)a.x, \
-        a.rope_cos, a.rope_sin, (uint32_t)a.base | (uint32_t)a.page_tokens << 16, (uint32_t)a.N | (uint32_t)a.ldx << 16, a)
-        if (n_new == 1) Q3_CAO3(1); else Q3_CAO3(2);
-#undef Q3_CAO3
-        Q3_HIP_CHECK(hipGetLastError());
-        return;
-    }
-    if (ver == 2) {
-#define Q3_CAO2(NEW, UU) hipLaunchKernelGGL((k_cp_attn_oproj2<NEW, UU>), grid, block, 0, s, a.W, a.qkv, (const float*)a.kc, (const float*)a.vc, (const float*)a.x, \
-        a.rope_cos, a.rope_sin, (uint32_t)a.base | (uint32_t)a.page_tokens << 16, (uint32_t)a.N | (uint32_t)a.ldx << 16, a)
-        if (n_new == 1) { if (a.base <= 8) Q3_CAO2(1, 1); else Q3_CAO2(1, 2); }
-        else { if (a.base <= 8) Q3_CAO2(2, 1); else Q3_CAO2(2, 2); }
-#undef Q3_CAO2
-        Q3_HIP_CHECK(hipGetLastError());
-        return;
-    }
+    // Two re-layouts of this launch (the kv group's two waves splitting the tokens instead of the heads; k_attn_tiny's one-wave layout)
+    // were built in round 3 and measured slower (b=1 step 2.10 ms against 2.29 / 2.30 ms): profiles/r03_negative_results.txt item 6.
 #define Q3_CAO(NEW, UU) hipLaunchKernelGGL((k_cp_attn_oproj<NEW, UU>), grid, block, 0, s, a.W, a.qkv, (const float*)a.kc, (const float*)a.vc, (const float*)a.x, \
         a.rope_cos, a.rope_sin, (uint32_t)a.base | (uint32_t)a.page_tokens << 16, (uint32_t)a.N | (uint32_t)a.ldx << 16, a)
     if (n_new == 1) { if (U == 1) Q3_CAO(1, 1); else if (U == 2) Q3_CAO(1, 2); else if (U == 3) Q3_CAO(1, 3); else Q3_CAO(1, 4); }

@@ -179,7 +179,6 @@ Engine::Engine(const q3tts_config& cfg, int device_, int max_batch, int max_ctx_
     if (const char* mr = getenv("Q3TTS_MFMA_MIN_ROWS")) mfma_min_rows = std::max(3, atoi(mr));   // A/B knob for the GEMV <-> GEMM crossover
     if (const char* sv = getenv("Q3TTS_SEAM")) seam_on = atoi(sv) != 0;
     if (const char* sv = getenv("Q3TTS_SEAM_SPIN")) seam_spin = std::max(1, atoi(sv));
-    if (const char* sv = getenv("Q3TTS_SEAM_INBAND")) seam_inband = atoi(sv) != 0;
     attn_keep_splits = getenv("Q3TTS_ATTN_KEEP_SPLITS") != nullptr;
     null_stream = getenv("Q3TTS_NULL_STREAM") && getenv("Q3TTS_NULL_STREAM")[0] == '1';
     if (null_stream) { stream = nullptr; flags |= Q3TTS_FLAG_NO_GRAPH; }
@@ -271,15 +270,6 @@ Engine::Engine(const q3tts_config& cfg, int device_, int max_batch, int max_ctx_
         ssq_b_d = fm((size_t)rows_max * 64);
     }
     gu_slab_d = fm((size_t)2 * 8 * rows_max * std::max(c.ffn, c.cp_ffn));   // gate | up halves of up to 8 K slices each
-    if (seam_on && seam_inband) {   // the in-band seam's own slabs: every word is the sentinel except between a slice's store and its owner's reset
-        const int seam_rows = std::min(rows_max, 128);
-        seam_slab_words = (size_t)12 * seam_rows * std::max(H, Hc);
-        seam_gu_slab_words = (size_t)2 * 8 * seam_rows * std::max(c.ffn, c.cp_ffn);
-        seam_slab_d = fm(seam_slab_words);
-        seam_gu_slab_d = fm(seam_gu_slab_words);
-        Q3_HIP_CHECK(hipMemsetAsync(seam_slab_d, 0xFF, seam_slab_words * sizeof(float), stream));
-        Q3_HIP_CHECK(hipMemsetAsync(seam_gu_slab_d, 0xFF, seam_gu_slab_words * sizeof(float), stream));
-    }
     ids_d = (int64_t*)dmalloc(64 * sizeof(int64_t));
     tok_d = (int64_t*)dmalloc(sizeof(int64_t));
     codes_d = (int32_t*)dmalloc((size_t)B * max_frames_cap * c.n_groups * sizeof(int32_t));
@@ -475,19 +465,6 @@ static int seam_gu_ksplit(int K) {
 }
 
 
-size_t Engine::seam_residue() {
-    if (!seam_slab_d) return 0;
-    Q3_HIP_CHECK(hipStreamSynchronize(stream));
-    size_t bad = 0;
-    std::vector<unsigned> h;
-    for (int k = 0; k < 2; ++k) {
-        const size_t n = k ? seam_gu_slab_words : seam_slab_words;
-        h.resize(n);
-        Q3_HIP_CHECK(hipMemcpy(h.data(), k ? seam_gu_slab_d : seam_slab_d, n * sizeof(unsigned), hipMemcpyDeviceToHost));
-        for (size_t i = 0; i < n; ++i) bad += h[i] != 0xFFFFFFFFu;
-    }
-    return bad;
-}
 bool Engine::seam_applies(const DecStack& W, int M, float* x, int ldx, bool has_slot_map) const {
     const int AO = W.nq * W.d, NTH = W.H / 64;
     const bool mfma = M >= mfma_min_rows && W.H % 128 == 0 && AO % 128 == 0 && W.ffn % 128 == 0 && W.H <= 4096;
@@ -539,8 +516,11 @@ bool Engine::run_layers(const DecStack& W, float* x, int ldx, int nb, int n_new,
             g.M = M; g.N = QKV; g.K = W.H; g.epi = EPI_STORE; g.nt = W.nt;
             launch_gemv(g, stream);
         }
-        if (!mfma && nb == 1 && pos_dev == nullptr && slot_map == nullptr && W.n_splits == 1 && W.pages_per_slot == 1 && !(flags & Q3TTS_FLAG_NO_FUSED_CP)) {
-            // code predictor at b = 1: attention + o_proj + residual in one launch (identity page table: slot s owns page s)
+        if (!mfma && nb == 1 && pos_dev == nullptr && slot_map == nullptr && W.n_splits == 1 && W.pages_per_slot == 1 && !W.kv_bf16 && !W.kv_round &&
+            !(flags & Q3TTS_FLAG_NO_FUSED_CP)) {
+            // code predictor at b = 1: attention + o_proj + residual in one launch (identity page table: slot s owns page s).  The gate is
+            // stack-agnostic — a talker with max_ctx <= 64 matches it too — and the fused kernel reads and writes an fp32 cache without
+            // rounding, so the bf16 / rounded-bf16 cache modes (talker only) stay on the general path.
             CpAttnOprojArgs f;
             const int ptok = 1 << W.page_shift;
             const size_t coff = (((size_t)slot_offset * W.L + l) * W.nkv) * ptok * W.d;
@@ -592,7 +572,6 @@ bool Engine::run_layers(const DecStack& W, float* x, int ldx, int nb, int n_new,
             if (seam) {   // x += sum(slabs); planes0 = gamma(post_norm) * x; ssq_a = per-tile sums of squares of x
                 o.seam = 1; o.seam_gen = seam_gen_d; o.seam_spin = seam_spin; o.seam_cnt = seam_counters(W.H / 64); o.sx = x; o.sldx = ldx; o.sgamma = w.post_norm;
                 o.oh = pl0h; o.ol = pl0l; o.ldp = ldp; o.ssq_out = ssq_a_d; o.ssq_nt = NTH;
-                if (seam_inband) { o.seam_inband = 1; o.out = seam_slab_d; }
             }
             launch_gemm2(o, ks_o, 4, stream);
             // x += sum(slabs); planes0 = RMSNorm(post_norm)(x)
@@ -605,7 +584,6 @@ bool Engine::run_layers(const DecStack& W, float* x, int ldx, int nb, int n_new,
             if (seam) {   // planes1 = SwiGLU of the slab sums scaled by 1 / rms(x) (from ssq_a)
                 f.seam = 2; f.seam_gen = seam_gen_d; f.seam_spin = seam_spin; f.seam_cnt = seam_counters(W.ffn / 64); f.oh = pl1h; f.ol = pl1l; f.ldp = ldp;
                 f.ssq_in = ssq_a_d; f.ssq_in_nt = NTH; f.seps = W.eps;
-                if (seam_inband) { f.seam_inband = 1; f.out = seam_gu_slab_d; f.out2 = seam_gu_slab_d + (size_t)ks_gu * M * W.ffn; }
             }
             launch_gemm2(f, ks_gu, 4, stream);
             if (!seam) launch_finish_swiglu(gu_slab_d, gu_slab_d + (size_t)ks_gu * rows_max * W.ffn, ks_q, (size_t)M * W.ffn, M, W.ffn, pl1h, pl1l, ldp, stream);
@@ -614,7 +592,6 @@ bool Engine::run_layers(const DecStack& W, float* x, int ldx, int nb, int n_new,
             if (seam && l + 1 < W.L) {   // x += sum(slabs); planes0 = gamma(next input norm) * x; ssq_b for the next layer's attention
                 d.seam = 1; d.seam_gen = seam_gen_d; d.seam_spin = seam_spin; d.seam_cnt = seam_counters(W.H / 64); d.sx = x; d.sldx = ldx; d.sgamma = W.layers[l + 1].in_norm;
                 d.oh = pl0h; d.ol = pl0l; d.ldp = ldp; d.ssq_out = ssq_b_d; d.ssq_nt = NTH;
-                if (seam_inband) { d.seam_inband = 1; d.out = seam_slab_d; }
                 launch_gemm2(d, ks_d, 4, stream);
                 continue;
             }

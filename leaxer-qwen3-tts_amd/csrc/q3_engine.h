@@ -203,12 +203,6 @@ public:
     float *ssq_a_d = nullptr, *ssq_b_d = nullptr;
     bool seam_step = false;      // inside record_step: run_layers may fold the finish launches into the GEMMs
     bool seam_on = true;         // Q3TTS_SEAM=0 at engine creation keeps the finish launches (the A/B knob and the tests' second path)
-    // in-band seam (GemmArgs::seam_inband): slab buffers only seam launches touch, resting at 0xFFFFFFFF words between launches
-    bool seam_inband = false;    // Q3TTS_SEAM_INBAND=1: third protocol, measured slower (5.00 vs 4.73 ms per b=64 step; profiles/r03_negative_results.txt 13)
-    float* seam_slab_d = nullptr;      // [<= 12][rows][H]
-    float* seam_gu_slab_d = nullptr;   // 2 x [<= 8][rows][ffn]
-    size_t seam_slab_words = 0, seam_gu_slab_words = 0;
-    size_t seam_residue();       // test hook: words of the two buffers that are not the sentinel (0 between steps)
     bool attn_keep_splits = false;   // Q3TTS_ATTN_KEEP_SPLITS at engine creation: the batched step keeps split-T attention + the combine launch (A/B knob, tests' second path)
     int seam_spin = 4096;        // Q3TTS_SEAM_SPIN: polls before an owner abandons its chunk (1 forces the rescue path in the tests)
     int32_t* codes_d = nullptr;

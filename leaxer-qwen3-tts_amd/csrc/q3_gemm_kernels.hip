@@ -303,7 +303,7 @@ __global__ __launch_bounds__(256) void k_gemm3(const bf16_t* pW, const bf16_t* p
     // at the seam it was a dependent memory round trip, ~1 us, between the body and the flag store)
     unsigned seam_gen_v = 0;
     if constexpr (SEAM != 0) seam_gen_v = __builtin_amdgcn_readfirstlane(*a.seam_gen);
-    const int seam_inband_v = a.seam_inband, seam_spin_v = a.seam_spin;
+    const int seam_spin_v = a.seam_spin;
 
     f32x4 acc[MTILES], acc2[DUAL ? MTILES : 1];
 #pragma unroll
@@ -372,195 +372,6 @@ __global__ __launch_bounds__(256) void k_gemm3(const bf16_t* pW, const bf16_t* p
         const size_t slab_bytes = (size_t)grid_ks * a.slab_rows * a.ldo * sizeof(float);
         __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (int)slab_bytes, 0x00020000);
         __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc(DUAL ? a.out2 : a.out, 0, (int)slab_bytes, 0x00020000);
-        if (seam_inband_v) {
-            // ---- third protocol: the slab words are their own ready flags.  Between launches every word of a seam slab buffer holds
-            // SEAM_SENTINEL (a NaN pattern no sum of bf16 products produces); a K slice writes its tile through (sc1) and does NOT wait
-            // for the drain; the owner of a 16-row chunk polls the DATA (sc1 loads of all K slices, re-issued only for slabs that still
-            // show a sentinel), sums in slab order, stores, and writes the sentinels back.  Against the flag protocol this takes the
-            // writers' drain (0.85 us), the flag's flight and the separate detection round trip (1.2 us) off the critical path.
-            // The flag line is kept for liveness only.  A flag now says "my slab stores are ISSUED and I will look at the abandoned
-            // marks once this store is acknowledged" (not "visible").  An owner whose bounded poll runs out marks its chunk abandoned;
-            // any slice that looks after its own flag and finds a mark takes the chunk by compare-and-swap and polls in turn; a holder
-            // that sees ALL flags set knows every slab is at least in flight, waits long (1 << 14 rounds) and then accepts what is there
-            // (a word that still reads as the sentinel is then data: the sum is NaN either way); a holder that does not gives the chunk
-            // back (mark again).  Each hand-off goes to a slice that had not flagged yet, so it ends at the last one, which sees all flags.
-            // Every chunk is summed and reset exactly once.  Rows past M are neither written nor read (a duplicate store landing after
-            // the reset would leave a non-sentinel word behind).
-            constexpr unsigned SENT = 0xFFFFFFFFu;
-            __shared__ unsigned sm_fail, sm_take, sm_complete;
-            const unsigned KS = grid_ks;
-            constexpr int NCHK = ROWS / 16;
-            unsigned* line = a.seam_cnt + ((size_t)blockIdx.z * grid_nt + blockIdx.x) * 16;
-            const int mine = (int)blockIdx.y < NCHK ? (int)blockIdx.y : -1;
-            const unsigned gbase = seam_gen_v << 2;
-            const size_t slab_stride = (size_t)a.slab_rows * a.ldo * sizeof(float);
-            if (tid == 0) sm_fail = 0;
-#pragma unroll
-            for (int p = 0; p < ROWS / 16; ++p) {
-                const int ml = erow + p * 16, m = m0 + ml;
-                if (m < M) {
-                    const unsigned off = (unsigned)(((sbase + m) * a.ldo + ng) * sizeof(float));
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, *reinterpret_cast<const f32x4*>(&ep[0][ml][ecol])), rs, off, 0, G3_AUX_SC1);
-                    if (DUAL) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, *reinterpret_cast<const f32x4*>(&ep[DUAL ? 1 : 0][ml][ecol])), rs2, off, 0, G3_AUX_SC1);
-                }
-            }
-            // every wave's slab stores are ISSUED (and sm_fail is 0) before the flag says so.  A bare s_barrier: __syncthreads() would put the
-            // workgroup-release wait (s_waitcnt vmcnt(0): the 0.85-1.0 us write-through drain) in front of it
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            if (tid == 0) __hip_atomic_store(line + blockIdx.y, gbase | 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            SP_SEAM(2);
-            unsigned lv = 0;          // wave 0: the line as seen AFTER the flag's acknowledgement
-            bool have_lv = false;
-            // one chunk: poll, agree, reduce, reset.  false = the bounded poll ran out somewhere in the workgroup (nothing was stored)
-            auto process = [&](int chunk, int bound, bool accept, bool first) -> bool {
-                if (!first) { __syncthreads(); if (tid == 0) sm_fail = 0; __syncthreads(); }
-                const int mr = m0 + chunk * 16 + erow;
-                const bool live = mr < M;
-                const int m = live ? mr : M - 1;
-                const unsigned off0 = (unsigned)(((size_t)m * a.ldo + ng) * sizeof(float));
-                u32x4 pp[NS], qq[DUAL ? NS : 1];
-#pragma unroll
-                for (int sidx = 0; sidx < NS; ++sidx) { pp[sidx] = u32x4{0u, 0u, 0u, 0u}; if (DUAL) qq[DUAL ? sidx : 0] = u32x4{0u, 0u, 0u, 0u}; }
-                bool fail = false;
-                // what the sums meet is requested before the poll (independent of the slabs)
-                f32x4 t = { 0.f, 0.f, 0.f, 0.f }, g = { 0.f, 0.f, 0.f, 0.f };
-                float rsc = 1.0f;
-                if constexpr (SEAM == 1) {
-                    t = *reinterpret_cast<const f32x4*>(a.sx + (size_t)m * a.sldx + ng);
-                    g = *reinterpret_cast<const f32x4*>(a.sgamma + ng);
-                } else if (a.ssq_in != nullptr) {
-                    const float* sq = a.ssq_in + (size_t)m * a.ssq_in_nt;
-                    float tot = 0.f;
-                    for (int t4 = 0; t4 < a.ssq_in_nt; t4 += 4) { const f32x4 v = *reinterpret_cast<const f32x4*>(sq + t4); tot += v.x; tot += v.y; tot += v.z; tot += v.w; }
-                    rsc = 1.0f / sqrtf(tot / (float)K + a.seps);
-                }
-                // round 0 asks for every slab at once (straight-line: one batch of loads, one wait); later rounds re-ask, wave-uniformly, for
-                // the slabs some lane still saw a sentinel in (a lane whose copy was already whole re-reads the same words)
-                auto sentinel_in = [&](int sidx) -> bool {
-                    const u32x4 v = pp[sidx];
-                    bool snt = v.x == SENT || v.y == SENT || v.z == SENT || v.w == SENT;
-                    if (DUAL) { const u32x4 w = qq[DUAL ? sidx : 0]; snt = snt || w.x == SENT || w.y == SENT || w.z == SENT || w.w == SENT; }
-                    return __ballot(snt && live) != 0ull;
-                };
-#pragma unroll
-                for (int sidx = 0; sidx < NS; ++sidx) {
-                    const unsigned so = off0 + (unsigned)((sidx < (int)KS ? sidx : (int)KS - 1) * slab_stride);
-                    pp[sidx] = __builtin_amdgcn_raw_buffer_load_b128(rs, so, 0, G3_AUX_SC1);
-                    if (DUAL) qq[DUAL ? sidx : 0] = __builtin_amdgcn_raw_buffer_load_b128(rs2, so, 0, G3_AUX_SC1);
-                }
-                unsigned pw = 0;
-#pragma unroll
-                for (int sidx = 0; sidx < NS; ++sidx) if (sidx < (int)KS && sentinel_in(sidx)) pw |= 1u << sidx;
-                if (first && mine >= 0 && wave == 0) {   // the owner's look rides behind its first round: flag acknowledged, one more load in flight
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    lv = __hip_atomic_load(line + (lane & 15), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    have_lv = true;
-                }
-                int rounds = 1;
-                for (int it = 1; pw != 0u; ++it) {
-                    if (it >= bound) { fail = !accept; break; }
-                    rounds = it + 1;
-                    asm volatile("" ::: "memory");   // the loads below are re-issued every round
-#pragma unroll
-                    for (int sidx = 0; sidx < NS; ++sidx)
-                        if (pw >> sidx & 1u) {
-                            const unsigned so = off0 + (unsigned)(sidx * slab_stride);
-                            pp[sidx] = __builtin_amdgcn_raw_buffer_load_b128(rs, so, 0, G3_AUX_SC1);
-                            if (DUAL) qq[DUAL ? sidx : 0] = __builtin_amdgcn_raw_buffer_load_b128(rs2, so, 0, G3_AUX_SC1);
-                        }
-                    unsigned npw = 0;
-#pragma unroll
-                    for (int sidx = 0; sidx < NS; ++sidx) if ((pw >> sidx & 1u) && sentinel_in(sidx)) npw |= 1u << sidx;
-                    pw = npw;
-                }
-#ifdef Q3_SAMPLE_PROF
-                if (blockIdx.x == 0 && blockIdx.z == 0 && tid == 0) g_seam_prof[SEAM == 2 ? 1 : (gridDim.y > 8 ? 2 : 0)][blockIdx.y & 15][6] = rounds;
-#endif
-                if (fail) sm_fail = 1u;
-                __syncthreads();
-                if (sm_fail != 0u) return false;
-                SP_SEAM(3);   // every slab word of the chunk has been seen
-                SP_SEAM(4);
-                if constexpr (SEAM == 1) {
-#pragma unroll
-                    for (int sidx = 0; sidx < NS; ++sidx) if (sidx < (int)KS) t += __builtin_bit_cast(f32x4, pp[sidx]);
-                    float ss = 0.f;
-                    ss = fmaf(t.x, t.x, ss); ss = fmaf(t.y, t.y, ss); ss = fmaf(t.z, t.z, ss); ss = fmaf(t.w, t.w, ss);
-                    ss += __shfl_xor(ss, 1, 16); ss += __shfl_xor(ss, 2, 16); ss += __shfl_xor(ss, 4, 16); ss += __shfl_xor(ss, 8, 16);
-                    if (live) {
-                        *reinterpret_cast<f32x4*>(a.sx + (size_t)m * a.sldx + ng) = t;
-                        const float y[4] = { g.x * t.x, g.y * t.y, g.z * t.z, g.w * t.w };
-                        split_store4(y, a.oh + (size_t)m * a.ldp + ng, a.ol + (size_t)m * a.ldp + ng);
-                        if ((tid & 15) == 0) a.ssq_out[(size_t)m * a.ssq_nt + blockIdx.x] = ss;
-                    }
-                } else {
-                    f32x4 gs = { 0.f, 0.f, 0.f, 0.f }, us = { 0.f, 0.f, 0.f, 0.f };
-#pragma unroll
-                    for (int sidx = 0; sidx < NS; ++sidx) if (sidx < (int)KS) { gs += __builtin_bit_cast(f32x4, pp[sidx]); us += __builtin_bit_cast(f32x4, qq[DUAL ? sidx : 0]); }
-                    gs *= rsc; us *= rsc;
-                    if (live) {
-                        const float o[4] = { silu_g(gs.x) * us.x, silu_g(gs.y) * us.y, silu_g(gs.z) * us.z, silu_g(gs.w) * us.w };
-                        split_store4(o, a.oh + (size_t)m * a.ldp + ng, a.ol + (size_t)m * a.ldp + ng);
-                    }
-                }
-                if (live) {   // the chunk's slab words go back to the sentinel (every load of them has returned: their values were just used)
-                    const u32x4 sv = { SENT, SENT, SENT, SENT };
-#pragma unroll
-                    for (int sidx = 0; sidx < NS; ++sidx)
-                        if (sidx < (int)KS) {
-                            const unsigned so = off0 + (unsigned)(sidx * slab_stride);
-                            __builtin_amdgcn_raw_buffer_store_b128(sv, rs, so, 0, G3_AUX_SC1);
-                            if (DUAL) __builtin_amdgcn_raw_buffer_store_b128(sv, rs2, so, 0, G3_AUX_SC1);
-                        }
-                }
-                SP_SEAM(5);
-                return true;
-            };
-            // the owner's own chunk first, outside the hand-off loop (straight-line from the slab stores to the first poll: inside the loop
-            // the compiler's wait-count join of the back edge puts a full vmcnt(0) — the drain again — in front of the first loads)
-            unsigned todo = 0, failed0 = 0;
-            if (mine >= 0 && !process(mine, seam_spin_v, false, true)) failed0 = 1u << mine;
-            int bound = seam_spin_v;
-            bool accept = false;
-            for (;;) {
-                unsigned failed = failed0;
-                failed0 = 0;
-                for (int c = 0; c < NCHK; ++c)
-                    if (todo >> c & 1u) { if (!process(c, bound, accept, false)) failed |= 1u << c; }
-                if (wave == 0) {
-                    if (failed) {
-                        if (lane == 0)
-                            for (int c = 0; c < NCHK; ++c)
-                                if (failed >> c & 1u) __hip_atomic_exchange(line + 12 + c, gbase | 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        have_lv = false;
-                    }
-                    if (!have_lv) {   // flag (and mark) stores acknowledged before the look: the hand-off's store -> load order
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        lv = __hip_atomic_load(line + (lane & 15), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                    have_lv = false;
-                    const unsigned long long in = __ballot((lane < (int)KS && lane != (int)blockIdx.y) ? lv == (gbase | 3u) : true);
-                    const unsigned long long ab = __ballot(lane >= 12 && lane < 16 && lv == (gbase | 1u));
-                    const unsigned marks = (unsigned)(ab >> 12) & 0xFu;
-                    unsigned take = 0;
-                    for (int c = 0; c < NCHK; ++c)
-                        if (marks >> c & 1u) {
-                            unsigned won = 0;
-                            if (lane == 0) { unsigned expect = gbase | 1u; won = __hip_atomic_compare_exchange_strong(line + 12 + c, &expect, gbase | 2u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1u : 0u; }
-                            won = __builtin_amdgcn_readfirstlane(won);
-                            if (won) take |= 1u << c;
-                        }
-                    if (lane == 0) { sm_take = take; sm_complete = in == ~0ull ? 1u : 0u; }
-                }
-                __syncthreads();
-                todo = sm_take;
-                if (todo == 0u) return;
-                accept = sm_complete != 0u;
-                bound = accept ? (1 << 14) : seam_spin_v;
-                __syncthreads();   // sm_take is read before the next round rewrites it
-            }
-        }
 #pragma unroll
         for (int p = 0; p < ROWS / 16; ++p) {
             const int ml = erow + p * 16, m = m0 + ml;
@@ -588,9 +399,14 @@ __global__ __launch_bounds__(256) void k_gemm3(const bf16_t* pW, const bf16_t* p
         const unsigned gbase = seam_gen_v << 2;
         if (wave == 0) {
             if (lane == 0) __hip_atomic_store(line + blockIdx.y, gbase | 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            // an owner polls at once (its own word counts as set: only the others' are awaited); everybody else looks once, AFTER its flag
-            // store is acknowledged (the rescue protocol's store -> load order)
-            if (mine < 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // Everybody looks only AFTER its own flag store is acknowledged (the rescue protocol's store -> load order: of two slices that
+            // each miss the other's last word, one must have looked before its own store landed).  Owners used to poll at once; they are the
+            // low-y workgroups, dispatched first and usually waiting for the later slices anyway, so the acknowledgement is hidden
+            // (-DQ3_SEAM_EAGER_POLL restores the old order for an A/B build).
+#ifdef Q3_SEAM_EAGER_POLL
+            if (mine < 0)
+#endif
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             auto look = [&](unsigned& marks) -> bool {   // one sc1 load of the line: all slices in? which chunks are abandoned?
                 const unsigned v = __hip_atomic_load(line + (lane & 15), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const unsigned long long in = __ballot((lane < (int)KS && lane != (int)blockIdx.y) ? v == (gbase | 3u) : true);
@@ -709,6 +525,9 @@ bool gemm_seam_ok(const GemmArgs& a, int ksplit) {
     if ((a.seam == 1) != (a.epi == EPI_SLAB) || (a.seam == 2) != (a.epi == EPI_SLAB2)) return false;
     const int ksl = ksplit > 0 && a.K % ksplit == 0 ? a.K / ksplit : 0;
     if (!(ksl == 128 || ksl == 256) || a.N % 64 != 0 || a.ldo % 4 != 0 || a.ldx % 8 != 0 || a.M < 1 || a.M > 128) return false;
+    // chunk c of a row block is reduced by K slice c (blockIdx.y == c): a launch with fewer slices than 16-row chunks per block (2 up to 64
+    // rows, 4 beyond) would leave chunks without an owner — those shapes (K = 128 .. 768 with 256-wide slices) keep the finish launches
+    if (ksplit < (a.M > 64 ? 4 : 2)) return false;
     if (a.seam == 1 && (ksplit > 12 || !a.sx || !a.sgamma || !a.ssq_out || a.ssq_nt != a.N / 64 || a.sldx % 4 != 0)) return false;
     if (a.seam == 2 && (ksplit > 8 || (a.ssq_in && a.ssq_in_nt % 4 != 0))) return false;
     return a.seam_cnt != nullptr && a.seam_gen != nullptr && a.oh != nullptr && a.ol != nullptr && a.ldp % 4 == 0 && (a.slab_rows == 0 || a.slab_rows == a.M);

@@ -83,7 +83,7 @@ EXPORTS = [
     "q3tts_sample_host", "q3tts_rng_uniform", "q3tts_build_prompt_host", "q3tts_slot_begin", "q3tts_decode_steps",
     "q3tts_slot_status", "q3tts_slot_codes_host", "q3tts_slot_codec_decode_host", "q3tts_slot_release",
     "q3tts_synthesize_batch_host", "q3tts_last_decode_ms", "q3tts_last_codec_ms", "q3tts_decode_step_bytes",
-    "q3tts_codec_decode_dev", "q3tts_stream", "q3tts_counters", "q3tts_stage_profile", "q3tts_codec_plane_stats", "q3tts_seam_residue", "q3tts_config_num_tensors", "q3tts_config_tensor_info", "q3tts_read_weights_config", "q3tts_load_weights_file", "q3tts_save_weights_file",
+    "q3tts_codec_decode_dev", "q3tts_stream", "q3tts_counters", "q3tts_stage_profile", "q3tts_codec_plane_stats", "q3tts_config_num_tensors", "q3tts_config_tensor_info", "q3tts_read_weights_config", "q3tts_load_weights_file", "q3tts_save_weights_file",
     "q3tts_tokenizer_create", "q3tts_tokenizer_destroy", "q3tts_tokenizer_load_vocab", "q3tts_tokenizer_load_merges",
     "q3tts_tokenizer_ready", "q3tts_tokenize",
     "q3tts_synthesize_clone_batch_host", "q3tts_synthesize_schedule_host", "q3tts_read_wav_host", "q3tts_resample_host", "q3tts_mel_host",
@@ -146,7 +146,6 @@ def lib():
     L.q3tts_last_codec_ms.argtypes = [vp, C.POINTER(f32)]
     L.q3tts_stage_profile.argtypes = [vp, i32, C.POINTER(C.c_double)]
     L.q3tts_codec_plane_stats.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
-    L.q3tts_seam_residue.argtypes = [vp, C.POINTER(C.c_int64)]
     L.q3tts_counters.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(C.c_double), C.POINTER(i64), i32]
     L.q3tts_decode_step_bytes.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.q3tts_read_weights_config.argtypes = [C.c_char_p, C.POINTER(Config)]
@@ -509,12 +508,6 @@ class Engine:
         self.L.q3tts_stream.restype = C.c_void_p
         self.L.q3tts_stream.argtypes = [C.c_void_p]
         return self.L.q3tts_stream(self.h)
-
-    def seam_residue(self):
-        """words of the batched step's partial-sum buffers that are not at rest (q3tts_seam_residue): 0 between steps"""
-        n = C.c_int64(0)
-        self._ck(self.L.q3tts_seam_residue(self.h, C.byref(n)))
-        return n.value
 
     def codec_plane_stats(self):
         """(two_product, three_product): codec weight tensors whose fp16 lo plane is empty / needed (q3tts_codec_plane_stats)"""

@@ -105,6 +105,27 @@ def test_generate_cached_equals_uncached_and_eos(oracle):
     assert len(c) == 30 and len(a) < 30 and (c[:, 0] < 64).all()   # benchmark mode never stops early
 
 
+def test_kv_cached_predictor_equals_the_reference_call_pattern_over_48_greedy_frames(oracle):
+    """Every GPU parity test feeds the oracle with cp_cached=True (the oracle's own KV-cached code predictor).  The reference re-runs
+    code_predictor.onnx on the whole growing sequence for each of the 15 sub-codes, with no cache
+    (/root/reference/src/tts_onnx.cpp:862-868).  Oracle against oracle: the two call patterns give the same ids over 48 free-running
+    greedy frames (768 decisions) and over 48 sampled frames, on the tiny and the medium config."""
+    ids = frame_tokens([7, 1, 9, 4, 4, 2, 8])
+    cases = [(oracle, "tiny")]
+    med = qo.Oracle(qo.config_medium(), max_ctx=96, weights=qo.random_weights(qo.config_medium(), 5))
+    cases.append((med, "medium"))
+    try:
+        for o, label in cases:
+            p = o.build_prompt(ids, 0)
+            for kw in (dict(temperature=1.0, top_p=1.0, top_k=1), dict(temperature=0.8, top_p=0.95, top_k=50)):
+                sp = qo.Sampling(max_new_tokens=48, **kw)
+                a = o.generate(p, sp, seed=6, stream=1, cp_cached=True, ignore_eos=True)
+                b = o.generate(p, sp, seed=6, stream=1, cp_cached=False, ignore_eos=True)
+                assert a.shape == (48, 16) and np.array_equal(a, b), (label, kw)
+    finally:
+        med.close()
+
+
 def test_vocoder_length_formula():
     cfg = qo.config_06b()
     # transformers Code2Wav trims k-s on both sides of every decoder transposed conv: F=1 -> 1365

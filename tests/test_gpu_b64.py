@@ -14,20 +14,19 @@ pytestmark = pytest.mark.gpu
 CHECK = (0, 16, 17, 31, 63)     # oracle cost: a spread of utterances, both sides of the 16/17-row kernel switch
 
 
-@pytest.fixture(scope="module", params=["fp32kv", "bf16kv", "finish-launches", "seam-rescue", "seam-inband", "attn-splits"])
+@pytest.fixture(scope="module", params=["fp32kv", "bf16kv", "finish-launches", "seam-rescue", "attn-splits"])
 def wide(request):
     """64 slots at 0.6B dims.  Rounds: the default engine (split-K seam inside k_gemm3: the slab GEMMs reduce their own slabs, deferred
     RMSNorm); the talker KV cache in bf16 (Q3TTS_FLAG_KV_BF16, oracle in the same mode); Q3TTS_SEAM=0, the k_finish* launches the seam
     replaces; Q3TTS_SEAM_SPIN=1, every chunk owner gives up after one look, so the abandon / compare-and-swap rescue path of the seam
-    produces the planes (a path a chip that runs the whole grid at once never takes); Q3TTS_SEAM_INBAND=1, the third seam protocol (a slice's
-    arrival is detected in the partial sums themselves, which rest at a sentinel between launches; kept as a measured negative result);
+    produces the planes (a path a chip that runs the whole grid at once never takes);
     Q3TTS_ATTN_KEEP_SPLITS + 64-token splits on a 192-token cache: the talker's attention as split-T partials + the combine launch (what a
     64-utterance batch runs beyond 512 tokens of context — the b64_f2048 bench — and never at the 64-token contexts of the other rounds)."""
     import os
     import q3tts
     cfg = q3tts.default_config("0.6b")
     bf = request.param == "bf16kv"
-    env = {"finish-launches": {"Q3TTS_SEAM": "0"}, "seam-rescue": {"Q3TTS_SEAM_SPIN": "1"}, "seam-inband": {"Q3TTS_SEAM_INBAND": "1"},
+    env = {"finish-launches": {"Q3TTS_SEAM": "0"}, "seam-rescue": {"Q3TTS_SEAM_SPIN": "1"},
            "attn-splits": {"Q3TTS_ATTN_KEEP_SPLITS": "1", "Q3TTS_ATTN_CHUNK": "64"}}.get(request.param, {})
     os.environ.update(env)             # read at engine creation
     try:
@@ -39,6 +38,10 @@ def wide(request):
     eng.fill_synthetic(seed=0)
     eng.margin_noise = 2e-2 if bf else 2e-4     # tests/test_gpu_full.py, bf16 KV note: what logit agreement this cache mode can honour
     eng.logit_bound = 2e-2 if bf else 2e-4
+    # bf16 KV: ids are NOT bit-exact against the oracle in this mode (rounding decorrelates two implementations); the margin gate above opens
+    # at the first decision whose top-2 gap is under 2e-2.  So that the gate cannot open at frame 0 unnoticed, the greedy test asserts a
+    # floor on the bit-exact prefix of every checked utterance and prints the count (fp32 KV rounds: the whole run).
+    eng.min_exact_frames = 8 if bf else None
     eng.long_run = request.param == "attn-splits"     # the 32-frame greedy test runs 56 frames there: contexts cross the 64-token split
     orc = qo.Oracle(to_ocfg(cfg), max_ctx=96 if eng.long_run else 48, kv_bf16=bf)
     for name, shape in eng.tensor_infos():
@@ -72,7 +75,6 @@ def test_batched_generation_full_size(wide, nb, sampled):
                 bad.append((u, f, g, float(mg[f, 2 + g])))
         assert np.isfinite(pcm[u]).all() and len(pcm[u]) == eng.codec_decode_len(8)
     assert not bad, bad
-    assert eng.seam_residue() == 0      # the in-launch reduction left every partial-sum word at rest (q3tts_seam_residue)
     # the batch is deterministic and every utterance independent of its neighbours: the first 24 of a 64-batch == the 24-batch
     if nb == 24:
         _, codes64, _ = eng.synthesize_batch(toks, sp, lang=0, seed=77, ignore_eos=True)
@@ -90,7 +92,6 @@ def test_batched_greedy_32_frames_margin_aware(wide):
     sp = q3tts.Sampling(max_new_tokens=F, temperature=1.0, top_p=1.0, top_k=1)
     _, codes, nfr = eng.synthesize_batch(toks, sp, lang=0, seed=9, ignore_eos=True)
     assert all(int(n) == F for n in nfr)
-    assert eng.seam_residue() == 0
     for u in (0, 17, 63):
         ref, mg = orc.generate_margins(orc.build_prompt(toks[u], 0), to_osampling(sp), seed=9, stream=u, cp_cached=True, ignore_eos=True)
         bad = np.argwhere(codes[u] != ref)
@@ -98,8 +99,11 @@ def test_batched_greedy_32_frames_margin_aware(wide):
             print("b=64 greedy, utterance %d: %d frames bit-exact, smallest top-2 margin %.3g" % (u, F, float(mg[:, 2:].min())))
             continue
         f, g = int(bad[0][0]), int(bad[0][1])
-        print("b=64 greedy, utterance %d: first divergence at frame %d group %d, oracle margin %.3g" % (u, f, g, float(mg[f, 2 + g])))
+        print("b=64 greedy, utterance %d: %d frames + %d decisions bit-exact, first divergence at frame %d group %d, oracle margin %.3g"
+              % (u, f, g, f, g, float(mg[f, 2 + g])))
         assert float(mg[f, 2 + g]) < eng.margin_noise, (u, f, g, float(mg[f, 2 + g]))
+        if eng.min_exact_frames is not None:
+            assert f >= eng.min_exact_frames, "bf16 KV: only %d bit-exact frames for utterance %d (floor %d)" % (f, u, eng.min_exact_frames)
         assert np.array_equal(codes[u][:f], ref[:f]) and np.array_equal(codes[u][f, :g], ref[f, :g])
 
 
@@ -118,7 +122,10 @@ def test_teacher_forced_logits_64_rows_full_size(wide):
         po = orc.build_prompt(toks[u], 0)
         ref = orc.generate(po, to_osampling(sp), seed=5, stream=u, cp_cached=True, ignore_eos=True)
         if not np.array_equal(codes[u], ref):   # bf16 KV mode: the frame may already hold a sub-noise decision; teacher-force what the ENGINE emitted
-            assert eng.margin_noise > 1e-3, u
+            _, mg = orc.generate_margins(po, to_osampling(sp), seed=5, stream=u, cp_cached=True, ignore_eos=True)
+            g = int(np.argwhere(codes[u][0] != ref[0])[0][0])
+            print("teacher-forced: utterance %d differs from the oracle at group %d, oracle decision margin %.3g" % (u, g, float(mg[0, 2 + g])))
+            assert eng.margin_noise > 1e-3 and float(mg[0, 2 + g]) < eng.margin_noise and np.array_equal(codes[u][0, :g], ref[0, :g]), (u, g, float(mg[0, 2 + g]))
             ref = codes[u]
         # teacher forcing: frame 0's embedding sum (tts_onnx.cpp:824-842) into the oracle's run_decode
         tro, _ = orc.trailing()
@@ -179,7 +186,7 @@ def test_batch_of_80_crosses_the_128_row_block():
         toks = [frame_tokens(rng.integers(0, 151643, int(n))) for n in rng.integers(3, 20, 80)]
         sp = q3tts.Sampling(max_new_tokens=8, temperature=0.8, top_p=0.95, top_k=50)
         pcm, codes, nfr = eng.synthesize_batch(toks, sp, lang=0, seed=5, ignore_eos=True)
-        assert all(int(n) == 8 for n in nfr) and eng.seam_residue() == 0
+        assert all(int(n) == 8 for n in nfr)
         bad = []
         for u in (0, 63, 64, 79):
             ref, mg = orc.generate_margins(orc.build_prompt(toks[u], 0), to_osampling(sp), seed=5, stream=u, cp_cached=True, ignore_eos=True)
@@ -215,7 +222,7 @@ def test_batch_of_32_with_long_prompts_one_split_attention_walks_several_batches
         F = 12
         sp = q3tts.Sampling(max_new_tokens=F, temperature=1.0, top_p=1.0, top_k=1)
         _, codes, nfr = eng.synthesize_batch(toks, sp, lang=0, seed=3, ignore_eos=True)
-        assert all(int(n) == F for n in nfr) and eng.seam_residue() == 0
+        assert all(int(n) == F for n in nfr)
         for u in (0, 15, 31):
             ref, mg = orc.generate_margins(orc.build_prompt(toks[u], 0), to_osampling(sp), seed=3, stream=u, cp_cached=True, ignore_eos=True)
             bad = np.argwhere(codes[u] != ref)

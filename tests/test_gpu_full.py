@@ -138,6 +138,7 @@ def test_free_running_sampled_margin_aware_full_size(full, seed):
 # oracle in the same mode, with the logit bound this mode can honour and the margin-aware verdict (ids equal up to the first decision
 # whose top-2 gap is under that bound).
 NOISE_BF16KV = 2e-2
+MIN_EXACT_FRAMES_BF16KV = 8     # floor on the bit-exact prefix of a free-running bf16-KV run (measured prefixes are printed by the tests)
 
 
 @pytest.fixture(scope="module")
@@ -181,6 +182,36 @@ def test_bf16_kv_storage_equals_rounded_fp32_storage(full_bf16kv):
     assert np.array_equal(ca, cb)
 
 
+def test_bf16_kv_single_page_talker_stays_off_the_fused_fp32_path():
+    """A talker whose whole context fits one KV page (max_ctx <= 64) has the shape of the code predictor's b = 1 fused attention + o_proj
+    launch, which addresses an fp32 cache.  In the bf16 / rounded-bf16 cache modes the engine must keep such a talker on the general
+    attention path: 16-bit storage == fp32 storage of the rounded rows bit for bit through talker_prefill (8 rows, then 2 rows) and 40
+    talker_decode steps, and the rounding is visible against an fp32-cache engine (run_prefill / run_decode,
+    /root/reference/src/tts_onnx.cpp:615-732)."""
+    import q3tts
+    cfg = q3tts.default_config("0.6b")
+    engs = [q3tts.Engine(cfg, device=0, max_batch=1, max_ctx=64, flags=f) for f in (q3tts.FLAG_KV_BF16, q3tts.FLAG_KV_ROUND_BF16, 0)]
+    try:
+        for e in engs:
+            e.fill_synthetic(seed=0)
+        rng = np.random.default_rng(19)
+        seen = 0.0
+        for S in (8, 2):
+            x = (rng.standard_normal((S, 1024)) * 0.05).astype(np.float32)
+            outs = [e.prefill(x) for e in engs]
+            assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]), S
+            assert np.isfinite(outs[0][0]).all()
+            for i in range(40 if S == 2 else 4):
+                v = (rng.standard_normal(1024) * 0.05).astype(np.float32)
+                outs = [e.decode(v) for e in engs]
+                assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]), (S, i)
+                seen = max(seen, float(np.abs(outs[0][0] - outs[2][0]).max()))
+        assert 1e-5 < seen < NOISE_BF16KV, seen      # the rounding is on (and only the rounding: an fp32 read of 16-bit rows would be garbage)
+    finally:
+        for e in engs:
+            e.close()
+
+
 def test_bf16_kv_session_ops_full_size(full, full_bf16kv):
     """Q3TTS_FLAG_KV_BF16 against the oracle in the same mode: prefill + decode logits within the bound this mode can honour (see the
     note above), and the mode is visibly on (the logits move by ~6e-3 against the fp32-cache engine).  Replaces the reference's fp32
@@ -214,7 +245,9 @@ def test_free_running_160_frames_greedy_bf16_kv(full_bf16kv, prompt_seed):
     eng, orc = full_bf16kv
     ids = frame_tokens(np.random.default_rng(prompt_seed).integers(0, 151643, 16))
     sp = q3tts.Sampling(max_new_tokens=160, temperature=1.0, top_p=1.0, top_k=1)
-    check_free_running(eng, orc, sp, ids, 5, "greedy, bf16 KV, prompt seed %d" % prompt_seed, noise=NOISE_BF16KV)
+    exact = check_free_running(eng, orc, sp, ids, 5, "greedy, bf16 KV, prompt seed %d" % prompt_seed, noise=NOISE_BF16KV)
+    # ids are not bit-exact against the oracle in this mode; the floor keeps the 2e-2 margin gate from opening at frame 0 unnoticed
+    assert exact >= MIN_EXACT_FRAMES_BF16KV, "bf16 KV: only %d bit-exact frames (floor %d)" % (exact, MIN_EXACT_FRAMES_BF16KV)
 
 
 def test_fused_predictor_attention_matches_separate_launches(full):

@@ -57,6 +57,25 @@ def test_projected_batch12_matrix_core_path():
     orc.close()
 
 
+@pytest.mark.parametrize("nb", [20, 70])
+def test_projected_batches_whose_gemms_have_fewer_k_slices_than_row_chunks(nb):
+    """config_medium_proj (talker 256 wide, o_proj K = 128, down K = 384) passes every shape test of the batched step's in-launch split-K
+    reduction except one: its o_proj runs ONE K slice and its down projection three, while a 17..64-row block has two 16-row chunks to
+    reduce and a 65..128-row block four — and chunk c is reduced by slice c.  Such launches must keep the finish kernels (gemm_seam_ok);
+    20 and 70 utterances, every utterance of the batch against its own oracle run."""
+    import q3tts
+    eng, orc, _ = tiny_pair(seed=17, max_batch=nb, max_ctx=64, ocfg=qo.config_medium_proj())
+    sp = q3tts.Sampling(temperature=0.8, top_p=0.95, top_k=50, max_new_tokens=10)
+    rng = np.random.default_rng(nb)
+    toks = [frame_tokens(rng.integers(0, 151643, int(n))) for n in rng.integers(1, 12, nb)]
+    pcm, codes, nfr = eng.synthesize_batch(toks, sp, lang=0, seed=8, ignore_eos=True)
+    for u, t in enumerate(toks):
+        ref = orc.generate(orc.build_prompt(t, 0), to_osampling(sp), seed=8, stream=u, cp_cached=True, ignore_eos=True)
+        assert nfr[u] == 10 and np.array_equal(codes[u], ref), u
+    eng.close()
+    orc.close()
+
+
 def test_full_1p7b_dims_greedy_b1_b2_b16():
     """1.7B dims, seeded weights: greedy codec ids bit-exact vs the oracle through the three row regimes of the talker
     (1 row: single-pass GEMV incl. K = 6144; 2 rows: chunked GEMV; 16 rows: matrix-core GEMM), plus the talker-wide speaker row."""
