@@ -241,6 +241,11 @@ int q3tts_codec_plane_stats(q3tts_engine* e, int* two_product, int* three_produc
  * events at the stage boundaries.  out_ms[0] sampler (n_groups launches), [1] code predictor (layer passes + heads; predict_subcodes,
  * tts_onnx.cpp:851-872), [2] talker decode (layers + codec head; run_decode :667-732), [3] their sum — milliseconds per step. */
 int q3tts_stage_profile(q3tts_engine* e, int n_steps, double* out_ms /* [4] */);
+/* Measurement aid (engines created with Q3TTS_FLAG_TEST_HOOKS only): every armed slot jumps n_frames ahead without generating them — frame
+ * counters and talker positions advance, the skipped frames' codes are zero and the talker's KV cache is refilled with seeded synthetic rows.
+ * What the slots emit afterwards is numerically meaningless; the decode step streams a context of the requested depth, which is what the
+ * rocprofv3 passes over run_decode's attention (tts_onnx.cpp:667-732) at 1000-2000 tokens of context need (tools/ctx_bench.py). */
+int q3tts_measure_skip_frames(q3tts_engine* e, int n_frames);
 /* Parity aid: ONE eager decode step of the armed slots (they advance like q3tts_decode_steps(1)) that also returns, for `slot`, the
  * logits row each of the frame's n_groups decisions was sampled from — out[n_groups][cols], cols >= max(vocab, sub_vocab); row 0 the
  * code0 logits (run_decode's output, before suppression), row j the code predictor's logits for sub-code j-1 (run_code_predictor,

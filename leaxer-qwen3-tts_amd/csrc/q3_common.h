@@ -109,6 +109,9 @@ struct AttnArgs {
     float* po = nullptr; float* pm = nullptr; float* pl = nullptr;
     // optional (hi, lo) bf16 plane outputs of launch_attn_combine for the MFMA GEMM path
     bf16_t* oh = nullptr; bf16_t* ol = nullptr; int ldp = 0;
+    // 1: k_attn_stream — the batched step's long-context kernel (one new token per row, d = 128, splits on page boundaries, K/V walked in
+    // a two-deep register ring); the engine asks for it where the launch is bound by the KV bytes it streams
+    int stream = 0;
 };
 void launch_attn(const AttnArgs& a, hipStream_t s);
 // code-predictor attention + o_proj (+ residual) for one utterance: see k_cp_attn_oproj

@@ -842,6 +842,295 @@ __global__ __launch_bounds__(256) void k_attn(const int* ppage_table, const int*
 }
 
 // ================================================================================================
+// k_attn_stream (round 4) — the talker's decode attention of the BATCHED step at long contexts, where the launch is bound by the KV
+// bytes it streams (64 rows x 1041 tokens: 546 MB fp32 / 273 MB bf16 per layer) instead of by its latency chain.  k_attn holds one batch
+// of 8 tokens per lane group in ~250 registers — two workgroups per CU, each one memory round deep, nothing in flight while it computes
+// or merges.  Here a workgroup = (kv head, split of `chunk` tokens, row) walks its split in batches of 16 U tokens through a two-deep
+// register ring: batch j+2 is requested as soon as batch j has been consumed (loads return in issue order, so the wait for batch j
+// leaves batch j+1 in flight), the rows stay PACKED in the ring (bf16 cache: 8 registers per token and lane for K and V, converted as
+// they are consumed), and the kernel fits 128 registers: four workgroups per CU, each with 2 x 16 KiB of K/V in flight.
+//   * one new token per row (decode), raw q/k/v slabs in, same prologue as k_attn: q heads and the new key through RMSNorm + RoPE, the
+//     new K/V row appended by the split that holds position `pos` and consumed from LDS;
+//   * a batch of 16 U tokens never crosses a 64-token page and a split starts on a page boundary, so the page of a batch is
+//     wave-uniform: the load address is {scalar base, 32-bit lane offset};
+//   * no load under a runtime condition: a batch past the split's end requests one hot line (every lane the split's first row) instead;
+//   * MAPC: lane `sub` of a token's 16 lanes owns dims [8 sub, 8 sub + 8) — one 16-byte piece of a bf16 row, two adjacent pieces of an
+//     fp32 row.  !MAPC (fp32 only): dims [4 sub, +4) and [64 + 4 sub, +4), so that each load instruction of the wave covers whole
+//     256-byte runs.  Q3TTS_FLAG_KV_ROUND_BF16 keeps MAPC: its sums then associate exactly like the bf16 cache's (bit-for-bit test);
+//   * output: un-normalised partials (m, l, sum p v) per split for k_attn_combine, or — one split — the normalised planes / rows.
+// Reference semantics: run_decode's attention over the grown KVCache, /root/reference/src/tts_onnx.cpp:667-732, tts_onnx.h:108-115.
+// ================================================================================================
+template <int G, bool KVB, bool MAPC, bool IDENT, int U, int WPE>
+__global__ __launch_bounds__(256, WPE) void k_attn_stream(const int* ppage_table, const int* ppos_dev, const float* pqkv, const float* pkcache, const float* pvcache,
+                                                         const float* pcos, const float* psin, int pn_splits, int pchunk, AttnArgs a) {
+    constexpr int D = 128, HALF = 64, EPL = 8;
+    constexpr int KR = KVB ? 1 : 2;                 // 16-byte pieces per (row, lane)
+    constexpr int ESZ = KVB ? 2 : 4;
+    constexpr int BT = 16 * U;                      // tokens per batch
+    constexpr unsigned PIECE1 = MAPC ? 16u : 256u;  // byte distance of a lane's second piece (fp32)
+    static_assert(64 % BT == 0, "a batch must not cross a KV page");
+    static_assert(!KVB || MAPC, "the bf16 cache has one piece per lane");
+    const int kvh = blockIdx.x, split = blockIdx.y, bi = blockIdx.z;
+    const int S = pn_splits;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int slot = a.slot_offset + bi, row = bi;
+    const int tg = wave * 4 + (lane >> 4), sub = lane & 15;
+
+    __shared__ float q_s[G][D];
+    __shared__ float knew[D], vnew[D];
+    __shared__ float cm[16][G], cl[16][G];
+    __shared__ float co[16][G][D];
+
+    // ---- round 1: the row's position ----
+    const int lo = split * pchunk;
+    const int pbase = lo >> 6;
+    // Pooled cache (!IDENT): a batch's page id is read from the slot's table row where the batch is requested — a scalar load from a
+    // line the scalar cache holds after the first one.  (Page ids kept in a private array, or in four scalars behind a select chain,
+    // made hipcc copy the whole argument block to scratch: 700-1100 bytes of private segment, every field reloaded from there.)
+    const int* ptr = ppage_table + (size_t)slot * a.pages_per_slot;
+    const int plast = a.pages_per_slot - 1;
+    int base = a.pos_scalar;
+    if (ppos_dev) base = ppos_dev[slot];
+    __builtin_amdgcn_sched_barrier(0);
+    const int hi = lo + pchunk < base + 1 ? lo + pchunk : base + 1;
+    if (lo >= hi) return;                            // empty split: the combiner derives the active split count from pos
+    const int cend = hi < base ? hi : base;          // cache tokens [lo, cend); position `base` is the new token
+    const bool has_new = hi > base;
+    const int nbat = (cend - lo + BT - 1) / BT;
+    const int last = cend - 1 - lo;                  // last cached token of the split, relative to lo (< 0: none)
+
+    const size_t unit = (size_t)64 * D * ESZ;        // bytes of one (page, layer, kv head) block
+    const unsigned lane_b0 = (unsigned)((MAPC ? 8 * sub : 4 * sub) * ESZ);
+    u32x4 kq[2][U][KR], vq[2][U][KR];
+    auto issue = [&](auto bufc, int j) __attribute__((always_inline)) {
+        constexpr int buf = decltype(bufc)::value;
+        const bool live = j < nbat;
+        const int jj = live ? j : 0;
+        const int pq = (jj * BT) >> 6;
+        const int page = IDENT ? slot * a.pages_per_slot + pbase + pq : ptr[pbase + pq < plast ? pbase + pq : plast];
+        const size_t ub = (((size_t)page * a.n_layers + a.layer) * a.nkv + kvh) * unit;
+        const char* kb = reinterpret_cast<const char*>(pkcache) + ub;
+        const char* vb = reinterpret_cast<const char*>(pvcache) + ub;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            int tl = jj * BT + 16 * u + tg;
+            tl = tl < last ? tl : last;
+            tl = live ? tl : 0;                       // past the end: every lane group asks for the split's first row (one hot line)
+            tl = tl > 0 ? tl : 0;
+            const unsigned off = (unsigned)((tl & 63) * D * ESZ) + lane_b0;
+#pragma unroll
+            for (int r = 0; r < KR; ++r) {
+                const u32x4* kp = reinterpret_cast<const u32x4*>(kb + off + r * PIECE1);
+                const u32x4* vp = reinterpret_cast<const u32x4*>(vb + off + r * PIECE1);
+                kq[buf][u][r] = __builtin_nontemporal_load(kp);   // read once per step and far larger than L2 + MALL: nt (A/B below)
+                vq[buf][u][r] = __builtin_nontemporal_load(vp);
+            }
+        }
+    };
+    auto unpack = [&](const u32x4 (&raw)[KR], float (&f)[EPL]) __attribute__((always_inline)) {
+        if (KVB) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { f[2 * e] = bf_lo(raw[0][e]); f[2 * e + 1] = bf_hi(raw[0][e]); }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { f[e] = __uint_as_float(raw[0][e]); f[4 + e] = __uint_as_float(raw[KR - 1][e]); }
+        }
+    };
+    auto dim_of = [&](int e) __attribute__((always_inline)) -> int { return MAPC ? 8 * sub + e : (e < 4 ? 4 * sub + e : HALF + 4 * sub + (e - 4)); };
+
+    // ---- round 2: the prologue's operands first (vmcnt is in order: their math then runs under the K/V batches), then two batches ----
+    constexpr int NVEC = G + 1;                     // G query heads + the new key
+    const int hl = lane < HALF ? lane : 0;
+    struct VecOps { float x0, x1, v0, v1, n0, n1, cs, sn; };
+    auto load_vec = [&](int v) __attribute__((always_inline)) -> VecOps {
+        const bool is_q = v < G;
+        const float* rowp = pqkv + (size_t)row * a.ld_qkv;
+        const float* src = rowp + (is_q ? (kvh * G + v) * D : (a.nq + kvh) * D);
+        const float* vs = rowp + (a.nq + a.nkv + kvh) * D;
+        VecOps r;
+        float px0[4], px1[4], pv0[4], pv1[4];
+#pragma unroll
+        for (int sb = 0; sb < 4; ++sb) {
+            const size_t so = (size_t)(sb < a.qkv_nslab ? sb : 0) * a.qkv_slab_stride;
+            px0[sb] = src[so + hl]; px1[sb] = src[so + hl + HALF];
+            pv0[sb] = vs[so + hl]; pv1[sb] = vs[so + hl + HALF];
+        }
+        const bool have_ssq = a.ssq_in != nullptr;
+        const int snt = have_ssq ? a.ssq_nt : 1;
+        const float spart = (have_ssq ? a.ssq_in + (size_t)row * a.ssq_nt : src)[lane < snt ? lane : 0];
+        r.x0 = px0[0]; r.x1 = px1[0]; r.v0 = pv0[0]; r.v1 = pv1[0];
+#pragma unroll
+        for (int sb = 1; sb < 4; ++sb)
+            if (sb < a.qkv_nslab) { r.x0 += px0[sb]; r.x1 += px1[sb]; r.v0 += pv0[sb]; r.v1 += pv1[sb]; }
+        const float rsc = ssq_row_scale(spart, snt, a.ssq_K, a.ssq_eps, have_ssq);
+        r.x0 *= rsc; r.x1 *= rsc; r.v0 *= rsc; r.v1 *= rsc;
+        const float* nw = is_q ? a.q_norm : a.k_norm;
+        r.n0 = 1.f; r.n1 = 1.f;
+        if (nw != nullptr) { r.n0 = nw[hl]; r.n1 = nw[hl + HALF]; }
+        r.cs = pcos[(size_t)base * HALF + hl]; r.sn = psin[(size_t)base * HALF + hl];
+        return r;
+    };
+    auto finish_vec = [&](int v, VecOps r) __attribute__((always_inline)) {
+        const bool is_q = v < G;
+        float x0 = lane < HALF ? r.x0 : 0.f, x1 = lane < HALF ? r.x1 : 0.f;
+        const float* nw = is_q ? a.q_norm : a.k_norm;
+        if (nw != nullptr) {
+            const float ss = wave_sum(x0 * x0 + x1 * x1);
+            const float rr = 1.0f / sqrtf(ss / (float)D + a.eps);
+            x0 = r.n0 * (x0 * rr); x1 = r.n1 * (x1 * rr);
+        }
+        if (lane < HALF) {
+            float y0 = x0 * r.cs + (-x1) * r.sn;
+            float y1 = x1 * r.cs + x0 * r.sn;
+            if (is_q) { q_s[v][lane] = y0; q_s[v][lane + HALF] = y1; }
+            else if (has_new) {
+                float v0 = r.v0, v1 = r.v1;
+                if (KVB || a.kv_round) { y0 = bf16_round_f(y0); y1 = bf16_round_f(y1); v0 = bf16_round_f(v0); v1 = bf16_round_f(v1); }
+                knew[lane] = y0; knew[lane + HALF] = y1;
+                vnew[lane] = v0; vnew[lane + HALF] = v1;
+                            const int page = IDENT ? slot * a.pages_per_slot + (base >> 6) : ptr[(base >> 6) < plast ? (base >> 6) : plast];
+                const size_t off = ((((size_t)page * a.n_layers + a.layer) * a.nkv + kvh) * 64 + (base & 63)) * D;
+                if (KVB) {
+                    uint16_t* kc16 = reinterpret_cast<uint16_t*>(a.kcache); uint16_t* vc16 = reinterpret_cast<uint16_t*>(a.vcache);
+                    kc16[off + lane] = (uint16_t)(__float_as_uint(y0) >> 16); kc16[off + lane + HALF] = (uint16_t)(__float_as_uint(y1) >> 16);
+                    vc16[off + lane] = (uint16_t)(__float_as_uint(v0) >> 16); vc16[off + lane + HALF] = (uint16_t)(__float_as_uint(v1) >> 16);
+                } else {
+                    a.kcache[off + lane] = y0; a.kcache[off + lane + HALF] = y1;
+                    a.vcache[off + lane] = v0; a.vcache[off + lane + HALF] = v1;
+                }
+            }
+        }
+    };
+    const VecOps first = load_vec(wave < NVEC ? wave : 0);
+    __builtin_amdgcn_sched_barrier(0);
+    issue(std::integral_constant<int, 0>{}, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (wave < NVEC) finish_vec(wave, first);
+    for (int v = wave + 4; v < NVEC; v += 4) finish_vec(v, load_vec(v));   // G = 4: five vectors over four waves
+    __builtin_amdgcn_sched_barrier(0);
+    issue(std::integral_constant<int, 1>{}, 1);       // behind the prologue: its operands' registers are free again
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+
+    // ---- online softmax over the split, two batches in flight ----
+    float qr[G][EPL], o[G][EPL], mrun[G], lrun[G];
+#pragma unroll
+    for (int h = 0; h < G; ++h) {
+        mrun[h] = -INFINITY; lrun[h] = 0.f;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) { qr[h][e] = q_s[h][dim_of(e)]; o[h][e] = 0.f; }
+    }
+    auto compute = [&](auto bufc, int j) __attribute__((always_inline)) {
+        constexpr int buf = decltype(bufc)::value;
+        float pw[U][G];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bool valid = j * BT + 16 * u + tg <= last;
+            float kf[EPL];
+            unpack(kq[buf][u], kf);
+#pragma unroll
+            for (int h = 0; h < G; ++h) {
+                float sdot = 0.f;
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) sdot = fmaf(qr[h][e], kf[e], sdot);
+                sdot = row_sum16(sdot) * a.scale;
+                pw[u][h] = valid ? sdot : -INFINITY;
+            }
+            __builtin_amdgcn_sched_barrier(0);   // one token's row unpacked at a time: left alone hipcc unpacks the whole batch first and spills
+        }
+#pragma unroll
+        for (int h = 0; h < G; ++h) {
+            float mn = mrun[h];
+#pragma unroll
+            for (int u = 0; u < U; ++u) mn = fmaxf(mn, pw[u][h]);
+            const float mu = mn == -INFINITY ? 0.f : mn;   // a lane group without a valid token yet: exp(-inf - 0) = 0 everywhere, no NaN
+            const float corr = __expf(mrun[h] - mu);
+            float l = lrun[h] * corr;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) o[h][e] *= corr;
+#pragma unroll
+            for (int u = 0; u < U; ++u) { pw[u][h] = __expf(pw[u][h] - mu); l += pw[u][h]; }
+            lrun[h] = l;
+            mrun[h] = mn;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float vf[EPL];
+            unpack(vq[buf][u], vf);        // a clamped token's row is a real row (finite), its weight is 0
+#pragma unroll
+            for (int h = 0; h < G; ++h)
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) o[h][e] = fmaf(pw[u][h], vf[e], o[h][e]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    for (int j = 0; j < nbat; j += 2) {
+        compute(std::integral_constant<int, 0>{}, j);
+        issue(std::integral_constant<int, 0>{}, j + 2);
+        compute(std::integral_constant<int, 1>{}, j + 1);   // past the end: every token invalid, the state does not move
+        issue(std::integral_constant<int, 1>{}, j + 3);
+    }
+    if (has_new && tg == 0) {   // the new token, from LDS
+        float kf[EPL], vf[EPL];
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) { kf[e] = knew[dim_of(e)]; vf[e] = vnew[dim_of(e)]; }
+#pragma unroll
+        for (int h = 0; h < G; ++h) {
+            float s = 0.f;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) s = fmaf(qr[h][e], kf[e], s);
+            s = row_sum16(s) * a.scale;
+            const float mn = fmaxf(mrun[h], s);
+            const float corr = __expf(mrun[h] - mn);
+            const float p1 = __expf(s - mn);
+            lrun[h] = lrun[h] * corr + p1;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) o[h][e] = o[h][e] * corr + p1 * vf[e];
+            mrun[h] = mn;
+        }
+    }
+    // ---- the 16 lane groups meet in LDS ----
+#pragma unroll
+    for (int h = 0; h < G; ++h) {
+        if (sub == 0) { cm[tg][h] = mrun[h]; cl[tg][h] = lrun[h]; }
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) co[tg][h][dim_of(e)] = o[h][e];
+    }
+    __syncthreads();
+    for (int idx = tid; idx < G * D; idx += 256) {
+        const int h = idx / D, e = idx % D;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) mx = fmaxf(mx, cm[g][h]);
+        float L = 0.f, O = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            const float w = cm[g][h] == -INFINITY ? 0.f : expf(cm[g][h] - mx);
+            L += w * cl[g][h];
+            O += w * co[g][h][e];
+        }
+        const int head = kvh * G + h;
+        if (a.po == nullptr) {
+            const float ov = O / L;
+            if (a.out) a.out[(size_t)row * a.ld_out + head * D + e] = ov;
+            if (a.oh) {
+                const uint32_t u = __float_as_uint(ov);
+                const bf16_t hb = (bf16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+                const float rem = ov - __uint_as_float((uint32_t)hb << 16);
+                const uint32_t v = __float_as_uint(rem);
+                a.oh[(size_t)row * a.ldp + head * D + e] = hb;
+                a.ol[(size_t)row * a.ldp + head * D + e] = (bf16_t)((v + 0x7FFFu + ((v >> 16) & 1u)) >> 16);
+            }
+        } else {
+            const size_t pi = ((size_t)row * a.nq + head) * S + split;
+            a.po[pi * D + e] = O;
+            if (e == 0) { a.pm[pi] = mx; a.pl[pi] = L; }
+        }
+    }
+}
+
+// ================================================================================================
 // k_attn_tiny — the code predictor's attention in the batched step: at most 32 cached tokens (one fixed page per slot), 1 or 2 new
 // tokens, position a launch argument.  k_attn spreads one (kv head, row) over 256 threads — 16 lane groups, two block barriers, an LDS
 // merge of 16 partial softmaxes — for a context of 1..17 tokens: 4.7 us in-kernel, 75 launches per step.  Here ONE WAVE owns a
@@ -1028,7 +1317,37 @@ __global__ __launch_bounds__(128) void k_attn_tiny(const float* pqkv, const floa
     KP_MARK(23);
 }
 
+static void launch_attn_stream(const AttnArgs& a, hipStream_t s) {
+    const int grp = a.nq / a.nkv;
+    if (a.d != 128 || a.n_new != 1 || !a.new_from_raw || a.window != 0 || a.slot_map != nullptr || a.nq % a.nkv || !(grp == 1 || grp == 2 || grp == 4))
+        throw Error("attn (stream): one new token per row, head_dim 128, GQA group 1 / 2 / 4, no window, no slot map");
+    if (a.n_splits < 1 || a.n_splits > 65535 || (a.n_splits > 1 && (a.po == nullptr || a.chunk % 64 != 0))) throw Error("attn (stream): splits start on page boundaries and need partial buffers");
+    if (a.page_shift != 6) throw Error("attn (stream): 64-token KV pages");
+    const int span = a.n_splits == 1 ? a.pages_per_slot << 6 : a.chunk;   // tokens one workgroup may walk
+    if (a.kv_bf16 && a.kv_round) throw Error("attn (stream): kv_bf16 and kv_round exclude each other");
+    const dim3 grid(a.nkv, a.n_splits, a.nb);
+#define Q3_AS_ARGS a.page_table, a.pos_dev, a.qkv, (const float*)a.kcache, (const float*)a.vcache, a.rope_cos, a.rope_sin, a.n_splits, span, a
+#define Q3_AS_GO(G_, KVB_, MAPC_, U_, WPE_) do { \
+        if (a.identity_pages) hipLaunchKernelGGL((k_attn_stream<G_, KVB_, MAPC_, true, U_, WPE_>), grid, dim3(256), 0, s, Q3_AS_ARGS); \
+        else hipLaunchKernelGGL((k_attn_stream<G_, KVB_, MAPC_, false, U_, WPE_>), grid, dim3(256), 0, s, Q3_AS_ARGS); } while (0)
+    // Tokens per lane group and batch (U) x waves per SIMD, measured at 64 rows x 1024 tokens (profiles/r04_attn_stream_ab.txt; step time,
+    // KV rate of the attention's share): bf16 cache 4 x 3 (a batch = one 64-token page); fp32 cache 4 x 2 across splits, 2 x 3 for the
+    // one-split launch of short contexts.  Non-temporal loads are worth 0.2-0.3 ms per step (fp32 7.35 -> 7.08 ms, bf16 5.98 -> 5.85);
+    // the bf16 cache's lane mapping on an fp32 cache costs 0.35 ms (used only under Q3TTS_FLAG_KV_ROUND_BF16, the bit-for-bit test aid).
+    const bool one = a.n_splits == 1;
+#define Q3_AS(G_) do { if (a.kv_bf16) Q3_AS_GO(G_, true, true, 4, 3); else if (a.kv_round) Q3_AS_GO(G_, false, true, 2, 3); \
+                       else if (one) Q3_AS_GO(G_, false, false, 2, 3); else Q3_AS_GO(G_, false, false, 4, 2); } while (0)
+    if (grp == 1) Q3_AS(1);
+    else if (grp == 2) Q3_AS(2);
+    else { if (a.kv_bf16) Q3_AS_GO(4, true, true, 2, 2); else if (a.kv_round) Q3_AS_GO(4, false, true, 2, 2); else Q3_AS_GO(4, false, false, 2, 2); }
+#undef Q3_AS
+#undef Q3_AS_GO
+#undef Q3_AS_ARGS
+    Q3_HIP_CHECK(hipGetLastError());
+}
+
 void launch_attn(const AttnArgs& a, hipStream_t s) {
+    if (a.stream) { launch_attn_stream(a, s); return; }
     const int grp = a.nq / a.nkv;
     if (grp < 1 || grp > ATT_MAX_GRP || a.nq % a.nkv) throw Error("attn: unsupported GQA group size");
     if (a.n_new > ATT_MAX_NEW && a.new_from_raw) throw Error("attn: too many new tokens per launch");

@@ -180,6 +180,8 @@ Engine::Engine(const q3tts_config& cfg, int device_, int max_batch, int max_ctx_
     if (const char* sv = getenv("Q3TTS_SEAM")) seam_on = atoi(sv) != 0;
     if (const char* sv = getenv("Q3TTS_SEAM_SPIN")) seam_spin = std::max(1, atoi(sv));
     attn_keep_splits = getenv("Q3TTS_ATTN_KEEP_SPLITS") != nullptr;
+    if (const char* sv = getenv("Q3TTS_ATTN_STREAM")) attn_stream = atoi(sv) != 0;
+    if (const char* sv = getenv("Q3TTS_ATTN_STREAM_ONE")) attn_stream_one = atoi(sv) != 0;
     null_stream = getenv("Q3TTS_NULL_STREAM") && getenv("Q3TTS_NULL_STREAM")[0] == '1';
     if (null_stream) { stream = nullptr; flags |= Q3TTS_FLAG_NO_GRAPH; }
     else if (const char* cm = getenv("Q3TTS_STREAM_CU_MASK")) {   // experiment aid (tools/overlap_probe.py): this engine's stream on a subset of the CUs;
@@ -338,10 +340,16 @@ Engine::Engine(const q3tts_config& cfg, int device_, int max_batch, int max_ctx_
     if (const char* ck = getenv("Q3TTS_ATTN_CHUNK")) talker.chunk = atoi(ck) == 64 ? 64 : 128;
     talker.n_splits = (max_ctx + talker.chunk - 1) / talker.chunk;
     if (talker.n_splits > 64) { talker.n_splits = 64; talker.chunk = ((max_ctx + 63) / 64 + 127) / 128 * 128; }
+    // k_attn_stream (batched step): splits of whole 64-token pages — 128 KB of K/V per split (256 tokens fp32, 512 bf16: measured against
+    // 128 / 256 / 512 / 1024, profiles/r04_attn_stream_ab.txt) unless Q3TTS_ATTN_STREAM_CHUNK says otherwise
+    talker.chunk_stream = talker.kv_bf16 ? 512 : 256;
+    if (const char* ck = getenv("Q3TTS_ATTN_STREAM_CHUNK")) { const int v = atoi(ck); if (v >= 64 && v % 64 == 0) talker.chunk_stream = v; }
+    talker.n_splits_stream = (max_ctx + talker.chunk_stream - 1) / talker.chunk_stream;
     for (DecStack* S : { &talker, &cp }) {
-        S->po = fm((size_t)rows_max * S->nq * S->n_splits * S->d);
-        S->pm = fm((size_t)rows_max * S->nq * S->n_splits);
-        S->pl = fm((size_t)rows_max * S->nq * S->n_splits);
+        const int ns = std::max(S->n_splits, S->n_splits_stream);
+        S->po = fm((size_t)rows_max * S->nq * ns * S->d);
+        S->pm = fm((size_t)rows_max * S->nq * ns);
+        S->pl = fm((size_t)rows_max * S->nq * ns);
     }
     sync();
 }
@@ -556,6 +564,13 @@ bool Engine::run_layers(const DecStack& W, float* x, int ldx, int nb, int n_new,
         if (mfma && W.n_splits > 1 && W.identity_pages && !attn_keep_splits && (size_t)nb * W.nkv >= 256 && (W.pages_per_slot << W.page_shift) <= 512) {
             a.n_splits = 1; a.chunk = 1 << 30;
         }
+        // Long contexts in the batched step: the launch is bound by the KV bytes it streams — k_attn_stream (page-aligned splits walked
+        // through a two-deep register ring, 3-4 workgroups per CU) instead of k_attn's one-batch 128-token splits.
+        const int grp_w = W.nkv > 0 ? W.nq / W.nkv : 0;
+        const bool stream_shape = attn_stream && mfma && n_new == 1 && W.d == 128 && slot_map == nullptr && W.page_shift == 6 && W.n_splits_stream > 0 &&
+                                  W.nq % W.nkv == 0 && (grp_w == 1 || grp_w == 2 || grp_w == 4);
+        if (stream_shape && a.n_splits > 1) { a.stream = 1; a.n_splits = W.n_splits_stream; a.chunk = W.chunk_stream; }
+        else if (stream_shape && attn_stream_one && a.n_splits == 1) a.stream = 1;
         const bool direct_planes = mfma && a.n_splits == 1;     // one split: the attention kernel normalises and writes the planes itself
         if (direct_planes) { a.out = nullptr; a.po = nullptr; a.pm = nullptr; a.pl = nullptr; a.oh = pl1h; a.ol = pl1l; a.ldp = ldp; }
         const bool direct_rows = !mfma && a.n_splits == 1;      // likewise for the GEMV family: normalised fp32 rows, nothing to combine
@@ -1115,6 +1130,36 @@ int Engine::decode_steps(int n_steps) {
     last_decode_steps = n_steps;
     total_decode_ms += last_decode_ms; total_decode_steps += n_steps;
     return *active_h;
+}
+
+// Measurement aid (q3tts_measure_skip_frames): every armed slot is moved n frames ahead WITHOUT generating them — frame counters and
+// positions advance, the skipped frames' codes are zero, and the talker's whole KV cache is refilled with seeded synthetic rows (finite,
+// |x| ~ 0.5), so what the slots decode afterwards is numerically meaningless but the step streams a context of the requested depth.  For
+// profiling the decode step at a long context (rocprofv3 passes that cannot afford 1000 eager steps of warm-up).
+void Engine::measure_skip_frames(int n) {
+    if (!(flags & Q3TTS_FLAG_TEST_HOOKS)) throw Error("measure_skip_frames needs Q3TTS_FLAG_TEST_HOOKS");
+    if (n < 1) throw Error("measure_skip_frames: n must be positive");
+    const int nb = nb_in_use();
+    if (nb == 0) throw Error("measure_skip_frames: no armed slot");
+    sync();
+    std::vector<SlotState> st;
+    slots_state(nb, st);
+    std::vector<int32_t> pos((size_t)nb, 0);
+    Q3_HIP_CHECK(hipMemcpy(pos.data(), talker_pos_d, (size_t)nb * sizeof(int32_t), hipMemcpyDeviceToHost));
+    for (int b = 0; b < nb; ++b) {
+        if (!st[(size_t)b].active || st[(size_t)b].finished) continue;
+        if (st[(size_t)b].n_frames + n >= st[(size_t)b].max_frames || pos[(size_t)b] + n >= max_ctx) throw Error("measure_skip_frames: past the slot's frame cap or max_ctx");
+        kv_reserve(b, pos[(size_t)b] + n + 1, false);
+        st[(size_t)b].n_frames += n; st_h[b].n_frames = st[(size_t)b].n_frames;
+        pos[(size_t)b] += n;
+    }
+    Q3_HIP_CHECK(hipMemcpy(st_d, st.data(), (size_t)nb * sizeof(SlotState), hipMemcpyHostToDevice));
+    Q3_HIP_CHECK(hipMemcpy(talker_pos_d, pos.data(), (size_t)nb * sizeof(int32_t), hipMemcpyHostToDevice));
+    const size_t page_elems = (size_t)talker.L * talker.nkv * ((size_t)1 << talker.page_shift) * talker.d;
+    const int64_t total = (int64_t)((size_t)kv.device_pages() * page_elems);
+    launch_fill_synth(talker.kc, talker.kv_bf16 ? 1 : 0, total, 0x5EEDull, 0.f, 0.5f, stream);
+    launch_fill_synth(talker.vc, talker.kv_bf16 ? 1 : 0, total, 0x5EEEull, 0.f, 0.5f, stream);
+    sync();
 }
 
 void Engine::slots_state(int nb, std::vector<SlotState>& out) {   // one copy for the whole batch (the scheduler polls it between step chunks)

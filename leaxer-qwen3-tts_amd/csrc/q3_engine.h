@@ -49,6 +49,7 @@ struct DecStack {
     float *rope_cos = nullptr, *rope_sin = nullptr;
     bool nt = false; // weights streamed once per step -> non-temporal loads
     int n_splits = 1, chunk = 1 << 30; // split-T attention
+    int n_splits_stream = 0, chunk_stream = 0; // k_attn_stream's splits (batched step, long contexts): whole pages, 256 tokens by default
     float *po = nullptr, *pm = nullptr, *pl = nullptr; // attention partials [rows][nq][n_splits]([d])
 };
 
@@ -125,6 +126,7 @@ public:
     int64_t slot_codec_decode(int slot, float* pcm, int64_t cap);
     void slot_release(int slot);
     void step_bytes(double* wbytes, double* kvbytes);
+    void measure_skip_frames(int n);                    // measurement aid: armed slots jump n frames ahead over a synthetic KV cache
     void stage_profile(int n_steps, double* out_ms4);   // eager steps with events at the stage boundaries (diagnostic)
     // one EAGER step of the armed slots that also keeps, for slot `slot`, the logits row every one of the frame's n_groups decisions was
     // sampled from (out: [n_groups][cols], cols >= max(vocab, sub_vocab)); the slots advance like decode_steps(1)
@@ -203,6 +205,8 @@ public:
     float *ssq_a_d = nullptr, *ssq_b_d = nullptr;
     bool seam_step = false;      // inside record_step: run_layers may fold the finish launches into the GEMMs
     bool seam_on = true;         // Q3TTS_SEAM=0 at engine creation keeps the finish launches (the A/B knob and the tests' second path)
+    bool attn_stream = true;         // Q3TTS_ATTN_STREAM=0 at engine creation: the batched step's long-context attention stays on k_attn (A/B knob, tests' second path)
+    bool attn_stream_one = true;     // Q3TTS_ATTN_STREAM_ONE=0: the one-split case (contexts <= 512 at >= 256 (row, kv head) pairs) back on k_attn (A/B knob): b=64 x 256 frames 4.67 -> 4.59 ms per step with it
     bool attn_keep_splits = false;   // Q3TTS_ATTN_KEEP_SPLITS at engine creation: the batched step keeps split-T attention + the combine launch (A/B knob, tests' second path)
     int seam_spin = 4096;        // Q3TTS_SEAM_SPIN: polls before an owner abandons its chunk (1 forces the rescue path in the tests)
     int32_t* codes_d = nullptr;

@@ -83,7 +83,7 @@ EXPORTS = [
     "q3tts_sample_host", "q3tts_rng_uniform", "q3tts_build_prompt_host", "q3tts_slot_begin", "q3tts_decode_steps",
     "q3tts_slot_status", "q3tts_slot_codes_host", "q3tts_slot_codec_decode_host", "q3tts_slot_release",
     "q3tts_synthesize_batch_host", "q3tts_last_decode_ms", "q3tts_last_codec_ms", "q3tts_decode_step_bytes",
-    "q3tts_codec_decode_dev", "q3tts_stream", "q3tts_counters", "q3tts_stage_profile", "q3tts_codec_plane_stats", "q3tts_config_num_tensors", "q3tts_config_tensor_info", "q3tts_read_weights_config", "q3tts_load_weights_file", "q3tts_save_weights_file",
+    "q3tts_codec_decode_dev", "q3tts_stream", "q3tts_counters", "q3tts_stage_profile", "q3tts_codec_plane_stats", "q3tts_measure_skip_frames", "q3tts_config_num_tensors", "q3tts_config_tensor_info", "q3tts_read_weights_config", "q3tts_load_weights_file", "q3tts_save_weights_file",
     "q3tts_tokenizer_create", "q3tts_tokenizer_destroy", "q3tts_tokenizer_load_vocab", "q3tts_tokenizer_load_merges",
     "q3tts_tokenizer_ready", "q3tts_tokenize",
     "q3tts_synthesize_clone_batch_host", "q3tts_synthesize_schedule_host", "q3tts_read_wav_host", "q3tts_resample_host", "q3tts_mel_host",
@@ -508,6 +508,11 @@ class Engine:
         self.L.q3tts_stream.restype = C.c_void_p
         self.L.q3tts_stream.argtypes = [C.c_void_p]
         return self.L.q3tts_stream(self.h)
+
+    def measure_skip_frames(self, n):
+        """measurement aid (FLAG_TEST_HOOKS engines): armed slots jump n frames ahead over a synthetic KV cache (q3tts_measure_skip_frames)"""
+        self.L.q3tts_measure_skip_frames.argtypes = [C.c_void_p, C.c_int]
+        self._ck(self.L.q3tts_measure_skip_frames(self.h, int(n)))
 
     def codec_plane_stats(self):
         """(two_product, three_product): codec weight tensors whose fp16 lo plane is empty / needed (q3tts_codec_plane_stats)"""

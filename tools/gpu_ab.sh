@@ -5,6 +5,7 @@ set -e
 #         b64 [ENV=1 ...]    bench.py --batch 64 --frames 256 with the given environment knobs set
 #         b1  [ENV=1 ...]    bench.py --batch 1  --frames 512
 #         codec [ENV=1 ...]  tools/codec_bench.py at F = 2048 / 256 / 64
+#         ctx [ENV=1 ...]    tools/ctx_bench.py (decode step at CTX tokens of context, both KV dtypes, per-stage split)
 #         default            the default bench line
 # Every mode appends its result lines to gpurun_out/<tag>/ab.txt; each GPU step runs under its own `timeout -k`.
 TAG=$1; MODE=$2; shift 2 || true
@@ -29,6 +30,12 @@ codec)
   for F in 2048 256 64; do
     echo -n "codec [$KNOBS] " | tee -a $O/ab.txt
     env $KNOBS timeout -k 10 200 python tools/codec_bench.py --frames $F --reps 5 | tee -a $O/ab.txt
+  done ;;
+ctx)
+  # decode step at a long talker context (tools/ctx_bench.py): CTX / BATCH / KVS from the environment, knobs as arguments
+  for KV in ${KVS:-fp32 bf16}; do
+    echo -n "ctx [$KNOBS] " | tee -a $O/ab.txt
+    env $KNOBS timeout -k 10 300 python tools/ctx_bench.py --batch ${BATCH:-64} --ctx ${CTX:-1024} --kv $KV --stages --max-ctx ${MAXCTX:-2112} | tee -a $O/ab.txt
   done ;;
 default)
   timeout -k 10 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err

@@ -6,9 +6,11 @@
 int main(int argc, char** argv) {
     const int steps = argc > 1 ? atoi(argv[1]) : 4;
     const int batch = argc > 2 ? atoi(argv[2]) : 1;   // armed slots: 1 = configs[1], 64 = configs[2]
+    const int ctx = argc > 3 ? atoi(argv[3]) : 0;     // > 0: the slots are moved to this talker context first (q3tts_measure_skip_frames)
+    const int bf16 = argc > 4 ? atoi(argv[4]) : 0;    // 1: Q3TTS_FLAG_KV_BF16
     q3tts_config c; q3tts_default_config("0.6b", &c);
     fprintf(stderr, "[1] create\n");
-    q3tts_engine* e = q3tts_create(&c, 0, batch, steps + 64, 0);
+    q3tts_engine* e = q3tts_create(&c, 0, batch, ctx + steps + 64, (ctx > 0 ? Q3TTS_FLAG_TEST_HOOKS : 0u) | (bf16 ? Q3TTS_FLAG_KV_BF16 : 0u));
     if (!e) { fprintf(stderr, "create failed: %s\n", q3tts_last_error(nullptr)); return 1; }
     fprintf(stderr, "[2] fill\n");
     q3tts_fill_synthetic(e, 0);
@@ -23,14 +25,21 @@ int main(int argc, char** argv) {
     fprintf(stderr, "[6] decode\n");
     q3tts_talker_decode_host(e, 0, x.data(), lg.data(), lh.data());
     fprintf(stderr, "[7] slot_begin\n");
-    q3tts_sampling sp{0.8f, 0.95f, 50, 1.0f, steps};
+    q3tts_sampling sp{0.8f, 0.95f, 50, 1.0f, ctx + steps + 8};
     std::vector<float> tr(4 * 1024, 0.01f);
     for (int b = 0; b < batch; ++b) q3tts_slot_begin(e, b, x.data(), 8, tr.data(), 4, &sp, 1, (uint32_t)b, 1);
+    if (ctx > 8) {
+        fprintf(stderr, "[7b] skip to context %d\n", ctx);
+        if (q3tts_measure_skip_frames(e, ctx - 8) != 0) { fprintf(stderr, "skip failed: %s\n", q3tts_last_error(e)); return 1; }
+    }
     fprintf(stderr, "[8] decode_steps\n");
     int act = q3tts_decode_steps(e, steps);
     fprintf(stderr, "[9] active=%d codec\n", act);
-    std::vector<float> pcm((size_t)(steps + 8) * 1920); int64_t n = 0;
-    q3tts_slot_codec_decode_host(e, 0, pcm.data(), (int64_t)pcm.size(), &n);
+    int64_t n = 0;
+    if (ctx == 0) {   // the long-context passes count the decode step only
+        std::vector<float> pcm((size_t)(steps + 8) * 1920);
+        q3tts_slot_codec_decode_host(e, 0, pcm.data(), (int64_t)pcm.size(), &n);
+    }
     fprintf(stderr, "[10] done n=%lld\n", (long long)n);
     q3tts_destroy(e);
     return 0;

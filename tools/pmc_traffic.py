@@ -43,6 +43,8 @@ def src_digest():
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, required=True)
+ap.add_argument("--ctx", type=int, default=0, help="talker context the passes were taken at (0: the first steps after the prompt, context ~10-20)")
+ap.add_argument("--kv", choices=["fp32", "bf16"], default="fp32")
 ap.add_argument("--fetch", required=True)
 ap.add_argument("--write", required=True)
 ap.add_argument("--frames", type=int, required=True)
@@ -64,7 +66,7 @@ else:
     method = f"one {a.frames}-step run, includes the one prefill"
 rd = sum(fetch.values()) * 1024 * 2
 wr = sum(write.values()) * 1024
-out = {"batch": a.batch, "steps_counted": n, "read_bytes_per_step": rd / n, "write_bytes_per_step": wr / n, "hbm_bytes_per_step": (rd + wr) / n,
+out = {"batch": a.batch, "ctx": a.ctx, "kv": a.kv, "steps_counted": n, "read_bytes_per_step": rd / n, "write_bytes_per_step": wr / n, "hbm_bytes_per_step": (rd + wr) / n,
        "method": method + "; decode-step kernels only; FETCH_SIZE doubled per the gfx950 correction",
        "src_digest": src_digest(),
        "by_kernel_read_MB_per_step": {k: round(v * 2048 / n / 1e6, 2) for k, v in sorted(fetch.items(), key=lambda kv: -kv[1])[:10]}}
@@ -79,6 +81,8 @@ if a.merge_into:
     if j.get("src_digest") != out["src_digest"]:
         j = {}                       # figures of another build are not carried over
     j["src_digest"] = out["src_digest"]
-    j[f"b{a.batch}"] = int(out["hbm_bytes_per_step"])
-    j[f"b{a.batch}_detail"] = {"read": int(out["read_bytes_per_step"]), "write": int(out["write_bytes_per_step"]), "method": out["method"]}
+    # keyed by (batch, context, kv dtype): "b64" = the short-context fp32 figure of earlier rounds, "b64_ctx1024_bf16" a long-context one
+    key = f"b{a.batch}" + (f"_ctx{a.ctx}" if a.ctx > 0 else "") + ("_bf16" if a.kv == "bf16" else "")
+    j[key] = int(out["hbm_bytes_per_step"])
+    j[key + "_detail"] = {"read": int(out["read_bytes_per_step"]), "write": int(out["write_bytes_per_step"]), "ctx": a.ctx, "kv": a.kv, "method": out["method"]}
     json.dump(j, open(a.merge_into, "w"), indent=1)
