@@ -143,6 +143,28 @@ int q3tts_codec_decode_chunked_host(q3tts_engine* e, const int64_t* codes, int F
 /* the same for frames of a slot that is still generating: call after q3tts_decode_steps has produced frame_end frames */
 int q3tts_slot_codec_decode_range_host(q3tts_engine* e, int slot, int frame_begin, int frame_end, int left_context, float* pcm, int64_t cap,
                                        int64_t* out_len);
+/* ---- the same sessions, batch-first, on DEVICE pointers ----
+ * For a host application that keeps embeddings, logits and ids in HBM: no PCIe round trip per call.  Row b of a call is slot b of the
+ * engine (batch <= max_batch).  Tensors (float / id buffers) are device pointers on the engine's GPU, any allocator; control arrays
+ * (`lens`, `active_mask`) are host pointers.  `stream` is the caller's hipStream_t (NULL: the engine's own stream, q3tts_stream): the
+ * engine's stream first waits for everything the caller has enqueued on it, and the caller's stream is made to wait for the call's
+ * work — the call is ordered inside the caller's stream like a kernel launch.  The calls that track positions on the host
+ * (prefill / decode / code_predictor) return after their launches have completed; q3tts_sample_dev returns at once.
+ * Per-slot state is shared with the "_host" entry points and the fused generation (positions, KV cache, the armed logits row). */
+/* run_prefill, tts_onnx.cpp:615-665: embeds[batch][S][hidden] (row block b: lens[b] <= S <= 16 rows; lens NULL = S for all) ->
+ * logits_last[batch][vocab] (the last prompt row's, all the reference consumes, :797-798), last_hidden[batch][hidden]; either may be NULL.
+ * Consecutive slots with equal lengths share one pass through the layers; a slot on its own takes q3tts_talker_prefill_host's launches. */
+int q3tts_talker_prefill_dev(q3tts_engine* e, const float* embeds, int batch, int S, const int32_t* lens, float* logits_last, float* last_hidden, void* stream);
+/* run_decode, tts_onnx.cpp:667-732: embeds[batch][hidden] -> logits[batch][vocab], last_hidden[batch][hidden]; one token appended to every
+ * slot whose active_mask[b] != 0 (NULL: all).  Masked rows keep the batch's shape and leave outputs, position and slot state untouched. */
+int q3tts_talker_decode_dev(q3tts_engine* e, const float* embeds, int batch, const uint8_t* active_mask, float* logits, float* last_hidden, void* stream);
+/* predict_subcodes, tts_onnx.cpp:851-872, fused: last_hidden[batch][hidden] + code0[batch] (int64, as the reference holds ids) ->
+ * sub[batch][n_groups - 1] int32: 15 KV-cached run_code_predictor passes (:734-757) with sample_token (:878-950) on device; row b draws
+ * sub-code j with q3tts_rng_uniform(seed, stream_id0 + b, frame, j + 1), the fused generation loop's draw for that utterance and frame. */
+int q3tts_code_predictor_dev(q3tts_engine* e, const float* last_hidden, const int64_t* code0, int batch, const q3tts_sampling* p, uint64_t seed,
+                             uint32_t stream_id0, uint32_t frame, int32_t* sub, void* stream);
+/* sample_token, tts_onnx.cpp:878-950, for a batch: logits[batch][n], u[batch] (uniforms in [0,1), one per row) -> ids[batch] int64 */
+int q3tts_sample_dev(q3tts_engine* e, const float* logits, int batch, int n, const q3tts_sampling* p, const float* u, int suppress, int64_t* ids, void* stream);
 /* sample_token, tts_onnx.cpp:878-905, on device; u in [0,1) replaces the mt19937 draw.
  * suppress != 0 applies the special-token suppression of tts_onnx.cpp:803-807 first. */
 int q3tts_sample_host(q3tts_engine* e, const float* logits, int n, const q3tts_sampling* p, float u, int suppress, int64_t* token);

@@ -578,6 +578,30 @@ int q3tts_stage_profile(q3tts_engine* h, int n_steps, double* out_ms) {
     return 0;
     Q3_API_END(h)
 }
+// ---- batch-first device-pointer entry points ----
+#define Q3_DEV_CALL(h, strm, body)                                       \
+    Q3_API_BEGIN(h)                                                      \
+    hipStream_t caller_ = (strm) ? (hipStream_t)(strm) : (h)->e->stream; \
+    (h)->e->stream_join(caller_);                                        \
+    body;                                                                \
+    (h)->e->stream_fork(caller_);                                        \
+    return 0;                                                            \
+    Q3_API_END(h)
+int q3tts_talker_prefill_dev(q3tts_engine* h, const float* embeds, int batch, int S, const int32_t* lens, float* logits_last, float* last_hidden, void* stream) {
+    Q3_DEV_CALL(h, stream, h->e->talker_prefill_dev(embeds, batch, S, lens, logits_last, last_hidden))
+}
+int q3tts_talker_decode_dev(q3tts_engine* h, const float* embeds, int batch, const uint8_t* active_mask, float* logits, float* last_hidden, void* stream) {
+    Q3_DEV_CALL(h, stream, h->e->talker_decode_dev(embeds, batch, active_mask, logits, last_hidden))
+}
+int q3tts_code_predictor_dev(q3tts_engine* h, const float* last_hidden, const int64_t* code0, int batch, const q3tts_sampling* p, uint64_t seed,
+                             uint32_t stream_id0, uint32_t frame, int32_t* sub, void* stream) {
+    if (!p) return -1;
+    Q3_DEV_CALL(h, stream, h->e->code_predictor_dev(last_hidden, code0, batch, *p, seed, stream_id0, frame, sub))
+}
+int q3tts_sample_dev(q3tts_engine* h, const float* logits, int batch, int n, const q3tts_sampling* p, const float* u, int suppress, int64_t* ids, void* stream) {
+    if (!p) return -1;
+    Q3_DEV_CALL(h, stream, h->e->sample_dev(logits, batch, n, *p, u, suppress, ids))
+}
 int q3tts_measure_skip_frames(q3tts_engine* h, int n_frames) {
     Q3_API_BEGIN(h)
     h->e->measure_skip_frames(n_frames);

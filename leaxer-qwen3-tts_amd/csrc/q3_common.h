@@ -195,6 +195,7 @@ struct SampleArgs {
     float temperature = 1.f, top_p = 1.f;
     int top_k = 0;
     float u = 0.f;
+    const float* u_dev = nullptr;   // standalone mode, optional: row b draws with u_dev[b] instead of u (q3tts_sample_dev)
     int suppress = 0;
     int64_t* token_out = nullptr;
     // fused epilogue (generation mode)
@@ -226,6 +227,9 @@ void launch_sample(const SampleArgs& a, hipStream_t s);
 void launch_gather_rows_bf16(const bf16_t* table, int H, const int64_t* ids_dev, int n, float* out, int ldo, hipStream_t s);
 void launch_fill_synth(void* dst, int is_bf16, int64_t n, uint64_t key, float mean, float stddev, hipStream_t s);
 void launch_copy_rows(const float* src, int lds, float* dst, int ldd, int rows, int cols, hipStream_t s);
+// rows whose flag is 0 are skipped (flags: device ints, one per row)
+void launch_copy_rows_masked(const float* src, int lds, float* dst, int ldd, int rows, int cols, const int* flags_dev, hipStream_t s);
+void launch_bump_u32(unsigned* counter, hipStream_t s);   // *counter += 1 (the split-K seam's step generation outside the fused step)
 void launch_count_active(const SlotState* st, int nb, int32_t* out, hipStream_t s);
 
 // ------------------------------------------------------------------------------------------------

@@ -15,6 +15,7 @@
 // explicit fmaf.
 #include "q3_common.h"
 #include "q3_wave_sort.h"
+#include <algorithm>
 
 namespace q3 {
 
@@ -1407,7 +1408,9 @@ __global__ __launch_bounds__(256) void k_attn_combine(AttnArgs a) {
     const int pos = (a.pos_dev ? a.pos_dev[a.slot_offset + bi] : a.pos_scalar) + inew;
     int nact = pos / a.chunk + 1;
     if (nact > a.n_splits) nact = a.n_splits;
-    for (int idx = threadIdx.x; idx < a.nq * a.d; idx += 256) {
+    // columns over blockIdx.y as well: one row's 2048 columns x S splits on ONE workgroup were 8 dependent load rounds (9.8 us per launch at
+    // 64 rows x 9 splits, 0.28 ms per step)
+    for (int idx = blockIdx.y * 256 + threadIdx.x; idx < a.nq * a.d; idx += 256 * gridDim.y) {
         const int head = idx / a.d, e = idx % a.d;
         const size_t pi = ((size_t)row * a.nq + head) * a.n_splits;
         // online merge in branch-free batches of 4 splits (clamped addresses, zero weight past nact)
@@ -1444,7 +1447,8 @@ __global__ __launch_bounds__(256) void k_attn_combine(AttnArgs a) {
     }
 }
 void launch_attn_combine(const AttnArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(k_attn_combine, dim3(a.nb * a.n_new), dim3(256), 0, s, a);
+    const int cols = a.nq * a.d, gy = std::max(1, std::min(8, cols / 256));
+    hipLaunchKernelGGL(k_attn_combine, dim3(a.nb * a.n_new, gy), dim3(256), 0, s, a);
 }
 
 // ================================================================================================
@@ -1917,7 +1921,7 @@ __global__ __launch_bounds__(256) void k_sample(const float* plogits, SlotState*
     SP_MARK(0);
     if (a.step_gen != nullptr && b == 0 && tid == 0) *a.step_gen += 1u;   // first launch of a step: the generation its seam flags will carry
     // ---- round trip 1: slot state (one 64-byte struct) and this wave's logits slices, all in flight ----
-    float temperature = a.temperature, top_p = a.top_p, u = a.u;
+    float temperature = a.temperature, top_p = a.top_p, u = a.u_dev ? a.u_dev[b] : a.u;
     int top_k = a.top_k, suppress = a.suppress, keep_eos = 1;
     int frame = 0;
     SlotState* st = pst ? pst + b : nullptr;
@@ -2323,6 +2327,17 @@ __global__ void k_copy_rows(const float* src, int lds, float* dst, int ldd, int 
 void launch_copy_rows(const float* src, int lds, float* dst, int ldd, int rows, int cols, hipStream_t s) {
     if (rows > 0) hipLaunchKernelGGL(k_copy_rows, dim3(rows), dim3(256), 0, s, src, lds, dst, ldd, cols);
 }
+
+__global__ void k_copy_rows_masked(const float* src, int lds, float* dst, int ldd, int cols, const int* flags) {
+    const int r = blockIdx.x;
+    if (flags[r] == 0) return;
+    for (int c = threadIdx.x; c < cols; c += blockDim.x) dst[(size_t)r * ldd + c] = src[(size_t)r * lds + c];
+}
+void launch_copy_rows_masked(const float* src, int lds, float* dst, int ldd, int rows, int cols, const int* flags_dev, hipStream_t s) {
+    if (rows > 0) hipLaunchKernelGGL(k_copy_rows_masked, dim3(rows), dim3(256), 0, s, src, lds, dst, ldd, cols, flags_dev);
+}
+__global__ void k_bump_u32(unsigned* p) { *p += 1u; }
+void launch_bump_u32(unsigned* counter, hipStream_t s) { hipLaunchKernelGGL(k_bump_u32, dim3(1), dim3(1), 0, s, counter); }
 
 __global__ void k_count_active(const SlotState* st, int nb, int32_t* out) {
     int n = 0;

@@ -366,6 +366,8 @@ Engine::~Engine() {
     if (active_h) (void)hipHostFree(active_h);
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
+    if (ev_join) (void)hipEventDestroy(ev_join);
+    if (ev_fork) (void)hipEventDestroy(ev_fork);
     if (stream && !null_stream) (void)hipStreamDestroy(stream);
 }
 
@@ -727,13 +729,10 @@ void Engine::cp_embed(int64_t id, int step, float* out) {
     sync();
 }
 
-void Engine::talker_prefill(int slot, const float* embeds, int S, float* logits, float* last_hidden) {
-    if (!finalized) throw Error("weights not finalized");
-    if (slot < 0 || slot >= B) throw Error("slot out of range");
-    if (S < 1 || S > 16) throw Error("prefill length must be 1..16 rows");
+// run_prefill's device work for one slot whose S prompt rows sit in xp: layers, final norm + codec head on every row (logits_p [S][V],
+// normalised rows hn [S][H]), the fused path armed with the last row, position = S.  Shared by the host and the device-pointer entry.
+void Engine::prefill_rows_in_xp(int slot, int S) {
     const int H = c.hidden, V = c.vocab;
-    kv_reserve(slot, S, false);
-    Q3_HIP_CHECK(hipMemcpyAsync(xp, embeds, (size_t)S * H * sizeof(float), hipMemcpyHostToDevice, stream));
     const bool pr = run_layers(talker, xp, H, 1, S, slot, nullptr, 0, talker_norm, c.rms_eps, hn, H);
     // final norm + codec head on every row; normalised rows kept for last_hidden
     head_proj(codec_head, xp, H, talker_norm, c.rms_eps, hn, H, logits_p, V, S, V, H, true, pr);
@@ -744,6 +743,16 @@ void Engine::talker_prefill(int slot, const float* embeds, int S, float* logits,
     st_h[slot].n_frames = 0;
     int32_t pos = S;
     Q3_HIP_CHECK(hipMemcpyAsync(talker_pos_d + slot, &pos, sizeof(int32_t), hipMemcpyHostToDevice, stream));
+}
+
+void Engine::talker_prefill(int slot, const float* embeds, int S, float* logits, float* last_hidden) {
+    if (!finalized) throw Error("weights not finalized");
+    if (slot < 0 || slot >= B) throw Error("slot out of range");
+    if (S < 1 || S > 16) throw Error("prefill length must be 1..16 rows");
+    const int H = c.hidden, V = c.vocab;
+    kv_reserve(slot, S, false);
+    Q3_HIP_CHECK(hipMemcpyAsync(xp, embeds, (size_t)S * H * sizeof(float), hipMemcpyHostToDevice, stream));
+    prefill_rows_in_xp(slot, S);
     if (logits) Q3_HIP_CHECK(hipMemcpyAsync(logits, logits_p, (size_t)S * V * sizeof(float), hipMemcpyDeviceToHost, stream));
     if (last_hidden) Q3_HIP_CHECK(hipMemcpyAsync(last_hidden, hn + (size_t)(S - 1) * H, (size_t)H * sizeof(float), hipMemcpyDeviceToHost, stream));
     sync();
@@ -770,6 +779,168 @@ void Engine::talker_decode(int slot, const float* embed, float* logits, float* l
     if (logits) Q3_HIP_CHECK(hipMemcpyAsync(logits, logits_p, (size_t)V * sizeof(float), hipMemcpyDeviceToHost, stream));
     if (last_hidden) Q3_HIP_CHECK(hipMemcpyAsync(last_hidden, hn, (size_t)H * sizeof(float), hipMemcpyDeviceToHost, stream));
     sync();
+}
+
+// ------------------------------------------------------------------------------------------------
+// batch-first session ops on device pointers: row b of a call is slot b of the engine
+// ------------------------------------------------------------------------------------------------
+void Engine::stream_join(hipStream_t caller) {
+    if (caller == stream) return;
+    if (!ev_join) { Q3_HIP_CHECK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming)); Q3_HIP_CHECK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming)); }
+    Q3_HIP_CHECK(hipEventRecord(ev_join, caller));
+    Q3_HIP_CHECK(hipStreamWaitEvent(stream, ev_join, 0));
+}
+void Engine::stream_fork(hipStream_t caller) {
+    if (caller == stream) return;
+    if (!ev_fork) { Q3_HIP_CHECK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming)); Q3_HIP_CHECK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming)); }
+    Q3_HIP_CHECK(hipEventRecord(ev_fork, stream));
+    Q3_HIP_CHECK(hipStreamWaitEvent(caller, ev_fork, 0));
+}
+void Engine::dev_scratch(int nb) {
+    if (nb < 1 || nb > B) throw Error("batch must be 1..max_batch (row b of a device-pointer call is slot b)");
+    if (dev_logits_d) return;
+    dev_logits_d = (float*)dmalloc((size_t)B * c.vocab * sizeof(float));
+    dev_flags_d = (int*)dmalloc((size_t)B * sizeof(int));
+    dev_pos_d = (int32_t*)dmalloc((size_t)B * sizeof(int32_t));
+    dev_pos_dummy_d = (int32_t*)dmalloc((size_t)B * sizeof(int32_t));
+    dev_st_d = (SlotState*)dmalloc((size_t)B * sizeof(SlotState));
+    dev_codes_d = (int32_t*)dmalloc((size_t)B * c.n_groups * sizeof(int32_t));
+}
+
+// run_prefill (tts_onnx.cpp:615-665) for nb slots at once, rows in HBM: embeds [nb][S][H] (row block b holds lens[b] <= S prompt rows,
+// lens == null: S for all) -> logits_last [nb][V] (the last prompt row's logits, all the reference consumes, :797-798) and
+// last_hidden [nb][H].  Each slot's KV cache restarts at its prompt.  Consecutive slots with equal lengths share one pass through the
+// layers (the scheduler's batched prefill, 128-row MFMA groups); a slot on its own takes exactly q3tts_talker_prefill_host's launches.
+void Engine::talker_prefill_dev(const float* embeds, int nb, int S, const int32_t* lens, float* logits_last, float* last_hidden) {
+    if (!finalized) throw Error("weights not finalized");
+    dev_scratch(nb);
+    if (S < 1 || S > 16) throw Error("prefill length must be 1..16 rows");
+    if (!embeds) throw Error("talker_prefill_dev: null input");
+    const int H = c.hidden, V = c.vocab;
+    for (int b = 0; b < nb; ++b) if (lens && (lens[b] < 1 || lens[b] > S)) throw Error("talker_prefill_dev: lens[b] must be 1..S");
+    auto len_of = [&](int b) { return lens ? (int)lens[b] : S; };
+    const bool mfma_ok = H % 128 == 0 && (c.n_heads * c.head_dim) % 128 == 0 && c.ffn % 128 == 0 && H <= 4096;   // run_layers' MFMA condition
+    std::vector<int32_t> pos_h;
+    int b0 = 0;
+    while (b0 < nb) {
+        const int L = len_of(b0), cap = mfma_ok ? std::max(1, std::min(std::min(rows_max, 128) / L, 128)) : 1;
+        int g = 1;
+        while (b0 + g < nb && g < cap && len_of(b0 + g) == L) ++g;
+        for (int k = 0; k < g; ++k) kv_reserve(b0 + k, L, false);
+        if (g == 1 || g * L < mfma_min_rows) {
+            for (int k = 0; k < g; ++k) {
+                const int slot = b0 + k;
+                Q3_HIP_CHECK(hipMemcpyAsync(xp, embeds + (size_t)slot * S * H, (size_t)L * H * sizeof(float), hipMemcpyDeviceToDevice, stream));
+                prefill_rows_in_xp(slot, L);
+                if (logits_last) launch_copy_rows(logits_p + (size_t)(L - 1) * V, V, logits_last + (size_t)slot * V, V, 1, V, stream);
+                if (last_hidden) launch_copy_rows(hn + (size_t)(L - 1) * H, H, last_hidden + (size_t)slot * H, H, 1, H, stream);
+            }
+        } else {
+            for (int k = 0; k < g; ++k)
+                Q3_HIP_CHECK(hipMemcpyAsync(xp + (size_t)k * L * H, embeds + (size_t)(b0 + k) * S * H, (size_t)L * H * sizeof(float), hipMemcpyDeviceToDevice, stream));
+            const bool pr = run_layers(talker, xp, H, g, L, b0, nullptr, 0, talker_norm, c.rms_eps, hn, H);
+            if (!pr) throw Error("batched prefill expects the MFMA path");
+            head_proj(codec_head, xp, H, talker_norm, c.rms_eps, nullptr, 0, logits_t + (size_t)b0 * V, V, g, V, H, true, true, L - 1, L);
+            launch_copy_rows(hn + (size_t)(L - 1) * H, L * H, x_cp + (size_t)b0 * 2 * H, 2 * H, g, H, stream);
+            if (logits_last) launch_copy_rows(logits_t + (size_t)b0 * V, V, logits_last + (size_t)b0 * V, V, g, V, stream);
+            if (last_hidden) launch_copy_rows(hn + (size_t)(L - 1) * H, L * H, last_hidden + (size_t)b0 * H, H, g, H, stream);
+            pos_h.assign((size_t)g, L);
+            Q3_HIP_CHECK(hipMemcpyAsync(talker_pos_d + b0, pos_h.data(), (size_t)g * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+            for (int k = 0; k < g; ++k) { st_h[b0 + k].prompt_len = L; st_h[b0 + k].n_frames = 0; }
+            sync();   // pos_h is reused by the next group
+        }
+        b0 += g;
+    }
+}
+
+// run_decode (tts_onnx.cpp:667-732) for nb slots in one pass: embeds [nb][H] -> logits [nb][V], last_hidden [nb][H]; every active row's
+// token is appended to its slot's cache and the slot's position advances.  Rows with active[b] == 0 are carried through the launches
+// (the batch keeps its shape) but leave no trace: outputs, cache contents that matter, position and the fused path's state of that slot
+// are untouched.  The same launches as the fused step's talker stage at nb rows (GEMV family / k_gemv16 / MFMA slab GEMMs by row count).
+void Engine::talker_decode_dev(const float* embeds, int nb, const uint8_t* active, float* logits, float* last_hidden) {
+    if (!finalized) throw Error("weights not finalized");
+    dev_scratch(nb);
+    if (!embeds) throw Error("talker_decode_dev: null input");
+    const int H = c.hidden, V = c.vocab;
+    std::vector<int32_t> pos((size_t)nb), run((size_t)nb), flag((size_t)nb);
+    Q3_HIP_CHECK(hipMemcpyAsync(pos.data(), talker_pos_d, (size_t)nb * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+    sync();
+    for (int b = 0; b < nb; ++b) {
+        const bool on = !active || active[b] != 0;
+        flag[(size_t)b] = on ? 1 : 0;
+        if (on) {
+            if (pos[(size_t)b] >= max_ctx) throw Error("KV cache full");
+            kv_reserve(b, pos[(size_t)b] + 1, false);
+        }
+        // a masked row still writes one K / V row: at its own next position (overwritten by its next real token), or — full slot — over its last
+        run[(size_t)b] = std::min(pos[(size_t)b], max_ctx - 1);
+    }
+    Q3_HIP_CHECK(hipMemcpyAsync(dev_pos_d, run.data(), (size_t)nb * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+    Q3_HIP_CHECK(hipMemcpyAsync(dev_flags_d, flag.data(), (size_t)nb * sizeof(int), hipMemcpyHostToDevice, stream));
+    Q3_HIP_CHECK(hipMemcpyAsync(x_talk, embeds, (size_t)nb * H * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    const bool pr = run_layers(talker, x_talk, H, nb, 1, 0, dev_pos_d, 0, talker_norm, c.rms_eps, hn, H);
+    head_proj(codec_head, x_talk, H, talker_norm, c.rms_eps, hn, H, dev_logits_d, V, nb, V, H, true, pr);
+    // active rows: into the fused path's state (as q3tts_talker_decode_host leaves it) and into the caller's buffers
+    launch_copy_rows_masked(dev_logits_d, V, logits_t, V, nb, V, dev_flags_d, stream);
+    launch_copy_rows_masked(hn, H, x_cp, 2 * H, nb, H, dev_flags_d, stream);
+    if (logits) launch_copy_rows_masked(dev_logits_d, V, logits, V, nb, V, dev_flags_d, stream);
+    if (last_hidden) launch_copy_rows_masked(hn, H, last_hidden, H, nb, H, dev_flags_d, stream);
+    for (int b = 0; b < nb; ++b) pos[(size_t)b] += flag[(size_t)b];
+    Q3_HIP_CHECK(hipMemcpyAsync(talker_pos_d, pos.data(), (size_t)nb * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+    sync();   // the host arrays above are read by the copies
+}
+
+// predict_subcodes (tts_onnx.cpp:851-872) for nb utterances, fused: last_hidden [nb][H] (run_decode's output) and code0 [nb] (int64 ids, as the
+// reference holds them) -> sub [nb][n_groups - 1] int32.  15 KV-cached predictor passes with on-device sampling (sample_token, :878-950):
+// row b draws its j-th sub-code with q3tts_rng_uniform(seed, stream0 + b, frame, j + 1) — the fused generation loop's stream for
+// utterance stream0 + b at that frame, so the sub-codes are those q3tts_decode_steps emits from the same state (its first pass takes its
+// input planes from the code0 sampler with the RMSNorm deferred, this call normalises them itself: equal up to fp32 rounding).  Uses the
+// per-slot workspaces of slots 0..nb-1 (predictor cache rows, predictor input rows): not for slots in the middle of a fused generation.
+void Engine::code_predictor_dev(const float* last_hidden, const int64_t* code0, int nb, const q3tts_sampling& p, uint64_t seed, uint32_t stream0,
+                                uint32_t frame, int32_t* sub) {
+    if (!finalized) throw Error("weights not finalized");
+    dev_scratch(nb);
+    if (!last_hidden || !code0 || !sub) throw Error("code_predictor_dev: null argument");
+    const int H = c.hidden, Hc = cp_width(), G = c.n_groups;
+    std::vector<SlotState> st((size_t)nb);
+    for (int b = 0; b < nb; ++b) {
+        SlotState& s = st[(size_t)b];
+        memset(&s, 0, sizeof s);
+        s.n_frames = (int32_t)frame; s.finished = 0; s.active = 1; s.prompt_len = 0; s.trailing_len = 0; s.max_frames = (int32_t)frame + 1;
+        s.top_k = p.top_k; s.ignore_eos = 1; s.temperature = p.temperature; s.top_p = p.top_p; s.stream_id = stream0 + (uint32_t)b; s.seed = seed;
+    }
+    Q3_HIP_CHECK(hipMemcpyAsync(dev_st_d, st.data(), (size_t)nb * sizeof(SlotState), hipMemcpyHostToDevice, stream));
+    // rows [last_hidden, embed(code0)] per utterance and the frame's running embedding sum = embed(code0) (what the code0 sampler leaves)
+    launch_copy_rows(last_hidden, H, x_cp, 2 * H, nb, H, stream);
+    launch_gather_rows_bf16(codec_embed_w, H, code0, nb, x_cp + H, 2 * H, stream);
+    launch_gather_rows_bf16(codec_embed_w, H, code0, nb, sum, H, stream);
+    SampleArgs s0;
+    s0.nb = nb; s0.sup_begin = c.suppress_begin; s0.sup_end = c.suppress_end; s0.eos_id = c.codec_eos;
+    s0.group = 0; s0.n_groups = G; s0.st = dev_st_d; s0.embed = codec_embed_w; s0.H = H;
+    s0.x_next = x_cp + H; s0.ld_xnext = 2 * H; s0.sum = sum; s0.x_talk = x_talk; s0.trailing = trailing_d; s0.max_trailing = max_trailing;
+    s0.tts_pad = tts_pad_d; s0.talker_pos = dev_pos_dummy_d;
+    // the sampler records group g of row b at codes[(b * cap + frame) * G + g]: cap = 1 and the base moved back by `frame` rows
+    s0.codes = dev_codes_d - (size_t)frame * G; s0.max_frames_cap = 1;
+    struct SeamScope { Engine& e; explicit SeamScope(Engine& en) : e(en) { e.seam_step = true; e.seam_cnt_used = 0; } ~SeamScope() { e.seam_step = false; } } seam_scope(*this);
+    if (seam_gen_d) launch_bump_u32(seam_gen_d, stream);     // the generation this call's seam flags carry (the fused step's first sampler does this)
+    static const bool no_sp = getenv("Q3TTS_NO_SAMPLER_PLANES") != nullptr;
+    const bool sp_ok = !no_sp && !cp_projected() && H <= 2048 && H % 256 == 0;
+    const bool spn = sp_ok && seam_applies(cp, nb, x_cp1, Hc, false);
+    predictor_passes(nb, s0, false, spn, [] {});
+    Q3_HIP_CHECK(hipMemcpy2DAsync(sub, (size_t)(G - 1) * sizeof(int32_t), dev_codes_d + 1, (size_t)G * sizeof(int32_t), (size_t)(G - 1) * sizeof(int32_t), (size_t)nb,
+                                   hipMemcpyDeviceToDevice, stream));
+    sync();   // `st` is read by the upload
+}
+
+// sample_token (tts_onnx.cpp:878-950) for nb rows: logits [nb][V] and u [nb] (uniforms in [0, 1), one per row) in HBM -> ids [nb] int64
+void Engine::sample_dev(const float* logits, int nb, int V, const q3tts_sampling& p, const float* u, int suppress, int64_t* ids) {
+    if (nb < 1 || nb > 65535) throw Error("sample_dev: batch out of range");
+    if (V < 1 || V > 4096) throw Error("sample: n out of range");
+    if (!logits || !u || !ids) throw Error("sample_dev: null argument");
+    SampleArgs a;
+    a.logits = logits; a.ld = V; a.V = V; a.nb = nb; a.sup_begin = c.suppress_begin; a.sup_end = c.suppress_end; a.eos_id = c.codec_eos;
+    a.temperature = p.temperature; a.top_p = p.top_p; a.top_k = p.top_k; a.u_dev = u; a.suppress = suppress; a.token_out = ids;
+    launch_sample(a, stream);
 }
 
 void Engine::code_predictor(const float* seq, int n, int step, float* logits) {
@@ -880,6 +1051,40 @@ float* Engine::cp_project(float* rows, int ld, int M) {
     return x_cpp;
 }
 
+// predict_subcodes (tts_onnx.cpp:851-872), KV-cached, for nb utterances: x_cp holds [last_hidden, embed(code0)] per utterance and `sum`
+// embed(code0); 15 x {predictor pass, head j, sampler of group j + 1} — the sampler gathers the sampled code's embedding as the next
+// pass's input and keeps the frame's running embedding sum.  sp0 / spn: the sampler in front of pass 0 / of a later pass also wrote that
+// pass's input planes (split-K seam, deferred RMSNorm).  Shared by the fused step (record_step) and q3tts_code_predictor_dev.
+void Engine::predictor_passes(int nb, const SampleArgs& s0, bool sp0, bool spn, const std::function<void()>& mark) {
+    const int H = c.hidden, Hc = cp_width(), SV = c.sub_vocab, G = c.n_groups;
+    auto with_planes = [&](SampleArgs& s, int mul, int add, const float* lh, int ld_lh) {
+        s.pl_h = pl0h; s.pl_l = pl0l; s.pl_ldp = ldp; s.gamma0 = cp.layers[0].in_norm; s.ssq_out = ssq_b_d; s.ssq_nt = Hc / 64;
+        s.pl_row_mul = mul; s.pl_row_add = add; s.lh = lh; s.ld_lh = ld_lh;
+    };
+    for (int j = 0; j < G - 1; ++j) {
+        // pass 0: rows [last_hidden, embed(code0)] of every utterance; later passes: the embedding of the code just sampled
+        float* xin = j == 0 ? cp_project(x_cp, H, nb * 2) : cp_project(x_cp1, H, nb);
+        bool pr;
+        planes_in_ready = j == 0 ? sp0 : spn;                   // the sampler in front of this pass made its input planes
+        if (j == 0) pr = run_layers(cp, xin, Hc, nb, 2, 0, nullptr, 0, cp_norm, c.cp_rms_eps);
+        else pr = run_layers(cp, xin, Hc, nb, 1, 0, nullptr, j + 1, cp_norm, c.cp_rms_eps);
+        // head j on the last row of every utterance (pass 0 holds two rows per utterance: planes row b*2+1)
+        // a traced step (step_logits) keeps plain logits rows: the head then takes the unsplit GEMM at any batch
+        const int nsl = head_proj(cp_head[j], j == 0 ? xin + Hc : xin, j == 0 ? 2 * Hc : Hc, cp_norm, c.cp_rms_eps, nullptr, 0, logits_cp, SV, nb, SV, Hc, false,
+                                  pr, j == 0 ? 1 : 0, j == 0 ? 2 : 1, trace_d ? nullptr : cp_logit_slab_d);
+        mark();
+        if (trace_d) launch_copy_rows(logits_cp + (size_t)trace_slot * SV, SV, trace_d + (size_t)(j + 1) * trace_cols, trace_cols, 1, SV, stream);
+        SampleArgs s = s0;
+        s.logits = nsl > 1 ? cp_logit_slab_d : logits_cp; s.nslab = nsl; s.slab_stride = (size_t)nb * SV;
+        s.ld = SV; s.V = SV; s.group = j + 1; s.embed = cp_embed_w[j];
+        s.x_next = j + 1 < G - 1 ? x_cp1 : nullptr; s.ld_xnext = H;
+        s.pl_h = nullptr; s.lh = nullptr; s.step_gen = nullptr;
+        if (spn && s.x_next) with_planes(s, 1, 0, nullptr, 0);
+        launch_sample(s, stream);
+        mark();
+    }
+}
+
 void Engine::record_step(int nb) {
     const int H = c.hidden, Hc = cp_width(), V = c.vocab, SV = c.sub_vocab, G = c.n_groups;
     SampleArgs s0;
@@ -908,28 +1113,7 @@ void Engine::record_step(int nb) {
     if (sp0) with_planes(s0, 2, 1, x_cp, 2 * H);
     launch_sample(s0, stream);                                  // code0 (tts_onnx.cpp:803-812)
     mark();
-    for (int j = 0; j < G - 1; ++j) {                           // predict_subcodes (:851-872), KV-cached
-        // pass 0: rows [last_hidden, embed(code0)] of every utterance; later passes: the embedding of the code just sampled
-        float* xin = j == 0 ? cp_project(x_cp, H, nb * 2) : cp_project(x_cp1, H, nb);
-        bool pr;
-        planes_in_ready = j == 0 ? sp0 : spn;                   // the sampler in front of this pass made its input planes
-        if (j == 0) pr = run_layers(cp, xin, Hc, nb, 2, 0, nullptr, 0, cp_norm, c.cp_rms_eps);
-        else pr = run_layers(cp, xin, Hc, nb, 1, 0, nullptr, j + 1, cp_norm, c.cp_rms_eps);
-        // head j on the last row of every utterance (pass 0 holds two rows per utterance: planes row b*2+1)
-        // a traced step (step_logits) keeps plain logits rows: the head then takes the unsplit GEMM at any batch
-        const int nsl = head_proj(cp_head[j], j == 0 ? xin + Hc : xin, j == 0 ? 2 * Hc : Hc, cp_norm, c.cp_rms_eps, nullptr, 0, logits_cp, SV, nb, SV, Hc, false,
-                                  pr, j == 0 ? 1 : 0, j == 0 ? 2 : 1, trace_d ? nullptr : cp_logit_slab_d);
-        mark();
-        if (trace_d) launch_copy_rows(logits_cp + (size_t)trace_slot * SV, SV, trace_d + (size_t)(j + 1) * trace_cols, trace_cols, 1, SV, stream);
-        SampleArgs s = s0;
-        s.logits = nsl > 1 ? cp_logit_slab_d : logits_cp; s.nslab = nsl; s.slab_stride = (size_t)nb * SV;
-        s.ld = SV; s.V = SV; s.group = j + 1; s.embed = cp_embed_w[j];
-        s.x_next = j + 1 < G - 1 ? x_cp1 : nullptr; s.ld_xnext = H;
-        s.pl_h = nullptr; s.lh = nullptr; s.step_gen = nullptr;
-        if (spn && s.x_next) with_planes(s, 1, 0, nullptr, 0);
-        launch_sample(s, stream);
-        mark();
-    }
+    predictor_passes(nb, s0, sp0, spn, mark);                   // predict_subcodes (:851-872), KV-cached
     const bool pr = run_layers(talker, x_talk, H, nb, 1, 0, talker_pos_d, 0, talker_norm, c.rms_eps, x_cp, 2 * H);  // run_decode (:845)
     head_proj(codec_head, x_talk, H, talker_norm, c.rms_eps, x_cp, 2 * H, logits_t, V, nb, V, H, true, pr);
     mark();

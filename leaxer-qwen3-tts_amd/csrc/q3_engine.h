@@ -1,5 +1,6 @@
 // q3_engine.h — the device-resident engine behind the C-ABI (include/q3tts.h).
 #pragma once
+#include <functional>
 #include <memory>
 #include <string>
 #include <unordered_map>
@@ -97,6 +98,7 @@ public:
     void codec_embed(const int64_t* ids, int n, float* out);
     void cp_embed(int64_t id, int step, float* out);
     void talker_prefill(int slot, const float* embeds, int S, float* logits, float* last_hidden);
+    void prefill_rows_in_xp(int slot, int S);   // run_prefill's device work for the S rows in xp (shared by the host and the device-pointer entry)
     void talker_decode(int slot, const float* embed, float* logits, float* last_hidden);
     void code_predictor(const float* seq, int n, int step, float* logits);
     void sample(const float* logits, int n, const q3tts_sampling& p, float u, int suppress, int64_t* tok);
@@ -111,6 +113,21 @@ public:
     int64_t codec_decode_range_dev(const int32_t* codes_dev, int a, int b, int left_context, float* pcm, int64_t cap);
     int64_t slot_codec_decode_range(int slot, int a, int b, int left_context, float* pcm, int64_t cap);
     int64_t codec_decode_chunked_host(const int64_t* codes, int F, int chunk, int left_context, float* pcm, int64_t cap);
+
+    // ---- batch-first session ops on DEVICE pointers (include/q3tts.h "_dev" entry points): row b <-> slot b ----
+    // caller stream: the engine's stream first waits for what the caller has enqueued, the caller's stream then waits for the call's work
+    void stream_join(hipStream_t caller);
+    void stream_fork(hipStream_t caller);
+    void talker_prefill_dev(const float* embeds, int nb, int S, const int32_t* lens, float* logits_last, float* last_hidden);
+    void talker_decode_dev(const float* embeds, int nb, const uint8_t* active, float* logits, float* last_hidden);
+    void code_predictor_dev(const float* last_hidden, const int64_t* code0, int nb, const q3tts_sampling& p, uint64_t seed, uint32_t stream0,
+                            uint32_t frame, int32_t* sub);
+    void sample_dev(const float* logits, int nb, int V, const q3tts_sampling& p, const float* u, int suppress, int64_t* ids);
+    void dev_scratch(int nb);                  // lazily allocated workspaces of the four calls above
+    float* dev_logits_d = nullptr; int* dev_flags_d = nullptr; int32_t* dev_pos_d = nullptr; int32_t* dev_pos_dummy_d = nullptr;
+    SlotState* dev_st_d = nullptr; int32_t* dev_codes_d = nullptr;
+    hipEvent_t ev_join = nullptr, ev_fork = nullptr;
+    void predictor_passes(int nb, const SampleArgs& s0, bool sp0, bool spn, const std::function<void()>& mark);
 
     // ---- fused generation ----
     struct SlotInit { int slot = 0; const float* prompt = nullptr; int S = 0; const float* trailing = nullptr; int n_trailing = 0; uint32_t stream_id = 0;

@@ -62,3 +62,51 @@ def tiny_pair(seed=0, max_batch=4, max_ctx=128, extra=None, flags=0, ocfg=None):
 
 def to_osampling(sp):
     return qo.Sampling(sp.temperature, sp.top_p, sp.top_k, sp.repetition_penalty, sp.max_new_tokens)
+
+
+class Hip:
+    """Device buffers for the tests of the "_dev" entry points: plain hipMalloc / hipMemcpy through the HIP runtime the library itself
+    uses (any allocator would do: the entry points take raw device addresses)."""
+
+    def __init__(self):
+        import ctypes as C
+        self.C = C
+        self.rt = C.CDLL("libamdhip64.so.7")
+        self.rt.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+        self.rt.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        self.rt.hipFree.argtypes = [C.c_void_p]
+        self.rt.hipStreamCreate.argtypes = [C.POINTER(C.c_void_p)]
+        self.rt.hipStreamSynchronize.argtypes = [C.c_void_p]
+        self.rt.hipStreamDestroy.argtypes = [C.c_void_p]
+        self.bufs = []
+
+    def alloc(self, nbytes):
+        p = self.C.c_void_p()
+        assert self.rt.hipMalloc(self.C.byref(p), max(int(nbytes), 16)) == 0
+        self.bufs.append(p)
+        return p.value
+
+    def put(self, arr):
+        a = np.ascontiguousarray(arr)
+        p = self.alloc(a.nbytes)
+        assert self.rt.hipMemcpy(p, a.ctypes.data_as(self.C.c_void_p), a.nbytes, 1) == 0
+        return p
+
+    def write(self, ptr, arr):
+        a = np.ascontiguousarray(arr)
+        assert self.rt.hipMemcpy(ptr, a.ctypes.data_as(self.C.c_void_p), a.nbytes, 1) == 0
+
+    def get(self, ptr, shape, dtype):
+        out = np.empty(shape, dtype)
+        assert self.rt.hipMemcpy(out.ctypes.data_as(self.C.c_void_p), ptr, out.nbytes, 2) == 0
+        return out
+
+    def stream(self):
+        s = self.C.c_void_p()
+        assert self.rt.hipStreamCreate(self.C.byref(s)) == 0
+        return s
+
+    def free(self):
+        for p in self.bufs:
+            self.rt.hipFree(p)
+        self.bufs = []
