@@ -85,9 +85,11 @@ def kernel_sources_digest():
     return h.hexdigest()[:16]
 
 
-def measured_traffic(batch, model):
+def measured_traffic(batch, model, ctx, kv_bf16):
     """HBM bytes per decode step from the rocprofv3 --pmc passes (tools/pmc_traffic.py writes profiles/decode_step_traffic.json with the
-    digest of the kernel sources it ran): quoted only when it was measured on THIS build at THIS batch, else null with the reason."""
+    digest of the kernel sources it ran, one entry per (batch, talker context, KV dtype)): quoted only when it was measured on THIS build
+    at THIS batch and KV dtype and at a context within 15 % (or 16 tokens) of the record's own mean context — the KV stream is
+    B x context x 229 KB (fp32) per step, so a short-context figure says nothing about a long-context record — else null with the reason."""
     tf = os.path.join(ROOT, "profiles", "decode_step_traffic.json")
     if model != "0.6b":
         return None, "no PMC pass for this model size"
@@ -97,12 +99,23 @@ def measured_traffic(batch, model):
         j = json.load(open(tf))
     except Exception as ex:
         return None, f"unreadable traffic file: {ex}"
-    rec = j.get(f"b{batch}")
-    if rec is None:
-        return None, f"no PMC pass at batch {batch} (rocprofv3 --pmc runs separately from the bench: counters cannot be read inside the timed process)"
     if j.get("src_digest") != kernel_sources_digest():
         return None, "PMC passes under profiles/ were taken on a different build of the kernels (src_digest mismatch); re-run tools/pmc_traffic.py"
-    return rec, "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over eager decode steps of this build (tools/pmc_traffic.py); FETCH_SIZE x2 (gfx950)"
+    best = None
+    for key, det in j.items():
+        if not key.endswith("_detail") or not key.startswith(f"b{batch}"):
+            continue
+        base = key[: -len("_detail")]
+        if base.split("_")[0] != f"b{batch}" or det.get("kv", "fp32") != ("bf16" if kv_bf16 else "fp32"):
+            continue
+        c = det.get("ctx", 0) or 14          # context 0 = the first steps after an 8-row prompt: contexts 10-20
+        if abs(c - ctx) <= max(16.0, 0.15 * ctx) and (best is None or abs(c - ctx) < abs(best[1] - ctx)):
+            best = (j[base], c)
+    if best is None:
+        return None, (f"no PMC pass at batch {batch}, context ~{ctx:.0f}, {'bf16' if kv_bf16 else 'fp32'} KV (rocprofv3 --pmc runs separately from the bench: "
+                      "counters cannot be read inside the timed process; tools/run_round_profile.sh <tag> pmc)")
+    return best[0], (f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over eager decode steps of this build at context {best[1]} "
+                     "(tools/pmc_traffic.py; slots moved there with q3tts_measure_skip_frames); FETCH_SIZE x2 (gfx950)")
 
 
 def stage_report(eng, cfg, toks, sp, B, F, ctr, kv_bf16=False):
@@ -153,7 +166,7 @@ def stage_report(eng, cfg, toks, sp, B, F, ctr, kv_bf16=False):
 def roofline_record(cfg, B, F, step_ms, model, kv_bf16=False):
     abytes = algorithmic_step_bytes(cfg, B, 8 + F / 2.0)
     achieved = abytes / (step_ms * 1e-3) / 1e9 if step_ms > 0 else 0.0
-    traffic, note = measured_traffic(B, model) if not kv_bf16 else (None, "no PMC pass in bf16-KV mode")
+    traffic, note = measured_traffic(B, model, 8 + F / 2.0, kv_bf16)
     return {"bound": "hbm", "kernel": "decode step = one hipGraph replay per frame ("
             + ("q3::k_gemv1 (QKV / o_proj / gate-up / down / heads), k_cp_attn_oproj x75, k_attn x28, k_sample x16" if B <= 2 else
                ("q3::k_gemv16 family" if B <= 16 else "q3::k_gemm3 (split-K slabs reduced in-launch: seam) + k_attn / k_attn_tiny + k_sample")) + ")",

@@ -134,3 +134,43 @@ def test_cli_synthetic_1p7b_spec(tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
     pcm = read_wav16(out)
     assert pcm.size > 6 * 1920 - 1920 and np.abs(pcm).max() > 0
+
+
+def test_onnx_converter_output_drives_the_engine(tmp_path):
+    """f4, the ONNX half: the eight self-made .onnx-format graphs (tools/make_onnx_fixture.py: the tiny config's tensors, Linear weights
+    anonymous and transposed) -> tools/import_onnx.py --by-shape-order (as a command line, the way a user would run it) -> model.q3w ->
+    q3tts_load_weights_file: the engine synthesizes exactly the codes and PCM of an engine filled with the same tensors directly, and the
+    codes the oracle makes from them.  A format round trip (the files a reference user holds are the graphs of
+    /root/reference/src/tts_onnx.cpp:91-107); no claim about a real export's initialiser names."""
+    import json
+    import sys
+    import q3tts
+    import q3_oracle as qo
+    sys.path.insert(0, ROOT)
+    from tools.make_onnx_fixture import write_fixture
+    eng, orc, w = tiny_pair(seed=9, max_batch=2, max_ctx=96)
+    try:
+        keys = json.load(open(os.path.join(ROOT, "tests", "golden", "hf_state_dict_keys.json")))
+        paths = write_fixture(str(tmp_path / "onnx"), qo.tensor_specs(orc.cfg), w, keys)
+        cfg_json = tmp_path / "cfg.json"
+        cfg_json.write_text(json.dumps(orc.cfg.to_dict()))
+        mdir = tmp_path / "model"
+        mdir.mkdir()
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "import_onnx.py"), "--out", str(mdir / "model.q3w"), "--config", str(cfg_json),
+                            "--by-shape-order"] + paths, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "[shape-order]" in r.stdout and "0 registry tensors missing" in r.stdout
+        conv = q3tts.Engine(eng.cfg, device=0, max_batch=2, max_ctx=96)
+        conv.load_weights(str(mdir / "model.q3w"))
+        sp = q3tts.Sampling(temperature=0.8, top_p=0.95, top_k=50, max_new_tokens=14)
+        toks = [frame_tokens([3, 1, 4, 1, 5]), frame_tokens([9, 2, 6])]
+        pa, ca, na = eng.synthesize_batch(toks, sp, lang=0, seed=2, ignore_eos=True)
+        pb, cb, nb_ = conv.synthesize_batch(toks, sp, lang=0, seed=2, ignore_eos=True)
+        conv.close()
+        for u in range(2):
+            assert np.array_equal(ca[u], cb[u]) and np.array_equal(pa[u], pb[u]), u
+            ref = orc.generate(orc.build_prompt(toks[u], 0), to_osampling(sp), seed=2, stream=u, cp_cached=True, ignore_eos=True)
+            assert np.array_equal(cb[u], ref), u
+    finally:
+        eng.close()
+        orc.close()

@@ -187,12 +187,12 @@ def _pb_field(no, wt, payload):
 
 
 def test_onnx_initializer_lister_reads_its_wire_format(tmp_path):
-    """tools/list_onnx_initializers.py (the artefacts the reference's users hold are .onnx graphs, /root/reference/src/tts_onnx.cpp:91-107):
+    """tools/import_onnx.py's reader (the artefacts the reference's users hold are .onnx graphs, /root/reference/src/tts_onnx.cpp:91-107):
     the dependency-free protobuf reader finds every initialiser of a ModelProto.  NOT a reference fixture — no .onnx file, ONNX Runtime
     or `onnx` package exists in the image — the file is written here, field by field, from the published schema (ModelProto.graph = 7,
     GraphProto.initializer = 5, TensorProto dims = 1 / data_type = 2 / name = 8 / raw_data = 9 / float_data = 4 / external_data = 13),
     with both dims encodings (packed and one varint per field) and a node field in front that must be skipped."""
-    from tools.list_onnx_initializers import initializers
+    from tools.import_onnx import initializers
     w = np.arange(12, dtype=np.float32).reshape(3, 4)
     t_raw = (_pb_field(1, 2, _pb_varint(3) + _pb_varint(4)) + _pb_field(2, 0, _pb_varint(1)) + _pb_field(8, 2, b"onnx::MatMul_1234") + _pb_field(9, 2, w.tobytes()))
     t_typed = (_pb_field(1, 0, _pb_varint(5)) + _pb_field(2, 0, _pb_varint(1)) + _pb_field(4, 2, np.ones(5, np.float32).tobytes()) + _pb_field(8, 2, b"talker.norm.weight"))
@@ -206,6 +206,8 @@ def test_onnx_initializer_lister_reads_its_wire_format(tmp_path):
     ts = initializers(str(path))
     assert [t["name"] for t in ts] == ["onnx::MatMul_1234", "talker.norm.weight", "big"]
     assert ts[0]["dims"] == [3, 4] and ts[0]["data_type"] == 1 and ts[0]["raw_bytes"] == 48 and not ts[0]["external"]
+    from tools.import_onnx import tensor_array
+    assert np.array_equal(tensor_array(ts[0], str(tmp_path)), w) and np.array_equal(tensor_array(ts[1], str(tmp_path)), np.ones(5, np.float32))
     assert ts[1]["dims"] == [5] and ts[1]["n_typed"] == 5
     assert ts[2]["dims"] == [2048, 1024] and ts[2]["data_type"] == 16 and ts[2]["external"]
     # truncated files are reported, not mis-read
@@ -215,3 +217,67 @@ def test_onnx_initializer_lister_reads_its_wire_format(tmp_path):
         assert False, "a truncated file must raise"
     except ValueError:
         pass
+
+
+def _onnx_fixture(tmp_path, cfg, seed=4):
+    from tools.make_onnx_fixture import write_fixture
+    w = qo.random_weights(cfg, seed)
+    keys = json.load(open(os.path.join(GOLD, "hf_state_dict_keys.json")))
+    paths = write_fixture(str(tmp_path / "onnx"), qo.tensor_specs(cfg), w, keys)
+    return w, paths
+
+
+def test_onnx_converter_round_trips_the_self_made_graphs_bit_for_bit(tmp_path):
+    """tools/import_onnx.py --by-shape-order on the eight .onnx-format files tools/make_onnx_fixture.py writes from the tiny config's seeded
+    tensors (one per session of /root/reference/src/tts_onnx.cpp:91-107; Linear weights anonymous and transposed, the rest under
+    state_dict names; raw / typed / bf16 / external data carriers; the talker stack twice; int64 constants): every registry tensor comes
+    back bit for bit, through the Q3TW0001 file too.  A FORMAT round trip — no claim about the names inside a real export."""
+    from tools.import_onnx import import_onnx
+    from tools.pack_weights import write_q3w
+    sys.path.insert(0, os.path.join(ROOT, "leaxer-qwen3-tts_amd"))
+    import q3tts
+    cfg = qo.config_tiny()
+    w, paths = _onnx_fixture(tmp_path, cfg)
+    assert [os.path.basename(p) for p in paths] == ["talker_prefill.onnx", "talker_decode.onnx", "codec_embed.onnx", "text_project.onnx", "code_predictor.onnx",
+                                                    "code_predictor_embed.onnx", "tokenizer12hz_decode.onnx", "speaker_encoder.onnx"]
+    qcfg = q3tts.Config.from_dict(cfg.to_dict())
+    lines = []
+    got, unused, missing = import_onnx(paths, qcfg, by_shape_order=True, log=lines.append)
+    assert not missing and not unused and set(got) == set(w)
+    for n in w:
+        assert got[n].shape == tuple(w[n].shape) and np.array_equal(got[n].view(np.uint32), np.ascontiguousarray(w[n], np.float32).view(np.uint32)), n
+    assert any("talker.layers.0.k_proj" in ln and "[in][out]" in ln for ln in lines)      # every heuristic assignment is reported
+    out = str(tmp_path / "model.q3w")
+    write_q3w(out, qcfg, got)          # validates against the registry: every tensor once, every shape right
+    assert os.path.getsize(out) > sum(int(np.prod(s)) for _n, s, _k in qo.tensor_specs(cfg)) * 2
+
+
+def test_onnx_converter_refuses_what_it_cannot_resolve(tmp_path):
+    """Without --by-shape-order the anonymous MatMul weights stay unresolved (named in the error); an explicit --map entry resolves one and
+    can transpose it; a shape class whose counts differ is refused; two graphs that disagree about a tensor are an error."""
+    import pytest
+    from tools.import_onnx import import_onnx
+    from tools.make_onnx_fixture import model_proto, tensor_proto
+    sys.path.insert(0, os.path.join(ROOT, "leaxer-qwen3-tts_amd"))
+    import q3tts
+    cfg = qo.config_tiny()
+    w, paths = _onnx_fixture(tmp_path, cfg)
+    qcfg = q3tts.Config.from_dict(cfg.to_dict())
+    with pytest.raises(ValueError, match="without a source"):
+        import_onnx(paths, qcfg)
+    got, unused, missing = import_onnx(paths, qcfg, allow_missing=True, log=lambda s: None)
+    assert "talker.layers.0.q_proj" in missing and "talker.norm" in got and any("onnx::MatMul" in u for u in unused)
+    first = [u for u in unused if u.startswith("talker_prefill:onnx::MatMul")][0]
+    import re
+    got2, _, _ = import_onnx(paths, qcfg, extra_rules=[(re.escape(first), "T:talker.layers.0.q_proj")], allow_missing=True, log=lambda s: None)
+    assert np.array_equal(got2["talker.layers.0.q_proj"], w["talker.layers.0.q_proj"])
+    # one more anonymous matrix of a class that is already full: counts no longer match
+    extra = str(tmp_path / "onnx" / "zz_extra.onnx")
+    open(extra, "wb").write(model_proto([tensor_proto("onnx::MatMul_9", np.zeros((cfg.hidden, cfg.ffn), np.float32) + 3, "raw32")]))
+    with pytest.raises(ValueError, match="counts must match"):
+        import_onnx(paths + [extra], qcfg, by_shape_order=True, log=lambda s: None)
+    # a second copy of a named tensor with different contents
+    bad = str(tmp_path / "onnx" / "zz_bad.onnx")
+    open(bad, "wb").write(model_proto([tensor_proto("talker.model.norm.weight", np.full(cfg.hidden, 2.0, np.float32), "raw32")]))
+    with pytest.raises(ValueError, match="graphs disagree"):
+        import_onnx(paths + [bad], qcfg, by_shape_order=True, log=lambda s: None)

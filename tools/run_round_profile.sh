@@ -9,18 +9,23 @@ MODE=${2:-main}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && mkdir -p gpurun_out/$TAG
 O=gpurun_out/$TAG
 if [ "$MODE" = "pmc" ]; then
-# PMC traffic, separate passes, eager steps on the default stream; two step counts so that the prefill cancels in the difference
-for B in 1 64; do
+# PMC traffic, separate passes, eager steps on the default stream; two step counts so that the prefill cancels in the difference.
+# Configurations: batch:context:kv, one per record of the bench line at that record's own mean context (8 + frames / 2); slots moved there with
+# q3tts_measure_skip_frames (tools/pmc_bisect <steps> <batch> <ctx> <bf16>)
+for CFG in ${PMC_CFGS:-1:1032:fp32 64:136:fp32 8:136:fp32 64:1032:fp32 64:1032:bf16 1:1032:bf16}; do
+  B=${CFG%%:*}; R=${CFG#*:}; CTX=${R%%:*}; KV=${R#*:}
+  BF=0; [ "$KV" = "bf16" ] && BF=1
   if [ $B = 1 ]; then S1=6; S2=12; else S1=4; S2=8; fi
+  T=${B}_${CTX}_${KV}
   for S in $S1 $S2; do
-    Q3TTS_NULL_STREAM=1 timeout -k 10 90 rocprofv3 --pmc FETCH_SIZE -d $O/pmc_f_${B}_$S -o f --output-format csv -- tools/pmc_bisect $S $B > $O/pmc_fetch.log 2>&1
-    Q3TTS_NULL_STREAM=1 timeout -k 10 90 rocprofv3 --pmc WRITE_SIZE -d $O/pmc_w_${B}_$S -o w --output-format csv -- tools/pmc_bisect $S $B > $O/pmc_write.log 2>&1
+    Q3TTS_NULL_STREAM=1 timeout -k 10 120 rocprofv3 --pmc FETCH_SIZE -d $O/pmc_f_${T}_$S -o f --output-format csv -- tools/pmc_bisect $S $B $CTX $BF > $O/pmc_fetch.log 2>&1
+    Q3TTS_NULL_STREAM=1 timeout -k 10 120 rocprofv3 --pmc WRITE_SIZE -d $O/pmc_w_${T}_$S -o w --output-format csv -- tools/pmc_bisect $S $B $CTX $BF > $O/pmc_write.log 2>&1
   done
-  python tools/pmc_traffic.py --batch $B --fetch $(ls $O/pmc_f_${B}_$S1/*/f_counter_collection.csv $O/pmc_f_${B}_$S1/f_counter_collection.csv 2>/dev/null | head -1) --write $(ls $O/pmc_w_${B}_$S1/*/w_counter_collection.csv $O/pmc_w_${B}_$S1/w_counter_collection.csv 2>/dev/null | head -1) --frames $S1 \
-      --fetch2 $(ls $O/pmc_f_${B}_$S2/*/f_counter_collection.csv $O/pmc_f_${B}_$S2/f_counter_collection.csv 2>/dev/null | head -1) --write2 $(ls $O/pmc_w_${B}_$S2/*/w_counter_collection.csv $O/pmc_w_${B}_$S2/w_counter_collection.csv 2>/dev/null | head -1) --frames2 $S2 \
-      --merge-into $O/decode_step_traffic.json > $O/pmc_traffic_b$B.json
-  cat $O/pmc_traffic_b$B.json
-  rm -rf $O/pmc_f_${B}_* $O/pmc_w_${B}_*
+  python tools/pmc_traffic.py --batch $B --ctx $CTX --kv $KV --fetch $(ls $O/pmc_f_${T}_$S1/*/f_counter_collection.csv $O/pmc_f_${T}_$S1/f_counter_collection.csv 2>/dev/null | head -1) --write $(ls $O/pmc_w_${T}_$S1/*/w_counter_collection.csv $O/pmc_w_${T}_$S1/w_counter_collection.csv 2>/dev/null | head -1) --frames $S1 \
+      --fetch2 $(ls $O/pmc_f_${T}_$S2/*/f_counter_collection.csv $O/pmc_f_${T}_$S2/f_counter_collection.csv 2>/dev/null | head -1) --write2 $(ls $O/pmc_w_${T}_$S2/*/w_counter_collection.csv $O/pmc_w_${T}_$S2/w_counter_collection.csv 2>/dev/null | head -1) --frames2 $S2 \
+      --merge-into $O/decode_step_traffic.json > $O/pmc_traffic_b${T}.json
+  cat $O/pmc_traffic_b${T}.json
+  rm -rf $O/pmc_f_${T}_* $O/pmc_w_${T}_*
 done
 cp $O/decode_step_traffic.json profiles/decode_step_traffic.json   # on the box only: the committed copy is made from gpurun_out/ afterwards
 timeout -k 10 600 python bench.py > $O/bench_default_with_traffic.json 2> $O/bench_default_with_traffic.err
