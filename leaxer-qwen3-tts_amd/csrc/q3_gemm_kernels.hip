@@ -400,12 +400,9 @@ __global__ __launch_bounds__(256) void k_gemm3(const bf16_t* pW, const bf16_t* p
         if (wave == 0) {
             if (lane == 0) __hip_atomic_store(line + blockIdx.y, gbase | 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             // Everybody looks only AFTER its own flag store is acknowledged (the rescue protocol's store -> load order: of two slices that
-            // each miss the other's last word, one must have looked before its own store landed).  Owners used to poll at once; they are the
-            // low-y workgroups, dispatched first and usually waiting for the later slices anyway, so the acknowledgement is hidden
-            // (-DQ3_SEAM_EAGER_POLL restores the old order for an A/B build).
-#ifdef Q3_SEAM_EAGER_POLL
-            if (mine < 0)
-#endif
+            // each miss the other's last word, one must have looked before its own store landed).  Round 3 let the chunk owners poll at once;
+            // they are the low-y workgroups, dispatched first and usually waiting for the later slices anyway, so the acknowledgement is
+            // hidden: b=64 step 4.586 / 4.607 ms with the wait against 4.637 / 4.603 without (same box, profiles/r04_negative_results.txt).
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             auto look = [&](unsigned& marks) -> bool {   // one sc1 load of the line: all slices in? which chunks are abandoned?
                 const unsigned v = __hip_atomic_load(line + (lane & 15), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -35,10 +35,12 @@ eng = q3tts.Engine(cfg, device=0, max_batch=1, max_ctx=256, flags=q3tts.FLAG_NO_
 eng.fill_synthetic(seed=0)
 rng = np.random.default_rng(0)
 logits = (rng.standard_normal(3072) * 2.5).astype(np.float32)
-for tag, kw in (("k_sample greedy", dict(top_k=1, top_p=1.0, temperature=1.0)), ("k_sample k50 p0.95", dict(top_k=50, top_p=0.95, temperature=0.8))):
+logits_sub = (rng.standard_normal(2048) * 2.5).astype(np.float32)   # a sub-code vocabulary: 8 slices per wave (k_sample<false, 8>), 15 of a frame's 16 samplers
+for tag, kw, lg in (("k_sample greedy", dict(top_k=1, top_p=1.0, temperature=1.0), logits), ("k_sample k50 p0.95", dict(top_k=50, top_p=0.95, temperature=0.8), logits),
+                    ("k_sample k50 p0.95 V=2048", dict(top_k=50, top_p=0.95, temperature=0.8), logits_sub)):
     acc = np.zeros(32)
     for i in range(40):
-        eng.sample(logits, q3tts.Sampling(max_new_tokens=1, **kw), (i + 0.5) / 40)
+        eng.sample(lg, q3tts.Sampling(max_new_tokens=1, **kw), (i + 0.5) / 40)
         t = marks()
         for k in range(1, 9):
             t[k] = max(t[k], t[k - 1])
