@@ -51,6 +51,14 @@ for BB in 8 64; do
   rm -rf $O/trace_b$BB
 done
 head -22 $O/decode_b64_f48_eager_by_grid.txt
+# 3a. the batched step at a long context (where the attention streams the KV cache): 64 slots moved to context 1024, both KV dtypes
+for KV in fp32 bf16; do
+  rocprofv3 --kernel-trace --stats -d $O/trace_ctx_$KV -o t -- python tools/ctx_bench.py --batch 64 --ctx 1024 --kv $KV --no-graph --steps 4 --max-ctx 2112 > $O/trace_ctx_$KV.log 2>&1
+  python tools/rocpd_summary.py $O/trace_ctx_$KV/t_results.db 24 > $O/decode_b64_ctx1024_${KV}_eager_by_grid.txt
+  rm -rf $O/trace_ctx_$KV
+  python tools/ctx_bench.py --batch 64 --ctx 1024 --kv $KV --stages --max-ctx 2112 >> $O/ctx_bench.txt
+done
+grep -h k_attn_stream $O/decode_b64_ctx1024_*_eager_by_grid.txt; cut -c1-300 $O/ctx_bench.txt
 # 3b. codec decoder alone, 2048 frames + short utterances
 rocprofv3 --kernel-trace --stats -d $O/trace_codec -o c -- python tools/codec_bench.py --reps 2 > $O/codec_bench.log 2>&1
 python tools/rocpd_summary.py $O/trace_codec/c_results.db 45 > $O/codec_f2048_by_grid.txt
