@@ -135,11 +135,21 @@ int q3tts_codec_decode_dev(q3tts_engine* e, const int32_t* codes_dev, int F, flo
 void* q3tts_stream(q3tts_engine* e);
 /* Streaming / chunked decode (the reference decodes the whole utterance in one run_vocoder call, tts_onnx.cpp:430).
  * The decoder is causal: frames [a, b) own the samples [L(a), L(b)) of the full decode (L = q3tts_codec_decode_len, L(0) = 0), and
- * they are final as soon as frame b-1 exists.  Each call decodes the window [a - left_context, b) and returns exactly those
- * samples; with left_context >= a the concatenation over chunks equals the whole-utterance decode (to RoPE rounding), smaller
- * values bound work and memory at the price of a truncated history (the pre-transformer looks back 72 frames per layer). */
+ * they are final as soon as frame b-1 exists.  With left_context >= a (exact mode) the call runs on a carried-state stream (below):
+ * O(b - a) work, and the concatenation over chunks equals the whole-utterance decode.  A smaller left_context decodes the window
+ * [a - left_context, b) instead and returns those samples: bounded memory of the past at the price of a truncated history (the
+ * pre-transformer looks back 72 frames per layer, 568 in all). */
 int q3tts_codec_decode_chunked_host(q3tts_engine* e, const int64_t* codes, int F, int chunk_frames, int left_context, float* pcm, int64_t cap,
                                     int64_t* out_len);
+/* Streaming decode with CARRIED state (round 4): a stream keeps the pre-transformer's K / V rows of every layer and its output rows, so a
+ * push of n new frames costs O(n + a few frames of conv look-back) instead of a decode of the history, and is exact: the concatenation of the
+ * pushes equals q3tts_codec_decode_host of all the frames (same kernels on the same rows).  max_frames bounds the stream's length; the
+ * buffers (about 0.07 MB per frame of capacity at 0.6B dims) are reused by the next stream of the same size.  q3tts_codec_decode_chunked_host
+ * with left_context >= F and q3tts_slot_codec_decode_range_host with left_context >= frame_begin run on such a stream by themselves. */
+int q3tts_codec_stream_begin(q3tts_engine* e, int max_frames, int* stream_id);
+/* codes[n_frames][n_groups] of the NEXT n_frames frames of the stream -> the samples those frames own (*out_len of them) */
+int q3tts_codec_stream_push_host(q3tts_engine* e, int stream_id, const int64_t* codes, int n_frames, float* pcm, int64_t cap, int64_t* out_len);
+int q3tts_codec_stream_end(q3tts_engine* e, int stream_id);
 /* the same for frames of a slot that is still generating: call after q3tts_decode_steps has produced frame_end frames */
 int q3tts_slot_codec_decode_range_host(q3tts_engine* e, int slot, int frame_begin, int frame_end, int left_context, float* pcm, int64_t cap,
                                        int64_t* out_len);

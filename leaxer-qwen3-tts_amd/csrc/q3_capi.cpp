@@ -171,6 +171,27 @@ int q3tts_codec_decode_chunked_host(q3tts_engine* h, const int64_t* codes, int F
     return 0;
     Q3_API_END(h)
 }
+int q3tts_codec_stream_begin(q3tts_engine* h, int max_frames, int* stream_id) {
+    Q3_API_BEGIN(h)
+    if (!stream_id) throw q3::Error("codec_stream_begin: null output");
+    *stream_id = h->e->codec_stream_begin(max_frames);
+    return 0;
+    Q3_API_END(h)
+}
+int q3tts_codec_stream_push_host(q3tts_engine* h, int stream_id, const int64_t* codes, int n_frames, float* pcm, int64_t cap, int64_t* out_len) {
+    Q3_API_BEGIN(h)
+    if (!codes) throw q3::Error("codec_stream_push: null codes");
+    const int64_t n = h->e->codec_stream_push_host(stream_id, codes, n_frames, pcm, cap);
+    if (out_len) *out_len = n;
+    return 0;
+    Q3_API_END(h)
+}
+int q3tts_codec_stream_end(q3tts_engine* h, int stream_id) {
+    Q3_API_BEGIN(h)
+    h->e->codec_stream_end(stream_id);
+    return 0;
+    Q3_API_END(h)
+}
 int q3tts_slot_codec_decode_range_host(q3tts_engine* h, int slot, int frame_begin, int frame_end, int left_context, float* pcm, int64_t cap,
                                        int64_t* out_len) {
     Q3_API_BEGIN(h)

@@ -56,6 +56,12 @@ struct CodecW {
     bool window_open = false, win0_recorded = false;
     int rr = 0;
     int submits = 0, fail_at_submit = 0;   // fault injection for the tests: the fail_at_submit-th submit of a job throws
+    // carried-state streaming decode (Engine::codec_stream_*): per stream the pre-transformer's K / V rows of every layer ([layer][k | v]
+    // [head][P][d]) and its output rows [cap][hidden]; work buffers of one push in a grow-only arena of their own
+    struct Stream { bool used = false; int cap = 0, P = 0, pshift = 0, n_done = 0; float* kv = nullptr; float* hpost = nullptr; };
+    std::vector<Stream> streams;
+    char* stream_arena = nullptr; size_t stream_arena_bytes = 0;
+    std::vector<int> slot_stream;          // slot -> stream id (-1: none): q3tts_slot_codec_decode_range_host's implicit stream
 };
 
 void Engine::codec_free() {
@@ -76,6 +82,8 @@ void Engine::codec_free() {
     if (codec->rope_cos) (void)hipFree(codec->rope_cos);
     if (codec->rope_sin) (void)hipFree(codec->rope_sin);
     if (codec->page_table) (void)hipFree(codec->page_table);
+    for (auto& s : codec->streams) { if (s.kv) (void)hipFree(s.kv); if (s.hpost) (void)hipFree(s.hpost); }
+    if (codec->stream_arena) (void)hipFree(codec->stream_arena);
     delete codec;
     codec = nullptr;
 }
@@ -207,6 +215,29 @@ static int tconv_out_len(const q3tts_config& c, int T, int k, int s, int* left_o
     return (T - 1) * s + k - left - pad;
 }
 
+// RoPE tables of the codec's pre-transformer for positions [0, P), oracle formula (fp32 libm); grow-only, shared by every lane and stream
+void Engine::codec_rope_tables(int P) {
+    CodecW& W = *codec;
+    if (W.rope_P >= P) return;
+    const int HD = c.cd_head_dim;
+    for (int i = 0; i < W.nlane; ++i) Q3_HIP_CHECK(hipStreamSynchronize(W.lane_stream[i])); // tables may be in use
+    if (W.rope_cos) (void)hipFree(W.rope_cos);
+    if (W.rope_sin) (void)hipFree(W.rope_sin);
+    const int half = HD / 2;
+    std::vector<float> cs((size_t)P * half), sn((size_t)P * half);
+    for (int p = 0; p < P; ++p)
+        for (int i = 0; i < half; ++i) {
+            const float inv = 1.0f / powf(c.cd_rope_theta, (float)(2 * i) / (float)HD);
+            const float ang = (float)p * inv;
+            cs[(size_t)p * half + i] = cosf(ang); sn[(size_t)p * half + i] = sinf(ang);
+        }
+    Q3_HIP_CHECK(hipMalloc((void**)&W.rope_cos, cs.size() * sizeof(float)));
+    Q3_HIP_CHECK(hipMalloc((void**)&W.rope_sin, sn.size() * sizeof(float)));
+    Q3_HIP_CHECK(hipMemcpy(W.rope_cos, cs.data(), cs.size() * sizeof(float), hipMemcpyHostToDevice));
+    Q3_HIP_CHECK(hipMemcpy(W.rope_sin, sn.data(), sn.size() * sizeof(float), hipMemcpyHostToDevice));
+    W.rope_P = P;
+}
+
 int64_t Engine::codec_run(const int32_t* codes_dev, int F, float** pcm_dev, int lane, const float* h_in, int h_stage, int nbatch, size_t h_ustride) {
     if (!codec) throw Error("codec decoder not finalized");
     CodecW& W = *codec;
@@ -218,24 +249,7 @@ int64_t Engine::codec_run(const int32_t* codes_dev, int F, float** pcm_dev, int 
     if (NH * HD != CH) throw Error("codec: heads*head_dim must equal hidden");
     int P = 1, pshift = 0;
     while (P < F) { P <<= 1; ++pshift; }
-    if (W.rope_P < P) { // RoPE tables, oracle formula (fp32 libm)
-        for (int i = 0; i < W.nlane; ++i) Q3_HIP_CHECK(hipStreamSynchronize(W.lane_stream[i])); // tables may be in use
-        if (W.rope_cos) (void)hipFree(W.rope_cos);
-        if (W.rope_sin) (void)hipFree(W.rope_sin);
-        const int half = HD / 2;
-        std::vector<float> cs((size_t)P * half), sn((size_t)P * half);
-        for (int p = 0; p < P; ++p)
-            for (int i = 0; i < half; ++i) {
-                const float inv = 1.0f / powf(c.cd_rope_theta, (float)(2 * i) / (float)HD);
-                const float ang = (float)p * inv;
-                cs[(size_t)p * half + i] = cosf(ang); sn[(size_t)p * half + i] = sinf(ang);
-            }
-        Q3_HIP_CHECK(hipMalloc((void**)&W.rope_cos, cs.size() * sizeof(float)));
-        Q3_HIP_CHECK(hipMalloc((void**)&W.rope_sin, sn.size() * sizeof(float)));
-        Q3_HIP_CHECK(hipMemcpy(W.rope_cos, cs.data(), cs.size() * sizeof(float), hipMemcpyHostToDevice));
-        Q3_HIP_CHECK(hipMemcpy(W.rope_sin, sn.data(), sn.size() * sizeof(float), hipMemcpyHostToDevice));
-        W.rope_P = P;
-    }
+    codec_rope_tables(P);
 
     int64_t n_pcm = 0;
     float* pcm = nullptr;
@@ -606,6 +620,200 @@ void Engine::codec_async_submit_dev(const int32_t* codes_dev, int nf, float* use
     CodecW::Pending& p = W.pend[lane];
     p.items.assign(1, CodecW::Item{ user_pcm, n, cap, 0, len_out });
     p.frames = nf; p.busy = true;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Streaming decode with CARRIED state (the reference decodes the whole utterance in one run_vocoder call,
+// /root/reference/src/tts_onnx.cpp:759-776, :430).  The decoder is causal.  Its only long memory is the pre-transformer (8 layers of
+// 72-frame sliding-window attention: 568 frames of receptive field): a stream keeps every layer's K / V rows and the transformer's
+// output rows, so a push of n new frames runs the transformer on n rows (positions n_done .. n_done + n, attention over the cached
+// window) instead of over the history.  Everything behind it — ConvNeXt upsampling, the conv decoder — looks back a few frames only
+// (stage_b_context: depthwise k7 convs, the 2r-tap transposed convs, three 7-tap dilated convs per block): it is decoded over the
+// window [n_done - context, n_done + n) of the kept transformer rows and the new frames' samples are cut out, exactly as the windowed
+// range decode does for the whole network.  Work per push: O(n + context), exact (same kernels as the one-shot decode on the same rows;
+// only the GEMM tile shapes a short launch picks differ).
+// ------------------------------------------------------------------------------------------------
+int Engine::codec_stage_b_context() const {
+    // frames the stages behind the pre-transformer look back, from the config: rows of lookback at each layer's rate / rows per frame
+    double frames = 0.0, rate = 1.0;
+    for (int s = 0; s < c.cd_n_up; ++s) { rate *= c.cd_up_ratios[s]; frames += 6.0 / rate; }            // ConvNeXt: depthwise causal k7 at the stage's output rate
+    frames += 6.0 / rate;                                                                                    // conv_in k7
+    for (int i = 0; i < c.cd_n_blocks; ++i) {
+        frames += 1.0 / rate;                                                                                // transposed conv k = 2 r: one input row back
+        rate *= c.cd_up_rates[i];
+        frames += 6.0 * (1 + 3 + 9) / rate;                                                                  // three 7-tap convs, dilations 1, 3, 9
+    }
+    frames += 6.0 / rate;                                                                                    // conv_out k7
+    return (int)frames + 3;                                                                                  // + margin for the transposed convs' trimming
+}
+
+int Engine::codec_stream_begin(int max_frames) {
+    if (!codec) throw Error("codec decoder not finalized");
+    if (max_frames < 1 || max_frames > (1 << 20)) throw Error("codec_stream_begin: max_frames out of range");
+    CodecW& W = *codec;
+    int sid = -1;
+    for (size_t i = 0; i < W.streams.size(); ++i) if (!W.streams[i].used) { sid = (int)i; break; }
+    if (sid < 0) { W.streams.emplace_back(); sid = (int)W.streams.size() - 1; }
+    CodecW::Stream& S = W.streams[(size_t)sid];
+    int P = 1, pshift = 0;
+    while (P < max_frames) { P <<= 1; ++pshift; }
+    if (S.cap < max_frames || S.P != P) {
+        sync();
+        if (S.kv) (void)hipFree(S.kv);
+        if (S.hpost) (void)hipFree(S.hpost);
+        S.kv = nullptr; S.hpost = nullptr;
+        Q3_HIP_CHECK(hipMalloc((void**)&S.kv, (size_t)c.cd_layers * 2 * c.cd_heads * P * c.cd_head_dim * sizeof(float)));
+        Q3_HIP_CHECK(hipMalloc((void**)&S.hpost, (size_t)max_frames * c.cd_hidden * sizeof(float)));
+        S.cap = max_frames; S.P = P; S.pshift = pshift;
+    }
+    S.used = true; S.n_done = 0;
+    codec_rope_tables(P);
+    return sid;
+}
+
+void Engine::codec_stream_end(int sid) {
+    if (!codec || sid < 0 || sid >= (int)codec->streams.size() || !codec->streams[(size_t)sid].used) throw Error("codec_stream_end: no such stream");
+    codec->streams[(size_t)sid].used = false;        // buffers are kept for the next stream of this size
+    codec->streams[(size_t)sid].n_done = 0;
+}
+
+int Engine::codec_stream_frames(int sid) const {
+    if (!codec || sid < 0 || sid >= (int)codec->streams.size() || !codec->streams[(size_t)sid].used) throw Error("codec_stream: no such stream");
+    return codec->streams[(size_t)sid].n_done;
+}
+
+// n new frames (codes_dev: int32 [n][n_groups] on the device) -> the samples they own, *pcm_dev pointing into the engine's decode arena
+// (valid until the next decode on the engine's stream); returns the sample count
+int64_t Engine::codec_stream_push_dev(int sid, const int32_t* codes_dev, int n, float** pcm_dev) {
+    if (!codec || sid < 0 || sid >= (int)codec->streams.size() || !codec->streams[(size_t)sid].used) throw Error("codec_stream_push: no such stream");
+    CodecW& W = *codec;
+    CodecW::Stream& S = W.streams[(size_t)sid];
+    if (n < 1) throw Error("codec_stream_push: no frames");
+    if (S.n_done + n > S.cap) throw Error("codec_stream_push: more frames than the stream was opened for");
+    const int CH = c.cd_hidden, NH = c.cd_heads, HD = c.cd_head_dim, FF = c.cd_ffn;
+    const int a0 = S.n_done, b0 = a0 + n, T = n;
+    auto bytes_of = [](size_t nfloat) { return (nfloat * sizeof(float) + 255) & ~(size_t)255; };
+    const size_t kslab_floats = (size_t)32 * 128 * 4096;
+    const size_t need = bytes_of((size_t)T * CH) * 3 + bytes_of((size_t)T * 3 * CH) + bytes_of((size_t)T * FF) * 2 + bytes_of(kslab_floats);
+    if (W.stream_arena_bytes < need) {
+        sync();
+        if (W.stream_arena) (void)hipFree(W.stream_arena);
+        W.stream_arena = nullptr;
+        Q3_HIP_CHECK(hipMalloc((void**)&W.stream_arena, need));
+        W.stream_arena_bytes = need;
+    }
+    size_t off = 0;
+    auto take = [&](size_t nfloat) { float* p = (float*)(W.stream_arena + off); off += bytes_of(nfloat); return p; };
+    float* h = take((size_t)T * CH);
+    float* hn = take((size_t)T * CH);
+    float* att = take((size_t)T * CH);
+    float* qkvb = take((size_t)T * 3 * CH);
+    float* ub = take((size_t)T * FF);
+    float* gb = take((size_t)T * FF);
+    float* kslab = take(kslab_floats);
+    auto conv = [&](ConvArgs a) {
+        a.slab = kslab; a.slab_floats = kslab_floats;
+        const auto it = W.planes.find(a.W);
+        if (it != W.planes.end()) { a.Wh = it->second.hi; a.Wl = it->second.lo; a.w_scale_inv = it->second.scale_inv; a.w_lo_zero = it->second.lo_zero; }
+        launch_conv(a, stream);
+    };
+    auto gemm = [&](const float* in, int Cin, const float* Wm, int Cout, float* out) {
+        ConvArgs a; a.in = in; a.T_in = T; a.C_in = Cin; a.out = out; a.T_out = T; a.C_out = Cout; a.W = Wm;
+        return a;
+    };
+    // ---- the pre-transformer on the new rows: positions [a0, b0), keys / values of earlier frames from the stream's caches ----
+    const int half = HD / 2;
+    const size_t layer_kv = (size_t)NH * S.P * HD;
+    launch_code_embed_mean(W.code_embed, codes_dev, T, c.n_groups, c.cd_codebook, CH, h, stream);
+    for (int l = 0; l < c.cd_layers; ++l) {
+        const CodecW::Layer& L = W.layers[l];
+        float* kc = S.kv + (size_t)l * 2 * layer_kv;
+        float* vc = kc + layer_kv;
+        launch_rmsnorm_rows(h, L.in_norm, c.cd_rms_eps, T, CH, hn, stream);
+        conv(gemm(hn, CH, L.qkv, 3 * CH, qkvb));
+        // row t of this push is position a0 + t: the tables and the cache rows start there
+        launch_rope_store(qkvb, 3 * CH, T, NH, NH, HD, W.rope_cos + (size_t)a0 * half, W.rope_sin + (size_t)a0 * half, kc + (size_t)a0 * HD, vc + (size_t)a0 * HD, S.P, stream);
+        AttnArgs a;
+        a.qkv = qkvb; a.ld_qkv = 3 * CH; a.out = att; a.ld_out = CH; a.kcache = kc; a.vcache = vc;
+        a.page_table = W.page_table; a.pages_per_slot = 1; a.page_shift = S.pshift; a.layer = 0; a.n_layers = 1;
+        a.pos_scalar = a0; a.slot_offset = 0; a.nb = 1; a.n_new = T; a.nq = NH; a.nkv = NH; a.d = HD;
+        a.scale = 1.0f / sqrtf((float)HD); a.window = c.cd_window; a.new_from_raw = 0;
+        launch_attn(a, stream);
+        { ConvArgs g = gemm(att, CH, L.o, CH, h); g.res_scale = L.attn_scale; g.res = h; conv(g); }
+        launch_rmsnorm_rows(h, L.post_norm, c.cd_rms_eps, T, CH, hn, stream);
+        conv(gemm(hn, CH, L.up, FF, ub));
+        { ConvArgs g = gemm(hn, CH, L.gate, FF, gb); g.act = 2; g.mul = ub; conv(g); }
+        { ConvArgs g = gemm(gb, FF, L.down, CH, h); g.res_scale = L.mlp_scale; g.res = h; conv(g); }
+    }
+    launch_rmsnorm_rows(h, W.norm, c.cd_rms_eps, T, CH, S.hpost + (size_t)a0 * CH, stream);
+    // ---- everything behind the transformer over the window [sB, b0) of its kept output rows ----
+    const int sB = std::max(0, a0 - codec_stage_b_context());
+    int64_t up = 1;
+    for (int i = 0; i < c.cd_n_up; ++i) up *= c.cd_up_ratios[i];
+    for (int i = 0; i < c.cd_n_blocks; ++i) up *= c.cd_up_rates[i];
+    auto len_of = [&](int nfr) -> int64_t { return nfr <= 0 ? 0 : q3tts_codec_decode_len(&c, nfr); };
+    const int64_t first = len_of(a0) - up * sB, n_own = len_of(b0) - len_of(a0);
+    float* pcm_d = nullptr;
+    const int64_t n_win = codec_run(nullptr, b0 - sB, &pcm_d, 0, S.hpost + (size_t)sB * CH, 1);
+    if (first < 0 || first + n_own != n_win) throw Error("codec_stream_push: window arithmetic does not match the decoder length formula");
+    S.n_done = b0;
+    if (pcm_dev) *pcm_dev = pcm_d + first;
+    return n_own;
+}
+
+int64_t Engine::codec_stream_push_host(int sid, const int64_t* codes, int n, float* pcm, int64_t cap) {
+    if (n < 1) throw Error("codec_stream_push: no frames");
+    const int G = c.n_groups;
+    std::vector<int32_t> tmp((size_t)n * G);
+    for (size_t i = 0; i < tmp.size(); ++i) {
+        if (codes[i] < 0 || codes[i] >= c.cd_codebook) throw Error("codec_decode: code out of range");
+        tmp[i] = (int32_t)codes[i];
+    }
+    if (n > max_frames_cap) throw Error("codec_stream_push: more frames in one push than the engine's frame capacity");
+    Q3_HIP_CHECK(hipMemcpyAsync(codes_scratch_d, tmp.data(), tmp.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+    float* pcm_d = nullptr;
+    Q3_HIP_CHECK(hipEventRecord(ev0, stream));
+    const int64_t n_own = codec_stream_push_dev(sid, codes_scratch_d, n, &pcm_d);
+    Q3_HIP_CHECK(hipEventRecord(ev1, stream));
+    const int64_t m = std::min(n_own, cap);
+    if (m > 0 && pcm) Q3_HIP_CHECK(hipMemcpyAsync(pcm, pcm_d, (size_t)m * sizeof(float), hipMemcpyDeviceToHost, stream));
+    sync();
+    Q3_HIP_CHECK(hipEventElapsedTime(&last_codec_ms, ev0, ev1));
+    total_codec_ms += last_codec_ms; total_codec_frames += n;
+    return n_own;
+}
+
+// the implicit stream behind q3tts_slot_codec_decode_range_host: consecutive exact ranges of a slot ([0, b1), [b1, b2), ...) are pushes
+int64_t Engine::slot_codec_stream_range(int slot, int a, int b, float* pcm, int64_t cap) {
+    CodecW& W = *codec;
+    if ((int)W.slot_stream.size() < B) W.slot_stream.assign((size_t)B, -1);
+    int sid = W.slot_stream[(size_t)slot];
+    if (sid < 0 || !W.streams[(size_t)sid].used || W.streams[(size_t)sid].n_done > a) {   // first range of the utterance, or a restart
+        if (sid >= 0 && W.streams[(size_t)sid].used) codec_stream_end(sid);
+        sid = codec_stream_begin(max_frames_cap);
+        W.slot_stream[(size_t)slot] = sid;
+    }
+    const int32_t* codes = codes_d + (size_t)slot * max_frames_cap * c.n_groups;
+    CodecW::Stream& S = W.streams[(size_t)sid];
+    if (S.n_done < a) codec_stream_push_dev(sid, codes + (size_t)S.n_done * c.n_groups, a - S.n_done, nullptr);   // frames nobody asked the audio of
+    float* pcm_d = nullptr;
+    Q3_HIP_CHECK(hipEventRecord(ev0, stream));
+    const int64_t n_own = codec_stream_push_dev(sid, codes + (size_t)a * c.n_groups, b - a, &pcm_d);
+    Q3_HIP_CHECK(hipEventRecord(ev1, stream));
+    const int64_t m = std::min(n_own, cap);
+    if (m > 0 && pcm) Q3_HIP_CHECK(hipMemcpyAsync(pcm, pcm_d, (size_t)m * sizeof(float), hipMemcpyDeviceToHost, stream));
+    sync();
+    Q3_HIP_CHECK(hipEventElapsedTime(&last_codec_ms, ev0, ev1));
+    total_codec_ms += last_codec_ms; total_codec_frames += b - a;
+    return n_own;
+}
+void Engine::slot_codec_stream_reset(int slot) {
+    if (!codec) return;
+    CodecW& W = *codec;
+    if (slot < 0 || slot >= (int)W.slot_stream.size()) return;
+    const int sid = W.slot_stream[(size_t)slot];
+    if (sid >= 0 && W.streams[(size_t)sid].used) codec_stream_end(sid);
+    W.slot_stream[(size_t)slot] = -1;
 }
 
 bool Engine::codec_batchable() const {

@@ -1272,6 +1272,7 @@ void Engine::slots_begin(const SlotInit* in, int n, const q3tts_sampling& p, uin
         const SlotInit& q = in[i];
         if (q.n_trailing > 0)
             Q3_HIP_CHECK(hipMemcpyAsync(trailing_d + (size_t)q.slot * max_trailing * H, q.trailing, (size_t)q.n_trailing * H * sizeof(float), hipMemcpyHostToDevice, stream));
+        slot_codec_stream_reset(q.slot);   // a new utterance: its streaming vocoder state starts over
         SlotState& s = st_h[q.slot];
         s.n_frames = 0; s.finished = 0; s.active = 1; s.prompt_len = q.S; s.trailing_len = q.n_trailing;
         s.max_frames = q.max_frames > 0 ? std::min(q.max_frames, p.max_new_tokens) : p.max_new_tokens;
@@ -1380,6 +1381,7 @@ void Engine::slot_release(int slot) {
     st_h[slot].active = 0;
     Q3_HIP_CHECK(hipMemcpy(st_d + slot, &st_h[slot], sizeof(SlotState), hipMemcpyHostToDevice));
     kv_release(slot);
+    slot_codec_stream_reset(slot);
 }
 
 int64_t Engine::slot_codec_decode(int slot, float* pcm, int64_t cap) {
@@ -1434,6 +1436,9 @@ int64_t Engine::slot_codec_decode_range(int slot, int a, int b, int left_context
     int nf = 0;
     slot_status(slot, &nf, nullptr);
     if (b > nf) throw Error("codec_decode_range: frames [" + std::to_string(a) + ", " + std::to_string(b) + ") are not generated yet (" + std::to_string(nf) + " so far)");
+    // exact mode (the context covers the history): the slot's carried-state stream — O(new frames) per call instead of O(history)
+    const bool no_carry = getenv("Q3TTS_CODEC_NO_CARRY") != nullptr;   // A/B knob, read per call: the windowed decode of the whole history
+    if (left_context >= a && a >= 0 && b > a && !no_carry) return slot_codec_stream_range(slot, a, b, pcm, cap);
     return codec_decode_range_dev(codes_d + (size_t)slot * max_frames_cap * c.n_groups, a, b, left_context, pcm, cap);
 }
 
@@ -1445,6 +1450,19 @@ int64_t Engine::codec_decode_chunked_host(const int64_t* codes, int F, int chunk
     for (size_t i = 0; i < tmp.size(); ++i) {
         if (codes[i] < 0 || codes[i] >= c.cd_codebook) throw Error("codec_decode: code out of range");
         tmp[i] = (int32_t)codes[i];
+    }
+    const bool no_carry = getenv("Q3TTS_CODEC_NO_CARRY") != nullptr;
+    if (left_context >= F && !no_carry) {   // exact mode: one carried-state stream, every chunk a push
+        const int sid = codec_stream_begin(F);
+        int64_t total = 0;
+        try {
+            for (int a = 0; a < F; a += chunk) {
+                const int b = std::min(F, a + chunk);
+                total += codec_stream_push_host(sid, codes + (size_t)a * G, b - a, pcm ? pcm + total : nullptr, std::max<int64_t>(0, cap - total));
+            }
+        } catch (...) { codec_stream_end(sid); throw; }
+        codec_stream_end(sid);
+        return total;
     }
     Q3_HIP_CHECK(hipMemcpyAsync(codes_scratch_d, tmp.data(), tmp.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
     int64_t total = 0;

@@ -113,6 +113,17 @@ public:
     int64_t codec_decode_range_dev(const int32_t* codes_dev, int a, int b, int left_context, float* pcm, int64_t cap);
     int64_t slot_codec_decode_range(int slot, int a, int b, int left_context, float* pcm, int64_t cap);
     int64_t codec_decode_chunked_host(const int64_t* codes, int F, int chunk, int left_context, float* pcm, int64_t cap);
+    // streaming decode with carried state (q3_codec.cpp): a stream keeps the pre-transformer's K / V rows and output rows, a push decodes
+    // n new frames in O(n + stage_b_context) work, exactly
+    int codec_stream_begin(int max_frames);
+    int64_t codec_stream_push_dev(int sid, const int32_t* codes_dev, int n, float** pcm_dev);
+    int64_t codec_stream_push_host(int sid, const int64_t* codes, int n, float* pcm, int64_t cap);
+    void codec_stream_end(int sid);
+    int codec_stream_frames(int sid) const;
+    int codec_stage_b_context() const;          // frames the stages behind the pre-transformer look back
+    int64_t slot_codec_stream_range(int slot, int a, int b, float* pcm, int64_t cap);
+    void slot_codec_stream_reset(int slot);
+    void codec_rope_tables(int P);
 
     // ---- batch-first session ops on DEVICE pointers (include/q3tts.h "_dev" entry points): row b <-> slot b ----
     // caller stream: the engine's stream first waits for what the caller has enqueued, the caller's stream then waits for the call's work

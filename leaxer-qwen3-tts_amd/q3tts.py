@@ -83,7 +83,7 @@ EXPORTS = [
     "q3tts_sample_host", "q3tts_rng_uniform", "q3tts_build_prompt_host", "q3tts_slot_begin", "q3tts_decode_steps",
     "q3tts_slot_status", "q3tts_slot_codes_host", "q3tts_slot_codec_decode_host", "q3tts_slot_release",
     "q3tts_synthesize_batch_host", "q3tts_last_decode_ms", "q3tts_last_codec_ms", "q3tts_decode_step_bytes",
-    "q3tts_codec_decode_dev", "q3tts_stream", "q3tts_counters", "q3tts_stage_profile", "q3tts_codec_plane_stats", "q3tts_measure_skip_frames", "q3tts_talker_prefill_dev", "q3tts_talker_decode_dev", "q3tts_code_predictor_dev", "q3tts_sample_dev", "q3tts_config_num_tensors", "q3tts_config_tensor_info", "q3tts_read_weights_config", "q3tts_load_weights_file", "q3tts_save_weights_file",
+    "q3tts_codec_decode_dev", "q3tts_stream", "q3tts_counters", "q3tts_stage_profile", "q3tts_codec_plane_stats", "q3tts_measure_skip_frames", "q3tts_codec_stream_begin", "q3tts_codec_stream_push_host", "q3tts_codec_stream_end", "q3tts_talker_prefill_dev", "q3tts_talker_decode_dev", "q3tts_code_predictor_dev", "q3tts_sample_dev", "q3tts_config_num_tensors", "q3tts_config_tensor_info", "q3tts_read_weights_config", "q3tts_load_weights_file", "q3tts_save_weights_file",
     "q3tts_tokenizer_create", "q3tts_tokenizer_destroy", "q3tts_tokenizer_load_vocab", "q3tts_tokenizer_load_merges",
     "q3tts_tokenizer_ready", "q3tts_tokenize",
     "q3tts_synthesize_clone_batch_host", "q3tts_synthesize_schedule_host", "q3tts_read_wav_host", "q3tts_resample_host", "q3tts_mel_host",
@@ -343,6 +343,27 @@ class Engine:
         out_len = C.c_int64(0)
         self._ck(self.L.q3tts_codec_decode_chunked_host(self.h, _p(c), c.shape[0], chunk_frames, left_context, _p(pcm), n, C.byref(out_len)))
         return pcm[: out_len.value]
+
+    def codec_stream_begin(self, max_frames):
+        """streaming vocoder with carried state: -> stream id (q3tts_codec_stream_begin)"""
+        sid = C.c_int(-1)
+        self.L.q3tts_codec_stream_begin.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+        self._ck(self.L.q3tts_codec_stream_begin(self.h, int(max_frames), C.byref(sid)))
+        return sid.value
+
+    def codec_stream_push(self, sid, codes):
+        """the next frames' codes [n][n_groups] -> the samples they own"""
+        c = np.ascontiguousarray(codes, dtype=np.int64)
+        cap = self.codec_decode_len(c.shape[0]) + 4096
+        pcm = np.empty(cap, np.float32)
+        n = C.c_int64(0)
+        self.L.q3tts_codec_stream_push_host.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+        self._ck(self.L.q3tts_codec_stream_push_host(self.h, sid, _p(c), c.shape[0], _p(pcm), cap, C.byref(n)))
+        return pcm[: n.value]
+
+    def codec_stream_end(self, sid):
+        self.L.q3tts_codec_stream_end.argtypes = [C.c_void_p, C.c_int]
+        self._ck(self.L.q3tts_codec_stream_end(self.h, sid))
 
     def slot_codec_decode_range(self, slot, frame_begin, frame_end, left_context):
         """samples owned by frames [frame_begin, frame_end) of a slot (streaming while it generates)"""

@@ -90,6 +90,44 @@ def test_chunked_decode_equals_whole_decode(pair):
         eng.codec_decode_chunked(codes, 0, 4)
 
 
+def test_carried_state_streams_equal_the_one_shot_decode(pair):
+    """q3tts_codec_stream_*: a stream keeps the pre-transformer's K / V rows and output rows; pushes of 1..13 frames concatenate to the
+    whole-utterance decode (the reference's one run_vocoder call, /root/reference/src/tts_onnx.cpp:759-776) and match the oracle; two
+    streams interleave without touching each other; the windowed decode of the whole history (Q3TTS_CODEC_NO_CARRY=1, the path a
+    truncated left_context still takes) gives the same samples."""
+    import os
+    eng, orc, _ = pair
+    G, CB = eng.cfg.n_groups, eng.cfg.cd_codebook
+    rng = np.random.default_rng(33)
+    ca = rng.integers(0, CB, (41, G)).astype(np.int64)
+    cb = rng.integers(0, CB, (29, G)).astype(np.int64)
+    wa, wb = eng.codec_decode(ca), eng.codec_decode(cb)
+    sa, sb = eng.codec_stream_begin(64), eng.codec_stream_begin(32)
+    assert sa != sb
+    pa, pb, ia, ib = [], [], 0, 0
+    for na, nbf in ((1, 4), (13, 2), (2, 9), (7, 1), (18, 13)):
+        pa.append(eng.codec_stream_push(sa, ca[ia:ia + na])); ia += na
+        pb.append(eng.codec_stream_push(sb, cb[ib:ib + nbf])); ib += nbf
+    assert ia == 41 and ib == 29
+    ga, gb = np.concatenate(pa), np.concatenate(pb)
+    assert ga.shape == wa.shape and gb.shape == wb.shape
+    assert float(np.abs(ga - wa).max()) < 2e-5 and float(np.abs(gb - wb).max()) < 2e-5, (float(np.abs(ga - wa).max()), float(np.abs(gb - wb).max()))
+    assert float(np.sqrt(np.mean((ga - orc.vocoder(ca)) ** 2))) < 1e-4
+    with pytest.raises(RuntimeError, match="more frames than the stream was opened for"):
+        eng.codec_stream_push(sb, cb[:4])
+    eng.codec_stream_end(sa)
+    eng.codec_stream_end(sb)
+    with pytest.raises(RuntimeError, match="no such stream"):
+        eng.codec_stream_push(sa, ca[:1])
+    os.environ["Q3TTS_CODEC_NO_CARRY"] = "1"
+    try:
+        windowed = eng.codec_decode_chunked(ca, 6, left_context=41)
+    finally:
+        del os.environ["Q3TTS_CODEC_NO_CARRY"]
+    carried = eng.codec_decode_chunked(ca, 6, left_context=41)
+    assert float(np.abs(windowed - wa).max()) < 2e-5 and float(np.abs(carried - wa).max()) < 2e-5
+
+
 def test_streaming_decode_while_generating(pair):
     """Audio for the frames generated so far is final: chunks pulled from a slot between decode_steps calls concatenate
     to exactly what the whole-utterance decode returns at the end."""

@@ -561,6 +561,39 @@ def test_talker_decode_at_context_2048_full_size(full):
         big.close()
 
 
+def test_codec_carried_state_streaming_full_size(full):
+    """0.6B dims, 400 frames in pushes of 25 (2 s of audio each): the carried-state stream (pre-transformer K / V rows and output rows kept,
+    everything behind it decoded over a window of codec_stage_b_context frames) equals the one-shot decode and the oracle, with the
+    pre-transformer's 72-frame window and 568-frame receptive field fully in play; and it does what it is for — the 16 pushes cost about
+    one decode of the utterance, not one decode of the growing history per push (device time printed).  Reference contract: one
+    run_vocoder call per utterance, /root/reference/src/tts_onnx.cpp:759-776."""
+    import os
+    eng, orc = full
+    F, chunk = 400, 25
+    codes = np.random.default_rng(400).integers(0, 2048, (F, 16)).astype(np.int64)
+    whole = eng.codec_decode(codes)
+    sid = eng.codec_stream_begin(F)
+    parts, ms_carried = [], 0.0
+    for a in range(0, F, chunk):
+        parts.append(eng.codec_stream_push(sid, codes[a:a + chunk]))
+        ms_carried += eng.last_codec_ms()
+    eng.codec_stream_end(sid)
+    got = np.concatenate(parts)
+    assert got.shape == whole.shape
+    d = float(np.abs(got - whole).max())
+    ref = orc.vocoder(codes)
+    err = float(np.sqrt(np.mean((got - ref) ** 2)))
+    os.environ["Q3TTS_CODEC_NO_CARRY"] = "1"
+    try:
+        win = eng.codec_decode_chunked(codes, chunk, left_context=F)      # the windowed decode of the growing history, chunk by chunk
+    finally:
+        del os.environ["Q3TTS_CODEC_NO_CARRY"]
+    print("codec streaming, %d frames in pushes of %d: max |carried - one-shot| %.3g, rms vs oracle %.3g; device time of the 16 pushes %.1f ms"
+          % (F, chunk, d, err, ms_carried))
+    assert d < 2e-5 and err < 1e-4, (d, err)
+    assert float(np.abs(win - whole).max()) < 2e-5
+
+
 @pytest.mark.parametrize("F", [300, 2048])
 def test_codec_long_utterances_full_size(full, F):
     """300 and 2048 frames (BASELINE configs[1]'s length: 3.9 M samples) at 0.6B dims — 300 is four times the pre-transformer's 72-frame attention window (the sliding-window mask is active on most rows),

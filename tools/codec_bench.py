@@ -15,6 +15,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--frames", type=int, default=2048)
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--fp32", action="store_true")
+ap.add_argument("--stream-chunk", type=int, default=0, help="also decode the utterance in pushes of N frames: carried-state stream vs the windowed decode of the growing history")
 a = ap.parse_args()
 cfg = q3tts.default_config("0.6b")
 eng = q3tts.Engine(cfg, device=0, max_batch=1, max_ctx=a.frames + 32, flags=q3tts.FLAG_FP32_CODEC if a.fp32 else 0)
@@ -29,4 +30,20 @@ for _ in range(a.reps):
 dt = time.perf_counter() - t0
 print(f"frames={a.frames} device {ms / a.reps:.2f} ms/decode = {ms / a.reps / a.frames * 1e3:.2f} us/frame "
       f"({5.0e9 * a.frames / (ms / a.reps * 1e-3) / 1e12:.1f} TF/s-equivalent), wall {dt / a.reps * 1e3:.1f} ms")
+if a.stream_chunk > 0:
+    ch = a.stream_chunk
+    sid = eng.codec_stream_begin(a.frames)
+    ms_c = 0.0
+    for s in range(0, a.frames, ch):
+        eng.codec_stream_push(sid, codes[s:s + ch])
+        ms_c += eng.last_codec_ms()
+    eng.codec_stream_end(sid)
+    os.environ["Q3TTS_CODEC_NO_CARRY"] = "1"
+    ms_w = 0.0
+    for s in range(0, a.frames, ch):      # what exact streaming cost before: every chunk decodes the window [0, b)
+        eng.codec_decode(codes[: min(a.frames, s + ch)])
+        ms_w += eng.last_codec_ms()
+    del os.environ["Q3TTS_CODEC_NO_CARRY"]
+    print(f"streaming frames={a.frames} in pushes of {ch}: carried state {ms_c:.1f} ms device ({ms_c / a.frames * 1e3:.1f} us/frame), "
+          f"windowed decode of the growing history {ms_w:.1f} ms ({ms_w / a.frames * 1e3:.1f} us/frame), one-shot {ms / a.reps:.1f} ms")
 eng.close()
