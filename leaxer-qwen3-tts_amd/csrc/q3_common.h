@@ -155,7 +155,7 @@ struct GemmArgs {
     unsigned* seam_cnt = nullptr;                    // one 64-byte line per (column tile, row block): words 0..11 slice flags, 12..15 abandoned-chunk marks
     const unsigned* seam_gen = nullptr;              // the step's generation (bumped once per step by the first sampler): every word a launch writes carries it,
                                                      // so nothing is ever reset and a copy of the line left over from an earlier step can never read as set
-    int seam_spin = 4096;                            // polls an owner makes before it abandons its chunk (~0.7 us each)
+    int seam_spin = 512;                             // polls an owner makes before it abandons its chunk (~0.7 us each)
     float* sx = nullptr; int sldx = 0;               // seam 1: residual stream rows, updated in place
     const float* sgamma = nullptr;                   // seam 1: the consumer's RMSNorm gain
     float* ssq_out = nullptr; int ssq_nt = 0;        // seam 1: [M][ssq_nt] partial sums of squares, one per 64-column tile

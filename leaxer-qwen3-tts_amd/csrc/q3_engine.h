@@ -236,7 +236,7 @@ public:
     bool attn_stream = true;         // Q3TTS_ATTN_STREAM=0 at engine creation: the batched step's long-context attention stays on k_attn (A/B knob, tests' second path)
     bool attn_stream_one = true;     // Q3TTS_ATTN_STREAM_ONE=0: the one-split case (contexts <= 512 at >= 256 (row, kv head) pairs) back on k_attn (A/B knob): b=64 x 256 frames 4.67 -> 4.59 ms per step with it
     bool attn_keep_splits = false;   // Q3TTS_ATTN_KEEP_SPLITS at engine creation: the batched step keeps split-T attention + the combine launch (A/B knob, tests' second path)
-    int seam_spin = 4096;        // Q3TTS_SEAM_SPIN: polls before an owner abandons its chunk (1 forces the rescue path in the tests)
+    int seam_spin = 512;         // Q3TTS_SEAM_SPIN: polls (~0.7 us each) before an owner abandons its chunk to whoever sees the tile complete (1 forces that rescue path in the tests).  A fast-path seam completes within a few polls; the bound only matters when the launch's workgroups are not co-resident (vocoder lanes, other engines, a CU mask): 512 keeps a stalled owner off its CU after ~0.35 ms instead of round 3's ~2.9 ms
     int32_t* codes_d = nullptr;
     int32_t* codes_scratch_d = nullptr;
     int32_t* talker_pos_d = nullptr;

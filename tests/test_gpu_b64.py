@@ -88,6 +88,32 @@ def test_batched_generation_full_size(wide, nb, sampled):
             assert np.array_equal(codes64[u], codes[u]), u
 
 
+def test_every_row_of_the_batch_against_its_own_oracle_run(wide):
+    """All 64 utterances, not a spread: 2 free-running greedy frames of the 64-row batch (32 code decisions per utterance, prompts of 8
+    to 24 tokens) against 64 single-utterance oracle runs — the other batched tests check 3 to 6 rows against the oracle and the rest only
+    against another batch.  fp32-cache default engine only (the oracle makes ~7 frames per second); margin-aware like the others."""
+    import q3tts
+    eng, orc, toks = wide
+    if eng.creation_env or eng.min_exact_frames is not None:
+        pytest.skip("one round is enough: 64 oracle runs")
+    sp = q3tts.Sampling(max_new_tokens=2, temperature=1.0, top_p=1.0, top_k=1)
+    _, codes, nfr = eng.synthesize_batch(toks, sp, lang=0, seed=13, ignore_eos=True)
+    assert all(int(n) == 2 for n in nfr)
+    exact = 0
+    for u in range(64):
+        ref, mg = orc.generate_margins(orc.build_prompt(toks[u], 0), to_osampling(sp), seed=13, stream=u, cp_cached=True, ignore_eos=True)
+        bad = np.argwhere(codes[u] != ref)
+        if bad.size == 0:
+            exact += 1
+            continue
+        f, g = int(bad[0][0]), int(bad[0][1])
+        print("all-rows check, utterance %d: first divergence at frame %d group %d, oracle margin %.3g" % (u, f, g, float(mg[f, 2 + g])))
+        assert float(mg[f, 2 + g]) < eng.margin_noise, (u, f, g, float(mg[f, 2 + g]))
+        assert np.array_equal(codes[u][:f], ref[:f]) and np.array_equal(codes[u][f, :g], ref[f, :g])
+    print("all-rows check: %d of 64 utterances bit-exact over 2 frames (32 decisions each)" % exact)
+    assert exact >= 60
+
+
 def test_batched_greedy_32_frames_margin_aware(wide):
     """64 utterances x 32 free-running greedy frames in one batch (the split-K slab GEMM path for every projection, 32 hipGraph replays):
     a spread of utterances against their own single-utterance oracle runs.  Margin-aware: a divergence is a failure unless the oracle's
