@@ -248,3 +248,60 @@ def test_code_predictor_dev_fused_subcodes_vs_the_reference_call_pattern(hip):
     finally:
         eng.close()
         orc.close()
+
+
+def test_dev_entries_on_the_projected_tiny_config_with_a_pooled_cache(hip):
+    """The "_dev" sessions where the other tests do not go: the 1.7B structure (predictor narrower than the talker behind cp.proj) on the
+    tiny config (GEMV-family kernels at 5 rows: dims that are no multiple of 128), and a bounded KV page pool (pages handed out as the
+    batched decode grows the contexts; table-mapped attention).  Every row against the oracle: prefill + 70 decode steps across a
+    64-token page boundary, then the fused sub-code predictor against the uncached reference pattern."""
+    import q3tts
+    from util import to_q3cfg
+    ocfg = qo.config_tiny_proj()
+    w = qo.random_weights(ocfg, 12)
+    B = 5
+    eng = q3tts.Engine(to_q3cfg(ocfg), device=0, max_batch=B, max_ctx=192, kv_pool_tokens=10 * 64)   # 10 pages for 5 slots of up to 76 tokens (a full pool would be 15)
+    eng.load(w)
+    orcs = [qo.Oracle(ocfg, max_ctx=192, weights=w) for _ in range(2)]
+    try:
+        H, V, G = eng.cfg.hidden, eng.cfg.vocab, eng.cfg.n_groups
+        rng = np.random.default_rng(3)
+        lens = np.array([6, 6, 3, 6, 2], np.int32)
+        x = rng.standard_normal((B, 6, H)).astype(np.float32)
+        x_d, lg_d, lh_d, e_d = hip.put(x), hip.alloc(B * V * 4), hip.alloc(B * H * 4), hip.alloc(B * H * 4)
+        eng.talker_prefill_dev(x_d, B, 6, lens, lg_d, lh_d)
+        check = (1, 4)
+        for o, b in zip(orcs, check):
+            lo_all, ho = o.prefill(x[b, : lens[b]])
+            lo = lo_all[-1] if lo_all.ndim == 2 else lo_all
+            assert np.abs(hip.get(lg_d, (B, V), np.float32)[b] - lo).max() < 2e-4 and np.abs(hip.get(lh_d, (B, H), np.float32)[b] - ho).max() < 2e-4, b
+        worst = 0.0
+        for i in range(70):
+            e = rng.standard_normal((B, H)).astype(np.float32)
+            hip.write(e_d, e)
+            eng.talker_decode_dev(e_d, B, None, lg_d, lh_d)
+            lg, lh = hip.get(lg_d, (B, V), np.float32), hip.get(lh_d, (B, H), np.float32)
+            for o, b in zip(orcs, check):
+                lo, ho = o.decode(e[b])
+                worst = max(worst, float(np.abs(lg[b] - lo).max()), float(np.abs(lh[b] - ho).max()))
+        print("talker _dev on the projected tiny config, pooled cache, 5 rows x 70 steps: worst |difference| vs oracle %.3g" % worst)
+        assert worst < 2e-4, worst
+        sp = q3tts.Sampling(max_new_tokens=1, temperature=1.0, top_p=1.0, top_k=1)
+        code0 = rng.integers(0, ocfg.sub_vocab, B).astype(np.int64)
+        c0_d, sub_d = hip.put(code0), hip.alloc(B * (G - 1) * 4)
+        eng.code_predictor_dev(lh_d, c0_d, B, sp, 7, 0, 3, sub_d)
+        sub = hip.get(sub_d, (B, G - 1), np.int32)
+        lh = hip.get(lh_d, (B, H), np.float32)
+        o = orcs[0]
+        for b in range(B):
+            seq = [lh[b], o.codec_embed([int(code0[b])])[0]]
+            for j in range(G - 1):
+                tok, margin = o.sample_margin(o.code_predictor(np.stack(seq), j), to_osampling(sp), 0.5)
+                if int(sub[b, j]) != tok:
+                    assert margin < 2e-4, (b, j, margin)
+                    break
+                seq.append(o.cp_embed(tok, j))
+    finally:
+        eng.close()
+        for o in orcs:
+            o.close()
