@@ -1340,8 +1340,8 @@ __global__ __launch_bounds__(128) void k_attn_tiny(const float* pqkv, const floa
 
 static void launch_attn_stream(const AttnArgs& a, hipStream_t s) {
     const int grp = a.nq / a.nkv;
-    if (a.d != 128 || a.n_new != 1 || !a.new_from_raw || a.window != 0 || a.slot_map != nullptr || a.nq % a.nkv || !(grp == 1 || grp == 2 || grp == 4))
-        throw Error("attn (stream): one new token per row, head_dim 128, GQA group 1 / 2 / 4, no window, no slot map");
+    if (a.d != 128 || a.n_new != 1 || !a.new_from_raw || a.window != 0 || a.slot_map != nullptr || a.nq % a.nkv || grp != 2)
+        throw Error("attn (stream): one new token per row, head_dim 128, two query heads per kv head (the 0.6B and 1.7B talkers), no window, no slot map");
     if (a.n_splits < 1 || a.n_splits > 65535 || (a.n_splits > 1 && (a.po == nullptr || a.chunk % 64 != 0))) throw Error("attn (stream): splits start on page boundaries and need partial buffers");
     if (a.page_shift != 6) throw Error("attn (stream): 64-token KV pages");
     const int span = a.n_splits == 1 ? a.pages_per_slot << 6 : a.chunk;   // tokens one workgroup may walk
@@ -1356,12 +1356,12 @@ static void launch_attn_stream(const AttnArgs& a, hipStream_t s) {
     // one-split launch of short contexts.  Non-temporal loads are worth 0.2-0.3 ms per step (fp32 7.35 -> 7.08 ms, bf16 5.98 -> 5.85);
     // the bf16 cache's lane mapping on an fp32 cache costs 0.35 ms (used only under Q3TTS_FLAG_KV_ROUND_BF16, the bit-for-bit test aid).
     const bool one = a.n_splits == 1;
-#define Q3_AS(G_) do { if (a.kv_bf16) Q3_AS_GO(G_, true, true, 4, 3); else if (a.kv_round) Q3_AS_GO(G_, false, true, 2, 3); \
-                       else if (one) Q3_AS_GO(G_, false, false, 2, 3); else Q3_AS_GO(G_, false, false, 4, 2); } while (0)
-    if (grp == 1) Q3_AS(1);
-    else if (grp == 2) Q3_AS(2);
-    else { if (a.kv_bf16) Q3_AS_GO(4, true, true, 2, 2); else if (a.kv_round) Q3_AS_GO(4, false, true, 2, 2); else Q3_AS_GO(4, false, false, 2, 2); }
-#undef Q3_AS
+    // Q3TTS_FLAG_KV_ROUND_BF16 (test aid): the bf16 cache's lane mapping AND batch shape (4 tokens per lane group and batch) on fp32 storage
+    // of the rounded rows, so that the online softmax associates exactly as the 16-bit cache's launch does (bit-for-bit test)
+    if (a.kv_bf16) Q3_AS_GO(2, true, true, 4, 3);
+    else if (a.kv_round) Q3_AS_GO(2, false, true, 4, 2);
+    else if (one) Q3_AS_GO(2, false, false, 2, 3);
+    else Q3_AS_GO(2, false, false, 4, 2);
 #undef Q3_AS_GO
 #undef Q3_AS_ARGS
     Q3_HIP_CHECK(hipGetLastError());

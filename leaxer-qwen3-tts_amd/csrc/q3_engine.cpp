@@ -342,7 +342,7 @@ Engine::Engine(const q3tts_config& cfg, int device_, int max_batch, int max_ctx_
     if (talker.n_splits > 64) { talker.n_splits = 64; talker.chunk = ((max_ctx + 63) / 64 + 127) / 128 * 128; }
     // k_attn_stream (batched step): splits of whole 64-token pages — 128 KB of K/V per split (256 tokens fp32, 512 bf16: measured against
     // 128 / 256 / 512 / 1024, profiles/r04_attn_stream_ab.txt) unless Q3TTS_ATTN_STREAM_CHUNK says otherwise
-    talker.chunk_stream = talker.kv_bf16 ? 512 : 256;
+    talker.chunk_stream = (talker.kv_bf16 || talker.kv_round) ? 512 : 256;   // kv_round (test aid) mirrors the bf16 cache's splits
     if (const char* ck = getenv("Q3TTS_ATTN_STREAM_CHUNK")) { const int v = atoi(ck); if (v >= 64 && v % 64 == 0) talker.chunk_stream = v; }
     talker.n_splits_stream = (max_ctx + talker.chunk_stream - 1) / talker.chunk_stream;
     for (DecStack* S : { &talker, &cp }) {
@@ -570,7 +570,7 @@ bool Engine::run_layers(const DecStack& W, float* x, int ldx, int nb, int n_new,
         // through a two-deep register ring, 3-4 workgroups per CU) instead of k_attn's one-batch 128-token splits.
         const int grp_w = W.nkv > 0 ? W.nq / W.nkv : 0;
         const bool stream_shape = attn_stream && mfma && n_new == 1 && W.d == 128 && slot_map == nullptr && W.page_shift == 6 && W.n_splits_stream > 0 &&
-                                  W.nq % W.nkv == 0 && (grp_w == 1 || grp_w == 2 || grp_w == 4);
+                                  W.nq % W.nkv == 0 && grp_w == 2;   // the kernel is built for two query heads per kv head (0.6B and 1.7B talkers)
         if (stream_shape && a.n_splits > 1) { a.stream = 1; a.n_splits = W.n_splits_stream; a.chunk = W.chunk_stream; }
         else if (stream_shape && attn_stream_one && a.n_splits == 1) a.stream = 1;
         const bool direct_planes = mfma && a.n_splits == 1;     // one split: the attention kernel normalises and writes the planes itself

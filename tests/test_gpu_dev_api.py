@@ -305,3 +305,42 @@ def test_dev_entries_on_the_projected_tiny_config_with_a_pooled_cache(hip):
         eng.close()
         for o in orcs:
             o.close()
+
+
+def test_bf16_cache_equals_rounded_fp32_cache_bit_for_bit_in_the_batched_step(hip):
+    """The pin of the bf16 KV data path (tests/test_gpu_full.py::test_bf16_kv_storage_equals_rounded_fp32_storage does it for the b = 1
+    kernels) for the batched step's streaming attention: 16 slots, 8-row prompts, 560 teacher-forced batched decode steps — across the
+    512-token split boundary — with the cache in bf16 (Q3TTS_FLAG_KV_BF16) and, on a second engine, in fp32 holding the same rounded rows
+    (Q3TTS_FLAG_KV_ROUND_BF16: the bf16 kernel's lane mapping, batch shape and splits on 4-byte storage).  Same rows before rounding,
+    same rounding, same arithmetic in the same order: logits and hidden rows identical bit for bit at every compared step."""
+    import q3tts
+    cfg = q3tts.default_config("0.6b")
+    B, T = 16, 560
+    a = q3tts.Engine(cfg, device=0, max_batch=B, max_ctx=640, flags=q3tts.FLAG_KV_BF16)
+    b = q3tts.Engine(cfg, device=0, max_batch=B, max_ctx=640, flags=q3tts.FLAG_KV_ROUND_BF16)
+    try:
+        a.fill_synthetic(seed=0)
+        b.fill_synthetic(seed=0)
+        H, V = cfg.hidden, cfg.vocab
+        rng = np.random.default_rng(5)
+        x0 = (rng.standard_normal((B, 8, H)) * 0.05).astype(np.float32)
+        x_d, e_d = hip.put(x0), hip.alloc(B * H * 4)
+        la, ha, lb, hb = hip.alloc(B * V * 4), hip.alloc(B * H * 4), hip.alloc(B * V * 4), hip.alloc(B * H * 4)
+        a.talker_prefill_dev(x_d, B, 8, None, la, ha)
+        b.talker_prefill_dev(x_d, B, 8, None, lb, hb)
+        assert np.array_equal(hip.get(la, (B, V), np.float32), hip.get(lb, (B, V), np.float32))
+        compared = 0
+        for i in range(T):
+            e = (rng.standard_normal((B, H)) * 0.05).astype(np.float32)
+            hip.write(e_d, e)
+            look = i < 4 or i % 37 == 0 or i >= T - 6 or 500 <= i <= 510      # incl. the steps around context 512
+            a.talker_decode_dev(e_d, B, None, la if look else 0, ha if look else 0)
+            b.talker_decode_dev(e_d, B, None, lb if look else 0, hb if look else 0)
+            if look:
+                assert np.array_equal(hip.get(la, (B, V), np.float32), hip.get(lb, (B, V), np.float32)), i
+                assert np.array_equal(hip.get(ha, (B, H), np.float32), hip.get(hb, (B, H), np.float32)), i
+                compared += 1
+        assert compared > 30
+    finally:
+        a.close()
+        b.close()
