@@ -879,6 +879,82 @@ __global__ __launch_bounds__(CO1_T) void k_conv_cout1(ConvKArgs a0) {
     }
 }
 
+// C_out == 1 with C_in a multiple of 32 (the decoder's last conv: 96 channels, 7 taps) — round 4.  k_conv_cout1 above reads every staged
+// element from LDS once per tap (672 four-byte LDS reads per output sample: the launch ran at 1.6 TB/s of HBM traffic).  Here nothing is
+// staged: eight lanes share an input row, lane s owning channels [s CPT, (s + 1) CPT) of it — straight from global memory, 16 bytes per
+// load, a row's eight lanes covering its C_in floats contiguously — with the `taps` x CPT weights of its slice resident in registers.  A
+// workgroup walks 256 rows in 8 passes of 32 (every load of the tile issued up front), each lane forms its slice of the row's per-tap
+// dot products d[tap] = sum_c W[tap][c] x[row][c], the eight slices meet by DPP (quad sums, then the half-row mirror), and the partial sums
+// change hands through LDS: output j adds d[tap] of rows j + tap * dil.  Causal taps, optional clamp.  A tile yields 256 - halo outputs.
+#define CO1R_ROWS 256
+template <int CPT>
+__global__ __launch_bounds__(256) void k_conv_cout1_reg(ConvKArgs a0) {
+    constexpr int MAXT = 8, NP = CO1R_ROWS / 32;
+    __shared__ float ds[CO1R_ROWS][MAXT + 1];
+    ConvKArgs a = a0;
+    const int bx = conv_batch_rebase(a, blockIdx.x);
+    const int tid = threadIdx.x, s8 = tid & 7, rl = tid >> 3;
+    const int halo = (a.taps - 1) * a.dil, TO = CO1R_ROWS - halo, t0 = bx * TO;
+    // every row of the tile first (clamped addresses; rows outside the sequence are zeroed below)
+    float x[NP][CPT];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const int src = t0 - halo + p * 32 + rl;
+        const int sc = src < 0 ? 0 : (src < a.T_in ? src : a.T_in - 1);
+        const float* xr = a.in + (size_t)sc * a.C_in + s8 * CPT;
+#pragma unroll
+        for (int c = 0; c < CPT; c += 4) {
+            const float4 v = *reinterpret_cast<const float4*>(xr + c);
+            x[p][c] = v.x; x[p][c + 1] = v.y; x[p][c + 2] = v.z; x[p][c + 3] = v.w;
+        }
+    }
+    float w[MAXT][CPT];
+#pragma unroll
+    for (int tap = 0; tap < MAXT; ++tap) {
+        const float* wr = a.W + (size_t)(tap < a.taps ? tap : 0) * a.C_in + s8 * CPT;   // [tap][0][ci]
+#pragma unroll
+        for (int c = 0; c < CPT; c += 4) {
+            const float4 v = *reinterpret_cast<const float4*>(wr + c);
+            const bool on = tap < a.taps;
+            w[tap][c] = on ? v.x : 0.f; w[tap][c + 1] = on ? v.y : 0.f; w[tap][c + 2] = on ? v.z : 0.f; w[tap][c + 3] = on ? v.w : 0.f;
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const int src = t0 - halo + p * 32 + rl;
+        const bool inr = src >= 0 && src < a.T_in;
+        float d[MAXT];
+#pragma unroll
+        for (int tap = 0; tap < MAXT; ++tap) {
+            float acc = 0.f;
+#pragma unroll
+            for (int c = 0; c < CPT; ++c) acc = fmaf(w[tap][c], x[p][c], acc);
+            acc = inr ? acc : 0.f;
+            // the row's eight channel slices: quad sums, then lanes 0..3 take lanes 4..7 (lane s8 == 0 ends up with the row's sum)
+            acc += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+            acc += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]: every lane holds its quad's sum
+            acc += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc), 0x141, 0xF, 0xF, true));   // row_half_mirror: lane i <-> lane 7 - i of its 8 lanes = the other quad
+            d[tap] = acc;
+        }
+        if (s8 == 0) {
+#pragma unroll
+            for (int tap = 0; tap < MAXT; ++tap) ds[p * 32 + rl][tap] = d[tap];
+        }
+    }
+    __syncthreads();
+    const int t = t0 + tid;
+    if (tid < TO && t < a.T_out) {
+        float acc = 0.f;
+#pragma unroll
+        for (int tap = 0; tap < MAXT; ++tap)
+            if (tap < a.taps) acc += ds[tid + tap * a.dil][tap];   // row t - (taps - 1 - tap) * dil
+        float v = acc + (a.bias ? a.bias[0] : 0.f);
+        if (a.clamp) v = v < -1.f ? -1.f : (v > 1.f ? 1.f : v);
+        a.out[t] = v;
+    }
+}
+
 void launch_conv(const ConvArgs& c, hipStream_t s) {
     if (c.C_in % 4 != 0) throw Error("conv: C_in must be a multiple of 4");
     ConvKArgs a;
@@ -910,6 +986,15 @@ void launch_conv(const ConvArgs& c, hipStream_t s) {
     const int rows = c.transposed ? c.T_in + c.taps / c.stride - 1 : c.T_out;
     dim3 grid((rows + CT_M - 1) / CT_M, (c.C_out + CT_N - 1) / CT_N, c.transposed ? c.stride : 1);
     if (rows <= 0) return;
+    if (c.C_out == 1 && !c.transposed && c.C_in == 96 && c.taps <= 8 && (c.taps - 1) * c.dil <= 64 && c.out && !c.out2 && !c.res && !c.mul &&
+        !c.res_scale && c.act == 0 && !getenv("Q3TTS_COUT1_LDS")) {   // Q3TTS_COUT1_LDS: the LDS-staged kernel (A/B knob)
+        const int to1 = CO1R_ROWS - (c.taps - 1) * c.dil, tiles = (c.T_out + to1 - 1) / to1;
+        if (nb > 1) a.batch_tiles = tiles;
+        const dim3 g1((unsigned)(tiles * nb));
+        hipLaunchKernelGGL(k_conv_cout1_reg<12>, g1, dim3(256), 0, s, a);   // 96 channels (the shipped decoders' last block); other widths take the LDS kernel below
+        Q3_HIP_CHECK(hipGetLastError());
+        return;
+    }
     if (c.C_out == 1 && !c.transposed && c.C_in % 4 == 0 && c.out && !c.out2 && !c.res && !c.mul && !c.res_scale && c.act == 0) {
         const size_t lds = (size_t)(CO1_T + (c.taps - 1) * c.dil) * (c.C_in + 1) * sizeof(float);
         if (lds <= 60 * 1024) {

@@ -1338,6 +1338,122 @@ __global__ __launch_bounds__(128) void k_attn_tiny(const float* pqkv, const floa
     KP_MARK(23);
 }
 
+// ================================================================================================
+// k_attn_win (round 4) — the sliding-window attention of the codec decoder's pre-transformer (8 layers, 16 heads x 64, window 72; every
+// row's K / V already in the layer's cache, q roped by k_rope_store).  k_attn served it with one workgroup per (head, QUERY): 2048 x 16
+// workgroups per layer each fetching its own 72-row window — 37 KB for 9 K multiply-adds, 1.2 GB of L2 traffic and 146 us per layer at
+// 2048 frames (1.2 ms of a 31 ms decode).  Here a workgroup takes 32 consecutive queries of one head: their windows overlap in all but 31
+// rows, so 103 K rows and 103 V rows are staged once in LDS (16-byte loads, rows padded by 4 floats).  A query is shared by 8 lanes: lane
+// j scores window offsets j, j + 8, ... against the query held in its registers, the 8 lanes agree on the maximum and the sum by DPP
+// (quad sums + half-row mirror), accumulate P.V over their own offsets and add up the 64 output dims the same way; lane j stores dims
+// [8 j, 8 j + 8).  Which lane handles which window offset depends on the offset alone, so a chunked decode (the carried-state stream)
+// and the one-shot decode sum in the same order.  fp32 throughout, __expf as in k_attn.
+// ================================================================================================
+template <int D, int WMAX>
+__global__ __launch_bounds__(256, 2) void k_attn_win(AttnArgs a) {
+    constexpr int QB = 32, ROWS = QB + WMAX - 1, LDK = D + 4, NM = (WMAX + 7) / 8;
+    __shared__ __attribute__((aligned(16))) float Ks[ROWS][LDK];
+    __shared__ __attribute__((aligned(16))) float Vs[ROWS][LDK];
+    const int kvh = blockIdx.x, q0 = blockIdx.y * QB, bi = blockIdx.z;
+    const int tid = threadIdx.x, qi = tid >> 3, j = tid & 7;
+    const int base = a.pos_scalar, W = a.window;
+    const int wbase = base + q0 - (W - 1);                       // position of staged row 0
+    const int last = base + a.n_new - 1;                         // newest position the cache holds
+    const int slot = a.slot_offset + bi;
+    const int page = a.page_table[(size_t)slot * a.pages_per_slot];
+    const int P = 1 << a.page_shift;
+    const size_t cb = (((size_t)page * a.n_layers + a.layer) * a.nkv + kvh) * (size_t)P * D;
+    const float* kc = a.kcache + cb;
+    const float* vc = a.vcache + cb;
+    const int nrows = QB + W - 1;
+    for (int i = tid; i < nrows * (D / 4); i += 256) {
+        const int r = i / (D / 4), c4 = (i % (D / 4)) * 4, pos = wbase + r;
+        const bool ok = pos >= 0 && pos <= last;
+        const int pc = pos < 0 ? 0 : (pos <= last ? pos : last);
+        float4 kv = *reinterpret_cast<const float4*>(kc + (size_t)pc * D + c4);
+        float4 vv = *reinterpret_cast<const float4*>(vc + (size_t)pc * D + c4);
+        if (!ok) { kv = make_float4(0.f, 0.f, 0.f, 0.f); vv = kv; }
+        *reinterpret_cast<float4*>(&Ks[r][c4]) = kv;
+        *reinterpret_cast<float4*>(&Vs[r][c4]) = vv;
+    }
+    const int inew = q0 + qi;
+    const int irow = inew < a.n_new ? inew : a.n_new - 1;         // clamped: the loads stay unconditional, the store is masked
+    const float* qrow = a.qkv + (size_t)(bi * a.n_new + irow) * a.ld_qkv + kvh * D;
+    float q[D];
+#pragma unroll
+    for (int d = 0; d < D; d += 4) {
+        const float4 v = *reinterpret_cast<const float4*>(qrow + d);
+        q[d] = v.x; q[d + 1] = v.y; q[d + 2] = v.z; q[d + 3] = v.w;
+    }
+    __syncthreads();
+    auto dpp8_sum = [&](float v) __attribute__((always_inline)) -> float {
+        v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));
+        v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));
+        v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));   // row_half_mirror: the other quad of the 8 lanes
+        return v;
+    };
+    auto dpp8_max = [&](float v) __attribute__((always_inline)) -> float {
+        v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true)));
+        v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true)));
+        v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true)));
+        return v;
+    };
+    const int p = base + irow;                                   // this query's position; its window = positions [p - W + 1, p]
+    float sc[NM];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int m = 0; m < NM; ++m) {
+        const int o = j + 8 * m;                                 // window offset; key position p - (W - 1) + o, staged row qi + o
+        const bool valid = o < W && p - (W - 1) + o >= 0;
+        const int row = o < W ? (irow - q0) + o : 0;
+        float s = 0.f;
+#pragma unroll
+        for (int d = 0; d < D; d += 4) {
+            const float4 kv = *reinterpret_cast<const float4*>(&Ks[row][d]);
+            s = fmaf(q[d], kv.x, s); s = fmaf(q[d + 1], kv.y, s); s = fmaf(q[d + 2], kv.z, s); s = fmaf(q[d + 3], kv.w, s);
+        }
+        sc[m] = valid ? s * a.scale : -INFINITY;
+        mx = fmaxf(mx, sc[m]);
+    }
+    mx = dpp8_max(mx);                                           // offset W - 1 (the query's own position) is always valid: finite
+    float l = 0.f, oacc[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) oacc[d] = 0.f;
+#pragma unroll
+    for (int m = 0; m < NM; ++m) {
+        const int o = j + 8 * m;
+        const int row = o < W ? (irow - q0) + o : 0;
+        const float pw = __expf(sc[m] - mx);                     // exp(-inf) = 0 for masked offsets
+        l += pw;
+#pragma unroll
+        for (int d = 0; d < D; d += 4) {
+            const float4 vv = *reinterpret_cast<const float4*>(&Vs[row][d]);
+            oacc[d] = fmaf(pw, vv.x, oacc[d]); oacc[d + 1] = fmaf(pw, vv.y, oacc[d + 1]); oacc[d + 2] = fmaf(pw, vv.z, oacc[d + 2]); oacc[d + 3] = fmaf(pw, vv.w, oacc[d + 3]);
+        }
+    }
+    l = dpp8_sum(l);
+#pragma unroll
+    for (int d = 0; d < D; ++d) oacc[d] = dpp8_sum(oacc[d]);
+    if (inew < a.n_new) {
+        float* out = a.out + (size_t)(bi * a.n_new + inew) * a.ld_out + kvh * D;
+        const float inv = 1.0f / l;
+#pragma unroll
+        for (int e8 = 0; e8 < D / 8; ++e8) {                     // lane j stores dims [8 j, 8 j + 8) (statically indexed registers: a select per 8-dim block)
+            if (j == e8) {
+#pragma unroll
+                for (int e = 0; e < 8; e += 4)
+                    *reinterpret_cast<float4*>(out + e8 * 8 + e) = make_float4(oacc[e8 * 8 + e] * inv, oacc[e8 * 8 + e + 1] * inv, oacc[e8 * 8 + e + 2] * inv, oacc[e8 * 8 + e + 3] * inv);
+            }
+        }
+    }
+}
+static bool attn_win_ok(const AttnArgs& a) {
+    static const bool off = getenv("Q3TTS_ATTN_WIN") && atoi(getenv("Q3TTS_ATTN_WIN")) == 0;   // A/B knob: back to k_attn
+    return !off && a.window > 0 && a.window <= 72 && !a.new_from_raw && a.d == 64 && a.nq == a.nkv && a.n_splits == 1 && a.out != nullptr && a.oh == nullptr &&
+           a.pos_dev == nullptr && a.slot_map == nullptr && a.pages_per_slot == 1 && !a.kv_bf16 && a.n_new >= 1 && a.ld_qkv % 4 == 0 && a.ld_out % 4 == 0 &&
+           (a.n_new + 31) / 32 <= 65535 && a.nb <= 65535;
+}
+
 static void launch_attn_stream(const AttnArgs& a, hipStream_t s) {
     const int grp = a.nq / a.nkv;
     if (a.d != 128 || a.n_new != 1 || !a.new_from_raw || a.window != 0 || a.slot_map != nullptr || a.nq % a.nkv || grp != 2)
@@ -1369,6 +1485,11 @@ static void launch_attn_stream(const AttnArgs& a, hipStream_t s) {
 
 void launch_attn(const AttnArgs& a, hipStream_t s) {
     if (a.stream) { launch_attn_stream(a, s); return; }
+    if (attn_win_ok(a)) {   // the codec decoder's windowed attention: 32 queries per workgroup over a shared K / V window
+        hipLaunchKernelGGL((k_attn_win<64, 72>), dim3(a.nkv, (a.n_new + 31) / 32, a.nb), dim3(256), 0, s, a);
+        Q3_HIP_CHECK(hipGetLastError());
+        return;
+    }
     const int grp = a.nq / a.nkv;
     if (grp < 1 || grp > ATT_MAX_GRP || a.nq % a.nkv) throw Error("attn: unsupported GQA group size");
     if (a.n_new > ATT_MAX_NEW && a.new_from_raw) throw Error("attn: too many new tokens per launch");
