@@ -1366,15 +1366,25 @@ __global__ __launch_bounds__(256, 2) void k_attn_win(AttnArgs a) {
     const float* kc = a.kcache + cb;
     const float* vc = a.vcache + cb;
     const int nrows = QB + W - 1;
-    for (int i = tid; i < nrows * (D / 4); i += 256) {
+    constexpr int NIT = (ROWS * (D / 4) + 255) / 256;             // every staging load of the workgroup in flight at once (7 x 2 per thread)
+    float4 kst[NIT], vst[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int i = tid + 256 * it;
         const int r = i / (D / 4), c4 = (i % (D / 4)) * 4, pos = wbase + r;
-        const bool ok = pos >= 0 && pos <= last;
-        const int pc = pos < 0 ? 0 : (pos <= last ? pos : last);
-        float4 kv = *reinterpret_cast<const float4*>(kc + (size_t)pc * D + c4);
-        float4 vv = *reinterpret_cast<const float4*>(vc + (size_t)pc * D + c4);
-        if (!ok) { kv = make_float4(0.f, 0.f, 0.f, 0.f); vv = kv; }
-        *reinterpret_cast<float4*>(&Ks[r][c4]) = kv;
-        *reinterpret_cast<float4*>(&Vs[r][c4]) = vv;
+        const int pc = pos < 0 ? 0 : (pos <= last ? pos : last);  // clamped address, zeroed below: rows before the utterance / past its end
+        kst[it] = *reinterpret_cast<const float4*>(kc + (size_t)pc * D + c4);
+        vst[it] = *reinterpret_cast<const float4*>(vc + (size_t)pc * D + c4);
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int i = tid + 256 * it;
+        const int r = i / (D / 4), c4 = (i % (D / 4)) * 4, pos = wbase + r;
+        if (r < nrows) {
+            const bool ok = pos >= 0 && pos <= last;
+            *reinterpret_cast<float4*>(&Ks[r][c4]) = ok ? kst[it] : make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(&Vs[r][c4]) = ok ? vst[it] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
     }
     const int inew = q0 + qi;
     const int irow = inew < a.n_new ? inew : a.n_new - 1;         // clamped: the loads stay unconditional, the store is masked
@@ -1451,7 +1461,8 @@ static bool attn_win_ok(const AttnArgs& a) {
     static const bool off = getenv("Q3TTS_ATTN_WIN") && atoi(getenv("Q3TTS_ATTN_WIN")) == 0;   // A/B knob: back to k_attn
     return !off && a.window > 0 && a.window <= 72 && !a.new_from_raw && a.d == 64 && a.nq == a.nkv && a.n_splits == 1 && a.out != nullptr && a.oh == nullptr &&
            a.pos_dev == nullptr && a.slot_map == nullptr && a.pages_per_slot == 1 && !a.kv_bf16 && a.n_new >= 1 && a.ld_qkv % 4 == 0 && a.ld_out % 4 == 0 &&
-           (a.n_new + 31) / 32 <= 65535 && a.nb <= 65535;
+           (a.n_new + 31) / 32 <= 65535 && a.nb <= 65535 &&
+           (size_t)a.n_new * a.nb >= 128;   // below that the launch is a handful of workgroups: k_attn's one-per-query grid is quicker (F = 64: 37.8 vs 38.6 us/frame)
 }
 
 static void launch_attn_stream(const AttnArgs& a, hipStream_t s) {

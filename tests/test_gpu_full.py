@@ -594,6 +594,40 @@ def test_codec_carried_state_streaming_full_size(full):
     assert float(np.abs(win - whole).max()) < 2e-5
 
 
+def test_batched_job_codec_equals_single_utterance_decodes_full_size():
+    """0.6B dims, a scheduler job of 5 utterances with ragged lengths (3 to 150 frames, two of them past the pre-transformer's 72-frame window):
+    the job's vocoder phase runs the pre-transformer over all utterances in one row block (one cache block and one grid z per utterance
+    in the windowed attention, padded rows masked) — every utterance's PCM equals the decode of its own codes alone, and the longest
+    one the fp32 oracle.  Reference: one run_vocoder call per utterance, /root/reference/src/tts_onnx.cpp:759-776."""
+    import q3tts
+    cfg = q3tts.default_config("0.6b")
+    eng = q3tts.Engine(cfg, device=0, max_batch=5, max_ctx=192)
+    orc = qo.Oracle(to_ocfg(cfg), max_ctx=192)
+    try:
+        eng.fill_synthetic(seed=0)
+        for name, shape in eng.tensor_infos():
+            if name.startswith("cd."):
+                orc.set_tensor(name, eng.get_tensor(name, shape))
+        rng = np.random.default_rng(23)
+        toks = [frame_tokens(rng.integers(0, 151643, int(n))) for n in (4, 9, 2, 12, 6)]
+        caps = np.array([150, 3, 97, 40, 72], np.int32)
+        sp = q3tts.Sampling(temperature=0.8, top_p=0.95, top_k=50, max_new_tokens=150)
+        pcm, codes, nfr = eng.synthesize_batch(toks, sp, lang=0, seed=6, ignore_eos=True, max_new_per_utt=caps)
+        assert np.array_equal(nfr, caps)
+        worst = 0.0
+        for u in range(5):
+            alone = eng.codec_decode(codes[u])
+            assert pcm[u].shape == alone.shape == (eng.codec_decode_len(int(caps[u])),)
+            worst = max(worst, float(np.abs(pcm[u] - alone).max()))
+        ref = orc.vocoder(codes[0])
+        err = float(np.sqrt(np.mean((pcm[0] - ref) ** 2)))
+        print("batched job codec, 5 utterances of %s frames: max |job - alone| %.3g, 150-frame utterance rms vs oracle %.3g" % (caps.tolist(), worst, err))
+        assert worst < 2e-5 and err < 1e-4, (worst, err)
+    finally:
+        eng.close()
+        orc.close()
+
+
 @pytest.mark.parametrize("F", [300, 2048])
 def test_codec_long_utterances_full_size(full, F):
     """300 and 2048 frames (BASELINE configs[1]'s length: 3.9 M samples) at 0.6B dims — 300 is four times the pre-transformer's 72-frame attention window (the sliding-window mask is active on most rows),
