@@ -582,6 +582,88 @@ void k_conv_split(ConvKArgs a0) {
         // chunk again (L2 hits, never used) instead of being skipped.
         const int c_last = c_first + n_chunks - 1;
         int it = 0;
+        if constexpr (!WLO) {   // launch_conv: the two-product kernels are peeled for 7-tap convs only
+            // Two taps per block barrier (7-tap convs, weights exact in fp16): without a lo plane half of each weight buffer is idle, so
+            // it takes a second TAP's tile: Bs[buf][0 | 1] = taps (2 p, 2 p + 1), and the seventh tap travels as the second tile of the
+            // pair (5, 6) whose first tile is not used.  4 barriers and 4 weight hand-overs per chunk instead of 7, 48 MFMAs between
+            // them instead of 24; same products in the same order (chunk-major, taps ascending): bit-identical sums.  Straight-line
+            // per chunk like the tap form below, for the same reason (in-order s_waitcnt): the next chunk's rows go out in pair 1.
+            constexpr int PBT2 = 2 * TN * SEG, PB2 = (PBT2 + 255) / 256;
+            static_assert(PBT2 % 256 == 0, "paired taps: the two tiles' segments divide over the 256 threads");
+            u32x4 breg2[PB2];
+            unsigned boff2[PB2];
+            const unsigned tap_bytes = (unsigned)a.C_out * (unsigned)a.C_in * 2u;
+#pragma unroll
+            for (int i = 0; i < PB2; ++i) {
+                const int idx = tid + 256 * i;
+                const int t2 = idx / (TN * SEG), rem = idx % (TN * SEG), brow = rem / SEG, bseg = rem % SEG;
+                const int co = co0 + brow;
+                const int cc = co < a.C_out ? co : a.C_out - 1;
+                boff2[i] = (t2 ? tap_bytes : 0u) + ((unsigned)cc * (unsigned)a.C_in + (unsigned)bseg * 8u) * 2u;
+            }
+            auto loadB2 = [&](int ci0, int tbase) __attribute__((always_inline)) {
+                const char* const base = w_bytes + ((size_t)tbase * a.C_out * a.C_in + ci0) * 2;
+#pragma unroll
+                for (int i = 0; i < PB2; ++i) breg2[i] = *reinterpret_cast<const u32x4*>(base + boff2[i]);
+            };
+            auto storeB2 = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+                for (int i = 0; i < PB2; ++i) {
+                    const int idx = tid + 256 * i;
+                    const int t2 = idx / (TN * SEG), rem = idx % (TN * SEG), brow = rem / SEG, bseg = rem % SEG;
+                    *reinterpret_cast<u32x4*>(&Bs[buf][t2][brow][bseg * 8]) = breg2[i];
+                }
+            };
+            auto mfma_tap = [&](int buf, int t2, int shift) __attribute__((always_inline)) {
+                const int roff = halo - shift + wm * MB * 32 + (lane & 31);
+#pragma unroll
+                for (int st = 0; st < KC / 16; ++st) {
+                    const int kof = st * 16 + 8 * (lane >> 5);
+                    f16x8 ah[MB], al[MB], bh[NB];
+#pragma unroll
+                    for (int i = 0; i < MB; ++i) {
+                        ah[i] = *reinterpret_cast<const f16x8*>(&As[0][roff + i * 32][kof]);
+                        al[i] = *reinterpret_cast<const f16x8*>(&As[1][roff + i * 32][kof]);
+                    }
+#pragma unroll
+                    for (int j = 0; j < NB; ++j) bh[j] = *reinterpret_cast<const f16x8*>(&Bs[buf][t2][wn * NB * 32 + j * 32 + (lane & 31)][kof]);
+#pragma unroll
+                    for (int i = 0; i < MB; ++i)
+#pragma unroll
+                        for (int j = 0; j < NB; ++j) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                        }
+                }
+            };
+            // pair p of a chunk: tiles from tap tb(p) = 0, 2, 4, 5; pair 3 uses its second tile only (tap 6)
+            auto pair = [&](int chunk, int nchunk, int p, bool rows_in, bool rows_out) __attribute__((always_inline)) {
+                const int buf = it & 1;
+                CP_MARK_L(1 + it * 4);
+                if (rows_in) { __syncthreads(); storeA(); }
+                storeB2(buf);
+                CP_MARK_L(2 + it * 4);
+                __syncthreads();
+                CP_MARK_L(3 + it * 4);
+                const bool more = p < 3;
+                loadB2((more ? chunk : nchunk) * KC, more ? (p == 2 ? 5 : 2 * (p + 1)) : 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (rows_out) loadA(nchunk * KC);
+                __builtin_amdgcn_sched_barrier(0);
+                if (p < 3) { mfma_tap(buf, 0, (6 - 2 * p) * a.dil); mfma_tap(buf, 1, (5 - 2 * p) * a.dil); }
+                else mfma_tap(buf, 1, 0);
+                CP_MARK_L(4 + it * 4);
+                ++it;
+            };
+            loadB2(c_first * KC, 0);      // the prologue's loadB fetched tap 0's tile only: both tiles of pair 0 again, behind the rows
+            for (int chunk = c_first; chunk <= c_last; ++chunk) {
+                const int nchunk = chunk < c_last ? chunk + 1 : c_last;
+                pair(chunk, nchunk, 0, true, false);
+                pair(chunk, nchunk, 1, false, true);
+                pair(chunk, nchunk, 2, false, false);
+                pair(chunk, nchunk, 3, false, false);
+            }
+        } else {
         auto tap = [&](int chunk, int nchunk, int ti, bool rows_in, bool rows_out) {
             const int buf = it & 1;
             CP_MARK_L(1 + it * 4);
@@ -605,6 +687,7 @@ void k_conv_split(ConvKArgs a0) {
             tap(chunk, nchunk, 1, false, true);
             tap(chunk, nchunk, 2, false, false);
             for (int ti = 3; ti < NT; ++ti) tap(chunk, nchunk, ti, false, false);
+        }
         }
     } else {
     int chunk = c_first, ti = 0;
@@ -832,7 +915,7 @@ template <int MB, int NB, int WM, int WN, bool APL = false>
 static void launch_split_pa(const ConvKArgs& a, dim3 grid, int extra, hipStream_t s) {
     constexpr int P0 = WM * MB;
     if constexpr (MB == 2 && NB == 3) {   // the decoder's 7-tap convs on 256 x 96 tiles
-        if (a.peel_taps && !a.transposed && a.taps >= 3 && extra >= 1) {
+        if (a.peel_taps && !a.transposed && (a.wlo ? a.taps >= 3 : a.taps == 7) && extra >= 1) {   // two-product kernels: the peeled loop is built for 7 taps (tap pairs)
             if (extra == 1) Q3_CS(grid, s, a, MB, NB, WM, WN, P0 + 1, 32, 2, false, true, APL);
             else Q3_CS(grid, s, a, MB, NB, WM, WN, P0 + 2, 32, 2, false, true, APL);
             return;
@@ -1020,7 +1103,7 @@ void launch_conv(const ConvArgs& c, hipStream_t s) {
         if (nb > 1) a.batch_tiles = tiles;
         const dim3 g((unsigned)(tiles * nb), 1, 1);
 #define Q3_FUSED(PA_, PEEL_, APL_) Q3_CS(g, s, a, 2, 3, 4, 1, PA_, 32, 2, true, PEEL_, APL_)
-        const bool peel = a.peel_taps && c.taps >= 3, wide = extra > 1;
+        const bool peel = a.peel_taps && (a.wlo ? c.taps >= 3 : c.taps == 7), wide = extra > 1;
         if (a.in_planes) { if (peel) { if (wide) Q3_FUSED(10, true, true); else Q3_FUSED(9, true, true); } else { if (wide) Q3_FUSED(10, false, true); else Q3_FUSED(9, false, true); } }
         else { if (peel) { if (wide) Q3_FUSED(10, true, false); else Q3_FUSED(9, true, false); } else { if (wide) Q3_FUSED(10, false, false); else Q3_FUSED(9, false, false); } }
 #undef Q3_FUSED

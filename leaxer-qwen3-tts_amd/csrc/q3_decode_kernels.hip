@@ -1432,8 +1432,10 @@ __global__ __launch_bounds__(256, 2) void k_attn_win(AttnArgs a) {
 #pragma unroll
     for (int m = 0; m < NM; ++m) {
         const int o = j + 8 * m;
-        const int row = o < W ? (irow - q0) + o : 0;
-        const float pw = __expf(sc[m] - mx);                     // exp(-inf) = 0 for masked offsets
+        // masked offsets read the query's own row (always in range and finite) with weight exp(-inf) = 0: a padded utterance's rows
+        // behind it may hold anything, and 0 x NaN would reach the sum
+        const int row = sc[m] != -INFINITY ? (irow - q0) + o : (irow - q0) + W - 1;
+        const float pw = __expf(sc[m] - mx);
         l += pw;
 #pragma unroll
         for (int d = 0; d < D; d += 4) {

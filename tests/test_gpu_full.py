@@ -618,7 +618,12 @@ def test_batched_job_codec_equals_single_utterance_decodes_full_size():
         for u in range(5):
             alone = eng.codec_decode(codes[u])
             assert pcm[u].shape == alone.shape == (eng.codec_decode_len(int(caps[u])),)
-            worst = max(worst, float(np.abs(pcm[u] - alone).max()))
+            d = np.abs(pcm[u] - alone)
+            if float(d.max()) > 2e-5:      # say where: which utterance, which frame, how many samples
+                off = np.nonzero(d > 2e-5)[0]
+                print("utterance %d (%d frames): |job - alone| %.3g at sample %d (frame %.2f), %d samples off between %d and %d; a second decode alone differs by %.3g"
+                      % (u, caps[u], float(d.max()), int(d.argmax()), d.argmax() / 1920.0, off.size, off[0], off[-1], float(np.abs(eng.codec_decode(codes[u]) - alone).max())))
+            worst = max(worst, float(d.max()))
         ref = orc.vocoder(codes[0])
         err = float(np.sqrt(np.mean((pcm[0] - ref) ** 2)))
         print("batched job codec, 5 utterances of %s frames: max |job - alone| %.3g, 150-frame utterance rms vs oracle %.3g" % (caps.tolist(), worst, err))
