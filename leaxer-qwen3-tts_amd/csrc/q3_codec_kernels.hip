@@ -582,7 +582,9 @@ void k_conv_split(ConvKArgs a0) {
         // chunk again (L2 hits, never used) instead of being skipped.
         const int c_last = c_first + n_chunks - 1;
         int it = 0;
-        if constexpr (!WLO) {   // launch_conv: the two-product kernels are peeled for 7-tap convs only
+        // the fused unit's dilation-9 variant (PA = 10) keeps one tap per barrier: with the pairs' third weight register it spills
+        constexpr bool PAIRS = !WLO && !(F2 && PA == 10);
+        if constexpr (PAIRS) {   // launch_conv: the two-product kernels are peeled for 7-tap convs only
             // Two taps per block barrier (7-tap convs, weights exact in fp16): without a lo plane half of each weight buffer is idle, so
             // it takes a second TAP's tile: Bs[buf][0 | 1] = taps (2 p, 2 p + 1), and the seventh tap travels as the second tile of the
             // pair (5, 6) whose first tile is not used.  4 barriers and 4 weight hand-overs per chunk instead of 7, 48 MFMAs between
