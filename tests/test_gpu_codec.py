@@ -244,3 +244,48 @@ def test_conv_ab_switches_reproduce_the_default_bit_for_bit():
     base = run({})
     for knob in ("Q3TTS_CONV_NO_XCD_MAP", "Q3TTS_CONV_GENERIC_EPILOGUE", "Q3TTS_CONV_NO_PEEL", "Q3TTS_CONV_FP32_ACT"):
         assert run({knob: "1"}) == base, knob
+
+
+_AB_CHILD_DUMP = r"""
+import sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+import q3tts
+cfg = q3tts.default_config("0.6b")
+eng = q3tts.Engine(cfg, device=0, max_batch=1, max_ctx=256)
+eng.fill_synthetic(seed=5)
+out = {}
+for F in (70, 200):                    # 200 frames: the pre-transformer's launches have >= 128 rows (k_attn_win), windows slide (72 < 200)
+    codes = np.random.default_rng(F).integers(0, cfg.cd_codebook, (F, cfg.n_groups)).astype(np.int64)
+    out["f%d" % F] = eng.codec_decode(codes)
+np.savez(sys.argv[2], **out)
+"""
+
+
+def test_round4_codec_kernels_against_the_kernels_they_replace(tmp_path):
+    """k_conv_cout1_reg (the last conv with its weights in registers) and k_attn_win (32 queries per workgroup over a shared K / V window)
+    add up in a different order than k_conv_cout1 and k_attn: the full-size decoder's PCM under Q3TTS_COUT1_LDS=1 / Q3TTS_ATTN_WIN=0 (the
+    old kernels) stays within 4e-6 of the default (measured 2e-7 and 1.2e-6).  Child processes: the switches are read once."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(root, "leaxer-qwen3-tts_amd")
+
+    def run(tag, extra):
+        env = dict(os.environ)
+        env.update(extra)
+        path = str(tmp_path / (tag + ".npz"))
+        r = subprocess.run([sys.executable, "-c", _AB_CHILD_DUMP, pkg, path], env=env, capture_output=True, text=True, timeout=280)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return np.load(path)
+
+    base = run("base", {})
+    for tag, knob in (("cout1_lds", {"Q3TTS_COUT1_LDS": "1"}), ("attn", {"Q3TTS_ATTN_WIN": "0"})):
+        got = run(tag, knob)
+        for k in ("f70", "f200"):
+            d = float(np.abs(got[k] - base[k]).max())
+            print("codec %s %s: max |old kernel - new kernel| %.3g" % (tag, k, d))
+            assert got[k].shape == base[k].shape and 0.0 <= d < 4e-6, (tag, k, d)
+        if tag == "attn":      # 70 frames stay on k_attn either way (launches under 128 rows): identical
+            assert np.array_equal(got["f70"], base["f70"])
