@@ -80,6 +80,7 @@ static __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + exp
 // k_gemv
 // ================================================================================================
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));   // one 16-byte access (HIP's float4 STRUCT is split into scalars by SROA and re-merged only where the vectorizer can prove it)
 template <bool NT>
 static __device__ __forceinline__ uint4 ldw(const bf16_t* p) {
     u32x4 v;
@@ -457,7 +458,10 @@ static void gemv1_launch(const GemvArgs& a, int grid, hipStream_t s) {
     if (comb) { Q3_G1(EPI_RESIDUAL, false, true); return; }
     switch (a.epi) {
     case EPI_STORE: if (norm) Q3_G1(EPI_STORE, true, false); else Q3_G1(EPI_STORE, false, false); break;
-    case EPI_SWIGLU: if (norm) Q3_G1(EPI_SWIGLU, true, false); else Q3_G1(EPI_SWIGLU, false, false); break;
+    case EPI_SWIGLU:   // gemv1_rw never gives a SwiGLU launch four rows per wave (two weight matrices: the register file); not instantiated
+        if constexpr (RW <= 3) { if (norm) Q3_G1(EPI_SWIGLU, true, false); else Q3_G1(EPI_SWIGLU, false, false); }
+        else throw Error("gemv: SwiGLU fast path takes at most 3 rows per wave");
+        break;
     case EPI_RESIDUAL: Q3_G1(EPI_RESIDUAL, false, false); break;
     case EPI_BIAS: Q3_G1(EPI_BIAS, false, false); break;
     default: Q3_G1(EPI_BIAS_SILU, false, false); break;
@@ -470,8 +474,10 @@ static void gemv1_rwsel(const GemvArgs& a, hipStream_t s) {
     const int grid = (a.N + 4 * rw - 1) / (4 * rw);
     if (rw == 1) gemv1_launch<MT, NCH, 1>(a, grid, s);
     else if (rw == 2) gemv1_launch<MT, NCH, 2>(a, grid, s);
-    else if (rw == 3) gemv1_launch<MT, NCH, 3>(a, grid, s);
-    else gemv1_launch<MT, NCH, 4>(a, grid, s);
+    else if constexpr (NCH <= 6) {   // K = 6144 stops at two rows per wave (gemv1_rw): the wider variants would spill and are not instantiated
+        if (rw == 3) gemv1_launch<MT, NCH, 3>(a, grid, s);
+        else gemv1_launch<MT, NCH, 4>(a, grid, s);
+    } else throw Error("gemv: K = 6144 fast path takes at most 2 rows per wave");
 }
 template <int MT>
 static void gemv1_nch(const GemvArgs& a, hipStream_t s) {
@@ -1354,6 +1360,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_win(AttnArgs a) {
     constexpr int QB = 32, ROWS = QB + WMAX - 1, LDK = D + 4, NM = (WMAX + 7) / 8;
     __shared__ __attribute__((aligned(16))) float Ks[ROWS][LDK];
     __shared__ __attribute__((aligned(16))) float Vs[ROWS][LDK];
+    __shared__ float Ss[NM][256];                                // a thread's scores between the two passes (its own column: no conflicts, no barrier)
     const int kvh = blockIdx.x, q0 = blockIdx.y * QB, bi = blockIdx.z;
     const int tid = threadIdx.x, qi = tid >> 3, j = tid & 7;
     const int base = a.pos_scalar, W = a.window;
@@ -1367,14 +1374,14 @@ __global__ __launch_bounds__(256, 2) void k_attn_win(AttnArgs a) {
     const float* vc = a.vcache + cb;
     const int nrows = QB + W - 1;
     constexpr int NIT = (ROWS * (D / 4) + 255) / 256;             // every staging load of the workgroup in flight at once (7 x 2 per thread)
-    float4 kst[NIT], vst[NIT];
+    f32x4 kst[NIT], vst[NIT];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int i = tid + 256 * it;
         const int r = i / (D / 4), c4 = (i % (D / 4)) * 4, pos = wbase + r;
         const int pc = pos < 0 ? 0 : (pos <= last ? pos : last);  // clamped address, zeroed below: rows before the utterance / past its end
-        kst[it] = *reinterpret_cast<const float4*>(kc + (size_t)pc * D + c4);
-        vst[it] = *reinterpret_cast<const float4*>(vc + (size_t)pc * D + c4);
+        kst[it] = *reinterpret_cast<const f32x4*>(kc + (size_t)pc * D + c4);
+        vst[it] = *reinterpret_cast<const f32x4*>(vc + (size_t)pc * D + c4);
     }
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
@@ -1382,8 +1389,8 @@ __global__ __launch_bounds__(256, 2) void k_attn_win(AttnArgs a) {
         const int r = i / (D / 4), c4 = (i % (D / 4)) * 4, pos = wbase + r;
         if (r < nrows) {
             const bool ok = pos >= 0 && pos <= last;
-            *reinterpret_cast<float4*>(&Ks[r][c4]) = ok ? kst[it] : make_float4(0.f, 0.f, 0.f, 0.f);
-            *reinterpret_cast<float4*>(&Vs[r][c4]) = ok ? vst[it] : make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<f32x4*>(&Ks[r][c4]) = ok ? kst[it] : f32x4{0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4*>(&Vs[r][c4]) = ok ? vst[it] : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     }
     const int inew = q0 + qi;
@@ -1392,7 +1399,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_win(AttnArgs a) {
     float q[D];
 #pragma unroll
     for (int d = 0; d < D; d += 4) {
-        const float4 v = *reinterpret_cast<const float4*>(qrow + d);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(qrow + d);
         q[d] = v.x; q[d + 1] = v.y; q[d + 2] = v.z; q[d + 3] = v.w;
     }
     __syncthreads();
@@ -1409,9 +1416,12 @@ __global__ __launch_bounds__(256, 2) void k_attn_win(AttnArgs a) {
         return v;
     };
     const int p = base + irow;                                   // this query's position; its window = positions [p - W + 1, p]
-    float sc[NM];
+    // The two passes over the window are ROLLED loops with the scores parked in the thread's own LDS column between them.  Unrolled (round
+    // 4) hipcc hoisted the LDS reads of all nine offsets as far as 256 registers allow and past that: 68 bytes of scratch per lane, and —
+    // with HIP's float4 struct split into scalars — 382 of the kernel's LDS reads came out as two-dword reads, each with its own address
+    // register.  Same operations in the same order: the sums are bit-identical to the unrolled kernel's.
     float mx = -INFINITY;
-#pragma unroll
+#pragma unroll 1
     for (int m = 0; m < NM; ++m) {
         const int o = j + 8 * m;                                 // window offset; key position p - (W - 1) + o, staged row qi + o
         const bool valid = o < W && p - (W - 1) + o >= 0;
@@ -1419,27 +1429,29 @@ __global__ __launch_bounds__(256, 2) void k_attn_win(AttnArgs a) {
         float s = 0.f;
 #pragma unroll
         for (int d = 0; d < D; d += 4) {
-            const float4 kv = *reinterpret_cast<const float4*>(&Ks[row][d]);
+            const f32x4 kv = *reinterpret_cast<const f32x4*>(&Ks[row][d]);
             s = fmaf(q[d], kv.x, s); s = fmaf(q[d + 1], kv.y, s); s = fmaf(q[d + 2], kv.z, s); s = fmaf(q[d + 3], kv.w, s);
         }
-        sc[m] = valid ? s * a.scale : -INFINITY;
-        mx = fmaxf(mx, sc[m]);
+        const float scv = valid ? s * a.scale : -INFINITY;
+        Ss[m][tid] = scv;
+        mx = fmaxf(mx, scv);
     }
     mx = dpp8_max(mx);                                           // offset W - 1 (the query's own position) is always valid: finite
     float l = 0.f, oacc[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) oacc[d] = 0.f;
-#pragma unroll
+#pragma unroll 1
     for (int m = 0; m < NM; ++m) {
         const int o = j + 8 * m;
+        const float scv = Ss[m][tid];
         // masked offsets read the query's own row (always in range and finite) with weight exp(-inf) = 0: a padded utterance's rows
         // behind it may hold anything, and 0 x NaN would reach the sum
-        const int row = sc[m] != -INFINITY ? (irow - q0) + o : (irow - q0) + W - 1;
-        const float pw = __expf(sc[m] - mx);
+        const int row = scv != -INFINITY ? (irow - q0) + o : (irow - q0) + W - 1;
+        const float pw = __expf(scv - mx);
         l += pw;
 #pragma unroll
         for (int d = 0; d < D; d += 4) {
-            const float4 vv = *reinterpret_cast<const float4*>(&Vs[row][d]);
+            const f32x4 vv = *reinterpret_cast<const f32x4*>(&Vs[row][d]);
             oacc[d] = fmaf(pw, vv.x, oacc[d]); oacc[d + 1] = fmaf(pw, vv.y, oacc[d + 1]); oacc[d + 2] = fmaf(pw, vv.z, oacc[d + 2]); oacc[d + 3] = fmaf(pw, vv.w, oacc[d + 3]);
         }
     }
@@ -1454,7 +1466,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_win(AttnArgs a) {
             if (j == e8) {
 #pragma unroll
                 for (int e = 0; e < 8; e += 4)
-                    *reinterpret_cast<float4*>(out + e8 * 8 + e) = make_float4(oacc[e8 * 8 + e] * inv, oacc[e8 * 8 + e + 1] * inv, oacc[e8 * 8 + e + 2] * inv, oacc[e8 * 8 + e + 3] * inv);
+                    *reinterpret_cast<f32x4*>(out + e8 * 8 + e) = f32x4{oacc[e8 * 8 + e] * inv, oacc[e8 * 8 + e + 1] * inv, oacc[e8 * 8 + e + 2] * inv, oacc[e8 * 8 + e + 3] * inv};
             }
         }
     }
@@ -1804,12 +1816,12 @@ void launch_cp_attn_oproj(const CpAttnOprojArgs& a, int n_new, hipStream_t s) {
 #define Q3_CAO(NEW, UU) hipLaunchKernelGGL((k_cp_attn_oproj<NEW, UU>), grid, block, 0, s, a.W, a.qkv, (const float*)a.kc, (const float*)a.vc, (const float*)a.x, \
         a.rope_cos, a.rope_sin, (uint32_t)a.base | (uint32_t)a.page_tokens << 16, (uint32_t)a.N | (uint32_t)a.ldx << 16, a)
     if (n_new == 1) { if (U == 1) Q3_CAO(1, 1); else if (U == 2) Q3_CAO(1, 2); else if (U == 3) Q3_CAO(1, 3); else Q3_CAO(1, 4); }
-    else { if (U == 1) Q3_CAO(2, 1); else if (U == 2) Q3_CAO(2, 2); else if (U == 3) Q3_CAO(2, 3); else Q3_CAO(2, 4); }
+    else { if (U == 1) Q3_CAO(2, 1); else if (U == 2) Q3_CAO(2, 2); else Q3_CAO(2, 3); }   // two new rows over > 12 cached tokens: refused by cp_attn_oproj_ok (the <2, 4> variant spilled; the predictor's two-row pass starts at base 0)
 #undef Q3_CAO
     Q3_HIP_CHECK(hipGetLastError());
 }
 bool cp_attn_oproj_ok(const CpAttnOprojArgs& a, int n_new) {
-    return (n_new == 1 || n_new == 2) && a.nq == 16 && a.nkv == 8 && a.d == 128 && a.K == 2048 && a.base >= 0 && a.base <= 16 &&
+    return (n_new == 1 || (n_new == 2 && a.base <= 12)) && a.nq == 16 && a.nkv == 8 && a.d == 128 && a.K == 2048 && a.base >= 0 && a.base <= 16 &&
            a.base + n_new <= a.page_tokens && a.q_norm && a.k_norm && a.ld_qkv == 4096 && a.N >= 1 && a.N < 65536 && a.ldx < 65536 && a.page_tokens < 65536;
 }
 

@@ -1,21 +1,39 @@
-import subprocess, sys, re
-L='/opt/rocm/lib/llvm/bin/'
-obj = sys.argv[1]
-pat = sys.argv[2] if len(sys.argv) > 2 else ''
-subprocess.run([L+'llvm-objcopy','-O','binary','--only-section=.hip_fatbin',obj,'/tmp/kres.fat'],check=True)
-out = subprocess.run([L+'clang-offload-bundler','--list','--type=o','--input=/tmp/kres.fat'],capture_output=True,text=True)
-tgt=[l for l in out.stdout.split() if 'gfx950' in l][0]
-subprocess.run([L+'clang-offload-bundler','--unbundle','--type=o','--input=/tmp/kres.fat','--targets='+tgt,'--output=/tmp/kres.co'],check=True)
-md = subprocess.run([L+'llvm-readelf','--notes','/tmp/kres.co'],capture_output=True,text=True).stdout
-blocks = md.split('  - .agpr_count')
-rows=[]
-for b in blocks[1:]:
-    name = re.search(r'\.name:\s+(\S+)', b).group(1)
-    g = lambda k: re.search(r'\.'+k+r':\s+(\d+)', b)
-    rows.append((name, g('vgpr_count').group(1), re.match(r':\s+(\d+)', b).group(1), g('sgpr_count').group(1), g('private_segment_fixed_size').group(1), g('group_segment_fixed_size').group(1)))
-dem = subprocess.run(['c++filt'], input='\n'.join(r[0] for r in rows), capture_output=True, text=True).stdout.split('\n')
-for r, d in zip(rows, dem):
-    d = d.replace('void q3::','')
-    d = re.sub(r'\(.*','',d)
-    if pat and pat not in d: continue
-    print(f"{d[:90]:90s} vgpr {r[1]:>4} agpr {r[2]:>4} sgpr {r[3]:>4} scratch {r[4]:>5} lds {r[5]:>6}")
+"""Register / scratch / LDS use of every gfx950 kernel in a built code object (the product .so or a .o):
+
+    python tools/kernel_resources.py leaxer-qwen3-tts_amd/libq3tts_hip.so [name-substring]
+
+`kernel_table(path)` is what tests/test_kernel_resources.py imports: the product library must not hold a kernel with a private
+(scratch) segment — a spill costs a memory round trip per access, and scratch on nine concurrent vocoder lane streams was round 4's
+suspect for the one wrong batched-vocoder result."""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+LLVM = "/opt/rocm/lib/llvm/bin/"
+
+
+def kernel_table(obj):
+    """[(demangled name, vgpr, agpr, sgpr, scratch bytes, lds bytes)] for the gfx950 code object bundled in `obj`."""
+    with tempfile.TemporaryDirectory() as tmp:
+        fat, co = os.path.join(tmp, "k.fat"), os.path.join(tmp, "k.co")
+        subprocess.run([LLVM + "llvm-objcopy", "-O", "binary", "--only-section=.hip_fatbin", obj, fat], check=True)
+        out = subprocess.run([LLVM + "clang-offload-bundler", "--list", "--type=o", "--input=" + fat], capture_output=True, text=True, check=True)
+        tgt = [l for l in out.stdout.split() if "gfx950" in l][0]
+        subprocess.run([LLVM + "clang-offload-bundler", "--unbundle", "--type=o", "--input=" + fat, "--targets=" + tgt, "--output=" + co], check=True)
+        md = subprocess.run([LLVM + "llvm-readelf", "--notes", co], capture_output=True, text=True, check=True).stdout
+    rows = []
+    for b in md.split("  - .agpr_count")[1:]:
+        g = lambda k: int(re.search(r"\." + k + r":\s+(\d+)", b).group(1))
+        rows.append((re.search(r"\.name:\s+(\S+)", b).group(1), g("vgpr_count"), int(re.match(r":\s+(\d+)", b).group(1)), g("sgpr_count"),
+                     g("private_segment_fixed_size"), g("group_segment_fixed_size")))
+    dem = subprocess.run(["c++filt"], input="\n".join(r[0] for r in rows), capture_output=True, text=True).stdout.split("\n")
+    return [(re.sub(r"\(.*", "", d.replace("void q3::", "")),) + r[1:] for r, d in zip(rows, dem)]
+
+
+if __name__ == "__main__":
+    pat = sys.argv[2] if len(sys.argv) > 2 else ""
+    for name, vgpr, agpr, sgpr, scratch, lds in kernel_table(sys.argv[1]):
+        if pat in name:
+            print(f"{name[:90]:90s} vgpr {vgpr:>4} agpr {agpr:>4} sgpr {sgpr:>4} scratch {scratch:>5} lds {lds:>6}")
