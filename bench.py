@@ -44,6 +44,7 @@ import numpy as np  # noqa: E402
 FRAME_SECONDS = 0.08  # 12.5 Hz codec frames
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 IM_START, ASSISTANT, TTS_BOS, TTS_EOS, IM_END = 151644, 77091, 151672, 151673, 151645
+HOOKS = False   # --hooks: engines honour the A/B environment knobs (measurement runs only)
 
 
 def layer_bytes(Hw, nq, nkv, d, ffn):
@@ -330,7 +331,7 @@ def run_workload(q3tts, cfg, local_rank, B, F, sp_kwargs, steps, warmup, rank, n
                  warm_frames=0):
     """W untimed warmup steps, then exactly K timed steps bracketed by barrier + synchronize; returns the engine and the raw measurements."""
     eng = q3tts.Engine(cfg, device=local_rank, max_batch=B, max_ctx=F + 32,
-                       flags=(q3tts.FLAG_NO_GRAPH if no_graph else 0) | (q3tts.FLAG_KV_BF16 if kv_bf16 else 0))
+                       flags=(q3tts.FLAG_NO_GRAPH if no_graph else 0) | (q3tts.FLAG_KV_BF16 if kv_bf16 else 0) | (q3tts.FLAG_TEST_HOOKS if HOOKS else 0))
     eng.fill_synthetic(seed=0)
     sp = q3tts.Sampling(max_new_tokens=F, **sp_kwargs)
     rng = np.random.default_rng(1 + rank)
@@ -377,23 +378,39 @@ def run_workload(q3tts, cfg, local_rank, B, F, sp_kwargs, steps, warmup, rank, n
 
 def dry_launch(args, rank, world):
     """--dry-launch: the launch / rendezvous / gather plumbing of the N-rank bench on CPU (gloo), no GPU and no synthesis: every rank
-    contributes fabricated codes for its shard and checks what the gather returns.  tests/test_dist_cpu.py runs it with --gpus 2."""
+    contributes fabricated ragged codes for its B utterances at the REAL payload shape ([B][--frames][16] int32 per rank: 8.4 MB at
+    configs[3]'s 64 x 2048) and checks what the gather returns; the ranks also partition a seeded list of world x B text lengths with
+    q3dist.shard_utterances (what a job with one global utterance list does) and report the shards' sizes and loads.
+    tests/test_dist_cpu.py runs it with --gpus 2 and, configs[3]'s shape, --gpus 8 --batch 64."""
+    import torch
     import torch.distributed as dist
     import q3dist
     assert world == args.gpus, f"world_size {world} != --gpus {args.gpus}"
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    B, F, G = args.batch, min(args.frames, 12), 16
-    codes = [np.full((3 + (rank * B + u) % 5, G), rank * B + u, np.int64) for u in range(B)]
+    B, F, G = args.batch, args.frames, 16
+    nfr = lambda g: 1 + (g * 37) % F                      # ragged lengths in [1, F]
+    codes = [np.full((nfr(rank * B + u), G), (rank * B + u) % 2048, np.int64) for u in range(B)]
     lens = [1920 * len(c) - 555 for c in codes]
     dist.barrier()
     t0 = time.perf_counter()
     allc, alln = q3dist.gather_codes(dist, codes, [rank * B + u for u in range(B)], world * B, F, G, pcm_lens=lens)
     dist.barrier()
     dt = time.perf_counter() - t0
-    ok = all(c is not None and len(c) == 3 + g % 5 and (c == g).all() and alln[g] == 1920 * len(c) - 555 for g, c in enumerate(allc))
+    ok = all(c is not None and len(c) == nfr(g) and (c == g % 2048).all() and alln[g] == 1920 * len(c) - 555 for g, c in enumerate(allc))
+    text_lens = np.random.default_rng(7).integers(3, 200, world * B).tolist()
+    mine = q3dist.shard_utterances(text_lens, world, rank)
+    mine_t = torch.tensor([len(mine), int(sum(text_lens[i] for i in mine))], dtype=torch.int64)
+    shards = [torch.zeros(2, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(shards, mine_t)
+    covered = torch.zeros(world * B, dtype=torch.int64)
+    covered[mine] = 1
+    dist.all_reduce(covered)                              # a partition: every utterance on exactly one rank
+    ok = ok and bool((covered == 1).all())
     if rank == 0:
         print(json.dumps({"metric": "dry launch (no GPU work)", "dry_launch": True, "n_gpus": world, "ranks_ok": bool(ok),
-                          "gathered_utterances": len(allc), "gather_ms": round(dt * 1e3, 3), "backend": "gloo"}), flush=True)
+                          "gathered_utterances": len(allc), "gather_ms": round(dt * 1e3, 3), "backend": "gloo",
+                          "payload_mb_per_rank": round(B * F * G * 4 / 1e6, 2), "shard_sizes": [int(s[0]) for s in shards],
+                          "shard_loads": [int(s[1]) for s in shards], "longest_text": int(max(text_lens))}), flush=True)
     dist.destroy_process_group()
     sys.exit(0 if ok else 1)
 
@@ -415,8 +432,12 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay (rocprofv3 kernel tracing "
                                                              "crashes inside hipGraphLaunch on this ROCm; same kernels either way)")
     ap.add_argument("--cpu-frames", type=int, default=160)
+    ap.add_argument("--hooks", action="store_true", help="create the engines with Q3TTS_FLAG_TEST_HOOKS so that the A/B environment knobs "
+                    "(Q3TTS_SEAM, Q3TTS_GEMM3_LA, ...) are honoured — A/B measurement runs only; the line then says so")
     ap.add_argument("--dry-launch", action="store_true", help="only the N-rank launch + gloo rendezvous + gather plumbing, on CPU")
     args = ap.parse_args()
+    global HOOKS
+    HOOKS = args.hooks
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args, sys.argv[1:])          # never returns
@@ -503,6 +524,8 @@ def main():
             "first_2s_audio_latency_ms": first_audio,
             "roofline": roofline_record(cfg, B, F, step_ms, args.model, args.kv_bf16),
         }
+        if HOOKS:
+            out["ab_knobs"] = {k: v for k, v in os.environ.items() if k.startswith("Q3TTS_")}   # an A/B run: which knobs were set
         if dist is not None:
             out["multi_gpu"] = {"backend": "nccl (RCCL)", "world_size": world, "gathered_utterances": gathered["utterances"],
                                 "gathered_pcm_samples": gathered["pcm_samples"],

@@ -142,10 +142,15 @@ void* q3tts_stream(q3tts_engine* e);
 int q3tts_codec_decode_chunked_host(q3tts_engine* e, const int64_t* codes, int F, int chunk_frames, int left_context, float* pcm, int64_t cap,
                                     int64_t* out_len);
 /* Streaming decode with CARRIED state (round 4): a stream keeps the pre-transformer's K / V rows of every layer and its output rows, so a
- * push of n new frames costs O(n + a few frames of conv look-back) instead of a decode of the history, and is exact: the concatenation of the
- * pushes equals q3tts_codec_decode_host of all the frames (same kernels on the same rows).  max_frames bounds the stream's length; the
- * buffers (about 0.07 MB per frame of capacity at 0.6B dims) are reused by the next stream of the same size.  q3tts_codec_decode_chunked_host
- * with left_context >= F and q3tts_slot_codec_decode_range_host with left_context >= frame_begin run on such a stream by themselves. */
+ * push of n new frames costs O(n + a few frames of conv look-back) instead of a decode of the history.  The concatenation of the pushes
+ * equals q3tts_codec_decode_host of all the frames to fp32 rounding (<= 2e-5 asserted in tests/test_gpu_codec.py, ~1e-6 measured): the
+ * arithmetic is the same, but a short push picks other GEMM tile shapes / split-K and, under 128 rows, k_attn instead of k_attn_win, so
+ * sums associate differently.  max_frames bounds the stream's length (and sizes the shared RoPE tables), NOT its memory: the state is a
+ * sliding buffer of the last window - 1 = 71 K / V rows per layer and the last 12 output rows plus room for the largest push so far
+ * (round 5; 16.8 MB of K / V + 0.4 MB of rows per stream at 0.6B dims for pushes of up to 114 frames, whatever max_frames is; a larger push
+ * grows it once).  A stream's buffers are kept when it ends and reused by the next stream; they are freed with the engine.
+ * q3tts_codec_decode_chunked_host with left_context >= F and q3tts_slot_codec_decode_range_host with left_context >= frame_begin run on
+ * such a stream by themselves (one per slot, created at the slot's first exact range). */
 int q3tts_codec_stream_begin(q3tts_engine* e, int max_frames, int* stream_id);
 /* codes[n_frames][n_groups] of the NEXT n_frames frames of the stream -> the samples those frames own (*out_len of them) */
 int q3tts_codec_stream_push_host(q3tts_engine* e, int stream_id, const int64_t* codes, int n_frames, float* pcm, int64_t cap, int64_t* out_len);
@@ -278,6 +283,10 @@ int q3tts_stage_profile(q3tts_engine* e, int n_steps, double* out_ms /* [4] */);
  * What the slots emit afterwards is numerically meaningless; the decode step streams a context of the requested depth, which is what the
  * rocprofv3 passes over run_decode's attention (tts_onnx.cpp:667-732) at 1000-2000 tokens of context need (tools/ctx_bench.py). */
 int q3tts_measure_skip_frames(q3tts_engine* e, int n_frames);
+/* Test hook (engines created with Q3TTS_FLAG_TEST_HOOKS only): fills the vocoder's reusable workspace (lane arenas, batched-front arena,
+ * streaming arena, pinned PCM staging, the job's code rows) with 0xFF bytes = NaN, so that a later decode which reads anything it did
+ * not write itself produces NaN instead of plausible stale samples (tests/test_gpu_codec_stress.py). */
+int q3tts_test_poison_workspace(q3tts_engine* e);
 /* Parity aid: ONE eager decode step of the armed slots (they advance like q3tts_decode_steps(1)) that also returns, for `slot`, the
  * logits row each of the frame's n_groups decisions was sampled from — out[n_groups][cols], cols >= max(vocab, sub_vocab); row 0 the
  * code0 logits (run_decode's output, before suppression), row j the code predictor's logits for sub-code j-1 (run_code_predictor,

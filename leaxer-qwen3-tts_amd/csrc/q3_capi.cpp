@@ -629,6 +629,12 @@ int q3tts_measure_skip_frames(q3tts_engine* h, int n_frames) {
     return 0;
     Q3_API_END(h)
 }
+int q3tts_test_poison_workspace(q3tts_engine* h) {
+    Q3_API_BEGIN(h)
+    h->e->codec_poison();
+    return 0;
+    Q3_API_END(h)
+}
 int q3tts_step_logits_host(q3tts_engine* h, int slot, float* out, int cols) {
     Q3_API_BEGIN(h)
     if (!out) throw q3::Error("step_logits: null output");

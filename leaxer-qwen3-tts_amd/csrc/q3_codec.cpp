@@ -58,7 +58,11 @@ struct CodecW {
     int submits = 0, fail_at_submit = 0;   // fault injection for the tests: the fail_at_submit-th submit of a job throws
     // carried-state streaming decode (Engine::codec_stream_*): per stream the pre-transformer's K / V rows of every layer ([layer][k | v]
     // [head][P][d]) and its output rows [cap][hidden]; work buffers of one push in a grow-only arena of their own
-    struct Stream { bool used = false; int cap = 0, P = 0, pshift = 0, n_done = 0; float* kv = nullptr; float* hpost = nullptr; };
+    // Both are SLIDING buffers (round 5; they used to hold every position up to the stream's capacity: 268 MB of K / V per stream at
+    // max_ctx 2112).  kv: [layer][k | v][head][P][d] with P = pow2 >= 2 (window - 1) + the largest push so far; `kv_rows` rows are stored,
+    // the last of them position n_done - 1; when a push would not fit, the newest window - 1 rows move to the front (the only ones a
+    // later query can reach).  hpost: [h_cap][hidden], `h_rows` stored, the newest codec_stage_b_context() rows kept the same way.
+    struct Stream { bool used = false; int cap = 0, P = 0, pshift = 0, n_done = 0, kv_rows = 0, h_cap = 0, h_rows = 0; float* kv = nullptr; float* hpost = nullptr; };
     std::vector<Stream> streams;
     char* stream_arena = nullptr; size_t stream_arena_bytes = 0;
     std::vector<int> slot_stream;          // slot -> stream id (-1: none): q3tts_slot_codec_decode_range_host's implicit stream
@@ -331,7 +335,7 @@ int64_t Engine::codec_run(const int32_t* codes_dev, int F, float** pcm_dev, int 
         // SnakeBeta outputs travel between the decoder's convs as (hi, lo) fp16 pairs (ConvArgs::in_planes / out2_planes): the producer's
         // epilogue splits each element once, the consumers stage it without converting.  Needs every decoder conv on the split-precision
         // path with 96-multiple widths (0.6B / 1.7B: 1536 .. 96); the last activation feeds the fp32 C_out = 1 conv and stays fp32.
-        static const bool fp32_act = getenv("Q3TTS_CONV_FP32_ACT") != nullptr || getenv("Q3TTS_CONV_GENERIC_EPILOGUE") != nullptr;   // A/B switches
+        const bool fp32_act = knob("Q3TTS_CONV_FP32_ACT") != nullptr || knob("Q3TTS_CONV_GENERIC_EPILOGUE") != nullptr;   // A/B switches
         bool act_planes = !fp32_act && !W.planes.empty() && CH % 32 == 0 && W.planes.count(W.conv_in.w) && !W.snake_pre.empty();
         for (int i = 0, Cw = D; i <= c.cd_n_blocks; ++i, Cw /= 2) act_planes = act_planes && Cw % 96 == 0;
         for (const CodecW::Block& B : W.blocks) {
@@ -365,7 +369,7 @@ int64_t Engine::codec_run(const int32_t* codes_dev, int F, float** pcm_dev, int 
                 // snake(x) with a tap halo reaching into its neighbours' rows, so the next layer's snake(x') goes to the OTHER buffer
                 // (ns <-> nt); x itself is updated in place (every element is read and written by the same thread).
                 const auto p2 = W.planes.find(R.c2.w);
-                if (Co == 96 && p2 != W.planes.end() && W.planes.count(R.c1.w) && !getenv("Q3TTS_NO_FUSED_RES")) {
+                if (Co == 96 && p2 != W.planes.end() && W.planes.count(R.c1.w) && !knob("Q3TTS_NO_FUSED_RES")) {
                     ConvArgs a; a.in = ns; a.T_in = To; a.C_in = Co; a.out = nx; a.T_out = To; a.C_out = Co; a.W = R.c1.w; a.bias = R.c1.b;
                     a.taps = 7; a.dil = dil[u]; a.mid_alpha = R.a2.alpha; a.mid_beta = R.a2.beta;
                     a.W2 = R.c2.w; a.W2h = p2->second.hi; a.W2l = p2->second.lo; a.w2_scale_inv = p2->second.scale_inv; a.w2_lo_zero = p2->second.lo_zero; a.bias2 = R.c2.b;
@@ -655,20 +659,59 @@ int Engine::codec_stream_begin(int max_frames) {
     for (size_t i = 0; i < W.streams.size(); ++i) if (!W.streams[i].used) { sid = (int)i; break; }
     if (sid < 0) { W.streams.emplace_back(); sid = (int)W.streams.size() - 1; }
     CodecW::Stream& S = W.streams[(size_t)sid];
-    int P = 1, pshift = 0;
-    while (P < max_frames) { P <<= 1; ++pshift; }
-    if (S.cap < max_frames || S.P != P) {
-        sync();
-        if (S.kv) (void)hipFree(S.kv);
-        if (S.hpost) (void)hipFree(S.hpost);
-        S.kv = nullptr; S.hpost = nullptr;
-        Q3_HIP_CHECK(hipMalloc((void**)&S.kv, (size_t)c.cd_layers * 2 * c.cd_heads * P * c.cd_head_dim * sizeof(float)));
-        Q3_HIP_CHECK(hipMalloc((void**)&S.hpost, (size_t)max_frames * c.cd_hidden * sizeof(float)));
-        S.cap = max_frames; S.P = P; S.pshift = pshift;
-    }
+    // buffers sized for pushes of up to 64 frames (16.8 MB of K / V + 0.4 MB of rows at 0.6B dims, whatever max_frames is); a larger
+    // push grows them (codec_stream_fit).  Kept across streams: begin / end of a pooled stream allocate nothing.
+    S.kv_rows = 0; S.h_rows = 0;                       // nothing of the buffers' previous stream is kept
+    codec_stream_fit(sid, std::min(max_frames, 64));
+    S.cap = max_frames;
     S.used = true; S.n_done = 0;
-    codec_rope_tables(P);
+    int P = 1;
+    while (P < max_frames) P <<= 1;
+    codec_rope_tables(P);   // positions are absolute in the RoPE tables (grow-only, shared)
     return sid;
+}
+
+// make room for a push of n frames: K / V rows [kv_rows, kv_rows + n) and hpost rows [h_rows, h_rows + n) exist afterwards, the rows a
+// later query / the stages behind the transformer still need are kept (moved to the front of the buffer, or into a larger one)
+void Engine::codec_stream_fit(int sid, int n) {
+    CodecW& W = *codec;
+    CodecW::Stream& S = W.streams[(size_t)sid];
+    const int CH = c.cd_hidden, NH = c.cd_heads, HD = c.cd_head_dim;
+    const int keep = std::max(c.cd_window - 1, 0), ctx = codec_stage_b_context();
+    const size_t blocks = (size_t)c.cd_layers * 2 * NH;   // (layer, k | v, head) row blocks of P rows each
+    if (S.kv == nullptr || S.kv_rows + n > S.P) {
+        const int keepN = std::min(keep, S.kv_rows);
+        if (S.kv == nullptr || 2 * keep + n > S.P) {       // grow (or first allocation): P rows so that an in-place move never overlaps
+            int P = 64, pshift = 6;
+            while (P < 2 * keep + n) { P <<= 1; ++pshift; }
+            float* nk = nullptr;
+            Q3_HIP_CHECK(hipMalloc((void**)&nk, blocks * P * HD * sizeof(float)));
+            if (S.kv && keepN > 0)
+                Q3_HIP_CHECK(hipMemcpy2DAsync(nk, (size_t)P * HD * sizeof(float), S.kv + (size_t)(S.kv_rows - keepN) * HD, (size_t)S.P * HD * sizeof(float),
+                                              (size_t)keepN * HD * sizeof(float), blocks, hipMemcpyDeviceToDevice, stream));
+            if (S.kv) { sync(); (void)hipFree(S.kv); }
+            S.kv = nk; S.P = P; S.pshift = pshift;
+        } else if (keepN > 0) {                            // kv_rows > P - n >= 2 keep: source rows [kv_rows - keepN, kv_rows) lie behind the destination rows [0, keepN)
+            Q3_HIP_CHECK(hipMemcpy2DAsync(S.kv, (size_t)S.P * HD * sizeof(float), S.kv + (size_t)(S.kv_rows - keepN) * HD, (size_t)S.P * HD * sizeof(float),
+                                          (size_t)keepN * HD * sizeof(float), blocks, hipMemcpyDeviceToDevice, stream));
+        }
+        S.kv_rows = keepN;
+    }
+    if (S.hpost == nullptr || S.h_rows + n > S.h_cap) {
+        const int ctxN = std::min(ctx, S.h_rows);
+        if (S.hpost == nullptr || 2 * ctx + n > S.h_cap) {
+            const int cap = 2 * ctx + std::max(n, 64);
+            float* nh = nullptr;
+            Q3_HIP_CHECK(hipMalloc((void**)&nh, (size_t)cap * CH * sizeof(float)));
+            if (S.hpost && ctxN > 0)
+                Q3_HIP_CHECK(hipMemcpyAsync(nh, S.hpost + (size_t)(S.h_rows - ctxN) * CH, (size_t)ctxN * CH * sizeof(float), hipMemcpyDeviceToDevice, stream));
+            if (S.hpost) { sync(); (void)hipFree(S.hpost); }
+            S.hpost = nh; S.h_cap = cap;
+        } else if (ctxN > 0) {                             // h_rows > h_cap - n >= 2 ctx: no overlap
+            Q3_HIP_CHECK(hipMemcpyAsync(S.hpost, S.hpost + (size_t)(S.h_rows - ctxN) * CH, (size_t)ctxN * CH * sizeof(float), hipMemcpyDeviceToDevice, stream));
+        }
+        S.h_rows = ctxN;
+    }
 }
 
 void Engine::codec_stream_end(int sid) {
@@ -692,6 +735,8 @@ int64_t Engine::codec_stream_push_dev(int sid, const int32_t* codes_dev, int n, 
     if (S.n_done + n > S.cap) throw Error("codec_stream_push: more frames than the stream was opened for");
     const int CH = c.cd_hidden, NH = c.cd_heads, HD = c.cd_head_dim, FF = c.cd_ffn;
     const int a0 = S.n_done, b0 = a0 + n, T = n;
+    codec_stream_fit(sid, n);
+    const int k0 = S.kv_rows, h0 = S.h_rows;   // where this push's rows go in the sliding buffers (position a0 = K / V row k0 = hpost row h0)
     auto bytes_of = [](size_t nfloat) { return (nfloat * sizeof(float) + 255) & ~(size_t)255; };
     const size_t kslab_floats = (size_t)32 * 128 * 4096;
     const size_t need = bytes_of((size_t)T * CH) * 3 + bytes_of((size_t)T * 3 * CH) + bytes_of((size_t)T * FF) * 2 + bytes_of(kslab_floats);
@@ -732,11 +777,12 @@ int64_t Engine::codec_stream_push_dev(int sid, const int32_t* codes_dev, int n, 
         launch_rmsnorm_rows(h, L.in_norm, c.cd_rms_eps, T, CH, hn, stream);
         conv(gemm(hn, CH, L.qkv, 3 * CH, qkvb));
         // row t of this push is position a0 + t: the tables and the cache rows start there
-        launch_rope_store(qkvb, 3 * CH, T, NH, NH, HD, W.rope_cos + (size_t)a0 * half, W.rope_sin + (size_t)a0 * half, kc + (size_t)a0 * HD, vc + (size_t)a0 * HD, S.P, stream);
+        launch_rope_store(qkvb, 3 * CH, T, NH, NH, HD, W.rope_cos + (size_t)a0 * half, W.rope_sin + (size_t)a0 * half, kc + (size_t)k0 * HD, vc + (size_t)k0 * HD, S.P, stream);
         AttnArgs a;
         a.qkv = qkvb; a.ld_qkv = 3 * CH; a.out = att; a.ld_out = CH; a.kcache = kc; a.vcache = vc;
         a.page_table = W.page_table; a.pages_per_slot = 1; a.page_shift = S.pshift; a.layer = 0; a.n_layers = 1;
-        a.pos_scalar = a0; a.slot_offset = 0; a.nb = 1; a.n_new = T; a.nq = NH; a.nkv = NH; a.d = HD;
+        a.pos_scalar = k0;   // cache rows are addressed relative to the sliding buffer; every row a window can reach is in it (RoPE is already applied, absolute)
+        a.slot_offset = 0; a.nb = 1; a.n_new = T; a.nq = NH; a.nkv = NH; a.d = HD;
         a.scale = 1.0f / sqrtf((float)HD); a.window = c.cd_window; a.new_from_raw = 0;
         launch_attn(a, stream);
         { ConvArgs g = gemm(att, CH, L.o, CH, h); g.res_scale = L.attn_scale; g.res = h; conv(g); }
@@ -745,18 +791,19 @@ int64_t Engine::codec_stream_push_dev(int sid, const int32_t* codes_dev, int n, 
         { ConvArgs g = gemm(hn, CH, L.gate, FF, gb); g.act = 2; g.mul = ub; conv(g); }
         { ConvArgs g = gemm(gb, FF, L.down, CH, h); g.res_scale = L.mlp_scale; g.res = h; conv(g); }
     }
-    launch_rmsnorm_rows(h, W.norm, c.cd_rms_eps, T, CH, S.hpost + (size_t)a0 * CH, stream);
+    launch_rmsnorm_rows(h, W.norm, c.cd_rms_eps, T, CH, S.hpost + (size_t)h0 * CH, stream);
     // ---- everything behind the transformer over the window [sB, b0) of its kept output rows ----
-    const int sB = std::max(0, a0 - codec_stage_b_context());
+    const int sB = std::max(0, a0 - codec_stage_b_context());   // h0 >= a0 - sB: codec_stream_fit keeps that many rows
     int64_t up = 1;
     for (int i = 0; i < c.cd_n_up; ++i) up *= c.cd_up_ratios[i];
     for (int i = 0; i < c.cd_n_blocks; ++i) up *= c.cd_up_rates[i];
     auto len_of = [&](int nfr) -> int64_t { return nfr <= 0 ? 0 : q3tts_codec_decode_len(&c, nfr); };
     const int64_t first = len_of(a0) - up * sB, n_own = len_of(b0) - len_of(a0);
     float* pcm_d = nullptr;
-    const int64_t n_win = codec_run(nullptr, b0 - sB, &pcm_d, 0, S.hpost + (size_t)sB * CH, 1);
+    if (h0 < a0 - sB) throw Error("codec_stream_push: the kept transformer rows do not cover the look-back window");
+    const int64_t n_win = codec_run(nullptr, b0 - sB, &pcm_d, 0, S.hpost + (size_t)(h0 - (a0 - sB)) * CH, 1);
     if (first < 0 || first + n_own != n_win) throw Error("codec_stream_push: window arithmetic does not match the decoder length formula");
-    S.n_done = b0;
+    S.n_done = b0; S.kv_rows = k0 + n; S.h_rows = h0 + n;
     if (pcm_dev) *pcm_dev = pcm_d + first;
     return n_own;
 }
@@ -814,6 +861,24 @@ void Engine::slot_codec_stream_reset(int slot) {
     const int sid = W.slot_stream[(size_t)slot];
     if (sid >= 0 && W.streams[(size_t)sid].used) codec_stream_end(sid);
     W.slot_stream[(size_t)slot] = -1;
+}
+
+// Test hook (Q3TTS_FLAG_TEST_HOOKS engines): every byte of the vocoder's reusable workspace — lane arenas, the batched front's arena,
+// the streaming arena, the pinned PCM staging buffers, the job's code rows — becomes 0xFF (NaN as fp32 and as fp16), so a decode that
+// reads anything it did not write in the same call shows up as NaN instead of as yesterday's plausible samples.
+void Engine::codec_poison() {
+    if (!(flags & Q3TTS_FLAG_TEST_HOOKS)) throw Error("codec_poison needs Q3TTS_FLAG_TEST_HOOKS");
+    if (!codec) return;
+    CodecW& W = *codec;
+    for (int i = 0; i < W.nlane; ++i) Q3_HIP_CHECK(hipStreamSynchronize(W.lane_stream[i]));
+    for (int i = 0; i < CodecW::NLANE; ++i) {
+        if (W.arena[i]) Q3_HIP_CHECK(hipMemset(W.arena[i], 0xFF, W.arena_bytes[i]));
+        if (W.pinned[i]) memset(W.pinned[i], 0xFF, W.pinned_floats[i] * sizeof(float));
+    }
+    if (W.batch_arena) Q3_HIP_CHECK(hipMemset(W.batch_arena, 0xFF, W.batch_arena_bytes));
+    if (W.stream_arena) Q3_HIP_CHECK(hipMemset(W.stream_arena, 0xFF, W.stream_arena_bytes));
+    if (W.job_codes) Q3_HIP_CHECK(hipMemset(W.job_codes, 0xFF, W.job_codes_n * sizeof(int32_t)));   // -1: clamped to code 0 by the gather, never out of the table
+    Q3_HIP_CHECK(hipDeviceSynchronize());
 }
 
 bool Engine::codec_batchable() const {

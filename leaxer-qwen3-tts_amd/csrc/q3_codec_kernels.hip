@@ -734,7 +734,13 @@ void k_conv_split(ConvKArgs a0) {
             ea1[j] = a.s1_pre[co];
             ib1[j] = a.s1_pre[C2 + co];
         }
+#ifdef Q3_FORCE_SPILL   // tools/build_spill_lib.sh only: the scale takes a round trip through a private (scratch) segment, so that the fused
+        volatile float q3_sp[4];   // units run WITH scratch on the concurrent vocoder lanes (round 4's suspect; tests/test_gpu_codec_stress.py under Q3TTS_LIB)
+        q3_sp[lane & 3] = a.acc_scale;
+        const float sc1 = q3_sp[lane & 3];
+#else
         const float sc1 = a.acc_scale;
+#endif
         a.bias = a.bias2; a.acc_scale = a.acc_scale2;          // from here on `a` describes the second conv's epilogue (no struct copy: it would live in scratch)
         // statically indexed row blocks (a rolled loop over i gives the accumulators a scratch home that the main loop keeps in sync)
         auto unit = [&](auto itag) {
@@ -1048,15 +1054,15 @@ void launch_conv(const ConvArgs& c, hipStream_t s) {
     a.res = c.res; a.res_scale = c.res_scale; a.mul = c.mul; a.act = c.act; a.clamp = c.clamp;
     a.out2 = c.out2; a.s2_alpha = c.snake_alpha; a.s2_beta = c.snake_beta; a.s2_pre = c.snake_pre; a.s1_pre = nullptr;
     a.Wh = c.Wh; a.Wl = c.Wl;
-    static const bool force_wlo = getenv("Q3TTS_CONV_3PRODUCT") != nullptr;   // A/B knob: always the three-product kernels
+    const bool force_wlo = knob("Q3TTS_CONV_3PRODUCT") != nullptr;   // A/B knob: always the three-product kernels
     a.wlo = (c.w_lo_zero && (c.W2h == nullptr || c.w2_lo_zero) && !force_wlo) ? 0 : 1;
     a.acc_scale = 1.0f;
     a.ksplit = 0; a.slab = nullptr; a.batch_tiles = 0;
-    static const bool no_xcd_map = getenv("Q3TTS_CONV_NO_XCD_MAP") != nullptr;   // A/B switch
+    const bool no_xcd_map = knob("Q3TTS_CONV_NO_XCD_MAP") != nullptr;   // A/B switch
     a.xcd_map = no_xcd_map ? 0 : 1;
-    static const bool no_fast_epi = getenv("Q3TTS_CONV_GENERIC_EPILOGUE") != nullptr;
+    const bool no_fast_epi = knob("Q3TTS_CONV_GENERIC_EPILOGUE") != nullptr;
     a.no_fast_epi = no_fast_epi ? 1 : 0;
-    static const bool no_peel = getenv("Q3TTS_CONV_NO_PEEL") != nullptr;
+    const bool no_peel = knob("Q3TTS_CONV_NO_PEEL") != nullptr;
     a.peel_taps = no_peel ? 0 : 1;
     a.in_planes = c.in_planes ? 1 : 0; a.out2_planes = c.out2_planes ? 1 : 0;
     if (c.in_planes || c.out2_planes) {   // only between convs of the split-precision path whose tiles have the plane variants
@@ -1072,7 +1078,7 @@ void launch_conv(const ConvArgs& c, hipStream_t s) {
     dim3 grid((rows + CT_M - 1) / CT_M, (c.C_out + CT_N - 1) / CT_N, c.transposed ? c.stride : 1);
     if (rows <= 0) return;
     if (c.C_out == 1 && !c.transposed && c.C_in == 96 && c.taps <= 8 && (c.taps - 1) * c.dil <= 64 && c.out && !c.out2 && !c.res && !c.mul &&
-        !c.res_scale && c.act == 0 && !getenv("Q3TTS_COUT1_LDS")) {   // Q3TTS_COUT1_LDS: the LDS-staged kernel (A/B knob)
+        !c.res_scale && c.act == 0 && !knob("Q3TTS_COUT1_LDS")) {   // Q3TTS_COUT1_LDS: the LDS-staged kernel (A/B knob)
         const int to1 = CO1R_ROWS - (c.taps - 1) * c.dil, tiles = (c.T_out + to1 - 1) / to1;
         if (nb > 1) a.batch_tiles = tiles;
         const dim3 g1((unsigned)(tiles * nb));

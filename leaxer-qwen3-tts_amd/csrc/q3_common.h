@@ -21,6 +21,17 @@ struct Error {
     explicit Error(std::string m) : msg(std::move(m)) {}
 };
 
+// A/B knobs of the measurement scripts and the test suite (Q3TTS_SEAM, Q3TTS_GEMM3_LA, Q3TTS_CONV_NO_PEEL, Q3TTS_ATTN_STREAM_*, ...; the
+// full list is in INTEGRATION.md).  knob() answers like getenv() ONLY while at least one engine created with Q3TTS_FLAG_TEST_HOOKS is
+// alive in the process, and nullptr otherwise: a stray environment variable cannot change which kernels a production engine launches.
+// Read at every use (no caching): a test may flip a knob between two calls.  Defined in q3_engine.cpp.
+const char* knob(const char* name);
+struct KnobScope {   // member of Engine: holds the process-wide count of hook-enabled engines for the engine's lifetime
+    bool on = false;
+    void enable();
+    ~KnobScope();
+};
+
 // fp32 -> bf16, round-to-nearest-even (inputs are finite weights)
 inline bf16_t f32_to_bf16(float f) {
     uint32_t u;

@@ -1472,7 +1472,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_win(AttnArgs a) {
     }
 }
 static bool attn_win_ok(const AttnArgs& a) {
-    static const bool off = getenv("Q3TTS_ATTN_WIN") && atoi(getenv("Q3TTS_ATTN_WIN")) == 0;   // A/B knob: back to k_attn
+    const bool off = knob("Q3TTS_ATTN_WIN") && atoi(knob("Q3TTS_ATTN_WIN")) == 0;   // A/B knob: back to k_attn
     return !off && a.window > 0 && a.window <= 72 && !a.new_from_raw && a.d == 64 && a.nq == a.nkv && a.n_splits == 1 && a.out != nullptr && a.oh == nullptr &&
            a.pos_dev == nullptr && a.slot_map == nullptr && a.pages_per_slot == 1 && !a.kv_bf16 && a.n_new >= 1 && a.ld_qkv % 4 == 0 && a.ld_out % 4 == 0 &&
            (a.n_new + 31) / 32 <= 65535 && a.nb <= 65535 &&
@@ -1523,7 +1523,7 @@ void launch_attn(const AttnArgs& a, hipStream_t s) {
     if (a.n_splits > 1 && (a.chunk >> a.page_shift) + 1 > 4) throw Error("attn: a split may touch at most 4 KV pages");
     if (a.n_splits == 1 && !a.identity_pages && a.pages_per_slot > 4 && a.window == 0) throw Error("attn: one split over more than 4 table-mapped KV pages");
     const bool tiny_ctx0 = a.n_splits == 1 && a.window == 0 && (a.pages_per_slot << a.page_shift) <= 32;
-    static const bool no_tiny = getenv("Q3TTS_NO_ATTN_TINY") != nullptr;   // A/B switch
+    const bool no_tiny = knob("Q3TTS_NO_ATTN_TINY") != nullptr;   // A/B switch
     if (!no_tiny && a.d == 128 && tiny_ctx0 && a.identity_pages && a.pages_per_slot == 1 && a.n_new >= 1 && a.n_new <= 2 && a.slot_map == nullptr &&
         a.pos_dev == nullptr && a.new_from_raw && a.po == nullptr && (a.out || a.oh) && a.nb >= 2 && a.pos_scalar + a.n_new <= 32 && a.qkv_nslab >= 1 && a.qkv_nslab <= 4) {
         const dim3 g((unsigned)((a.nb * a.nkv + 1) / 2));

@@ -4,6 +4,7 @@
 #include "q3_engine.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -162,10 +163,19 @@ std::vector<TensorSpec> tensor_specs(const q3tts_config& c) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// A/B knobs: environment variables honoured only while a Q3TTS_FLAG_TEST_HOOKS engine is alive (q3_common.h)
+// ------------------------------------------------------------------------------------------------
+static std::atomic<int> g_hook_engines{0};
+const char* knob(const char* name) { return g_hook_engines.load(std::memory_order_relaxed) > 0 ? getenv(name) : nullptr; }
+void KnobScope::enable() { if (!on) { on = true; g_hook_engines.fetch_add(1, std::memory_order_relaxed); } }
+KnobScope::~KnobScope() { if (on) g_hook_engines.fetch_sub(1, std::memory_order_relaxed); }
+
+// ------------------------------------------------------------------------------------------------
 // construction
 // ------------------------------------------------------------------------------------------------
 Engine::Engine(const q3tts_config& cfg, int device_, int max_batch, int max_ctx_, uint32_t flags_, int64_t kv_pool_tokens)
     : c(cfg), device(device_), B(max_batch), max_ctx(max_ctx_), flags(flags_) {
+    if (flags & Q3TTS_FLAG_TEST_HOOKS) knob_scope.enable();   // before the first knob() below
     if (B < 1 || B > 1024) throw Error("max_batch out of range");
     if (kv_pool_tokens < 0) throw Error("kv_pool_tokens must be >= 0");
     if (c.cp_hidden < 0) throw Error("cp_hidden must be >= 0");
@@ -176,15 +186,15 @@ Engine::Engine(const q3tts_config& cfg, int device_, int max_batch, int max_ctx_
     Q3_HIP_CHECK(hipSetDevice(device));
     // Q3TTS_NULL_STREAM=1 (profiling aid): rocprofv3 --pmc crashes on user-created streams on this ROCm; run on the
     // default stream instead (forces eager launches: the default stream cannot be captured)
-    if (const char* mr = getenv("Q3TTS_MFMA_MIN_ROWS")) mfma_min_rows = std::max(3, atoi(mr));   // A/B knob for the GEMV <-> GEMM crossover
-    if (const char* sv = getenv("Q3TTS_SEAM")) seam_on = atoi(sv) != 0;
-    if (const char* sv = getenv("Q3TTS_SEAM_SPIN")) seam_spin = std::max(1, atoi(sv));
-    attn_keep_splits = getenv("Q3TTS_ATTN_KEEP_SPLITS") != nullptr;
-    if (const char* sv = getenv("Q3TTS_ATTN_STREAM")) attn_stream = atoi(sv) != 0;
-    if (const char* sv = getenv("Q3TTS_ATTN_STREAM_ONE")) attn_stream_one = atoi(sv) != 0;
+    if (const char* mr = knob("Q3TTS_MFMA_MIN_ROWS")) mfma_min_rows = std::max(3, atoi(mr));   // A/B knob for the GEMV <-> GEMM crossover
+    if (const char* sv = knob("Q3TTS_SEAM")) seam_on = atoi(sv) != 0;
+    if (const char* sv = knob("Q3TTS_SEAM_SPIN")) seam_spin = std::max(1, atoi(sv));
+    attn_keep_splits = knob("Q3TTS_ATTN_KEEP_SPLITS") != nullptr;
+    if (const char* sv = knob("Q3TTS_ATTN_STREAM")) attn_stream = atoi(sv) != 0;
+    if (const char* sv = knob("Q3TTS_ATTN_STREAM_ONE")) attn_stream_one = atoi(sv) != 0;
     null_stream = getenv("Q3TTS_NULL_STREAM") && getenv("Q3TTS_NULL_STREAM")[0] == '1';
     if (null_stream) { stream = nullptr; flags |= Q3TTS_FLAG_NO_GRAPH; }
-    else if (const char* cm = getenv("Q3TTS_STREAM_CU_MASK")) {   // experiment aid (tools/overlap_probe.py): this engine's stream on a subset of the CUs;
+    else if (const char* cm = knob("Q3TTS_STREAM_CU_MASK")) {   // experiment aid (tools/overlap_probe.py): this engine's stream on a subset of the CUs;
         const uint32_t pat = (uint32_t)strtoul(cm, nullptr, 16);    // the 32-bit pattern is repeated over the 256-CU mask
         if (pat == 0) throw Error("Q3TTS_STREAM_CU_MASK must be a non-zero hexadecimal CU pattern (a stream with no CU never runs)");
         uint32_t mask[8];
@@ -337,13 +347,13 @@ Engine::Engine(const q3tts_config& cfg, int device_, int max_batch, int max_ctx_
     // 128 cache tokens per workgroup; 64 for engines of one or two slots, where the attention launch is 72 workgroups at a 1041-token context
     // and each one's K/V ingest (128 KB) and softmax loop set its length: b=1 step 2.178 -> 2.156 ms.  Q3TTS_ATTN_CHUNK is the A/B knob.
     talker.chunk = B <= 2 ? 64 : 128;
-    if (const char* ck = getenv("Q3TTS_ATTN_CHUNK")) talker.chunk = atoi(ck) == 64 ? 64 : 128;
+    if (const char* ck = knob("Q3TTS_ATTN_CHUNK")) talker.chunk = atoi(ck) == 64 ? 64 : 128;
     talker.n_splits = (max_ctx + talker.chunk - 1) / talker.chunk;
     if (talker.n_splits > 64) { talker.n_splits = 64; talker.chunk = ((max_ctx + 63) / 64 + 127) / 128 * 128; }
     // k_attn_stream (batched step): splits of whole 64-token pages — 128 KB of K/V per split (256 tokens fp32, 512 bf16: measured against
     // 128 / 256 / 512 / 1024, profiles/r04_attn_stream_ab.txt) unless Q3TTS_ATTN_STREAM_CHUNK says otherwise
     talker.chunk_stream = (talker.kv_bf16 || talker.kv_round) ? 512 : 256;   // kv_round (test aid) mirrors the bf16 cache's splits
-    if (const char* ck = getenv("Q3TTS_ATTN_STREAM_CHUNK")) { const int v = atoi(ck); if (v >= 64 && v % 64 == 0) talker.chunk_stream = v; }
+    if (const char* ck = knob("Q3TTS_ATTN_STREAM_CHUNK")) { const int v = atoi(ck); if (v >= 64 && v % 64 == 0) talker.chunk_stream = v; }
     talker.n_splits_stream = (max_ctx + talker.chunk_stream - 1) / talker.chunk_stream;
     for (DecStack* S : { &talker, &cp }) {
         const int ns = std::max(S->n_splits, S->n_splits_stream);
@@ -469,7 +479,7 @@ static int pick_ksplit(int K) { // K slices per GEMM: 256 (two LDS chunks) per w
 // K slices of the gate/up GEMM under the seam: 4 (256-wide at K = 1024).  Q3TTS_SEAM_GU_KS=8 is the A/B knob for 128-wide slices (twice the
 // workgroups, half the body each, 8 slab pairs per seam): measured slower, 4.90 vs 4.78 ms per b=64 step (profiles/r03_negative_results.txt).
 static int seam_gu_ksplit(int K) {
-    static const int forced = getenv("Q3TTS_SEAM_GU_KS") ? atoi(getenv("Q3TTS_SEAM_GU_KS")) : 0;
+    const int forced = knob("Q3TTS_SEAM_GU_KS") ? atoi(knob("Q3TTS_SEAM_GU_KS")) : 0;
     const int ks4 = std::min(4, pick_ksplit(K));
     return forced == 8 && K % (128 * 8) == 0 && K / 8 == 128 ? 8 : ks4;
 }
@@ -656,7 +666,7 @@ int Engine::head_proj(const bf16_t* Wm, const float* x, int ldx, const float* ga
         g.out = out; g.ldo = ldo; g.M = M; g.N = N; g.K = K; g.epi = EPI_STORE; g.nt = nt;
         // a head of N columns is N / 64 workgroups walking all of K (32 for the predictor's 2048 columns: 14.8 us per launch at 64 rows);
         // with the consumer summing 4 K slices it is 4x the workgroups on a quarter of the bytes each
-        if (slab_out != nullptr && M <= 128 && (K == 512 || K == 1024) && ldo % 4 == 0 && !getenv("Q3TTS_NO_HEAD_SLABS")) {
+        if (slab_out != nullptr && M <= 128 && (K == 512 || K == 1024) && ldo % 4 == 0 && !knob("Q3TTS_NO_HEAD_SLABS")) {
             g.out = slab_out; g.epi = EPI_SLAB; g.slab_rows = M;
             launch_gemm2(g, 4, 4, stream);
             return 4;
@@ -923,7 +933,7 @@ void Engine::code_predictor_dev(const float* last_hidden, const int64_t* code0, 
     s0.codes = dev_codes_d - (size_t)frame * G; s0.max_frames_cap = 1;
     struct SeamScope { Engine& e; explicit SeamScope(Engine& en) : e(en) { e.seam_step = true; e.seam_cnt_used = 0; } ~SeamScope() { e.seam_step = false; } } seam_scope(*this);
     if (seam_gen_d) launch_bump_u32(seam_gen_d, stream);     // the generation this call's seam flags carry (the fused step's first sampler does this)
-    static const bool no_sp = getenv("Q3TTS_NO_SAMPLER_PLANES") != nullptr;
+    const bool no_sp = knob("Q3TTS_NO_SAMPLER_PLANES") != nullptr;
     const bool sp_ok = !no_sp && !cp_projected() && H <= 2048 && H % 256 == 0;
     const bool spn = sp_ok && seam_applies(cp, nb, x_cp1, Hc, false);
     predictor_passes(nb, s0, false, spn, [] {});
@@ -1103,7 +1113,7 @@ void Engine::record_step(int nb) {
     if (trace_d) launch_copy_rows(logits_t + (size_t)trace_slot * V, V, trace_d, trace_cols, 1, V, stream);
     // With the seam's deferred RMSNorm in place the sampler also writes the next predictor pass's input planes (gamma0 * row + the row's
     // sum of squares): the pass then starts at its QKV projection, without an RMSNorm launch in front (15 launches per step).
-    static const bool no_sp = getenv("Q3TTS_NO_SAMPLER_PLANES") != nullptr;   // A/B knob
+    const bool no_sp = knob("Q3TTS_NO_SAMPLER_PLANES") != nullptr;   // A/B knob
     const bool sp_ok = !no_sp && !cp_projected() && H <= 2048 && H % 256 == 0;
     const bool sp0 = sp_ok && seam_applies(cp, nb * 2, x_cp, Hc, false), spn = sp_ok && seam_applies(cp, nb, x_cp1, Hc, false);
     auto with_planes = [&](SampleArgs& s, int mul, int add, const float* lh, int ld_lh) {
@@ -1437,7 +1447,7 @@ int64_t Engine::slot_codec_decode_range(int slot, int a, int b, int left_context
     slot_status(slot, &nf, nullptr);
     if (b > nf) throw Error("codec_decode_range: frames [" + std::to_string(a) + ", " + std::to_string(b) + ") are not generated yet (" + std::to_string(nf) + " so far)");
     // exact mode (the context covers the history): the slot's carried-state stream — O(new frames) per call instead of O(history)
-    const bool no_carry = getenv("Q3TTS_CODEC_NO_CARRY") != nullptr;   // A/B knob, read per call: the windowed decode of the whole history
+    const bool no_carry = knob("Q3TTS_CODEC_NO_CARRY") != nullptr;   // A/B knob, read per call: the windowed decode of the whole history
     if (left_context >= a && a >= 0 && b > a && !no_carry) return slot_codec_stream_range(slot, a, b, pcm, cap);
     return codec_decode_range_dev(codes_d + (size_t)slot * max_frames_cap * c.n_groups, a, b, left_context, pcm, cap);
 }
@@ -1451,7 +1461,7 @@ int64_t Engine::codec_decode_chunked_host(const int64_t* codes, int F, int chunk
         if (codes[i] < 0 || codes[i] >= c.cd_codebook) throw Error("codec_decode: code out of range");
         tmp[i] = (int32_t)codes[i];
     }
-    const bool no_carry = getenv("Q3TTS_CODEC_NO_CARRY") != nullptr;
+    const bool no_carry = knob("Q3TTS_CODEC_NO_CARRY") != nullptr;
     if (left_context >= F && !no_carry) {   // exact mode: one carried-state stream, every chunk a push
         const int sid = codec_stream_begin(F);
         int64_t total = 0;

@@ -73,6 +73,7 @@ public:
     void kv_upload_row(int slot);                        // after KvPool changed a slot's table row behind the engine's back (scheduler policy)
     void kv_release(int slot);
 
+    KnobScope knob_scope;                      // first member: counts this engine among the hook-enabled ones until it is destroyed (also when the constructor throws)
     q3tts_config c;
     int device, B, max_ctx;
     KvPool kv;                                 // q3_kvpool.h: free list, per-slot pages, host mirror of talker.page_table
@@ -115,7 +116,9 @@ public:
     int64_t codec_decode_chunked_host(const int64_t* codes, int F, int chunk, int left_context, float* pcm, int64_t cap);
     // streaming decode with carried state (q3_codec.cpp): a stream keeps the pre-transformer's K / V rows and output rows, a push decodes
     // n new frames in O(n + stage_b_context) work, exactly
+    void codec_poison();                                // test hook: the vocoder's reusable workspace filled with NaN bytes
     int codec_stream_begin(int max_frames);
+    void codec_stream_fit(int sid, int n);              // room for a push of n frames in the stream's sliding K / V and row buffers
     int64_t codec_stream_push_dev(int sid, const int32_t* codes_dev, int n, float** pcm_dev);
     int64_t codec_stream_push_host(int sid, const int64_t* codes, int n, float* pcm, int64_t cap);
     void codec_stream_end(int sid);

@@ -547,7 +547,7 @@ static void gemm3_go(const GemmArgs& a, int ksplit, hipStream_t s) {
     constexpr int LA4 = MTILES <= 4 ? 4 : 2;
     // activation chunks two ahead (default) or all four at once (Q3TTS_GEMM3_LA=4, the A/B knob): issuing 24-32 loads per lane before the
     // first ds_write keeps the wave in its issue queue for ~2.5 us (the CU takes ~50 GB/s); two ahead measured 5.49 vs 5.63 ms per b=64 step
-    static const bool la2 = !(getenv("Q3TTS_GEMM3_LA") && atoi(getenv("Q3TTS_GEMM3_LA")) == 4);
+    const bool la2 = !(knob("Q3TTS_GEMM3_LA") && atoi(knob("Q3TTS_GEMM3_LA")) == 4);
     if (nch == 4 && la2) { hipLaunchKernelGGL((k_gemm3<MTILES, EPI, 4, 2, NT>), grid, block, 0, s, a.W, a.W2, a.xh, a.xl, a.ldx, a.M, a.N, a.K, a); return; }
     if (nch == 2) hipLaunchKernelGGL((k_gemm3<MTILES, EPI, 2, 2, NT>), grid, block, 0, s, a.W, a.W2, a.xh, a.xl, a.ldx, a.M, a.N, a.K, a);
     else hipLaunchKernelGGL((k_gemm3<MTILES, EPI, 4, LA4, NT>), grid, block, 0, s, a.W, a.W2, a.xh, a.xl, a.ldx, a.M, a.N, a.K, a);
@@ -555,7 +555,7 @@ static void gemm3_go(const GemmArgs& a, int ksplit, hipStream_t s) {
 // the shapes k_gemm3 is built for: slab epilogues, K slices of 128 or 256, 16-byte aligned slab rows
 static bool gemm3_ok(const GemmArgs& a, int ksplit) {
     if (a.epi != EPI_SLAB && a.epi != EPI_SLAB2) return false;
-    if (getenv("Q3TTS_GEMM2")) return false;   // A/B knob: the second-generation kernel
+    if (knob("Q3TTS_GEMM2")) return false;   // A/B knob: the second-generation kernel
     const int ksl = a.K / ksplit;
     return a.K % ksplit == 0 && (ksl == 128 || ksl == 256) && a.ldo % 4 == 0 && a.ldx % 8 == 0 && a.M >= 1 && a.M <= 128;
 }
@@ -564,14 +564,14 @@ static void launch_gemm3(const GemmArgs& a, int ksplit, hipStream_t s) {
     // nt weight loads measured on the b=64 step (graph replay, same box): 4.961 ms with, 4.917 ms without — the slab GEMM's launches are
     // bound by their latency chain, not by where the weights come from, and a replayed GEMM body loses what default-policy loads leave in
     // L2 / MALL (MI355X guide, nt-weights: "replayed back to back 0-34 % longer").  Off by default; Q3TTS_GEMM_NT=1 is the A/B knob.
-    static const bool want_nt = getenv("Q3TTS_GEMM_NT") != nullptr;
+    const bool want_nt = knob("Q3TTS_GEMM_NT") != nullptr;
     const bool nt = a.nt && want_nt;
 #define Q3_G3(MT) do { if (dual) { if (nt) gemm3_go<MT, EPI_SLAB2, true>(a, ksplit, s); else gemm3_go<MT, EPI_SLAB2, false>(a, ksplit, s); } \
                        else { if (nt) gemm3_go<MT, EPI_SLAB, true>(a, ksplit, s); else gemm3_go<MT, EPI_SLAB, false>(a, ksplit, s); } } while (0)
     // rows over workgroups (grid z): a 64-row workgroup ingests 32 KB of weights + 64 KB of planes; two 32-row workgroups ingest 32 + 32 KB
     // each (the second one's weights are L2 hits: same XCD under round-robin placement since N / 64 is a multiple of 8) and there are
     // twice as many of them.  Q3TTS_GEMM_ROWSPLIT=0 keeps one workgroup per column tile and K slice (the A/B knob).
-    static const int rowsplit = getenv("Q3TTS_GEMM_ROWSPLIT") ? atoi(getenv("Q3TTS_GEMM_ROWSPLIT")) : 1;
+    const int rowsplit = knob("Q3TTS_GEMM_ROWSPLIT") ? atoi(knob("Q3TTS_GEMM_ROWSPLIT")) : 1;
     if (rowsplit && a.M > 32) { if (a.M <= 64) Q3_G3(2); else Q3_G3(4); return; }
     if (a.M <= 16) Q3_G3(1); else if (a.M <= 32) Q3_G3(2); else if (a.M <= 64) Q3_G3(4); else Q3_G3(8);
 #undef Q3_G3
@@ -823,9 +823,9 @@ template <int KWMAX, int NWV>
 static void gemv16_epi(const GemvArgs& a, hipStream_t s) {
     const dim3 grid((a.N + 15) / 16), block(NWV * 64);
     const bool norm = a.gamma != nullptr;
-    static const bool no_r8 = getenv("Q3TTS_GEMV16_R8") && atoi(getenv("Q3TTS_GEMV16_R8")) == 0;   // A/B knob
+    const bool no_r8 = knob("Q3TTS_GEMV16_R8") && atoi(knob("Q3TTS_GEMV16_R8")) == 0;   // A/B knob
     const bool r8 = a.M <= 8 && !no_r8;
-    static const bool no_gl = getenv("Q3TTS_GEMV16_GL") && atoi(getenv("Q3TTS_GEMV16_GL")) == 0;
+    const bool no_gl = knob("Q3TTS_GEMV16_GL") && atoi(knob("Q3TTS_GEMV16_GL")) == 0;
     const bool gl = norm && !no_gl && (a.K / NWV) % 4 == 0;
 #define Q3_G16_(EPI, NORM, R8_, GL_) hipLaunchKernelGGL((k_gemv16<KWMAX, NWV, EPI, NORM, R8_, GL_>), grid, block, 0, s, a.W, a.W2, a.x, a.gamma, \
         (a.epi == EPI_RESIDUAL ? a.res : a.bias), a.N, a.M, a.ldx, a.ldres, (uint32_t)a.K | (a.nt ? 0x80000000u : 0u), a)

@@ -87,7 +87,29 @@ def test_bench_gpus2_self_launches_two_ranks():
     assert len(lines) == 1, r.stdout
     j = json.loads(lines[0])
     assert j["dry_launch"] and j["n_gpus"] == 2 and j["ranks_ok"] and j["gathered_utterances"] == 6
+    assert j["shard_sizes"] == [3, 3]
     # a rank count that does not match --gpus is refused (exit code 2), not silently run as one rank
     env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-launch"], env=env2, capture_output=True, text=True, timeout=120)
     assert r2.returncode == 2 and "WORLD_SIZE=1" in r2.stderr
+
+
+def test_bench_gpus8_dry_launch_at_configs3_shape():
+    """BASELINE configs[3] at its real shape, without hardware: `bench.py --gpus 8 --dry-launch --batch 64` starts 8 child ranks (gloo,
+    127.0.0.1), every rank contributes 64 ragged utterances in the real payload shape ([64][2048][16] int32 = 8.4 MB per rank), all 512
+    come back from the gather on every rank with their PCM lengths, and q3dist.shard_utterances cuts a 512-utterance list into 8
+    shards of 64 whose text loads differ by less than the longest text.  No scaling curve is measured anywhere (one GPU per call)."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry-launch", "--batch", "64", "--frames", "2048"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["dry_launch"] and j["n_gpus"] == 8 and j["ranks_ok"] and j["gathered_utterances"] == 512
+    assert j["shard_sizes"] == [64] * 8
+    assert max(j["shard_loads"]) - min(j["shard_loads"]) <= j["longest_text"]
+    print("configs[3] dry launch: 8 ranks x 64 utterances, %.1f MB per rank, gather %.0f ms (gloo, CPU)" % (j["payload_mb_per_rank"], j["gather_ms"]))

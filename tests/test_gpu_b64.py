@@ -36,7 +36,7 @@ def wide(request):
            "attn-stream-bf16kv": {"Q3TTS_ATTN_KEEP_SPLITS": "1", "Q3TTS_ATTN_STREAM_CHUNK": "64"}}.get(request.param, {})
     os.environ.update(env)             # read at engine creation
     try:
-        eng = q3tts.Engine(cfg, device=0, max_batch=64, max_ctx=192 if long_run else 64, flags=q3tts.FLAG_KV_BF16 if bf else 0)
+        eng = q3tts.Engine(cfg, device=0, max_batch=64, max_ctx=192 if long_run else 64, flags=(q3tts.FLAG_KV_BF16 if bf else 0) | q3tts.FLAG_TEST_HOOKS)   # the rounds' A/B knobs need the hooks flag
     finally:
         for k in env:
             del os.environ[k]

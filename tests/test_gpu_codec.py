@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(scope="module")
 def pair():
-    eng, orc, w = tiny_pair(seed=2, max_batch=3, max_ctx=192)
+    eng, orc, w = tiny_pair(seed=2, max_batch=3, max_ctx=192, flags=32)   # Q3TTS_FLAG_TEST_HOOKS: the A/B knob Q3TTS_CODEC_NO_CARRY below is honoured only then
     yield eng, orc, w
     eng.close()
     orc.close()
@@ -211,7 +211,7 @@ import numpy as np
 sys.path.insert(0, sys.argv[1])
 import q3tts
 cfg = q3tts.default_config("0.6b")
-eng = q3tts.Engine(cfg, device=0, max_batch=1, max_ctx=128)
+eng = q3tts.Engine(cfg, device=0, max_batch=1, max_ctx=128, flags=q3tts.FLAG_TEST_HOOKS)   # A/B knobs are honoured only by hook-enabled engines
 eng.fill_synthetic(seed=5)
 out = []
 for F in (9, 70):                      # one 256-row tile with a tail; several tiles, transposed-conv phase tails, a narrower last XCD group
@@ -252,7 +252,7 @@ import numpy as np
 sys.path.insert(0, sys.argv[1])
 import q3tts
 cfg = q3tts.default_config("0.6b")
-eng = q3tts.Engine(cfg, device=0, max_batch=1, max_ctx=256)
+eng = q3tts.Engine(cfg, device=0, max_batch=1, max_ctx=256, flags=q3tts.FLAG_TEST_HOOKS if len(sys.argv) < 4 else 0)
 eng.fill_synthetic(seed=5)
 out = {}
 for F in (70, 200):                    # 200 frames: the pre-transformer's launches have >= 128 rows (k_attn_win), windows slide (72 < 200)
@@ -272,20 +272,25 @@ def test_round4_codec_kernels_against_the_kernels_they_replace(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     pkg = os.path.join(root, "leaxer-qwen3-tts_amd")
 
-    def run(tag, extra):
+    def run(tag, extra, hooks=True):
         env = dict(os.environ)
         env.update(extra)
         path = str(tmp_path / (tag + ".npz"))
-        r = subprocess.run([sys.executable, "-c", _AB_CHILD_DUMP, pkg, path], env=env, capture_output=True, text=True, timeout=280)
+        r = subprocess.run([sys.executable, "-c", _AB_CHILD_DUMP, pkg, path] + ([] if hooks else ["nohooks"]), env=env, capture_output=True, text=True, timeout=280)
         assert r.returncode == 0, r.stderr[-2000:]
         return np.load(path)
 
     base = run("base", {})
+    # an engine WITHOUT Q3TTS_FLAG_TEST_HOOKS ignores the knob (round 5: a stray environment variable cannot change a production
+    # engine's kernels): bit-identical to the default
+    ignored = run("ignored", {"Q3TTS_ATTN_WIN": "0"}, hooks=False)
+    for k in ("f70", "f200"):
+        assert np.array_equal(ignored[k], base[k]), k
     for tag, knob in (("cout1_lds", {"Q3TTS_COUT1_LDS": "1"}), ("attn", {"Q3TTS_ATTN_WIN": "0"})):
         got = run(tag, knob)
         for k in ("f70", "f200"):
             d = float(np.abs(got[k] - base[k]).max())
             print("codec %s %s: max |old kernel - new kernel| %.3g" % (tag, k, d))
             assert got[k].shape == base[k].shape and 0.0 <= d < 4e-6, (tag, k, d)
-        if tag == "attn":      # 70 frames stay on k_attn either way (launches under 128 rows): identical
-            assert np.array_equal(got["f70"], base["f70"])
+        if tag == "attn":      # 70 frames stay on k_attn either way (launches under 128 rows): identical; 200 frames: the knob took effect
+            assert np.array_equal(got["f70"], base["f70"]) and not np.array_equal(got["f200"], base["f200"])

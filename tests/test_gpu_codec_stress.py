@@ -1,0 +1,109 @@
+"""Stress of the scheduler job's vocoder phase (round 5; the reference contract is one run_vocoder call per utterance,
+/root/reference/src/tts_onnx.cpp:759-776).
+
+Round 4 saw ONE wrong result on this path: a ragged 5-utterance job whose PCM differed from the utterance's own decode by 3.8e-3
+(38x the north_star budget) in one run out of ~70, on an intermediate build with a spilling kernel.  These tests repeat that job many
+times on the multi-lane path and on one lane, with every reusable buffer of the vocoder NaN-poisoned between jobs
+(q3tts_test_poison_workspace), compare EVERY utterance with the fp32 oracle — so a failure names the wrong side — and run a job whose
+blocks go batched -> batched -> single -> batched -> single, so that codec_lanes_join, the re-recorded fork event, lane re-use and the
+batched front's arena re-use all occur.  tests/test_kernel_resources.py holds the CPU-side invariant (no kernel with scratch)."""
+import os
+
+import numpy as np
+import pytest
+
+import q3_oracle as qo
+from util import frame_tokens, to_ocfg
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(lanes, max_batch):
+    import q3tts
+    cfg = q3tts.default_config("0.6b")
+    if lanes is not None:
+        os.environ["Q3TTS_CODEC_LANES"] = str(lanes)      # read when the codec decoder is finalized
+    try:
+        eng = q3tts.Engine(cfg, device=0, max_batch=max_batch, max_ctx=192, flags=q3tts.FLAG_TEST_HOOKS)
+        eng.fill_synthetic(seed=0)
+    finally:
+        os.environ.pop("Q3TTS_CODEC_LANES", None)
+    return eng
+
+
+def _oracle_for(eng):
+    orc = qo.Oracle(to_ocfg(eng.cfg), max_ctx=192)
+    for name, shape in eng.tensor_infos():
+        if name.startswith("cd."):
+            orc.set_tensor(name, eng.get_tensor(name, shape))
+    return orc
+
+
+def _run_jobs(eng, orc, toks, caps, reps, seed, tag):
+    import q3tts
+    sp = q3tts.Sampling(temperature=0.8, top_p=0.95, top_k=50, max_new_tokens=int(caps.max()))
+    n = len(toks)
+    first_codes, alone0, worst, worst_orc, bad = None, None, 0.0, 0.0, []
+    for rep in range(reps):
+        eng.poison_workspace()
+        pcm, codes, nfr = eng.synthesize_batch(toks, sp, lang=0, seed=seed, ignore_eos=True, max_new_per_utt=caps)
+        assert np.array_equal(nfr, caps)
+        if rep == 0:
+            first_codes = [c.copy() for c in codes]
+            # every utterance against the fp32 oracle, and its single-utterance decode too: a later mismatch names the wrong side
+            eng.poison_workspace()
+            alone0 = [eng.codec_decode(codes[u]) for u in range(n)]
+            for u in range(n):
+                ref = orc.vocoder(codes[u])
+                assert ref.shape == pcm[u].shape == alone0[u].shape == (eng.codec_decode_len(int(caps[u])),)
+                e_job = float(np.sqrt(np.mean((pcm[u] - ref) ** 2)))
+                e_alone = float(np.sqrt(np.mean((alone0[u] - ref) ** 2)))
+                worst_orc = max(worst_orc, e_job, e_alone)
+                assert e_job < 1e-4 and e_alone < 1e-4, ("rms vs oracle", tag, u, int(caps[u]), e_job, e_alone)
+        for u in range(n):
+            assert np.array_equal(codes[u], first_codes[u]), ("codes changed between repetitions", tag, rep, u)
+            assert np.isfinite(pcm[u]).all(), ("NaN in a job's PCM: the vocoder read workspace it had not written", tag, rep, u)
+            alone = alone0[u] if rep % 5 else eng.codec_decode(codes[u])      # every 5th repetition decodes alone again (the other side of the comparison)
+            d = float(np.abs(pcm[u] - alone).max())
+            worst = max(worst, d)
+            if d > 2e-5:
+                dd = np.abs(pcm[u] - alone)
+                off = np.nonzero(dd > 2e-5)[0]
+                bad.append("rep %d utterance %d (%d frames): |job - alone| %.3g at sample %d (frame %.2f), %d samples off in [%d, %d]; job vs rep-0 oracle-checked alone %.3g"
+                           % (rep, u, caps[u], d, int(dd.argmax()), dd.argmax() / 1920.0, off.size, off[0], off[-1], float(np.abs(pcm[u] - alone0[u]).max())))
+    print("%s: %d jobs x %d utterances of %s frames, poisoned workspace: max |job - alone| %.3g, worst rms vs oracle %.3g"
+          % (tag, reps, n, caps.tolist(), worst, worst_orc))
+    assert not bad, "\n".join(bad)
+
+
+@pytest.mark.parametrize("lanes", [None, 1], ids=["default-lanes", "one-lane"])
+def test_ragged_job_vocoder_30_repetitions_poisoned(lanes):
+    """The job of tests/test_gpu_full.py::test_batched_job_codec_equals_single_utterance_decodes_full_size (5 utterances of 150 / 3 / 97 /
+    40 / 72 frames: two batched blocks and a single) x 30, on the default nine lanes and with Q3TTS_CODEC_LANES=1."""
+    eng = _engine(lanes, 5)
+    orc = _oracle_for(eng)
+    try:
+        rng = np.random.default_rng(23)
+        toks = [frame_tokens(rng.integers(0, 151643, int(n))) for n in (4, 9, 2, 12, 6)]
+        caps = np.array([150, 3, 97, 40, 72], np.int32)
+        _run_jobs(eng, orc, toks, caps, 30, 6, "ragged job, %s" % ("default lanes" if lanes is None else "%d lane" % lanes))
+    finally:
+        eng.close()
+        orc.close()
+
+
+def test_job_blocks_batched_batched_single_batched_single():
+    """10 utterances through 4 slots (slots are re-armed mid-job) whose lengths sort into the blocks {120, 100, 90} batched, {44, 40}
+    batched, {19} single, {9, 8, 6} batched, {2} single: the engine stream joins the lanes before each batched front overwrites its
+    arena, the fork event is recorded again per group while lanes still hold waits on the earlier record, both group lanes and a
+    single-utterance lane are reused.  12 repetitions, poisoned workspace, every utterance against the oracle in the first."""
+    eng = _engine(None, 4)
+    orc = _oracle_for(eng)
+    try:
+        rng = np.random.default_rng(31)
+        caps = np.array([40, 9, 120, 2, 90, 19, 8, 100, 6, 44], np.int32)
+        toks = [frame_tokens(rng.integers(0, 151643, int(n))) for n in rng.integers(2, 14, len(caps))]
+        _run_jobs(eng, orc, toks, caps, 12, 9, "block sequence b-b-s-b-s")
+    finally:
+        eng.close()
+        orc.close()

@@ -467,7 +467,7 @@ cfg = q3tts.default_config("0.6b")
 rng = np.random.default_rng(88)
 toks = [np.array([151644, 77091, 151672] + list(rng.integers(0, 151643, int(n))) + [151673, 151645], np.int64) for n in rng.integers(3, 16, 8)]
 sp = q3tts.Sampling(max_new_tokens=12, temperature=0.8, top_p=0.95, top_k=50)
-eng = q3tts.Engine(cfg, device=0, max_batch=8, max_ctx=64)
+eng = q3tts.Engine(cfg, device=0, max_batch=8, max_ctx=64, flags=q3tts.FLAG_TEST_HOOKS)   # the A/B knobs are honoured only by hook-enabled engines
 eng.fill_synthetic(seed=0)
 res = {}
 for nb in (8, 5):

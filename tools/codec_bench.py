@@ -18,7 +18,7 @@ ap.add_argument("--fp32", action="store_true")
 ap.add_argument("--stream-chunk", type=int, default=0, help="also decode the utterance in pushes of N frames: carried-state stream vs the windowed decode of the growing history")
 a = ap.parse_args()
 cfg = q3tts.default_config("0.6b")
-eng = q3tts.Engine(cfg, device=0, max_batch=1, max_ctx=a.frames + 32, flags=q3tts.FLAG_FP32_CODEC if a.fp32 else 0)
+eng = q3tts.Engine(cfg, device=0, max_batch=1, max_ctx=a.frames + 32, flags=(q3tts.FLAG_FP32_CODEC if a.fp32 else 0) | q3tts.FLAG_TEST_HOOKS)   # hooks: the A/B knobs (Q3TTS_CONV_*, Q3TTS_CODEC_NO_CARRY, ...) are honoured
 eng.fill_synthetic(seed=0)
 codes = np.random.default_rng(0).integers(0, 2048, (a.frames, 16)).astype(np.int64)
 eng.codec_decode(codes)

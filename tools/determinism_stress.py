@@ -24,7 +24,7 @@ sp = q3tts.Sampling(max_new_tokens=a.frames, temperature=0.8, top_p=0.95, top_k=
 ENV = {"default": {}, "no-seam": {"Q3TTS_SEAM": "0"}, "no-sampler-planes": {"Q3TTS_NO_SAMPLER_PLANES": "1"}}
 for name in a.variants.split(","):
     os.environ.update(ENV[name])
-    eng = q3tts.Engine(cfg, device=0, max_batch=64, max_ctx=a.frames + 40)
+    eng = q3tts.Engine(cfg, device=0, max_batch=64, max_ctx=a.frames + 40, flags=q3tts.FLAG_TEST_HOOKS)
     eng.fill_synthetic(seed=0)
     first, bad = None, []
     for r in range(a.runs):

@@ -18,13 +18,13 @@ tests)
   timeout -k 10 1100 python -m pytest tests -m gpu -x -q --timeout 600 > $O/gpu_tests.log 2>&1 || { tail -30 $O/gpu_tests.log; exit 1; }
   tail -3 $O/gpu_tests.log ;;
 b64)
-  env $KNOBS timeout -k 10 300 python bench.py --batch 64 --frames 256 --steps 3 --warmup 1 --no-cpu-baseline > $O/b64_$$.json 2> $O/b64_$$.err
+  env $KNOBS timeout -k 10 300 python bench.py ${KNOBS:+--hooks} --batch 64 --frames 256 --steps 3 --warmup 1 --no-cpu-baseline > $O/b64_$$.json 2> $O/b64_$$.err
   pick $O/b64_$$.json "b64 [$KNOBS]" | tee -a $O/ab.txt ;;
 b8)
-  env $KNOBS timeout -k 10 300 python bench.py --batch 8 --frames 256 --steps 3 --warmup 1 --no-cpu-baseline > $O/b8_$$.json 2> $O/b8_$$.err
+  env $KNOBS timeout -k 10 300 python bench.py ${KNOBS:+--hooks} --batch 8 --frames 256 --steps 3 --warmup 1 --no-cpu-baseline > $O/b8_$$.json 2> $O/b8_$$.err
   pick $O/b8_$$.json "b8 [$KNOBS]" | tee -a $O/ab.txt ;;
 b1)
-  env $KNOBS timeout -k 10 300 python bench.py --batch 1 --frames 512 --steps 3 --warmup 1 --no-cpu-baseline --no-b64 > $O/b1_$$.json 2> $O/b1_$$.err
+  env $KNOBS timeout -k 10 300 python bench.py ${KNOBS:+--hooks} --batch 1 --frames 512 --steps 3 --warmup 1 --no-cpu-baseline --no-b64 > $O/b1_$$.json 2> $O/b1_$$.err
   pick $O/b1_$$.json "b1 [$KNOBS]" | tee -a $O/ab.txt ;;
 codec)
   for F in 2048 256 64; do

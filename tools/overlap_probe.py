@@ -21,7 +21,7 @@ ap.add_argument("--steps", type=int, default=192)
 a = ap.parse_args()
 cfg = q3tts.default_config("0.6b")
 os.environ.pop("Q3TTS_STREAM_CU_MASK", None)
-A = q3tts.Engine(cfg, device=0, max_batch=a.batch, max_ctx=1200)
+A = q3tts.Engine(cfg, device=0, max_batch=a.batch, max_ctx=1200, flags=q3tts.FLAG_TEST_HOOKS)
 A.fill_synthetic(seed=0)
 rng = np.random.default_rng(1)
 sp = q3tts.Sampling(temperature=0.8, top_p=0.95, top_k=50, max_new_tokens=1100)
@@ -52,7 +52,7 @@ for pat in a.patterns.split(","):
         os.environ.pop("Q3TTS_STREAM_CU_MASK", None)
     else:
         os.environ["Q3TTS_STREAM_CU_MASK"] = pat
-    B = q3tts.Engine(cfg, device=0, max_batch=1, max_ctx=300)
+    B = q3tts.Engine(cfg, device=0, max_batch=1, max_ctx=300, flags=q3tts.FLAG_TEST_HOOKS)
     B.fill_synthetic(seed=0)
     for _ in range(2):
         B.codec_decode(codes)
