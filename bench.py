@@ -92,8 +92,7 @@ def measured_traffic(batch, model, ctx, kv_bf16):
     at THIS batch and KV dtype and at a context within 15 % (or 16 tokens) of the record's own mean context — the KV stream is
     B x context x 229 KB (fp32) per step, so a short-context figure says nothing about a long-context record — else null with the reason."""
     tf = os.path.join(ROOT, "profiles", "decode_step_traffic.json")
-    if model != "0.6b":
-        return None, "no PMC pass for this model size"
+    pre = "" if model == "0.6b" else f"m{model}_"     # tools/pmc_traffic.py --model 1.7b: keys "m1.7b_b8_ctx136"
     if not os.path.exists(tf):
         return None, "profiles/decode_step_traffic.json absent (run tools/pmc_traffic.py under gpurun)"
     try:
@@ -104,10 +103,10 @@ def measured_traffic(batch, model, ctx, kv_bf16):
         return None, "PMC passes under profiles/ were taken on a different build of the kernels (src_digest mismatch); re-run tools/pmc_traffic.py"
     best = None
     for key, det in j.items():
-        if not key.endswith("_detail") or not key.startswith(f"b{batch}"):
+        if not key.endswith("_detail") or not key.startswith(f"{pre}b{batch}") or det.get("model", "0.6b") != model:
             continue
         base = key[: -len("_detail")]
-        if base.split("_")[0] != f"b{batch}" or det.get("kv", "fp32") != ("bf16" if kv_bf16 else "fp32"):
+        if base[len(pre):].split("_")[0] != f"b{batch}" or det.get("kv", "fp32") != ("bf16" if kv_bf16 else "fp32"):
             continue
         c = det.get("ctx", 0) or 14          # context 0 = the first steps after an 8-row prompt: contexts 10-20
         if abs(c - ctx) <= max(16.0, 0.15 * ctx) and (best is None or abs(c - ctx) < abs(best[1] - ctx)):
@@ -141,6 +140,13 @@ def stage_report(eng, cfg, toks, sp, B, F, ctr, kv_bf16=False):
                                        + 2.0 * Hc * cfg.sub_vocab + (2.0 * H * Hc if Hc != H else 0.0))
     for b in range(B):
         eng.slot_release(b)
+    # run_prefill (tts_onnx.cpp:615-665): B prompts x 8 rows (Auto language: S = 8) as one batched pass; the weights cross HBM once per
+    # group of up to 128 rows, SURVEY.md 8d budgets them once (887 MB at 0.6B) + the prompt's KV rows written
+    try:
+        prefill_dev_ms = eng.prefill_profile(B, 8, reps=4)
+    except Exception:
+        prefill_dev_ms = None
+    prefill_groups = -(-B * 8 // 128)
 
     def hbm(ms, nbytes):
         gbs = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
@@ -159,7 +165,13 @@ def stage_report(eng, cfg, toks, sp, B, F, ctr, kv_bf16=False):
                          "note": "fp32-grade products from fp16 (hi, lo) split operands: a weight tensor that is exact in fp16 (every bf16-origin tensor, "
                                  "incl. these synthetic weights) takes 2 matrix-core products per fp32 product (exact), any other tensor 3; "
                                  "matrix-core issue is that multiple of the algorithmic rate"},
-        "prompt_and_prefill": {"ms_per_utterance_wall": round(prefill_ms, 3), "note": "host prompt assembly (text_project calls) + talker prefill"},
+        "prompt_and_prefill": {"ms_per_utterance_wall": round(prefill_ms, 3), "note": "host prompt assembly (text_project calls) + talker prefill, one slot at a time"},
+        "prefill": (dict(hbm(prefill_dev_ms, talker_w + kv_step_bytes(cfg, B, 8, 4.0)), rows=B * 8, weight_passes=prefill_groups,
+                         bytes_streamed=int(prefill_groups * talker_w),
+                         note="device time of one batched prefill pass over B x 8 prompt rows already in HBM (q3tts_prefill_profile, HIP events on the "
+                              "engine's stream; eager launches: prefill is not graph-captured); algorithmic bytes = the talker's weights once + the "
+                              "prompt's fp32 KV rows; rows beyond 128 walk the weights again per 128-row group (bytes_streamed)")
+                    if prefill_dev_ms else {"error": "prefill_profile failed"}),
         "eager_step_ms": round(st["step_ms"], 4),
     }
 
@@ -259,6 +271,22 @@ def cpu_baseline(eng, cfg, ids, sp_kwargs, frames):
     codes = orc.generate(prompt, sp, seed=3, stream=0, cp_cached=False, ignore_eos=True)
     pcm = orc.vocoder(codes)
     dt = time.perf_counter() - t0
+    # the reference pins ONNX Runtime to 4 intra-op threads (tts_onnx.cpp:140); the same port on 4 threads, on a
+    # shorter sample (a quarter of the frames: the run stays bounded)
+    four = None
+    try:
+        f4 = max(8, frames // 4)
+        orc.L.q3o_set_threads(4)
+        sp4 = qo.Sampling(max_new_tokens=f4, **sp_kwargs)
+        t4 = time.perf_counter()
+        codes4 = orc.generate(orc.build_prompt(ids, 0), sp4, seed=3, stream=0, cp_cached=False, ignore_eos=True)
+        orc.vocoder(codes4)
+        d4 = time.perf_counter() - t4
+        four = {"value": round(len(codes4) * FRAME_SECONDS / d4, 5), "unit": "x real-time (audio s / wall s)", "cores": 4, "threads": 4, "kind": "port",
+                "frames_per_s": round(len(codes4) / d4, 3),
+                "sample": f"the same port pinned to 4 OpenMP threads (the reference's SetIntraOpNumThreads(4), tts_onnx.cpp:140): prefill + {len(codes4)} frames + vocoder, {d4:.1f} s wall"}
+    except Exception as ex:
+        four = {"error": str(ex)}
     orc.close()
     try:
         affinity = len(os.sched_getaffinity(0))
@@ -266,7 +294,7 @@ def cpu_baseline(eng, cfg, ids, sp_kwargs, frames):
         affinity = os.cpu_count()
     return {"value": round(len(codes) * FRAME_SECONDS / dt, 5), "unit": "x real-time (audio s / wall s)", "cores": threads,
             "threads": threads, "nproc": os.cpu_count(), "cpus_allowed": affinity,
-            "kind": "port", "frames_per_s": round(len(codes) / dt, 3),
+            "kind": "port", "frames_per_s": round(len(codes) / dt, 3), "threads4": four,
             "sample": f"1 utterance, 16-token prompt, prefill + {len(codes)} frames (reference call pattern, no predictor KV cache) "
                       f"+ vocoder of {len(codes)} frames ({len(pcm)} samples), fp32 oracle on {threads} OpenMP threads "
                       f"(the box reports {os.cpu_count()} logical CPUs, {affinity} allowed), {dt:.1f} s wall; {why}"}
@@ -374,6 +402,118 @@ def run_workload(q3tts, cfg, local_rank, B, F, sp_kwargs, steps, warmup, rank, n
     barrier()
     dt = time.perf_counter() - t0
     return eng, toks, sp, dt, frames, samples, eng.counters(), gathered
+
+
+def write_sweep_wav(path, seconds, f0, f1, sr=24000):
+    """SURVEY.md 8d's clone reference: a 24 kHz 16-bit mono sine sweep"""
+    import wave
+    t = np.arange(int(seconds * sr)) / sr
+    x = (0.5 * np.sin(2 * np.pi * (f0 * t + (f1 - f0) * t * t / (2 * seconds))) * 32767).astype("<i2")
+    with wave.open(path, "wb") as w:
+        w.setnchannels(1)
+        w.setsampwidth(2)
+        w.setframerate(sr)
+        w.writeframes(x.tobytes())
+
+
+def clone_record(q3tts, local_rank, sp_kwargs, sampling_txt, B=8, F=256, steps=3, warmup=1):
+    """BASELINE.json configs[4]: Qwen3-TTS-1.7B dims, --ref voice-clone path, batch 8.  A timed step = for each of the 8 utterances
+    the reference's synthesize_clone front end — read_wav -> resample to 24 kHz -> 128-bin log-mel -> speaker encoder (ECAPA-TDNN on
+    the GPU) -> [hidden] embedding (tts_onnx.cpp:264-318, 331-403) — and then the batch: prompt assembly with the speaker row spliced
+    before CODEC_BOS (:481-498), prefill, F frames, vocoder.  Everything inside the timed region."""
+    import tempfile
+    cfg = q3tts.default_config("1.7b")
+    eng = q3tts.Engine(cfg, device=local_rank, max_batch=B, max_ctx=F + 40, flags=q3tts.FLAG_TEST_HOOKS if HOOKS else 0)
+    eng.fill_synthetic(seed=0)
+    td = tempfile.mkdtemp(prefix="q3clone_")
+    wavs = []
+    for u in range(B):                      # 3 s references at 16 kHz: the resampler to 24 kHz is on the path
+        wavs.append(os.path.join(td, "ref%d.wav" % u))
+        write_sweep_wav(wavs[-1], 3.0, 80.0 + 10 * u, 3000.0 + 200 * u, sr=16000)
+    rng = np.random.default_rng(17)
+    toks = [np.array([IM_START, ASSISTANT, TTS_BOS] + list(rng.integers(0, 151643, 16)) + [TTS_EOS, IM_END], np.int64) for _ in range(B)]
+    sp = q3tts.Sampling(max_new_tokens=F, **sp_kwargs)
+    front = []
+
+    def step(i):
+        t0 = time.perf_counter()
+        spks = [eng.extract_speaker_embedding(w) for w in wavs]
+        front.append(time.perf_counter() - t0)
+        pcm, _, nfr = eng.synthesize_batch(toks, sp, lang=1, seed=200 + i, ignore_eos=True, want_codes=False, speakers=spks)
+        return int(nfr.sum()), sum(len(p) for p in pcm)
+
+    for i in range(warmup):
+        step(-1 - i)
+    eng.counters(reset=True)
+    del front[:]
+    t0 = time.perf_counter()
+    frames = samples = 0
+    for i in range(steps):
+        f, s = step(i)
+        frames += f
+        samples += s
+    dt = time.perf_counter() - t0
+    ctr = eng.counters()
+    sm = ctr["decode_ms"] / max(ctr["decode_steps"], 1)
+    rec = {"config": {"workload": f"Qwen3-TTS-1.7B dims, --ref voice-clone path, batch={B}/GPU, 16-token prompt, {sampling_txt}, max-tokens={F} (EOS suppressed), "
+                                  "3 s 16 kHz reference wav per utterance, hipGraph decode loop, synthetic seeded weights",
+                      "batch_per_gpu": B, "frames_per_utterance": F},
+           "value": round(frames * FRAME_SECONDS / dt, 3), "unit": "x real-time (audio s / wall s)", "steps": steps, "warmup": warmup,
+           "ms_per_step": round(dt / steps * 1e3, 3), "codec_frames_per_s": round(frames / dt, 2), "pcm_samples": samples,
+           "clone_front_end_ms_per_utterance": round(sum(front) / max(len(front), 1) / B * 1e3, 3),
+           "clone_front_end_note": "wav read + resample 16 -> 24 kHz + log-mel on the host, speaker encoder on the GPU; inside the timed region",
+           "decode_ms_per_frame_step": round(sm, 4),
+           "codec_decode_ms_per_frame": round(ctr["codec_ms"] / max(ctr["codec_frames"], 1), 5),
+           "roofline": roofline_record(cfg, B, F, sm, "1.7b", False)}
+    eng.close()
+    shutil.rmtree(td, ignore_errors=True)
+    return rec
+
+
+def capacity_record(q3tts, cfg, local_rank, sp_kwargs, n_eng=3, B=128, F=96):
+    """NOT a BASELINE config (the reference is batch 1; configs[2] is ONE 64-slot engine): what one MI355X sustains when the latency-bound
+    decode chains of several engines overlap — n_eng engines x B slots stepping concurrently from n_eng host threads (one hipGraph replay
+    per step and engine).  Decode chain only: the vocoder (15 us per frame) would add ~20 %."""
+    import threading
+    rng = np.random.default_rng(1)
+    engs = []
+    try:
+        for g in range(n_eng):
+            e = q3tts.Engine(cfg, device=local_rank, max_batch=B, max_ctx=F + 32)
+            e.fill_synthetic(seed=0)
+            engs.append(e)
+            sp = q3tts.Sampling(max_new_tokens=F, **sp_kwargs)
+            ids = np.array([IM_START, ASSISTANT, TTS_BOS] + list(rng.integers(0, 151643, 16)) + [TTS_EOS, IM_END], np.int64)
+            p, tr = e.build_prompt(ids, 0)
+            for b in range(B):
+                e.slot_begin(b, p, tr, sp, seed=5, stream_id=g * B + b, ignore_eos=True)
+            e.decode_steps(4)           # graph captured, caches warm
+        n = F - 8
+        bar = threading.Barrier(n_eng + 1)
+
+        def run(e):
+            bar.wait()
+            e.decode_steps(n)
+            bar.wait()
+        th = [threading.Thread(target=run, args=(e,)) for e in engs]
+        for t in th:
+            t.start()
+        bar.wait()
+        t0 = time.perf_counter()
+        bar.wait()
+        dt = time.perf_counter() - t0
+        for t in th:
+            t.join()
+        dev = [e.last_decode_ms()[0] / n for e in engs]
+    finally:
+        for e in engs:
+            e.close()
+    utt = n_eng * B
+    return {"config": {"workload": f"{n_eng} engines x {B} slots on one GPU stepping concurrently ({utt} utterances in flight), {n} decode steps each, "
+                                   "decode chain only (no vocoder, no prompt assembly)", "engines": n_eng, "slots_per_engine": B},
+            "label": "capacity (not a BASELINE config; the headline values are the single-engine records)",
+            "wall_ms_per_step_of_all": round(dt * 1e3 / n, 4), "per_engine_device_ms_per_step": [round(d, 4) for d in dev],
+            "codec_frames_per_s": round(utt * n / dt, 1), "value": round(utt * n * FRAME_SECONDS / dt, 1), "unit": "x real-time (audio s / wall s), decode chain only"}
 
 
 def dry_launch(args, rank, world):
@@ -570,6 +710,16 @@ def main():
                     out[key] = sub_record(B2, F2, steps2, warm2, with_stages, kvb)
                 except Exception as ex:
                     out[key] = {"error": str(ex)}
+        if world == 1 and dist is None and B == 1 and args.model == "0.6b" and not args.no_b64 and not args.no_graph:
+            try:      # BASELINE configs[4]: 1.7B dims, --ref voice-clone path, batch 8
+                out["b8_1p7b_clone"] = clone_record(q3tts, local_rank, sp_kwargs, sampling_txt)
+            except Exception as ex:
+                out["b8_1p7b_clone"] = {"error": str(ex)}
+            if not args.no_long:
+                try:
+                    out["capacity"] = capacity_record(q3tts, cfg, local_rank, sp_kwargs)
+                except Exception as ex:
+                    out["capacity"] = {"error": str(ex)}
         if world == 1 and dist is None and not args.no_cpu_baseline:
             try:
                 e3 = q3tts.Engine(cfg, device=local_rank, max_batch=1, max_ctx=64)   # weights only: the oracle copies the same seeded tensors

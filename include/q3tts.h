@@ -278,6 +278,11 @@ int q3tts_codec_plane_stats(q3tts_engine* e, int* two_product, int* three_produc
  * events at the stage boundaries.  out_ms[0] sampler (n_groups launches), [1] code predictor (layer passes + heads; predict_subcodes,
  * tts_onnx.cpp:851-872), [2] talker decode (layers + codec head; run_decode :667-732), [3] their sum — milliseconds per step. */
 int q3tts_stage_profile(q3tts_engine* e, int n_steps, double* out_ms /* [4] */);
+/* Device time of the prefill stage (run_prefill, tts_onnx.cpp:615-665): `reps` batched prefill passes of slots 0..n_slots-1 (all free)
+ * over n_rows synthetic prompt rows each, already in HBM — the launches a job's equal-length prompts take (groups of up to 128 rows
+ * share one pass over the talker's weights) — with HIP events around each pass; *ms_per_pass = mean device milliseconds.  The slots
+ * are released again.  bench.py's stages.prefill. */
+int q3tts_prefill_profile(q3tts_engine* e, int n_slots, int n_rows, int reps, double* ms_per_pass);
 /* Measurement aid (engines created with Q3TTS_FLAG_TEST_HOOKS only): every armed slot jumps n_frames ahead without generating them — frame
  * counters and talker positions advance, the skipped frames' codes are zero and the talker's KV cache is refilled with seeded synthetic rows.
  * What the slots emit afterwards is numerically meaningless; the decode step streams a context of the requested depth, which is what the

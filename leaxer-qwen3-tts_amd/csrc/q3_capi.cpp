@@ -592,6 +592,13 @@ int q3tts_codec_plane_stats(q3tts_engine* h, int* two_product, int* three_produc
     return 0;
     Q3_API_END(h)
 }
+int q3tts_prefill_profile(q3tts_engine* h, int n_slots, int n_rows, int reps, double* ms_per_pass) {
+    Q3_API_BEGIN(h)
+    if (!ms_per_pass) throw q3::Error("prefill_profile: null output");
+    h->e->prefill_profile(n_slots, n_rows, reps, ms_per_pass);
+    return 0;
+    Q3_API_END(h)
+}
 int q3tts_stage_profile(q3tts_engine* h, int n_steps, double* out_ms) {
     Q3_API_BEGIN(h)
     if (!out_ms) throw q3::Error("stage_profile: null output");

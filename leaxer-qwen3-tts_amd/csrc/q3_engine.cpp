@@ -861,6 +861,9 @@ void Engine::talker_prefill_dev(const float* embeds, int nb, int S, const int32_
         }
         b0 += g;
     }
+    // every entry point returns after its launches and copies have completed (include/q3tts.h): the single-slot path above queues
+    // asynchronous copies from host memory (a stack-local position in prefill_rows_in_xp, the page-table mirror row in kv_upload_row)
+    sync();
 }
 
 // run_decode (tts_onnx.cpp:667-732) for nb slots in one pass: embeds [nb][H] -> logits [nb][V], last_hidden [nb][H]; every active row's
@@ -1157,6 +1160,34 @@ void Engine::stage_profile(int n_steps, double* out) {
     stage_ev.clear();
     for (int k = 0; k < 3; ++k) out[k] = acc[k] / n_steps;
     out[3] = out[0] + out[1] + out[2];
+}
+
+// Device time of run_prefill (tts_onnx.cpp:615-665) for nb slots x S prompt rows: `reps` batched prefill passes over synthetic prompt rows
+// that are already in HBM (the same launches slots_begin issues for a job's equal-length prompts: groups of up to 128 rows share one pass
+// over the weights), HIP events on the engine's stream around each pass.  Slots 0..nb-1 must be free; they are released again afterwards.
+void Engine::prefill_profile(int nb, int S, int reps, double* ms_per_pass) {
+    if (!finalized) throw Error("weights not finalized");
+    if (nb < 1 || nb > B || S < 1 || S > 16 || reps < 1) throw Error("prefill_profile: bad shape");
+    for (int b = 0; b < nb; ++b) if (st_h[b].active) throw Error("prefill_profile: slots in use");
+    float* emb = nullptr;
+    const size_t n = (size_t)nb * S * c.hidden;
+    Q3_HIP_CHECK(hipMalloc((void**)&emb, n * sizeof(float)));
+    double acc = 0.0;
+    try {
+        Q3_HIP_CHECK(hipMemsetAsync(emb, 0x3C, n * sizeof(float), stream));   // 0x3C3C3C3C = 0.0115f in every element
+        for (int r = -1; r < reps; ++r) {                                     // pass -1 warms the caches / lazy allocations, untimed
+            Q3_HIP_CHECK(hipEventRecord(ev0, stream));
+            talker_prefill_dev(emb, nb, S, nullptr, nullptr, nullptr);
+            Q3_HIP_CHECK(hipEventRecord(ev1, stream));
+            sync();
+            float ms = 0.f;
+            Q3_HIP_CHECK(hipEventElapsedTime(&ms, ev0, ev1));
+            if (r >= 0) acc += ms;
+            for (int b = 0; b < nb; ++b) slot_release(b);
+        }
+    } catch (...) { (void)hipFree(emb); for (int b = 0; b < nb; ++b) { try { slot_release(b); } catch (...) { } } throw; }
+    (void)hipFree(emb);
+    *ms_per_pass = acc / reps;
 }
 
 void Engine::step_logits(int slot, float* out, int cols) {

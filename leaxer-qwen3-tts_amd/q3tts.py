@@ -83,7 +83,7 @@ EXPORTS = [
     "q3tts_sample_host", "q3tts_rng_uniform", "q3tts_build_prompt_host", "q3tts_slot_begin", "q3tts_decode_steps",
     "q3tts_slot_status", "q3tts_slot_codes_host", "q3tts_slot_codec_decode_host", "q3tts_slot_release",
     "q3tts_synthesize_batch_host", "q3tts_last_decode_ms", "q3tts_last_codec_ms", "q3tts_decode_step_bytes",
-    "q3tts_codec_decode_dev", "q3tts_stream", "q3tts_counters", "q3tts_stage_profile", "q3tts_codec_plane_stats", "q3tts_measure_skip_frames", "q3tts_test_poison_workspace", "q3tts_codec_stream_begin", "q3tts_codec_stream_push_host", "q3tts_codec_stream_end", "q3tts_talker_prefill_dev", "q3tts_talker_decode_dev", "q3tts_code_predictor_dev", "q3tts_sample_dev", "q3tts_config_num_tensors", "q3tts_config_tensor_info", "q3tts_read_weights_config", "q3tts_load_weights_file", "q3tts_save_weights_file",
+    "q3tts_codec_decode_dev", "q3tts_stream", "q3tts_counters", "q3tts_stage_profile", "q3tts_prefill_profile", "q3tts_codec_plane_stats", "q3tts_measure_skip_frames", "q3tts_test_poison_workspace", "q3tts_codec_stream_begin", "q3tts_codec_stream_push_host", "q3tts_codec_stream_end", "q3tts_talker_prefill_dev", "q3tts_talker_decode_dev", "q3tts_code_predictor_dev", "q3tts_sample_dev", "q3tts_config_num_tensors", "q3tts_config_tensor_info", "q3tts_read_weights_config", "q3tts_load_weights_file", "q3tts_save_weights_file",
     "q3tts_tokenizer_create", "q3tts_tokenizer_destroy", "q3tts_tokenizer_load_vocab", "q3tts_tokenizer_load_merges",
     "q3tts_tokenizer_ready", "q3tts_tokenize",
     "q3tts_synthesize_clone_batch_host", "q3tts_synthesize_schedule_host", "q3tts_read_wav_host", "q3tts_resample_host", "q3tts_mel_host",
@@ -564,6 +564,13 @@ class Engine:
         a, b = C.c_int32(0), C.c_int32(0)
         self._ck(self.L.q3tts_codec_plane_stats(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def prefill_profile(self, n_slots, n_rows=8, reps=4):
+        """mean device ms of a batched prefill pass of n_slots free slots x n_rows synthetic prompt rows (q3tts_prefill_profile)"""
+        out = C.c_double(0.0)
+        self.L.q3tts_prefill_profile.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
+        self._ck(self.L.q3tts_prefill_profile(self.h, int(n_slots), int(n_rows), int(reps), C.byref(out)))
+        return out.value
 
     def stage_profile(self, n_steps=32):
         """ms per step of {sampler, code predictor, talker decode, sum}: eager steps with events at the stage boundaries."""

@@ -157,7 +157,7 @@ def test_onnx_converter_output_drives_the_engine(tmp_path):
         mdir = tmp_path / "model"
         mdir.mkdir()
         r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "import_onnx.py"), "--out", str(mdir / "model.q3w"), "--config", str(cfg_json),
-                            "--by-shape-order"] + paths, capture_output=True, text=True, timeout=300)
+                            "--by-shape-order", "--assume-square-transposed"] + paths, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stdout + r.stderr
         assert "[shape-order]" in r.stdout and "0 registry tensors missing" in r.stdout
         conv = q3tts.Engine(eng.cfg, device=0, max_batch=2, max_ctx=96)

@@ -209,7 +209,7 @@ def _fit(a, want, name, dst, transposed_hint):
     raise ValueError(f"{name} -> {dst}: shape {tuple(a.shape)} does not fit {tuple(want)}")
 
 
-def import_onnx(paths, cfg, prefixes=None, extra_rules=(), by_shape_order=False, allow_missing=False, log=print):
+def import_onnx(paths, cfg, prefixes=None, extra_rules=(), by_shape_order=False, allow_missing=False, log=print, assume_square_transposed=False):
     """-> ({registry name: float32 array}, unused initialiser names, missing registry names)."""
     from tools.import_safetensors import map_names
     q3tts = _binding()
@@ -249,8 +249,17 @@ def import_onnx(paths, cfg, prefixes=None, extra_rules=(), by_shape_order=False,
         if i not in used and bare in named and named[bare] in want:
             take(i, named[bare])
     if by_shape_order:                                    # 3. shape classes in order of appearance
+        # A class is an EXACT registry shape ([out][in] for a Linear weight).  An anonymous 2-D initialiser ("onnx::MatMul_<n>": the
+        # constant operand of a MatMul node, [in][out]) belongs to the class of its TRANSPOSE, a named one to the class of its own
+        # shape — so q_proj [2048][1024] and o_proj [1024][2048] never share a class (they did when classes were sorted dims), and
+        # only tensors of one shape AND orientation (gate / up; the layers of a stack) are told apart by order of appearance alone.
+        # A square anonymous matrix fits its class in either orientation: it is taken as [in][out] only under
+        # --assume-square-transposed (said on the command line, printed per tensor), otherwise refused by name.
+        def is_anon(bare):
+            return not re.search(r"[A-Za-z_]\.[A-Za-z_]", bare) or bare.startswith("onnx::")
+
         def key(shape):
-            return tuple(sorted(shape)) if len(shape) == 2 else tuple(shape)
+            return tuple(shape)
         left_reg = {}
         for n, s in specs:
             if n not in out:
@@ -261,6 +270,13 @@ def import_onnx(paths, cfg, prefixes=None, extra_rules=(), by_shape_order=False,
             if i in used:
                 continue
             k = key(a.shape if a.ndim else ())
+            if a.ndim == 2 and is_anon(_bare):
+                k = (k[1], k[0])
+            if k not in left_reg and a.size > 1:          # only unit dims differ ([1][C] biases, [C][1][k] depthwise kernels): the class of that squeezed shape
+                sq = tuple(x for x in k if x != 1)
+                alt = [r for r in left_reg if tuple(x for x in r if x != 1) == sq]
+                if len(alt) == 1:
+                    k = alt[0]
             if k not in left_reg:
                 continue
             h = (k, a.tobytes())                          # the same tensor repeated by another graph counts once
@@ -277,7 +293,11 @@ def import_onnx(paths, cfg, prefixes=None, extra_rules=(), by_shape_order=False,
                 raise ValueError(f"--by-shape-order: {len(idx)} unresolved initialisers of shape class {k} for {len(regs)} registry tensors "
                                  f"({regs[:3]} ...): counts must match; resolve them with --map")
             for i, dst in zip(idx, regs):
-                anon = not re.search(r"[A-Za-z_]\.[A-Za-z_]", src[i][1]) or src[i][1].startswith("onnx::")
+                anon = is_anon(src[i][1])
+                if anon and len(k) == 2 and k[0] == k[1] and not assume_square_transposed:
+                    raise ValueError(f"--by-shape-order: {src[i][0]} is an anonymous SQUARE matrix {k} (for {dst}): its orientation cannot be read "
+                                     f"from its shape; map it explicitly (--map, 'T:' in front of the target transposes) or pass "
+                                     f"--assume-square-transposed to take every such matrix as [in][out]")
                 log(f"  [shape-order] {src[i][0]} {tuple(src[i][2].shape)} -> {dst}{' (as [in][out])' if anon else ''}")
                 take(i, dst, transposed_hint=anon)
         used.update(i for i, first in dup_of.items() if first in used)
@@ -295,6 +315,8 @@ def main():
     ap.add_argument("--prefix", action="append", default=[], help="component=prefix for the parameter-name rules (talker, predictor, code2wav, speaker)")
     ap.add_argument("--map", help='JSON list of [regex, replacement] on "<file stem>:<initialiser name>"; "T:" in front of a replacement transposes')
     ap.add_argument("--by-shape-order", action="store_true", help="assign what is still unresolved by shape, in order of appearance (printed; heuristic)")
+    ap.add_argument("--assume-square-transposed", action="store_true", help="with --by-shape-order: anonymous SQUARE matrices are [in][out] like the "
+                    "other anonymous MatMul operands (refused otherwise: their orientation cannot be read from the shape)")
     ap.add_argument("--allow-missing", action="store_true")
     ap.add_argument("--tconv-trim", type=int, choices=[0, 1], default=None)
     ap.add_argument("--list", action="store_true", help="print the initialisers and exit")
@@ -328,7 +350,7 @@ def main():
         ap.error("--out is required")
     prefixes = dict(p.split("=", 1) for p in a.prefix)
     extra = [tuple(r) for r in json.load(open(a.map))] if a.map else []
-    tensors, unused, missing = import_onnx(a.files, cfg, prefixes, extra, a.by_shape_order, a.allow_missing)
+    tensors, unused, missing = import_onnx(a.files, cfg, prefixes, extra, a.by_shape_order, a.allow_missing, assume_square_transposed=a.assume_square_transposed)
     from tools.pack_weights import write_q3w
     write_q3w(a.out, cfg, tensors, validate=not a.allow_missing)
     print(f"wrote {a.out}: {len(tensors)} tensors; {len(unused)} initialisers unused; {len(missing)} registry tensors missing")

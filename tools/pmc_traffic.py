@@ -45,6 +45,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, required=True)
 ap.add_argument("--ctx", type=int, default=0, help="talker context the passes were taken at (0: the first steps after the prompt, context ~10-20)")
 ap.add_argument("--kv", choices=["fp32", "bf16"], default="fp32")
+ap.add_argument("--model", default="0.6b", help='"1.7b": BASELINE configs[4] dims (keys get an "m1.7b_" prefix)')
 ap.add_argument("--fetch", required=True)
 ap.add_argument("--write", required=True)
 ap.add_argument("--frames", type=int, required=True)
@@ -82,7 +83,7 @@ if a.merge_into:
         j = {}                       # figures of another build are not carried over
     j["src_digest"] = out["src_digest"]
     # keyed by (batch, context, kv dtype): "b64" = the short-context fp32 figure of earlier rounds, "b64_ctx1024_bf16" a long-context one
-    key = f"b{a.batch}" + (f"_ctx{a.ctx}" if a.ctx > 0 else "") + ("_bf16" if a.kv == "bf16" else "")
+    key = ("" if a.model == "0.6b" else f"m{a.model}_") + f"b{a.batch}" + (f"_ctx{a.ctx}" if a.ctx > 0 else "") + ("_bf16" if a.kv == "bf16" else "")
     j[key] = int(out["hbm_bytes_per_step"])
-    j[key + "_detail"] = {"read": int(out["read_bytes_per_step"]), "write": int(out["write_bytes_per_step"]), "ctx": a.ctx, "kv": a.kv, "method": out["method"]}
+    j[key + "_detail"] = {"read": int(out["read_bytes_per_step"]), "write": int(out["write_bytes_per_step"]), "ctx": a.ctx, "kv": a.kv, "model": a.model, "method": out["method"]}
     json.dump(j, open(a.merge_into, "w"), indent=1)

@@ -12,16 +12,16 @@ if [ "$MODE" = "pmc" ]; then
 # PMC traffic, separate passes, eager steps on the default stream; two step counts so that the prefill cancels in the difference.
 # Configurations: batch:context:kv, one per record of the bench line at that record's own mean context (8 + frames / 2); slots moved there with
 # q3tts_measure_skip_frames (tools/pmc_bisect <steps> <batch> <ctx> <bf16>)
-for CFG in ${PMC_CFGS:-1:1032:fp32 64:136:fp32 8:136:fp32 64:1032:fp32 64:1032:bf16 1:1032:bf16}; do
-  B=${CFG%%:*}; R=${CFG#*:}; CTX=${R%%:*}; KV=${R#*:}
+for CFG in ${PMC_CFGS:-1:1032:fp32:0.6b 64:136:fp32:0.6b 8:136:fp32:0.6b 64:1032:fp32:0.6b 64:1032:bf16:0.6b 1:1032:bf16:0.6b 8:136:fp32:1.7b}; do
+  IFS=: read B CTX KV MODEL <<< "$CFG"; MODEL=${MODEL:-0.6b}
   BF=0; [ "$KV" = "bf16" ] && BF=1
   if [ $B = 1 ]; then S1=6; S2=12; else S1=4; S2=8; fi
-  T=${B}_${CTX}_${KV}
+  T=${B}_${CTX}_${KV}_${MODEL}
   for S in $S1 $S2; do
-    Q3TTS_NULL_STREAM=1 timeout -k 10 120 rocprofv3 --pmc FETCH_SIZE -d $O/pmc_f_${T}_$S -o f --output-format csv -- tools/pmc_bisect $S $B $CTX $BF > $O/pmc_fetch.log 2>&1
-    Q3TTS_NULL_STREAM=1 timeout -k 10 120 rocprofv3 --pmc WRITE_SIZE -d $O/pmc_w_${T}_$S -o w --output-format csv -- tools/pmc_bisect $S $B $CTX $BF > $O/pmc_write.log 2>&1
+    Q3TTS_NULL_STREAM=1 timeout -k 10 120 rocprofv3 --pmc FETCH_SIZE -d $O/pmc_f_${T}_$S -o f --output-format csv -- tools/pmc_bisect $S $B $CTX $BF $MODEL > $O/pmc_fetch.log 2>&1
+    Q3TTS_NULL_STREAM=1 timeout -k 10 120 rocprofv3 --pmc WRITE_SIZE -d $O/pmc_w_${T}_$S -o w --output-format csv -- tools/pmc_bisect $S $B $CTX $BF $MODEL > $O/pmc_write.log 2>&1
   done
-  python tools/pmc_traffic.py --batch $B --ctx $CTX --kv $KV --fetch $(ls $O/pmc_f_${T}_$S1/*/f_counter_collection.csv $O/pmc_f_${T}_$S1/f_counter_collection.csv 2>/dev/null | head -1) --write $(ls $O/pmc_w_${T}_$S1/*/w_counter_collection.csv $O/pmc_w_${T}_$S1/w_counter_collection.csv 2>/dev/null | head -1) --frames $S1 \
+  python tools/pmc_traffic.py --batch $B --ctx $CTX --kv $KV --model $MODEL --fetch $(ls $O/pmc_f_${T}_$S1/*/f_counter_collection.csv $O/pmc_f_${T}_$S1/f_counter_collection.csv 2>/dev/null | head -1) --write $(ls $O/pmc_w_${T}_$S1/*/w_counter_collection.csv $O/pmc_w_${T}_$S1/w_counter_collection.csv 2>/dev/null | head -1) --frames $S1 \
       --fetch2 $(ls $O/pmc_f_${T}_$S2/*/f_counter_collection.csv $O/pmc_f_${T}_$S2/f_counter_collection.csv 2>/dev/null | head -1) --write2 $(ls $O/pmc_w_${T}_$S2/*/w_counter_collection.csv $O/pmc_w_${T}_$S2/w_counter_collection.csv 2>/dev/null | head -1) --frames2 $S2 \
       --merge-into $O/decode_step_traffic.json > $O/pmc_traffic_b${T}.json
   cat $O/pmc_traffic_b${T}.json
