@@ -157,6 +157,7 @@ struct GemmArgs {
     int M = 0, N = 0, K = 0, epi = EPI_STORE;
     int slab_rows = 0;   // EPI_SLAB / EPI_SLAB2: rows per slab (0 = M); launch_gemm2 sets it when it cuts M into 128-row blocks
     bool nt = false;     // non-temporal weight loads (weights this step reads once: the talker's)
+    bool plain_slabs = false;   // A/B knob Q3TTS_GEMM_PLAIN_SLABS: k_gemm3's slabs as plain stores instead of write-through (sc1)
     // ---- split-K seam (k_gemm3 only): the slabs are reduced INSIDE the launch by the K-slice workgroups of a column tile themselves
     // (sc1 slab stores, a flag per slice, slice s < 16-row-chunk count owns chunk s once every flag is set), instead of by a k_finish* launch.
     // seam 1: x += sum(slabs); planes = split(gamma * x) — NOT normalised: the consumer applies 1/rms from the per-(row, tile) sums of

@@ -1345,6 +1345,184 @@ __global__ __launch_bounds__(128) void k_attn_tiny(const float* pqkv, const floa
 }
 
 // ================================================================================================
+// k_attn_tiny2 (round 5) — k_attn_tiny for two query heads per kv head and at most 16 tokens in all (every launch of the code predictor in
+// the batched step), with the wave's lanes laid out for 16-BYTE accesses.  k_attn_tiny asked for its operands as (lane, lane + 64) dwords:
+// ~80 load instructions per wave — 1.14 us of ISSUE before the first byte was needed — and ran the three q / k RMSNorms of a new token
+// as three 64-lane reductions one after the other, 1.9 us of single-wave vector issue (profiles/r03_attn_tiny_phase_stamps.txt).  Here a
+// 16-lane row owns ONE vector of the kv group (row 0 / 1: the two query heads, row 2: the new key, row 3: the new value), lane s of a row
+// the dims [4s, 4s + 4) and [64 + 4s, 64 + 4s + 4) — both halves of every rotate-half RoPE pair in the same lane:
+//   * split-K slabs, RoPE tables, norm gains: two 16-byte loads per slab and lane instead of eight dword loads per vector: 8 + 2 + 2
+//     instead of 32 + 2 + 4 instructions per new token;
+//   * the four vectors are normalised and rotated AT ONCE (one 16-lane row sum, one rsqrt, one rotation) instead of one after the other;
+//   * cached V rows as (token = row + 4 i, dims of lane s): 8 sixteen-byte loads instead of 32 dwords; a row accumulates P.V over its
+//     four tokens and the rows meet through two permlane swaps per value; p_t arrives by ds_bpermute instead of 16 v_readlane;
+//   * the new tokens go through the wave's LDS slice into the same (token, 32-dim chunk) score layout as the cached ones: one code path
+//     for all <= 16 tokens, no per-new-token wave reductions.
+// Same arithmetic per element (slab sums in slab order, deferred 1 / rms, RMSNorm, rotate-half RoPE, softmax in fp32); sums associate
+// differently from k_attn_tiny's (fp32, ~1e-7).  Q3TTS_ATTN_TINY2=0 falls back to k_attn_tiny.
+// ================================================================================================
+template <int NN>
+__global__ __launch_bounds__(128) void k_attn_tiny2(const float* pqkv, const float* pkcache, const float* pvcache, const float* pcos, const float* psin,
+                                                     int pbase, AttnArgs a) {
+    constexpr int D = 128, HALF = 64, G = 2;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int pair = blockIdx.x * 2 + wave;
+    if (pair >= a.nb * a.nkv) return;                                   // wave-uniform
+    const int bi = pair / a.nkv, kvh = pair - bi * a.nkv;
+    const int slot = a.slot_offset + bi, base = pbase;
+    const int PT = 1 << a.page_shift;
+    const size_t cbase = ((((size_t)slot * a.pages_per_slot) * a.n_layers + a.layer) * a.nkv + kvh) * (size_t)PT * D;
+    const float* kc = pkcache + cbase;
+    const float* vc = pvcache + cbase;
+    __shared__ __attribute__((aligned(16))) float new_sh[2][NN][4][D];   // [wave][new token][q head 0 | q head 1 | key | value][dim], after norm + RoPE
+    float (*ns)[4][D] = new_sh[wave];
+    const int row = lane >> 4, s = lane & 15;
+
+    // ---- every load of the launch, before any use ----
+    const int voff = row < 2 ? (kvh * G + row) * D : (row == 2 ? (a.nq + kvh) * D : (a.nq + a.nkv + kvh) * D);
+    f32x4 xa[NN][4], xb[NN][4], cs4[NN], sn4[NN];
+#pragma unroll
+    for (int j = 0; j < NN; ++j) {
+        const float* rowp = pqkv + (size_t)(bi * NN + j) * a.ld_qkv + voff + 4 * s;
+#pragma unroll
+        for (int sb = 0; sb < 4; ++sb) {
+            const size_t so = (size_t)(sb < a.qkv_nslab ? sb : 0) * a.qkv_slab_stride;
+            xa[j][sb] = *reinterpret_cast<const f32x4*>(rowp + so);
+            xb[j][sb] = *reinterpret_cast<const f32x4*>(rowp + so + HALF);
+        }
+        cs4[j] = *reinterpret_cast<const f32x4*>(pcos + (size_t)(base + j) * HALF + 4 * s);
+        sn4[j] = *reinterpret_cast<const f32x4*>(psin + (size_t)(base + j) * HALF + 4 * s);
+    }
+    const bool have_ssq = a.ssq_in != nullptr;
+    const int snt = have_ssq ? a.ssq_nt : 1;
+    float spart[NN];
+#pragma unroll
+    for (int j = 0; j < NN; ++j) spart[j] = (have_ssq ? a.ssq_in + (size_t)(bi * NN + j) * a.ssq_nt : pqkv + (size_t)(bi * NN + j) * a.ld_qkv)[lane < snt ? lane : 0];
+    const float* nwq = a.q_norm ? a.q_norm : pcos;      // address select: the loads stay unconditional, the values are replaced below
+    const float* nwk = a.k_norm ? a.k_norm : pcos;
+    const float* nw = row < 2 ? nwq : nwk;
+    const f32x4 nwa = *reinterpret_cast<const f32x4*>(nw + 4 * s), nwb = *reinterpret_cast<const f32x4*>(nw + HALF + 4 * s);
+    // cached K as (token = lane / 4, 32-dim chunk = lane % 4); cached V as (token = row + 4 i, this lane's 8 dims); tokens past `base` repeat the last one
+    const int tk = lane >> 2, ch = lane & 3;
+    const int last = base > 0 ? base - 1 : 0;
+    f32x4 kk[8];
+    {
+        const int t = tk < base ? tk : last;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) kk[e] = *reinterpret_cast<const f32x4*>(kc + (size_t)t * D + ch * 32 + e * 4);
+    }
+    f32x4 va[4], vb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int t = row + 4 * i, tt = t < base ? t : last;
+        va[i] = *reinterpret_cast<const f32x4*>(vc + (size_t)tt * D + 4 * s);
+        vb[i] = *reinterpret_cast<const f32x4*>(vc + (size_t)tt * D + HALF + 4 * s);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- new tokens: slab sums (slab order), deferred 1 / rms, RMSNorm, RoPE — the row's vector; K / V appended to the cache; all four to LDS ----
+    const bool do_norm = row < 2 ? a.q_norm != nullptr : (row == 2 && a.k_norm != nullptr);
+    const bool do_rope = row < 3;
+#pragma unroll
+    for (int j = 0; j < NN; ++j) {
+        const float rsc = ssq_row_scale(spart[j], snt, a.ssq_K, a.ssq_eps, have_ssq);
+        f32x4 ya = xa[j][0], yb = xb[j][0];
+#pragma unroll
+        for (int sb = 1; sb < 4; ++sb) if (sb < a.qkv_nslab) { ya += xa[j][sb]; yb += xb[j][sb]; }
+        ya *= rsc; yb *= rsc;
+        float ss = (ya.x * ya.x + yb.x * yb.x) + (ya.y * ya.y + yb.y * yb.y);
+        ss += (ya.z * ya.z + yb.z * yb.z) + (ya.w * ya.w + yb.w * yb.w);
+        ss = row_sum16(ss);
+        const float rr = 1.0f / sqrtf(ss / (float)D + a.eps);
+        if (do_norm) { ya = nwa * (ya * rr); yb = nwb * (yb * rr); }
+        const f32x4 za = do_rope ? ya * cs4[j] + (-yb) * sn4[j] : ya;
+        const f32x4 zb = do_rope ? yb * cs4[j] + ya * sn4[j] : yb;
+        *reinterpret_cast<f32x4*>(&ns[j][row][4 * s]) = za;
+        *reinterpret_cast<f32x4*>(&ns[j][row][HALF + 4 * s]) = zb;
+        if (row >= 2) {                                                  // rows 2 / 3: the cache append of the new key / value
+            float* dst = (row == 2 ? a.kcache : a.vcache) + cbase + (size_t)(base + j) * D;
+            *reinterpret_cast<f32x4*>(dst + 4 * s) = za;
+            *reinterpret_cast<f32x4*>(dst + HALF + 4 * s) = zb;
+        }
+    }
+    wave_lds_sync();
+
+    // ---- all tokens in one layout: slot t < base from the cache, slots base .. base + NN - 1 the new tokens (from LDS) ----
+    {
+        const int jn = tk - base;
+        const bool isnew = jn >= 0 && jn < NN;
+        const int jc = isnew ? jn : 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const f32x4 kn = *reinterpret_cast<const f32x4*>(&ns[jc][2][ch * 32 + e * 4]);
+            kk[e] = isnew ? kn : kk[e];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int t = row + 4 * i, j2 = t - base;
+            const bool vnew = j2 >= 0 && j2 < NN;
+            const int j2c = vnew ? j2 : 0;
+            const f32x4 na = *reinterpret_cast<const f32x4*>(&ns[j2c][3][4 * s]), nb2 = *reinterpret_cast<const f32x4*>(&ns[j2c][3][HALF + 4 * s]);
+            const f32x4 zero = { 0.f, 0.f, 0.f, 0.f };
+            va[i] = vnew ? na : (t < base ? va[i] : zero);              // never-written cache rows may hold anything: 0 x NaN
+            vb[i] = vnew ? nb2 : (t < base ? vb[i] : zero);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NN; ++j) {
+        const int orow = bi * NN + j;
+#pragma unroll
+        for (int h = 0; h < G; ++h) {
+            float part = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const f32x4 q4 = *reinterpret_cast<const f32x4*>(&ns[j][h][ch * 32 + e * 4]);
+                part = fmaf(q4.x, kk[e].x, part); part = fmaf(q4.y, kk[e].y, part); part = fmaf(q4.z, kk[e].z, part); part = fmaf(q4.w, kk[e].w, part);
+            }
+            part += dpp_f<Q3_DPP_XOR1, 0xF>(0.f, part);
+            part += dpp_f<Q3_DPP_XOR2, 0xF>(0.f, part);
+            const float sc = tk <= base + j ? part * a.scale : -INFINITY;   // causal: the cached tokens and the new ones up to this one; all four lanes of a token hold its score
+            const float m = wave_max(sc);                                   // the token itself is always there: m is finite
+            const float pt = __expf(sc - m);                                // exp(-inf) = 0
+            const float l = wave_sum(ch == 0 ? pt : 0.f);
+            f32x4 oa = { 0.f, 0.f, 0.f, 0.f }, ob = { 0.f, 0.f, 0.f, 0.f };
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float pi = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((row + 4 * i) << 4, __builtin_bit_cast(int, pt)));   // lane 4 t holds p_t
+                oa += pi * va[i]; ob += pi * vb[i];
+            }
+            float o[8] = { oa.x, oa.y, oa.z, oa.w, ob.x, ob.y, ob.z, ob.w };
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { o[e] += wave_xor_lane_f<16>(o[e], lane); o[e] += wave_xor_lane_f<32>(o[e], lane); o[e] /= l; }
+            if (row == 0) {                                                 // every row holds the sums: row 0 stores
+                const int head = kvh * G + h;
+                if (a.out) {
+                    float* dst = a.out + (size_t)orow * a.ld_out + head * D;
+                    *reinterpret_cast<f32x4*>(dst + 4 * s) = f32x4{ o[0], o[1], o[2], o[3] };
+                    *reinterpret_cast<f32x4*>(dst + HALF + 4 * s) = f32x4{ o[4], o[5], o[6], o[7] };
+                }
+                if (a.oh) {
+                    uint32_t hh[8], ll[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const uint32_t u = __float_as_uint(o[e]);
+                        hh[e] = (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+                        const uint32_t v = __float_as_uint(o[e] - __uint_as_float(hh[e] << 16));
+                        ll[e] = (v + 0x7FFFu + ((v >> 16) & 1u)) >> 16;
+                    }
+                    const size_t po = (size_t)orow * a.ldp + head * D + 4 * s;
+                    *reinterpret_cast<uint2*>(a.oh + po) = make_uint2(hh[0] | hh[1] << 16, hh[2] | hh[3] << 16);
+                    *reinterpret_cast<uint2*>(a.oh + po + HALF) = make_uint2(hh[4] | hh[5] << 16, hh[6] | hh[7] << 16);
+                    *reinterpret_cast<uint2*>(a.ol + po) = make_uint2(ll[0] | ll[1] << 16, ll[2] | ll[3] << 16);
+                    *reinterpret_cast<uint2*>(a.ol + po + HALF) = make_uint2(ll[4] | ll[5] << 16, ll[6] | ll[7] << 16);
+                }
+            }
+        }
+    }
+}
+
+// ================================================================================================
 // k_attn_win (round 4) — the sliding-window attention of the codec decoder's pre-transformer (8 layers, 16 heads x 64, window 72; every
 // row's K / V already in the layer's cache, q roped by k_rope_store).  k_attn served it with one workgroup per (head, QUERY): 2048 x 16
 // workgroups per layer each fetching its own 72-row window — 37 KB for 9 K multiply-adds, 1.2 GB of L2 traffic and 146 us per layer at
@@ -1527,6 +1705,13 @@ void launch_attn(const AttnArgs& a, hipStream_t s) {
     if (!no_tiny && a.d == 128 && tiny_ctx0 && a.identity_pages && a.pages_per_slot == 1 && a.n_new >= 1 && a.n_new <= 2 && a.slot_map == nullptr &&
         a.pos_dev == nullptr && a.new_from_raw && a.po == nullptr && (a.out || a.oh) && a.nb >= 2 && a.pos_scalar + a.n_new <= 32 && a.qkv_nslab >= 1 && a.qkv_nslab <= 4) {
         const dim3 g((unsigned)((a.nb * a.nkv + 1) / 2));
+        const bool tiny2_off = knob("Q3TTS_ATTN_TINY2") && atoi(knob("Q3TTS_ATTN_TINY2")) == 0;   // A/B knob: back to k_attn_tiny
+        if (!tiny2_off && grp == 2 && a.pos_scalar + a.n_new <= 16 && a.ld_qkv % 4 == 0 && a.qkv_slab_stride % 4 == 0 && (!a.out || a.ld_out % 4 == 0) && (!a.oh || a.ldp % 4 == 0)) {
+            if (a.n_new == 1) hipLaunchKernelGGL((k_attn_tiny2<1>), g, dim3(128), 0, s, a.qkv, (const float*)a.kcache, (const float*)a.vcache, a.rope_cos, a.rope_sin, a.pos_scalar, a);
+            else hipLaunchKernelGGL((k_attn_tiny2<2>), g, dim3(128), 0, s, a.qkv, (const float*)a.kcache, (const float*)a.vcache, a.rope_cos, a.rope_sin, a.pos_scalar, a);
+            Q3_HIP_CHECK(hipGetLastError());
+            return;
+        }
 #define Q3_TINY(G_, NN_) hipLaunchKernelGGL((k_attn_tiny<G_, NN_>), g, dim3(128), 0, s, a.qkv, (const float*)a.kcache, (const float*)a.vcache, a.rope_cos, a.rope_sin, a.pos_scalar, a)
         if (grp == 1) { if (a.n_new == 1) Q3_TINY(1, 1); else Q3_TINY(1, 2); }
         else if (grp == 2) { if (a.n_new == 1) Q3_TINY(2, 1); else Q3_TINY(2, 2); }

@@ -481,6 +481,7 @@ static int pick_ksplit(int K) { // K slices per GEMM: 256 (two LDS chunks) per w
 static int seam_gu_ksplit(int K) {
     const int forced = knob("Q3TTS_SEAM_GU_KS") ? atoi(knob("Q3TTS_SEAM_GU_KS")) : 0;
     const int ks4 = std::min(4, pick_ksplit(K));
+    if (forced == 2 && K == 1024) return 2;   // 512-wide slices (A/B knob; measured in round 5, profiles/r05_negative_results.txt)
     return forced == 8 && K % (128 * 8) == 0 && K / 8 == 128 ? 8 : ks4;
 }
 

@@ -189,7 +189,10 @@ static void launch_gemm3(const GemmArgs& a, int ksplit, hipStream_t s);
 static void launch_gemm3_seam(const GemmArgs& a, int ksplit, hipStream_t s);
 template <int MTILES>
 static void gemm2_nw(const GemmArgs& a, int ksplit, int nw, hipStream_t s) {
-    if (nw == 2) gemm2_epi<MTILES, 2>(a, ksplit, s); else gemm2_epi<MTILES, 4>(a, ksplit, s);
+    if constexpr (MTILES == 8) {   // 128 rows on two-wave workgroups spills (196 bytes per lane) and has no caller: not instantiated
+        if (nw != 4) throw Error("gemm2: 65..128 rows run on four-wave workgroups");
+        gemm2_epi<MTILES, 4>(a, ksplit, s);
+    } else { if (nw == 2) gemm2_epi<MTILES, 2>(a, ksplit, s); else gemm2_epi<MTILES, 4>(a, ksplit, s); }
 }
 // ksplit: number of K slices (1 = complete sums, direct epilogue; >1 requires EPI_SLAB); nw: waves (= 16-column tiles) per workgroup
 void launch_gemm2(const GemmArgs& a0, int ksplit, int nw, hipStream_t s) {
@@ -491,6 +494,25 @@ __global__ __launch_bounds__(256) void k_gemm3(const bf16_t* pW, const bf16_t* p
         }
         return;
     }
+    // Slabs are read by ANOTHER launch (the attention prologue, k_finish*, the slab sampler), in general on other XCDs: stored write-through
+    // (sc1) they reach the fabric while the launch still runs; as plain stores they sit dirty in this XCD's L2 until the kernel boundary
+    // writes them back (MI355X guide, boundary row: + B / 6 TB/s behind B dirty bytes — 0.7 us behind the QKV projection's 4.2 MB at 64
+    // rows).  Q3TTS_GEMM_PLAIN_SLABS=1 (a.plain_slabs) is the A/B knob.
+    if (!a.plain_slabs && (a.N & 3) == 0) {
+        const size_t slab_bytes = (size_t)gridDim.y * a.slab_rows * a.ldo * sizeof(float);
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (int)slab_bytes, 0x00020000);
+        __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc(DUAL ? a.out2 : a.out, 0, (int)slab_bytes, 0x00020000);
+#pragma unroll
+        for (int p = 0; p < ROWS / 16; ++p) {
+            const int ml = erow + p * 16, m = m0 + ml;
+            if (m < M && ng < a.N) {
+                const unsigned off = (unsigned)(((sbase + m) * a.ldo + ng) * sizeof(float));
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, *reinterpret_cast<const f32x4*>(&ep[0][ml][ecol])), rs, off, 0, G3_AUX_SC1);
+                if (DUAL) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, *reinterpret_cast<const f32x4*>(&ep[DUAL ? 1 : 0][ml][ecol])), rs2, off, 0, G3_AUX_SC1);
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int p = 0; p < ROWS / 16; ++p) {
         const int ml = erow + p * 16, m = m0 + ml;
@@ -514,6 +536,9 @@ template <int MTILES, int EPI, int SEAM, int NS>
 static void gemm3_seam_go(const GemmArgs& a, int ksplit, hipStream_t s) {
     const dim3 grid(a.N / 64, ksplit, (a.M + MTILES * 16 - 1) / (MTILES * 16)), block(256);
     const int nch = a.K / ksplit / G3_CH;
+    if constexpr (SEAM == 2 && NS == 4 && MTILES == 2) {   // Q3TTS_SEAM_GU_KS=2 (A/B knob): 512-wide K slices for gate/up — two slab pairs per seam instead of four
+        if (nch == 8) { hipLaunchKernelGGL((k_gemm3<MTILES, EPI, 8, 2, false, SEAM, NS>), grid, block, 0, s, a.W, a.W2, a.xh, a.xl, a.ldx, a.M, a.N, a.K, a); return; }
+    }
     if (nch == 4) hipLaunchKernelGGL((k_gemm3<MTILES, EPI, 4, 2, false, SEAM, NS>), grid, block, 0, s, a.W, a.W2, a.xh, a.xl, a.ldx, a.M, a.N, a.K, a);
     else hipLaunchKernelGGL((k_gemm3<MTILES, EPI, 2, 2, false, SEAM, NS>), grid, block, 0, s, a.W, a.W2, a.xh, a.xl, a.ldx, a.M, a.N, a.K, a);
 }
@@ -521,7 +546,7 @@ bool gemm_seam_ok(const GemmArgs& a, int ksplit) {
     if (a.seam != 1 && a.seam != 2) return false;
     if ((a.seam == 1) != (a.epi == EPI_SLAB) || (a.seam == 2) != (a.epi == EPI_SLAB2)) return false;
     const int ksl = ksplit > 0 && a.K % ksplit == 0 ? a.K / ksplit : 0;
-    if (!(ksl == 128 || ksl == 256) || a.N % 64 != 0 || a.ldo % 4 != 0 || a.ldx % 8 != 0 || a.M < 1 || a.M > 128) return false;
+    if (!(ksl == 128 || ksl == 256 || (ksl == 512 && a.seam == 2 && a.M <= 64)) || a.N % 64 != 0 || a.ldo % 4 != 0 || a.ldx % 8 != 0 || a.M < 1 || a.M > 128) return false;
     // chunk c of a row block is reduced by K slice c (blockIdx.y == c): a launch with fewer slices than 16-row chunks per block (2 up to 64
     // rows, 4 beyond) would leave chunks without an owner — those shapes (K = 128 .. 768 with 256-wide slices) keep the finish launches
     if (ksplit < (a.M > 64 ? 4 : 2)) return false;
@@ -530,7 +555,10 @@ bool gemm_seam_ok(const GemmArgs& a, int ksplit) {
     return a.seam_cnt != nullptr && a.seam_gen != nullptr && a.oh != nullptr && a.ol != nullptr && a.ldp % 4 == 0 && (a.slab_rows == 0 || a.slab_rows == a.M);
 }
 static void launch_gemm3_seam(const GemmArgs& a, int ksplit, hipStream_t s) {
-    const bool big = a.M > 64;   // 32-row blocks up to 64 rows, 64-row blocks beyond
+    // 32-row blocks up to 64 rows, 64-row blocks beyond.  Q3TTS_SEAM_BIG (A/B knob, bit 0: the residual seams, bit 1: gate/up): 64-row
+    // blocks from 33 rows on — half the workgroups, the weights fetched once instead of once per row block
+    const int bigk = knob("Q3TTS_SEAM_BIG") ? atoi(knob("Q3TTS_SEAM_BIG")) : 0;
+    const bool big = a.M > 64 || (a.M > 32 && ksplit >= 4 && ((bigk >> (a.seam - 1)) & 1));
     if (a.seam == 1) {
         if (ksplit <= 8) { if (big) gemm3_seam_go<4, EPI_SLAB, 1, 8>(a, ksplit, s); else gemm3_seam_go<2, EPI_SLAB, 1, 8>(a, ksplit, s); }
         else { if (big) gemm3_seam_go<4, EPI_SLAB, 1, 12>(a, ksplit, s); else gemm3_seam_go<2, EPI_SLAB, 1, 12>(a, ksplit, s); }
@@ -559,7 +587,9 @@ static bool gemm3_ok(const GemmArgs& a, int ksplit) {
     const int ksl = a.K / ksplit;
     return a.K % ksplit == 0 && (ksl == 128 || ksl == 256) && a.ldo % 4 == 0 && a.ldx % 8 == 0 && a.M >= 1 && a.M <= 128;
 }
-static void launch_gemm3(const GemmArgs& a, int ksplit, hipStream_t s) {
+static void launch_gemm3(const GemmArgs& a0, int ksplit, hipStream_t s) {
+    GemmArgs a = a0;
+    a.plain_slabs = knob("Q3TTS_GEMM_PLAIN_SLABS") != nullptr;
     const bool dual = a.epi == EPI_SLAB2;
     // nt weight loads measured on the b=64 step (graph replay, same box): 4.961 ms with, 4.917 ms without — the slab GEMM's launches are
     // bound by their latency chain, not by where the weights come from, and a replayed GEMM body loses what default-policy loads leave in
@@ -816,6 +846,9 @@ bool gemv16_ok(const GemvArgs& a) {
     if (a.K % 128 != 0 || a.K > 6144 || a.ldx % 4 != 0) return false;
     if (a.K > 1024 && a.K % 256 != 0) return false;   // 8 waves from there on
     if (a.gamma && a.epi != EPI_STORE && a.epi != EPI_SWIGLU) return false;
+    // K > 3072 (24 k-steps per wave: the 1.7B talker's down projection) covers the residual / bias / plain-store epilogues only: with a
+    // fused RMSNorm or two weight matrices on top the kernel spills (20 .. 524 bytes per lane), and no shipped config has such a shape
+    if (a.K > 3072 && (a.gamma || a.epi == EPI_SWIGLU)) return false;
     return true;
 }
 
@@ -832,8 +865,14 @@ static void gemv16_epi(const GemvArgs& a, hipStream_t s) {
 #define Q3_G16(EPI, NORM) do { if (NORM && gl) { if (r8) Q3_G16_(EPI, NORM, true, NORM); else Q3_G16_(EPI, NORM, false, NORM); } \
                                else { if (r8) Q3_G16_(EPI, NORM, true, false); else Q3_G16_(EPI, NORM, false, false); } } while (0)
     switch (a.epi) {
-    case EPI_STORE: if (norm) Q3_G16(EPI_STORE, true); else Q3_G16(EPI_STORE, false); break;
-    case EPI_SWIGLU: if (norm) Q3_G16(EPI_SWIGLU, true); else Q3_G16(EPI_SWIGLU, false); break;
+    case EPI_STORE:
+        if constexpr (KWMAX <= 12) { if (norm) Q3_G16(EPI_STORE, true); else Q3_G16(EPI_STORE, false); }
+        else { if (norm) throw Error("gemv16: K > 3072 has no fused-norm variant"); Q3_G16(EPI_STORE, false); }
+        break;
+    case EPI_SWIGLU:
+        if constexpr (KWMAX <= 12) { if (norm) Q3_G16(EPI_SWIGLU, true); else Q3_G16(EPI_SWIGLU, false); }
+        else throw Error("gemv16: K > 3072 has no SwiGLU variant");
+        break;
     case EPI_RESIDUAL: Q3_G16(EPI_RESIDUAL, false); break;
     case EPI_BIAS: Q3_G16(EPI_BIAS, false); break;
     case EPI_BIAS_SILU: Q3_G16(EPI_BIAS_SILU, false); break;

@@ -15,19 +15,30 @@ LLVM = "/opt/rocm/lib/llvm/bin/"
 
 
 def kernel_table(obj):
-    """[(demangled name, vgpr, agpr, sgpr, scratch bytes, lds bytes)] for the gfx950 code object bundled in `obj`."""
-    with tempfile.TemporaryDirectory() as tmp:
-        fat, co = os.path.join(tmp, "k.fat"), os.path.join(tmp, "k.co")
-        subprocess.run([LLVM + "llvm-objcopy", "-O", "binary", "--only-section=.hip_fatbin", obj, fat], check=True)
-        out = subprocess.run([LLVM + "clang-offload-bundler", "--list", "--type=o", "--input=" + fat], capture_output=True, text=True, check=True)
-        tgt = [l for l in out.stdout.split() if "gfx950" in l][0]
-        subprocess.run([LLVM + "clang-offload-bundler", "--unbundle", "--type=o", "--input=" + fat, "--targets=" + tgt, "--output=" + co], check=True)
-        md = subprocess.run([LLVM + "llvm-readelf", "--notes", co], capture_output=True, text=True, check=True).stdout
+    """[(demangled name, vgpr, agpr, sgpr, scratch bytes, lds bytes)] for EVERY gfx950 code object bundled in `obj` (a .so linked from
+    several .hip sources holds one offload bundle per source, back to back in .hip_fatbin)."""
     rows = []
-    for b in md.split("  - .agpr_count")[1:]:
-        g = lambda k: int(re.search(r"\." + k + r":\s+(\d+)", b).group(1))
-        rows.append((re.search(r"\.name:\s+(\S+)", b).group(1), g("vgpr_count"), int(re.match(r":\s+(\d+)", b).group(1)), g("sgpr_count"),
-                     g("private_segment_fixed_size"), g("group_segment_fixed_size")))
+    with tempfile.TemporaryDirectory() as tmp:
+        fat = os.path.join(tmp, "k.fat")
+        subprocess.run([LLVM + "llvm-objcopy", "-O", "binary", "--only-section=.hip_fatbin", obj, fat], check=True)
+        blob = open(fat, "rb").read()
+        magic = b"__CLANG_OFFLOAD_BUNDLE__"
+        starts = [m.start() for m in re.finditer(re.escape(magic), blob)]
+        if not starts:
+            raise RuntimeError("no offload bundle in " + obj)
+        for n, (a, b) in enumerate(zip(starts, starts[1:] + [len(blob)])):
+            one, co = os.path.join(tmp, "b%d.fat" % n), os.path.join(tmp, "b%d.co" % n)
+            open(one, "wb").write(blob[a:b])
+            out = subprocess.run([LLVM + "clang-offload-bundler", "--list", "--type=o", "--input=" + one], capture_output=True, text=True, check=True)
+            tgts = [l for l in out.stdout.split() if "gfx950" in l]
+            if not tgts:
+                continue
+            subprocess.run([LLVM + "clang-offload-bundler", "--unbundle", "--type=o", "--input=" + one, "--targets=" + tgts[0], "--output=" + co], check=True)
+            md = subprocess.run([LLVM + "llvm-readelf", "--notes", co], capture_output=True, text=True, check=True).stdout
+            for blk in md.split("  - .agpr_count")[1:]:
+                g = lambda k: int(re.search(r"\." + k + r":\s+(\d+)", blk).group(1))
+                rows.append((re.search(r"\.name:\s+(\S+)", blk).group(1), g("vgpr_count"), int(re.match(r":\s+(\d+)", blk).group(1)), g("sgpr_count"),
+                             g("private_segment_fixed_size"), g("group_segment_fixed_size")))
     dem = subprocess.run(["c++filt"], input="\n".join(r[0] for r in rows), capture_output=True, text=True).stdout.split("\n")
     return [(re.sub(r"\(.*", "", d.replace("void q3::", "")),) + r[1:] for r, d in zip(rows, dem)]
 
