@@ -2119,15 +2119,17 @@ static __device__ __forceinline__ void wave_lds_sync() {   // wave-private LDS s
 // softmax -> top-p -> renormalise -> inverse-CDF draw (tts_onnx.cpp:886-904) over at most 64 candidates, one per lane IN INDEX ORDER
 // (lanes >= nk hold e = 0): e = exp(logit - max) numerators, id = token ids.  Every sum is the reference's left fold.  sb: 3 x 64 floats
 // of wave-private LDS.  Returns the drawn token id (wave-uniform).
-static __device__ __forceinline__ int draw_small_exact(float e, int id, int nk, float top_p, float u, int lane, float (*sb)[64]) {
+// have: this lane holds a candidate (the candidates need not be packed to the front: the fast path leaves them where the index-ordered
+// gather put them).
+static __device__ __forceinline__ int draw_small_exact(float e, int id, bool have, int nk, float top_p, float u, int lane, float (*sb)[64]) {
     sb[0][lane] = e;
     wave_lds_sync();
     const float S = seq_sum_lds(sb[0], 64);
     float p = e / S;                                                          // :913-914
     if (top_p < 1.0f) {                                                       // :929-950: order (p desc, index asc), keep through the first running sum > top_p
-        float sk = lane < nk ? p : -INFINITY;
+        float sk = have ? p : -INFINITY;
         int tag = lane;
-        wave_sort_desc_kv(sk, tag, lane);
+        wave_sort_desc_kv(sk, tag, lane);                                     // the nk candidates come first (everything else is -inf)
         sb[1][lane] = lane < nk ? sk : 0.f;
         wave_lds_sync();
         const int cut = seq_find_lds(sb[1], 64, top_p);
@@ -2189,13 +2191,15 @@ static __device__ __forceinline__ int draw_small(float e, int id, int nk, float 
         const int pick = hit ? __ffsll((long long)hit) - 1 : (pos ? 63 - __clzll((long long)pos) : 0);
         return lane_bcast_i(id, pick);
     }
-    return draw_small_exact(e, id, nk, top_p, u, lane, sb);
+    return draw_small_exact(e, id, lane < nk, nk, top_p, u, lane, sb);
 }
 
 // draw_small for candidates that arrive sorted by (logit desc, index asc), one per lane, the kept ones in lanes [0, nk) — the order the
 // fast path's threshold sort leaves them in, which is also the top-p order (p is monotone in the logit; two different logits whose
-// probabilities collide are covered by the neighbour test at the cut).  One more sort (by index) instead of two.
-static __device__ __forceinline__ int draw_sorted(float v, int id, int nk, float mx, float top_p, float u, int lane, float (*sb)[64]) {
+// probabilities collide are covered by the neighbour test at the cut).  `tag` = the lane each candidate came from: the gather put the
+// candidates there IN INDEX ORDER (contiguous slices per wave), so the draw's order is restored by pushing every probability back to
+// its lane (one ds_permute; rounds 1-4 sorted a second time, by index).  id0 = the id this lane held before the sort.
+static __device__ __forceinline__ int draw_sorted(float v, int tag, int id0, int nk, float mx, float top_p, float u, int lane, float (*sb)[64]) {
     const bool kept = lane < nk;
     const float e = kept ? q3_expf(v - mx) : 0.f;                              // softmax numerators over the kept entries (:907-915)
     const float Sa = wave_sum(e);
@@ -2212,12 +2216,8 @@ static __device__ __forceinline__ int draw_sorted(float v, int id, int nk, float
         const float s2 = wave_sum(p);
         if (s2 > 0.f) p = p / s2;
     }
-    // index order for the draw: sort by index, pull (p, index) along with a backward permute
-    float key = kept ? -(float)id : -INFINITY;
-    int from = lane;
-    wave_sort_desc_kv(key, from, lane);
-    const float pi = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(from << 2, __builtin_bit_cast(int, p)));
-    const int idi = __builtin_amdgcn_ds_bpermute(from << 2, id);
+    // index order for the draw: the tags are a permutation of 0..63, every lane receives the probability of the candidate it gathered
+    const float pi = __builtin_bit_cast(float, __builtin_amdgcn_ds_permute(tag << 2, __builtin_bit_cast(int, p)));
     const float total = wave_sum(pi);
     const float target = u * total;
     const float cum = wave_scan_incl_f(pi);
@@ -2226,10 +2226,11 @@ static __device__ __forceinline__ int draw_sorted(float v, int id, int nk, float
         const unsigned long long hit = __ballot(pi > 0.f && cum > target);
         const unsigned long long pos = __ballot(pi > 0.f);
         const int pick = hit ? __ffsll((long long)hit) - 1 : (pos ? 63 - __clzll((long long)pos) : 0);
-        return lane_bcast_i(idi, pick);
+        return lane_bcast_i(id0, pick);
     }
-    const float ei = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(from << 2, __builtin_bit_cast(int, e)));
-    return draw_small_exact(ei, idi, nk, top_p, u, lane, sb);
+    const float ei = __builtin_bit_cast(float, __builtin_amdgcn_ds_permute(tag << 2, __builtin_bit_cast(int, e)));
+    const int havei = __builtin_amdgcn_ds_permute(tag << 2, kept ? 1 : 0);
+    return draw_small_exact(ei, id0, havei != 0, nk, top_p, u, lane, sb);
 }
 
 // k-th largest of one value per lane (ties allowed), -inf when fewer than k lanes hold a finite value: the wave sorts its 64
@@ -2241,7 +2242,9 @@ static __device__ __forceinline__ float kth_largest_of_lanes(float v, int k) {
     return lane_bcast(sorted, r < 0 ? 0 : (r > 63 ? 63 : r));
 }
 
-// Four waves per utterance: wave w owns the 64-element slices j = w, w+4, ... of the logits row (registers),
+// Four waves per utterance: wave w owns the CONTIGUOUS 64-element slices j = w PW .. w PW + PW - 1 of the logits row (registers; round 5 —
+// they were interleaved, j = w, w + 4, ...: with contiguous ranges the four waves' survivor lists concatenate in index order, so the
+// draw's index order is the gather order and no second sort is needed),
 // the few cross-wave hand-offs go through LDS; the serial tail (threshold rounds, top-p, draw) runs on wave 0
 // only, the embedding epilogue on all 256 threads.
 // PW = 64-element slices per wave: 16 covers 4096 logits; 8 (vocabularies up to 2048: fifteen of a frame's sixteen samplers) and 12 (up to
@@ -2289,7 +2292,7 @@ __global__ __launch_bounds__(256) void k_sample(const float* plogits, SlotState*
         float xp[PW][4];
 #pragma unroll
         for (int jj = 0; jj < PW; ++jj) {
-            const int i = (jj * 4 + wave) * 64 + lane;
+            const int i = (wave * PW + jj) * 64 + lane;
 #pragma unroll
             for (int sb = 0; sb < 4; ++sb) xp[jj][sb] = lg[(size_t)(sb < a.nslab ? sb : 0) * a.slab_stride + (i < V ? i : V - 1)];
         }
@@ -2304,7 +2307,7 @@ __global__ __launch_bounds__(256) void k_sample(const float* plogits, SlotState*
     } else {
 #pragma unroll
         for (int jj = 0; jj < PW; ++jj) {
-            const int i = (jj * 4 + wave) * 64 + lane;
+            const int i = (wave * PW + jj) * 64 + lane;
             x[jj] = lg[i < V ? i : V - 1];           // clamped, unconditional
         }
     }
@@ -2326,7 +2329,7 @@ __global__ __launch_bounds__(256) void k_sample(const float* plogits, SlotState*
     float lmax = -INFINITY;
 #pragma unroll
     for (int jj = 0; jj < PW; ++jj) {
-        const int i = (jj * 4 + wave) * 64 + lane;
+        const int i = (wave * PW + jj) * 64 + lane;
         float v = x[jj];
         const bool sup = suppress && i >= a.sup_begin && i < a.sup_end && !(i == a.eos_id && keep_eos);
         const float vt = v / temperature;
@@ -2344,9 +2347,9 @@ __global__ __launch_bounds__(256) void k_sample(const float* plogits, SlotState*
     bool fast_done = false;
     if (top_k >= 2 && top_k <= 64 && top_k < V) {
         const float tsort = wave_sort_desc(lmax, lane);
-        if (lane < 16) svb[wave * 16 + lane] = tsort;
+        if (lane < 16) svb[wave * 16 + ((wave & 1) ? 15 - lane : lane)] = tsort;   // odd waves' runs reversed: runs 0|1 and 2|3 form bitonic blocks of 32
         __syncthreads();
-        const float msort = wave_sort_desc(svb[lane], lane);                  // every wave redoes the 64-value merge: no second barrier
+        const float msort = wave_merge4x16_desc(svb[lane], lane);             // every wave redoes the 64-value merge (11 stages: the runs are sorted): no second barrier
         const float B = lane_bcast(msort, __builtin_amdgcn_readfirstlane(top_k) - 1);
         const float mxf = lane_bcast(msort, 0);
         SP_MARK(3);
@@ -2358,7 +2361,7 @@ __global__ __launch_bounds__(256) void k_sample(const float* plogits, SlotState*
             const int ppos = nw + __popcll(m & lt_mask);
             const int slot = (sv && ppos < 256) ? ppos : 256 + lane;
             svw[wave][slot] = x[jj];
-            cand_idx[wave * (256 + 64) + slot] = (jj * 4 + wave) * 64 + lane;
+            cand_idx[wave * (256 + 64) + slot] = (wave * PW + jj) * 64 + lane;
             nw += __popcll(m);
         }
         if (lane == 0) svn[wave] = nw;
@@ -2372,15 +2375,16 @@ __global__ __launch_bounds__(256) void k_sample(const float* plogits, SlotState*
                 int id = 0x7FFFFFFF;
                 const int w = lane < n0 ? 0 : (lane < n0 + n1 ? 1 : (lane < n0 + n1 + n2 ? 2 : 3));
                 const int off = lane - (w == 0 ? 0 : (w == 1 ? n0 : (w == 2 ? n0 + n1 : n0 + n1 + n2)));
-                if (lane < n) { v = svw[w][off]; id = cand_idx[w * (256 + 64) + off]; }
-                wave_sort_desc_kv(v, id, lane);
+                if (lane < n) { v = svw[w][off]; id = cand_idx[w * (256 + 64) + off]; }   // index order: wave w's list precedes wave w + 1's
+                int tag = lane;
+                wave_sort_desc_kv(v, tag, lane);                                    // (logit desc, index asc): lane order IS index order
                 const int kk = __builtin_amdgcn_readfirstlane(top_k);
                 const float thrf = n >= kk ? lane_bcast(v, kk - 1) : -INFINITY;     // ties at the threshold stay (:917-927)
                 const bool kept = lane < n && v >= thrf;
                 const int nk = __popcll(__ballot(kept));
                 SP_MARK(5);
                 SP_MARK(6);
-                tok = draw_sorted(v, id, nk, mxf, top_p, u, lane, sb);   // lanes [0, nk) are the kept ones: the sort put them first
+                tok = draw_sorted(v, tag, id, nk, mxf, top_p, u, lane, sb);   // lanes [0, nk) are the kept ones: the sort put them first
                 SP_MARK(7);
                 if (lane == 0) sh_i[3] = tok;
             }
@@ -2464,7 +2468,7 @@ __global__ __launch_bounds__(256) void k_sample(const float* plogits, SlotState*
                     const uint32_t cand = prefix | (1u << bit);
                     int c = 0;
     #pragma unroll
-                    for (int jj = 0; jj < PW; ++jj) c += ((jj * 4 + wave) * 64 + lane < V && fkey(x[jj]) >= cand) ? 1 : 0;
+                    for (int jj = 0; jj < PW; ++jj) c += ((wave * PW + jj) * 64 + lane < V && fkey(x[jj]) >= cand) ? 1 : 0;
                     c = wave_sum_i(c);
                     __syncthreads();
                     if (lane == 0) svn[wave] = c;
@@ -2482,7 +2486,7 @@ __global__ __launch_bounds__(256) void k_sample(const float* plogits, SlotState*
         for (int jj = 0; jj < PW; ++jj) {
             const bool keep = x[jj] >= thr && x[jj] != -INFINITY;
             km[jj] = __ballot(keep);
-            const int j = jj * 4 + wave;
+            const int j = wave * PW + jj;
             if (lane == 0 && j < PER) cnt_s[j] = __popcll(km[jj]);
         }
         __syncthreads();
@@ -2492,7 +2496,7 @@ __global__ __launch_bounds__(256) void k_sample(const float* plogits, SlotState*
         const int n_kept = lane_bcast_i(cincl, 63);
     #pragma unroll
         for (int jj = 0; jj < PW; ++jj) {
-            const int j = jj * 4 + wave;
+            const int j = wave * PW + jj;
             if (km[jj]) { // wave-uniform: most slices hold no survivor
                 const int base = lane_bcast_i(cincl, j) - lane_bcast_i(cmine, j);
                 const bool keep = (km[jj] >> lane) & 1ull;

@@ -47,6 +47,16 @@ static __device__ __forceinline__ float wave_sort_desc(float v, int lane) {
     return v;
 }
 
+// Four sorted runs of 16 (lanes 0-15 descending, 16-31 ASCENDING, 32-47 descending, 48-63 ASCENDING: two bitonic blocks of 32) -> all 64
+// descending: the two bitonic merges of the network only, 11 stages instead of the full sort's 21.
+static __device__ __forceinline__ float wave_merge4x16_desc(float v, int lane) {
+    v = wave_sort_step<32, 16>(v, lane); v = wave_sort_step<32, 8>(v, lane); v = wave_sort_step<32, 4>(v, lane); v = wave_sort_step<32, 2>(v, lane);
+    v = wave_sort_step<32, 1>(v, lane);
+    v = wave_sort_step<64, 32>(v, lane); v = wave_sort_step<64, 16>(v, lane); v = wave_sort_step<64, 8>(v, lane); v = wave_sort_step<64, 4>(v, lane);
+    v = wave_sort_step<64, 2>(v, lane); v = wave_sort_step<64, 1>(v, lane);
+    return v;
+}
+
 // (key, tag) pairs: descending key, ascending tag among equal keys (tags distinct)
 template <int K, int J>
 static __device__ __forceinline__ void wave_sort_step_kv(float& k, int& t, int lane) {
