@@ -14,7 +14,9 @@ metric ("0.6B @ b1/b64", north_star "batch 1/8/64") as sub-records run in the sa
 timed region of `value`: "b64" = configs[2] (64 utterances in one batch x 256 frames, 5 timed steps),
 "b8", "b64_f2048" (64 x 2048 frames: the length configs[1] and the reference default state), and the
 same long workloads with the talker KV cache in bf16 ("b64_f2048_kv_bf16", "b1_f2048_kv_bf16"), each
-with its own `roofline`.
+with its own `roofline`; "b8_1p7b_clone" = configs[4] (1.7B dims, batch 8, the --ref voice-clone front end — wav -> resample ->
+log-mel -> speaker encoder -> speaker row — inside the timed region); "capacity" = three 128-slot engines stepping concurrently
+(labelled: not a BASELINE config).  `stages` carries per-stage device time incl. `prefill` (bytes and fraction of HBM).
 
 Multi-GPU (configs[3]): utterances are independent, each rank runs its own batch on its own GPU
 (weak scaling); RCCL carries only the final gather of codes + PCM lengths.  `--gpus N` with
@@ -25,7 +27,8 @@ already there.  Either way world_size must equal --gpus.
 Rank 0 prints ONE JSON line.  `roofline` is for the decode step (the hipGraph replayed per frame):
 algorithmic bytes / device time measured with HIP events on the engine's stream.
 `cpu_baseline` is the reference CLI on ONNX Runtime's CPU EP when an operator supplies it (probe below),
-else the CPU oracle (a port of the reference's call pattern, fp32) timed on a bounded sample.
+else the CPU oracle (a port of the reference's call pattern, fp32) timed on a bounded sample — on all allowed cores (capped at 16
+OpenMP threads) and, `threads4`, on the 4 threads the reference pins ONNX Runtime to (tts_onnx.cpp:140).
 """
 import argparse
 import json
