@@ -594,6 +594,37 @@ def test_codec_carried_state_streaming_full_size(full):
     assert float(np.abs(win - whole).max()) < 2e-5
 
 
+def test_codec_stream_sliding_state_grows_and_shifts_full_size(full):
+    """Round 5: a stream's carried state is a sliding buffer (the last 71 K / V rows per layer and the last 12 output rows + room for the
+    largest push so far, 256 rows by default).  Pushes of 130, 7, 200, 1 and 62 frames at 0.6B dims: 130 and 200 exceed the default room
+    (the buffers grow, the kept rows are carried over), the later ones find the buffer full (the kept rows move to the front); two streams
+    of different push patterns interleave.  The concatenation equals the one-shot decode (the reference's single run_vocoder call,
+    /root/reference/src/tts_onnx.cpp:759-776) to fp32 rounding."""
+    eng, _ = full
+    F = 400
+    codes = np.random.default_rng(401).integers(0, 2048, (F, 16)).astype(np.int64)
+    whole = eng.codec_decode(codes)
+    sa, sb = eng.codec_stream_begin(F), eng.codec_stream_begin(F)
+    pa, pb, ia, ib = [], [], 0, 0
+    for na, nb in ((130, 3), (7, 120), (200, 40), (1, 115), (62, 122)):
+        pa.append(eng.codec_stream_push(sa, codes[ia:ia + na])); ia += na
+        pb.append(eng.codec_stream_push(sb, codes[ib:ib + nb])); ib += nb
+    assert ia == F and ib == F
+    eng.codec_stream_end(sa)
+    eng.codec_stream_end(sb)
+    for tag, parts in (("a", pa), ("b", pb)):
+        got = np.concatenate(parts)
+        assert got.shape == whole.shape
+        d = float(np.abs(got - whole).max())
+        print("sliding stream %s: max |pushes - one-shot| %.3g over %d frames" % (tag, d, F))
+        assert d < 2e-5, (tag, d)
+    # a third stream reuses a pooled buffer that the large pushes have grown: small pushes again, from position 0
+    sc = eng.codec_stream_begin(64)
+    got = np.concatenate([eng.codec_stream_push(sc, codes[a:a + 16]) for a in range(0, 64, 16)])
+    eng.codec_stream_end(sc)
+    assert float(np.abs(got - eng.codec_decode(codes[:64])).max()) < 2e-5
+
+
 def test_batched_job_codec_equals_single_utterance_decodes_full_size():
     """0.6B dims, a scheduler job of 5 utterances with ragged lengths (3 to 150 frames, two of them past the pre-transformer's 72-frame window):
     the job's vocoder phase runs the pre-transformer over all utterances in one row block (one cache block and one grid z per utterance
