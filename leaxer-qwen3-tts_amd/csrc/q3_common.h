@@ -82,6 +82,18 @@ void launch_gemv(const GemvArgs& a, hipStream_t s);
 bool gemv_fast_path(const GemvArgs& a); // single-pass kernel available (M <= 2, K in {1024,2048,3072})
 bool gemv16_ok(const GemvArgs& a);        // 3..16 rows on the matrix cores, same contract (q3_gemm_kernels.hip); launch_gemv picks it
 void launch_gemv16(const GemvArgs& a, hipStream_t s);
+// Fragment-packed copies of the bf16 weight matrices for the matrix-core decode kernels (k_gemv16, k_gemm3; round 5).  The B operand of
+// v_mfma_f32_16x16x32_bf16 wants lane (r16, q) to hold row n0 + r16, k = 32 s + 8 q .. + 7: read from the row-major [N][K] matrix that is
+// 16 rows x 64 bytes per load instruction — sixteen half-used 128-byte lines.  The packed copy stores, for every (16-row tile t, k-step s),
+// the 64 lanes' 16 bytes back to back: P[((t K/32 + s) 64 + lane) 8 + e] = W[min(16 t + (lane & 15), N - 1)][32 s + 8 (lane >> 4) + e], so a
+// load instruction is ONE contiguous KB (eight whole lines).  Same values into the same registers: results are bit-identical.  The kernels
+// find the copy through a process-wide registry keyed by the row-major pointer (engines register at finalize, unregister when destroyed);
+// Q3TTS_PACKED_W=0 (A/B knob) ignores it.
+void launch_pack_mfma_b(const bf16_t* W, bf16_t* P, int N, int K, hipStream_t s);
+size_t packed_mfma_b_elems(int N, int K);
+void register_packed_weight(const bf16_t* W, const bf16_t* P);
+void unregister_packed_weight(const bf16_t* W);
+const bf16_t* find_packed_weight(const bf16_t* W);   // nullptr: none (or the knob says no)
 
 // Decode-time attention over a paged fp32 KV cache with the new tokens' q/k-norm + RoPE + append fused.
 struct AttnArgs {
@@ -157,6 +169,7 @@ struct GemmArgs {
     int M = 0, N = 0, K = 0, epi = EPI_STORE;
     int slab_rows = 0;   // EPI_SLAB / EPI_SLAB2: rows per slab (0 = M); launch_gemm2 sets it when it cuts M into 128-row blocks
     bool nt = false;     // non-temporal weight loads (weights this step reads once: the talker's)
+    bool w_packed = false;      // W / W2 point at fragment-packed copies (set by launch_gemm3 from the registry)
     bool plain_slabs = false;   // A/B knob Q3TTS_GEMM_PLAIN_SLABS: k_gemm3's slabs as plain stores instead of write-through (sc1)
     // ---- split-K seam (k_gemm3 only): the slabs are reduced INSIDE the launch by the K-slice workgroups of a column tile themselves
     // (sc1 slab stores, a flag per slice, slice s < 16-row-chunk count owns chunk s once every flag is set), instead of by a k_finish* launch.

@@ -372,6 +372,7 @@ Engine::~Engine() {
     if (proj_out_d) (void)hipFree(proj_out_d);
     codec_free();
     speaker_free();
+    free_packed_weights();
     for (void* p : allocs) (void)hipFree(p);
     if (active_h) (void)hipHostFree(active_h);
     if (ev0) (void)hipEventDestroy(ev0);
@@ -428,6 +429,37 @@ void Engine::fill_synthetic(uint64_t seed) {
     finalized = false;
 }
 
+// Fragment-packed copies of every matrix the matrix-core decode kernels stream (q3_common.h: launch_pack_mfma_b): + one copy of the
+// bf16 projection weights (1.05 GB at 0.6B dims, 3 GB at 1.7B), registered under the row-major pointer the launch sites keep using.
+void Engine::free_packed_weights() {
+    for (auto& pr : packed_w) { unregister_packed_weight(pr.first); (void)hipFree(pr.second); }
+    packed_w.clear();
+}
+void Engine::pack_mfma_weights() {
+    free_packed_weights();
+    auto pack = [&](const bf16_t* W, int N, int K) {
+        if (W == nullptr || N < 1 || K < 32 || K % 32 != 0) return;
+        for (auto& pr : packed_w) if (pr.first == W) return;
+        bf16_t* P = nullptr;
+        Q3_HIP_CHECK(hipMalloc((void**)&P, packed_mfma_b_elems(N, K) * sizeof(bf16_t)));
+        launch_pack_mfma_b(W, P, N, K, stream);
+        packed_w.emplace_back(W, P);
+    };
+    auto stack = [&](const DecStack& S) {
+        for (const DecLayerW& w : S.layers) {
+            pack(w.qkv, (S.nq + 2 * S.nkv) * S.d, S.H); pack(w.o, S.H, S.nq * S.d);
+            pack(w.gate, S.ffn, S.H); pack(w.up, S.ffn, S.H); pack(w.down, S.H, S.ffn);
+        }
+    };
+    stack(talker); stack(cp);
+    pack(codec_head, c.vocab, c.hidden);
+    for (const bf16_t* h : cp_head) pack(h, c.sub_vocab, cp_width());
+    if (cp_proj_w) pack(cp_proj_w, cp_width(), c.hidden);
+    pack(fc1_w, c.text_hidden, c.text_hidden); pack(fc2_w, c.hidden, c.text_hidden);
+    sync();
+    for (auto& pr : packed_w) register_packed_weight(pr.first, pr.second);
+}
+
 void Engine::finalize() {
     auto fp = [&](const std::string& n) { return (const float*)T(n).dev; };
     auto bp = [&](const std::string& n) { return (const bf16_t*)T(n).dev; };
@@ -453,6 +485,7 @@ void Engine::finalize() {
     for (int j = 0; j < c.n_groups - 1; ++j) { cp_head.push_back(bp("cp.head." + std::to_string(j))); cp_embed_w.push_back(bp("cp.embed." + std::to_string(j))); }
     codec_finalize();
     speaker_finalize();
+    pack_mfma_weights();
     finalized = true;
     // tts_pad_embed_ = text_project(TTS_PAD) (tts_onnx.cpp:459-463), model-wide constant kept on device
     if (TTS_PAD < c.text_vocab) {

@@ -158,6 +158,9 @@ public:
     void slot_release(int slot);
     void step_bytes(double* wbytes, double* kvbytes);
     void measure_skip_frames(int n);                    // measurement aid: armed slots jump n frames ahead over a synthetic KV cache
+    void pack_mfma_weights();                           // fragment-packed copies of the projection matrices for k_gemv16 / k_gemm3 (finalize)
+    void free_packed_weights();
+    std::vector<std::pair<const bf16_t*, bf16_t*>> packed_w;
     void prefill_profile(int nb, int S, int reps, double* ms_per_pass);   // device time of a batched prefill pass (diagnostic)
     void stage_profile(int n_steps, double* out_ms4);   // eager steps with events at the stage boundaries (diagnostic)
     // one EAGER step of the armed slots that also keeps, for slot `slot`, the logits row every one of the frame's n_groups decisions was

@@ -14,6 +14,8 @@
 // Summation order is fixed everywhere: results are bit-reproducible run to run.
 #include <algorithm>
 #include <cstdlib>
+#include <mutex>
+#include <unordered_map>
 
 #include "q3_common.h"
 
@@ -54,6 +56,37 @@ static __device__ __forceinline__ void split_store4(const float (&y)[4], bf16_t*
     *reinterpret_cast<uint2*>(hi) = make_uint2((uint32_t)h[0] | (uint32_t)h[1] << 16, (uint32_t)h[2] | (uint32_t)h[3] << 16);
     *reinterpret_cast<uint2*>(lo) = make_uint2((uint32_t)l[0] | (uint32_t)l[1] << 16, (uint32_t)l[2] | (uint32_t)l[3] << 16);
 }
+// ---- fragment-packed weight copies (q3_common.h) ----
+__global__ void k_pack_mfma_b(const bf16_t* W, bf16_t* P, int N, int K) {
+    const int KS = K / 32;
+    const size_t n_frag = (size_t)((N + 15) / 16) * KS * 64;            // one 16-byte fragment per (tile, k-step, lane)
+    for (size_t f = (size_t)blockIdx.x * blockDim.x + threadIdx.x; f < n_frag; f += (size_t)gridDim.x * blockDim.x) {
+        const int lane = (int)(f & 63);
+        const size_t ts = f >> 6;
+        const int s = (int)(ts % KS), t = (int)(ts / KS);
+        int row = t * 16 + (lane & 15);
+        row = row < N ? row : N - 1;
+        const uint4 v = *reinterpret_cast<const uint4*>(W + (size_t)row * K + s * 32 + (lane >> 4) * 8);
+        *reinterpret_cast<uint4*>(P + f * 8) = v;
+    }
+}
+size_t packed_mfma_b_elems(int N, int K) { return (size_t)((N + 15) / 16) * (K / 32) * 64 * 8; }
+void launch_pack_mfma_b(const bf16_t* W, bf16_t* P, int N, int K, hipStream_t s) {
+    if (K % 32 != 0) throw Error("pack_mfma_b: K must be a multiple of 32");
+    hipLaunchKernelGGL(k_pack_mfma_b, dim3(2048), dim3(256), 0, s, W, P, N, K);
+}
+static std::mutex g_packed_mu;
+static std::unordered_map<const bf16_t*, const bf16_t*> g_packed;
+void register_packed_weight(const bf16_t* W, const bf16_t* P) { std::lock_guard<std::mutex> lk(g_packed_mu); g_packed[W] = P; }
+void unregister_packed_weight(const bf16_t* W) { std::lock_guard<std::mutex> lk(g_packed_mu); g_packed.erase(W); }
+const bf16_t* find_packed_weight(const bf16_t* W) {
+    if (W == nullptr) return nullptr;
+    if (const char* k = knob("Q3TTS_PACKED_W")) if (atoi(k) == 0) return nullptr;
+    std::lock_guard<std::mutex> lk(g_packed_mu);
+    const auto it = g_packed.find(W);
+    return it == g_packed.end() ? nullptr : it->second;
+}
+
 // ================================================================================================
 // k_gemm2 — second-generation batched-decode GEMM.  Workgroup = (n-group of NW*16 columns, K slice):
 // its NW waves each own one 16-column tile and SHARE the activation slice, staged once per 128-wide
@@ -187,6 +220,7 @@ static void gemm2_epi(const GemmArgs& a, int ksplit, hipStream_t s) {
 static bool gemm3_ok(const GemmArgs& a, int ksplit);                       // third generation of the slab GEMM, below
 static void launch_gemm3(const GemmArgs& a, int ksplit, hipStream_t s);
 static void launch_gemm3_seam(const GemmArgs& a, int ksplit, hipStream_t s);
+static GemmArgs gemm3_with_packed(const GemmArgs& a0);
 template <int MTILES>
 static void gemm2_nw(const GemmArgs& a, int ksplit, int nw, hipStream_t s) {
     if constexpr (MTILES == 8) {   // 128 rows on two-wave workgroups spills (196 bytes per lane) and has no caller: not instantiated
@@ -270,8 +304,12 @@ __global__ __launch_bounds__(256) void k_gemm3(const bf16_t* pW, const bf16_t* p
     // 1. every weight fragment of the slice: lane (r16, q) = weight row n0 + r16, k = 8 q .. 8 q + 7 of each 32-wide k-step
     int nrow = n0 + r16;
     nrow = nrow < pN ? nrow : pN - 1;
-    const bf16_t* wp = pW + (size_t)nrow * K + kbeg + q * 8;
-    const bf16_t* wp2 = DUAL ? pW2 + (size_t)nrow * K + kbeg + q * 8 : nullptr;
+    // a.w_packed: pW / pW2 are the fragment-packed copies (q3_common.h): this wave's tile, k-step s = 1 KB at ((tile K/32 + s) 64 + lane) 8
+    const bool wpk = a.w_packed;
+    const int wstep = wpk ? 512 : 32;                                 // elements between consecutive k-steps of this lane's fragment
+    const size_t woff = wpk ? ((size_t)(blockIdx.x * 4 + wave) * (K >> 5) + (kbeg >> 5)) * 512 + (size_t)lane * 8 : (size_t)nrow * K + kbeg + q * 8;
+    const bf16_t* wp = pW + woff;
+    const bf16_t* wp2 = DUAL ? pW2 + woff : nullptr;
     bf16x8 b[NCH][2], b2[DUAL ? NCH : 1][2];
 #pragma unroll
     for (int c = 0; c < NCH; ++c)
@@ -280,11 +318,11 @@ __global__ __launch_bounds__(256) void k_gemm3(const bf16_t* pW, const bf16_t* p
             // NT: weights one launch reads once per step (the talker's 887 MB) leave no footprint in L2 / the Infinity Cache, so the
             // predictor's 161 MB, re-read 15 times per frame, stay resident there (MI355X guide, nt-weights)
             if (NT) {
-                b[c][st] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp + c * G3_CH + st * 32));
-                if (DUAL) b2[DUAL ? c : 0][st] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp2 + c * G3_CH + st * 32));
+                b[c][st] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp + (c * 2 + st) * wstep));
+                if (DUAL) b2[DUAL ? c : 0][st] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp2 + (c * 2 + st) * wstep));
             } else {
-                b[c][st] = *reinterpret_cast<const bf16x8*>(wp + c * G3_CH + st * 32);
-                if (DUAL) b2[DUAL ? c : 0][st] = *reinterpret_cast<const bf16x8*>(wp2 + c * G3_CH + st * 32);
+                b[c][st] = *reinterpret_cast<const bf16x8*>(wp + (c * 2 + st) * wstep);
+                if (DUAL) b2[DUAL ? c : 0][st] = *reinterpret_cast<const bf16x8*>(wp2 + (c * 2 + st) * wstep);
             }
         }
     // 2. activation chunks: 8 threads per row (16 B each), 32 rows per pass; rows past M repeat row M - 1 (their products are never stored)
@@ -554,7 +592,8 @@ bool gemm_seam_ok(const GemmArgs& a, int ksplit) {
     if (a.seam == 2 && (ksplit > 8 || (a.ssq_in && a.ssq_in_nt % 4 != 0))) return false;
     return a.seam_cnt != nullptr && a.seam_gen != nullptr && a.oh != nullptr && a.ol != nullptr && a.ldp % 4 == 0 && (a.slab_rows == 0 || a.slab_rows == a.M);
 }
-static void launch_gemm3_seam(const GemmArgs& a, int ksplit, hipStream_t s) {
+static void launch_gemm3_seam(const GemmArgs& a0, int ksplit, hipStream_t s) {
+    const GemmArgs a = gemm3_with_packed(a0);
     // 32-row blocks up to 64 rows, 64-row blocks beyond.  Q3TTS_SEAM_BIG (A/B knob, bit 0: the residual seams, bit 1: gate/up): 64-row
     // blocks from 33 rows on — half the workgroups, the weights fetched once instead of once per row block
     const int bigk = knob("Q3TTS_SEAM_BIG") ? atoi(knob("Q3TTS_SEAM_BIG")) : 0;
@@ -587,8 +626,18 @@ static bool gemm3_ok(const GemmArgs& a, int ksplit) {
     const int ksl = a.K / ksplit;
     return a.K % ksplit == 0 && (ksl == 128 || ksl == 256) && a.ldo % 4 == 0 && a.ldx % 8 == 0 && a.M >= 1 && a.M <= 128;
 }
-static void launch_gemm3(const GemmArgs& a0, int ksplit, hipStream_t s) {
+// the fragment-packed copies of this launch's weights, when the engine registered them (N a multiple of 64: every column tile of the grid
+// then exists in the packed buffer; both matrices of a dual launch, or neither)
+static GemmArgs gemm3_with_packed(const GemmArgs& a0) {
     GemmArgs a = a0;
+    if (a.N % 64 != 0 || a.K % 32 != 0) return a;
+    const bf16_t* Wp = find_packed_weight(a.W);
+    const bf16_t* W2p = a.W2 ? find_packed_weight(a.W2) : nullptr;
+    if (Wp != nullptr && (a.W2 == nullptr || W2p != nullptr)) { a.W = Wp; if (a.W2) a.W2 = W2p; a.w_packed = true; }
+    return a;
+}
+static void launch_gemm3(const GemmArgs& a0, int ksplit, hipStream_t s) {
+    GemmArgs a = gemm3_with_packed(a0);
     a.plain_slabs = knob("Q3TTS_GEMM_PLAIN_SLABS") != nullptr;
     const bool dual = a.epi == EPI_SLAB2;
     // nt weight loads measured on the b=64 step (graph replay, same box): 4.961 ms with, 4.917 ms without — the slab GEMM's launches are
@@ -662,8 +711,8 @@ __global__ __launch_bounds__(NWV * 64) void k_gemv16(const bf16_t* pW, const bf1
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r16 = lane & 15, q = lane >> 4;
     const int n0 = blockIdx.x * 16;
-    const int K = (int)(pKnt & 0x7FFFFFFFu), M = pM, N = pN;
-    const bool nt = (pKnt >> 31) != 0;
+    const int K = (int)(pKnt & 0x3FFFFFFFu), M = pM, N = pN;
+    const bool nt = (pKnt >> 31) != 0, wpk = ((pKnt >> 30) & 1u) != 0;
     const int kslice = K / NWV, kw = kslice >> 5;   // k-steps of 32 this wave owns (1..KWMAX)
     const int kbeg = wave * kslice;
 #ifdef Q3_SAMPLE_PROF
@@ -716,14 +765,17 @@ __global__ __launch_bounds__(NWV * 64) void k_gemv16(const bf16_t* pW, const bf1
     __builtin_amdgcn_sched_barrier(0);
     // weights: the whole K slice of this wave's 16 rows in flight at once
     const int nrow = n0 + r16 < N ? n0 + r16 : N - 1;
-    const bf16_t* wp = pW + (size_t)nrow * K + kbeg + q * 8;
-    const bf16_t* wp2 = DUAL ? pW2 + (size_t)nrow * K + kbeg + q * 8 : nullptr;
+    // bit 30 of pKnt: pW / pW2 are the fragment-packed copies (q3_common.h): tile blockIdx.x, k-step s = 1 KB at ((tile K/32 + s) 64 + lane) 8
+    const int wstep = wpk ? 512 : 32;
+    const size_t woff = wpk ? ((size_t)blockIdx.x * (K >> 5) + (kbeg >> 5)) * 512 + (size_t)lane * 8 : (size_t)nrow * K + kbeg + q * 8;
+    const bf16_t* wp = pW + woff;
+    const bf16_t* wp2 = DUAL ? pW2 + woff : nullptr;
     g16_u32x4 w[KWMAX], w2[DUAL ? KWMAX : 1];
 #pragma unroll
     for (int ks = 0; ks < KWMAX; ++ks) {
         const int kk = ks < kw ? ks : kw - 1;
-        w[ks] = g16_ldw(wp + kk * 32, nt);
-        if (DUAL) w2[ks] = g16_ldw(wp2 + kk * 32, nt);
+        w[ks] = g16_ldw(wp + kk * wstep, nt);
+        if (DUAL) w2[ks] = g16_ldw(wp2 + kk * wstep, nt);
     }
     // epilogue operand (residual / bias) of the output this thread finishes: (m, n) = (tid / 16, tid % 16)
     const int em = tid >> 4, en = n0 + (tid & 15);
@@ -860,8 +912,14 @@ static void gemv16_epi(const GemvArgs& a, hipStream_t s) {
     const bool r8 = a.M <= 8 && !no_r8;
     const bool no_gl = knob("Q3TTS_GEMV16_GL") && atoi(knob("Q3TTS_GEMV16_GL")) == 0;
     const bool gl = norm && !no_gl && (a.K / NWV) % 4 == 0;
-#define Q3_G16_(EPI, NORM, R8_, GL_) hipLaunchKernelGGL((k_gemv16<KWMAX, NWV, EPI, NORM, R8_, GL_>), grid, block, 0, s, a.W, a.W2, a.x, a.gamma, \
-        (a.epi == EPI_RESIDUAL ? a.res : a.bias), a.N, a.M, a.ldx, a.ldres, (uint32_t)a.K | (a.nt ? 0x80000000u : 0u), a)
+    // fragment-packed weight copies, when the engine registered them for these matrices (both of a dual launch, or neither)
+    const bf16_t* Wp = find_packed_weight(a.W);
+    const bf16_t* W2p = a.W2 ? find_packed_weight(a.W2) : nullptr;
+    const bool pk = Wp != nullptr && (a.W2 == nullptr || W2p != nullptr);
+    const bf16_t* Wk = pk ? Wp : a.W;
+    const bf16_t* W2k = pk && a.W2 ? W2p : a.W2;
+#define Q3_G16_(EPI, NORM, R8_, GL_) hipLaunchKernelGGL((k_gemv16<KWMAX, NWV, EPI, NORM, R8_, GL_>), grid, block, 0, s, Wk, W2k, a.x, a.gamma, \
+        (a.epi == EPI_RESIDUAL ? a.res : a.bias), a.N, a.M, a.ldx, a.ldres, (uint32_t)a.K | (a.nt ? 0x80000000u : 0u) | (pk ? 0x40000000u : 0u), a)
 #define Q3_G16(EPI, NORM) do { if (NORM && gl) { if (r8) Q3_G16_(EPI, NORM, true, NORM); else Q3_G16_(EPI, NORM, false, NORM); } \
                                else { if (r8) Q3_G16_(EPI, NORM, true, false); else Q3_G16_(EPI, NORM, false, false); } } while (0)
     switch (a.epi) {

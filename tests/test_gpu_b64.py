@@ -201,6 +201,39 @@ def test_gemm3_slabs_are_bit_identical_to_gemm2(wide):
         assert np.array_equal(a, b) and np.array_equal(ah, bh)
 
 
+@pytest.mark.parametrize("nb", [64, 8])
+def test_fragment_packed_weights_are_bit_identical_to_row_major(nb):
+    """Round 5: k_gemm3 (12..128 rows) and k_gemv16 (3..16 rows) stream a fragment-packed copy of every projection matrix — per (16-row
+    tile, 32-wide k-step) the 64 lanes' 16 bytes back to back, one contiguous KB per load instruction instead of sixteen half-used lines —
+    registered by the engine at finalize.  The same values reach the same registers: with Q3TTS_PACKED_W=0 (the A/B knob: row-major
+    matrices) a twin engine must produce bit-identical codes over 6 sampled frames and bit-identical logits, at 64 rows (slab GEMM + seam)
+    and at 8 rows (the GEMV-contract kernel; its prefill too)."""
+    import os
+    import q3tts
+    cfg = q3tts.default_config("0.6b")
+    rng = np.random.default_rng(65)
+    toks = [frame_tokens(rng.integers(0, 151643, int(n))) for n in rng.integers(3, 20, nb)]
+    sp = q3tts.Sampling(temperature=0.8, top_p=0.95, top_k=50, max_new_tokens=6)
+    res = []
+    for knob in (None, "0"):
+        if knob is not None:
+            os.environ["Q3TTS_PACKED_W"] = knob
+        try:
+            e = q3tts.Engine(cfg, device=0, max_batch=nb, max_ctx=64, flags=q3tts.FLAG_TEST_HOOKS)
+            e.fill_synthetic(seed=0)
+            _, codes, _ = e.synthesize_batch(toks, sp, seed=22, ignore_eos=True)
+            lg = [e.slot_logits(u) for u in (0, nb // 2, nb - 1)]
+            e.close()
+        finally:
+            os.environ.pop("Q3TTS_PACKED_W", None)
+        res.append((codes, lg))
+    (c1, l1), (c0, l0) = res
+    for u in range(nb):
+        assert np.array_equal(c1[u], c0[u]), u
+    for (a, ah), (b, bh) in zip(l1, l0):
+        assert np.array_equal(a, b) and np.array_equal(ah, bh)
+
+
 def test_batch_of_80_crosses_the_128_row_block():
     """80 utterances in one batch at 0.6B dims: the talker's projections run 80 rows (64-row blocks of the split-K seam GEMM), predictor
     pass 0 runs 160 rows — past the 128 rows one GEMM block and the seam cover, so those launches walk 128-row blocks and keep the
