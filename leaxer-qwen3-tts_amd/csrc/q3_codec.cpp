@@ -31,7 +31,10 @@ struct CodecW {
     SnakeP snake_out;
     std::vector<float*> packed; // owned
     // (hi, lo) bf16 planes of every conv / linear weight, keyed by the fp32 pointer the layer list holds (owned)
-    struct Planes { bf16_t* hi; bf16_t* lo; float scale_inv; bool lo_zero; };   // lo_zero: the weight is exact in fp16 (bf16- / fp16-origin): two products instead of three
+    // lo_zero: the weight is exact in fp16 (bf16- / fp16-origin): two products instead of three.  cm: the same planes chunk-major
+    // ([plane][tap][C_in / 32][C_out][32], ConvArgs::Whc; null when C_in is not a multiple of 32); fh / fl: a 96 x 96 second conv of a
+    // fused residual unit in B-fragment order (ConvArgs::W2fh / W2fl; one allocation)
+    struct Planes { bf16_t* hi; bf16_t* lo; float scale_inv; bool lo_zero; bf16_t* cm = nullptr; bf16_t* fh = nullptr; bf16_t* fl = nullptr; };
     int n_lo_zero = 0, n_lo_used = 0;
     std::unordered_map<const float*, Planes> planes;
     // SnakeBeta constants [2][C] (exp(alpha) | 1 / (exp(beta) + 1e-9)) keyed by the alpha pointer (owned; split-precision path only)
@@ -71,7 +74,11 @@ struct CodecW {
 void Engine::codec_free() {
     if (!codec) return;
     for (float* p : codec->packed) (void)hipFree(p);
-    for (auto& kv : codec->planes) (void)hipFree(kv.second.hi);   // lo lives in the same allocation
+    for (auto& kv : codec->planes) {
+        (void)hipFree(kv.second.hi);   // lo lives in the same allocation
+        if (kv.second.cm) (void)hipFree(kv.second.cm);
+        if (kv.second.fh) (void)hipFree(kv.second.fh);   // fl lives in the same allocation
+    }
     for (auto& kv : codec->snake_pre) (void)hipFree(kv.second);
     for (int i = 0; i < CodecW::NLANE; ++i) {
         if (codec->arena[i]) (void)hipFree(codec->arena[i]);
@@ -149,7 +156,7 @@ void Engine::codec_finalize() {
     W.conv_out = pack("cd.dec.conv_out", D >> c.cd_n_blocks, 1, 7, false);
     if (!(flags & Q3TTS_FLAG_FP32_CODEC)) { // fp16 hi/lo planes for the split-precision matrix-core path
         unsigned* amax_d = (unsigned*)dmalloc(sizeof(unsigned));
-        auto split = [&](const float* w, size_t n) {
+        auto split = [&](const float* w, size_t n, int taps = 0, int cout = 0, int cin = 0) {
             if (!w || W.planes.count(w)) return;
             // power-of-two pre-scale: largest |w| lands in [2^11, 2^12) so the low plane of ordinary weights stays normal
             unsigned bits = 0;
@@ -172,19 +179,30 @@ void Engine::codec_finalize() {
             launch_or_mag16(lo, n, amax_d, stream);
             Q3_HIP_CHECK(hipMemcpyAsync(&lo_bits, amax_d, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
             sync();
-            W.planes[w] = { hi, lo, ldexpf(1.0f, -k), lo_bits == 0 };
+            CodecW::Planes pl{ hi, lo, ldexpf(1.0f, -k), lo_bits == 0 };
+            if (taps > 0 && cin % 32 == 0 && (size_t)taps * cout * cin == n) {   // the chunk-major copy for the 32-wide-chunk kernels
+                Q3_HIP_CHECK(hipMalloc((void**)&pl.cm, 2 * np * sizeof(bf16_t)));
+                launch_repack_planes_cm(hi, pl.cm, taps, cout, cin, np, stream);
+            }
+            if (taps == 1 && cout == 96 && cin == 96) {                           // a fused unit's second conv: B fragments
+                Q3_HIP_CHECK(hipMalloc((void**)&pl.fh, 2 * n * sizeof(bf16_t)));
+                pl.fl = pl.fh + n;
+                launch_pack_w2_frags(hi, pl.fh, 96, stream);
+                launch_pack_w2_frags(lo, pl.fl, 96, stream);
+            }
+            W.planes[w] = pl;
             (lo_bits == 0 ? W.n_lo_zero : W.n_lo_used) += 1;
         };
         const size_t FFn = (size_t)c.cd_ffn;
         for (const CodecW::Layer& L : W.layers) {
-            split(L.qkv, (size_t)3 * CH * CH); split(L.o, (size_t)CH * CH);
-            split(L.gate, FFn * CH); split(L.up, FFn * CH); split(L.down, FFn * CH);
+            split(L.qkv, (size_t)3 * CH * CH, 1, 3 * CH, CH); split(L.o, (size_t)CH * CH, 1, CH, CH);
+            split(L.gate, FFn * CH, 1, (int)FFn, CH); split(L.up, FFn * CH, 1, (int)FFn, CH); split(L.down, FFn * CH, 1, CH, (int)FFn);
         }
         for (const CodecW::Up& u : W.up) {
-            split(u.tconv.w, (size_t)u.tconv.cin * u.tconv.cout * u.tconv.k);
-            split(u.pw1_w, (size_t)4 * CH * CH); split(u.pw2_w, (size_t)4 * CH * CH);
+            split(u.tconv.w, (size_t)u.tconv.cin * u.tconv.cout * u.tconv.k, u.tconv.k, u.tconv.cout, u.tconv.cin);
+            split(u.pw1_w, (size_t)4 * CH * CH, 1, 4 * CH, CH); split(u.pw2_w, (size_t)4 * CH * CH, 1, CH, 4 * CH);
         }
-        auto pc = [&](const PackedConv& p) { split(p.w, (size_t)p.cin * p.cout * p.k); };
+        auto pc = [&](const PackedConv& p) { split(p.w, (size_t)p.cin * p.cout * p.k, p.k, p.cout, p.cin); };
         pc(W.conv_in);
         for (const CodecW::Block& B : W.blocks) { pc(B.tconv); for (int u = 0; u < 3; ++u) { pc(B.res[u].c1); pc(B.res[u].c2); } }
         auto pre = [&](const SnakeP& sp) {   // exp(alpha), 1 / (exp(beta) + 1e-9) once per activation instead of once per 32-row block of every launch
@@ -272,7 +290,7 @@ int64_t Engine::codec_run(const int32_t* codes_dev, int F, float** pcm_dev, int 
             if (plan) return;
             a.slab = kslab; a.slab_floats = kslab_floats; a.batch = nbatch;
             const auto it = W.planes.find(a.W);
-            if (it != W.planes.end()) { a.Wh = it->second.hi; a.Wl = it->second.lo; a.w_scale_inv = it->second.scale_inv; a.w_lo_zero = it->second.lo_zero; }
+            if (it != W.planes.end()) { a.Wh = it->second.hi; a.Wl = it->second.lo; a.Whc = it->second.cm; a.w_scale_inv = it->second.scale_inv; a.w_lo_zero = it->second.lo_zero; }
             if (a.snake_alpha) { const auto sp = W.snake_pre.find(a.snake_alpha); if (sp != W.snake_pre.end()) a.snake_pre = sp->second; }
             if (a.mid_alpha) { const auto sp = W.snake_pre.find(a.mid_alpha); if (sp != W.snake_pre.end()) a.mid_pre = sp->second; }
             launch_conv(a, stream);
@@ -372,7 +390,7 @@ int64_t Engine::codec_run(const int32_t* codes_dev, int F, float** pcm_dev, int 
                 if (Co == 96 && p2 != W.planes.end() && W.planes.count(R.c1.w) && !knob("Q3TTS_NO_FUSED_RES")) {
                     ConvArgs a; a.in = ns; a.T_in = To; a.C_in = Co; a.out = nx; a.T_out = To; a.C_out = Co; a.W = R.c1.w; a.bias = R.c1.b;
                     a.taps = 7; a.dil = dil[u]; a.mid_alpha = R.a2.alpha; a.mid_beta = R.a2.beta;
-                    a.W2 = R.c2.w; a.W2h = p2->second.hi; a.W2l = p2->second.lo; a.w2_scale_inv = p2->second.scale_inv; a.w2_lo_zero = p2->second.lo_zero; a.bias2 = R.c2.b;
+                    a.W2 = R.c2.w; a.W2h = p2->second.hi; a.W2l = p2->second.lo; a.W2fh = p2->second.fh; a.W2fl = p2->second.fl; a.w2_scale_inv = p2->second.scale_inv; a.w2_lo_zero = p2->second.lo_zero; a.bias2 = R.c2.b;
                     a.res = nx; a.out2 = nt; a.snake_alpha = nxt.alpha; a.snake_beta = nxt.beta;
                     a.in_planes = act_planes; a.out2_planes = nxt_planes;
                     conv(a);
@@ -464,7 +482,7 @@ const float* Engine::codec_pre_batch(const int32_t* codes_dev, int codes_stride_
     auto conv = [&](ConvArgs a) {
         a.slab = kslab; a.slab_floats = kslab_floats;
         const auto it = W.planes.find(a.W);
-        if (it != W.planes.end()) { a.Wh = it->second.hi; a.Wl = it->second.lo; a.w_scale_inv = it->second.scale_inv; a.w_lo_zero = it->second.lo_zero; }
+        if (it != W.planes.end()) { a.Wh = it->second.hi; a.Wl = it->second.lo; a.Whc = it->second.cm; a.w_scale_inv = it->second.scale_inv; a.w_lo_zero = it->second.lo_zero; }
         if (a.snake_alpha) { const auto sp = W.snake_pre.find(a.snake_alpha); if (sp != W.snake_pre.end()) a.snake_pre = sp->second; }
         launch_conv(a, stream);
     };
@@ -759,7 +777,7 @@ int64_t Engine::codec_stream_push_dev(int sid, const int32_t* codes_dev, int n, 
     auto conv = [&](ConvArgs a) {
         a.slab = kslab; a.slab_floats = kslab_floats;
         const auto it = W.planes.find(a.W);
-        if (it != W.planes.end()) { a.Wh = it->second.hi; a.Wl = it->second.lo; a.w_scale_inv = it->second.scale_inv; a.w_lo_zero = it->second.lo_zero; }
+        if (it != W.planes.end()) { a.Wh = it->second.hi; a.Wl = it->second.lo; a.Whc = it->second.cm; a.w_scale_inv = it->second.scale_inv; a.w_lo_zero = it->second.lo_zero; }
         launch_conv(a, stream);
     };
     auto gemm = [&](const float* in, int Cin, const float* Wm, int Cout, float* out) {

@@ -99,6 +99,8 @@ struct ConvKArgs {
     // fused residual unit (k_conv_split<..., F2 = true>): second (1x1) conv behind a SnakeBeta on the first conv's output
     const bf16_t* W2h; const bf16_t* W2l; float acc_scale2; const float* bias2; const float* s1_alpha; const float* s1_beta;
     int wlo;                            // 0: every weight plane `lo` of this launch is identically zero (bf16- / fp16-origin weights) -> the WLO = false kernels
+    int w_cm;                           // Wh / Wl are the CHUNK-major planes [tap][C_in / 32][C_out][32] (ConvArgs::Whc): a (tap, chunk) tile is contiguous
+    const bf16_t* W2fh; const bf16_t* W2fl;   // fused unit: W2's planes in B-fragment order (ConvArgs::W2fh), or null
 };
 
 // batched launch: rebase the sequence-shaped pointers to this workgroup's sequence and return its row-tile index
@@ -491,6 +493,8 @@ void k_conv_split(ConvKArgs a0) {
     // behind the hi plane in one allocation (launch_conv checks the distance)
     const char* const w_bytes = reinterpret_cast<const char*>(a.Wh);
     const unsigned w_lo = (unsigned)(reinterpret_cast<const char*>(a.Wl) - reinterpret_cast<const char*>(a.Wh));
+    const bool w_cm = KC == 32 && a.w_cm != 0;                         // chunk-major planes: a weight row of the tile is 64 bytes, rows back to back
+    const unsigned w_rowb = w_cm ? 64u : (unsigned)a.C_in * 2u;        // bytes between the tile's consecutive weight rows
     unsigned boff[PB];
 #pragma unroll
     for (int i = 0; i < PB; ++i) {
@@ -499,11 +503,11 @@ void k_conv_split(ConvKArgs a0) {
         const int plane = idx / (TN * SEG), rem = idx % (TN * SEG), brow = rem / SEG, bseg = rem % SEG;
         const int co = co0 + brow;
         const int cc = co < a.C_out ? co : a.C_out - 1;                   // rows past C_out repeat the last one; their columns are never stored
-        boff[i] = (plane ? w_lo : 0u) + ((unsigned)cc * (unsigned)a.C_in + (unsigned)bseg * 8u) * 2u;
+        boff[i] = (plane ? w_lo : 0u) + (unsigned)cc * w_rowb + (unsigned)bseg * 16u;
     }
     auto loadB = [&](int ci0, int ti) {
         const int wtap = a.transposed ? phase + ti * a.stride : ti;
-        const char* const base = w_bytes + ((size_t)wtap * a.C_out * a.C_in + ci0) * 2;
+        const char* const base = w_bytes + (w_cm ? ((size_t)wtap * (a.C_in >> 5) + (ci0 >> 5)) * a.C_out * 64 : ((size_t)wtap * a.C_out * a.C_in + ci0) * 2);
 #pragma unroll
         for (int i = 0; i < PB; ++i) breg[i] = *reinterpret_cast<const u32x4*>(base + boff[i]);
     };
@@ -601,10 +605,10 @@ void k_conv_split(ConvKArgs a0) {
                 const int t2 = idx / (TN * SEG), rem = idx % (TN * SEG), brow = rem / SEG, bseg = rem % SEG;
                 const int co = co0 + brow;
                 const int cc = co < a.C_out ? co : a.C_out - 1;
-                boff2[i] = (t2 ? tap_bytes : 0u) + ((unsigned)cc * (unsigned)a.C_in + (unsigned)bseg * 8u) * 2u;
+                boff2[i] = (t2 ? tap_bytes : 0u) + (unsigned)cc * w_rowb + (unsigned)bseg * 16u;   // the next tap's tile is tap_bytes on in either layout
             }
             auto loadB2 = [&](int ci0, int tbase) __attribute__((always_inline)) {
-                const char* const base = w_bytes + ((size_t)tbase * a.C_out * a.C_in + ci0) * 2;
+                const char* const base = w_bytes + (w_cm ? ((size_t)tbase * (a.C_in >> 5) + (ci0 >> 5)) * a.C_out * 64 : ((size_t)tbase * a.C_out * a.C_in + ci0) * 2);
 #pragma unroll
                 for (int i = 0; i < PB2; ++i) breg2[i] = *reinterpret_cast<const u32x4*>(base + boff2[i]);
             };
@@ -741,6 +745,9 @@ void k_conv_split(ConvKArgs a0) {
 #else
         const float sc1 = a.acc_scale;
 #endif
+        const bool w2f = a.W2fh != nullptr;
+        const _Float16* const w2hp = reinterpret_cast<const _Float16*>(w2f ? a.W2fh : a.W2h);
+        const _Float16* const w2lp = reinterpret_cast<const _Float16*>(w2f ? a.W2fl : a.W2l);
         a.bias = a.bias2; a.acc_scale = a.acc_scale2;          // from here on `a` describes the second conv's epilogue (no struct copy: it would live in scratch)
         // statically indexed row blocks (a rolled loop over i gives the accumulators a scratch home that the main loop keeps in sync)
         auto unit = [&](auto itag) {
@@ -773,9 +780,10 @@ void k_conv_split(ConvKArgs a0) {
             auto loadW = [&](int buf, int st) {
 #pragma unroll
                 for (int j = 0; j < NB; ++j) {
-                    const size_t wo = (size_t)(j * 32 + col0) * C2 + st * 16 + 8 * rsel;   // weight row = output channel, [C_out][C_in] with C_in == C2
-                    wbh[buf][j] = *reinterpret_cast<const f16x8*>(reinterpret_cast<const _Float16*>(a.W2h) + wo);
-                    if constexpr (WLO) wbl[buf][j] = *reinterpret_cast<const f16x8*>(reinterpret_cast<const _Float16*>(a.W2l) + wo);
+                    // fragment order (a.W2fh: one contiguous KB per load) or weight row = output channel, [C_out][C_in] with C_in == C2
+                    const size_t wo = w2f ? ((size_t)(st * NB + j) * 64 + lane) * 8 : (size_t)(j * 32 + col0) * C2 + st * 16 + 8 * rsel;
+                    wbh[buf][j] = *reinterpret_cast<const f16x8*>(w2hp + wo);
+                    if constexpr (WLO) wbl[buf][j] = *reinterpret_cast<const f16x8*>(w2lp + wo);
                 }
             };
             loadW(0, 0);
@@ -1071,6 +1079,10 @@ void launch_conv(const ConvArgs& c, hipStream_t s) {
             throw Error("conv: (hi, lo)-plane activations need a 96-multiple decoder conv on the split-precision path");
     }
     a.W2h = nullptr; a.W2l = nullptr; a.acc_scale2 = 1.0f; a.bias2 = nullptr; a.s1_alpha = nullptr; a.s1_beta = nullptr;
+    a.w_cm = 0; a.W2fh = nullptr; a.W2fl = nullptr;
+    // the 32-wide-chunk kernels take the chunk-major planes when the layer has them (Q3TTS_CONV_ROWMAJOR_W=1: the A/B knob)
+    const bool cm_ok = c.Whc != nullptr && c.Wh != nullptr && c.Wl != nullptr && c.C_in % 32 == 0 && !knob("Q3TTS_CONV_ROWMAJOR_W");
+    auto use_cm = [&]() { if (cm_ok) { a.Wl = c.Whc + (c.Wl - c.Wh); a.Wh = c.Whc; a.w_cm = 1; } };
     a.in_ustride = c.in_ustride ? c.in_ustride : (size_t)c.T_in * c.C_in;
     const int nb = c.batch > 1 ? c.batch : 1;
     if (c.transposed && c.taps % c.stride != 0) throw Error("conv: transposed kernel must be a multiple of the stride");
@@ -1107,6 +1119,8 @@ void launch_conv(const ConvArgs& c, hipStream_t s) {
             throw Error("conv: fused residual unit needs 96 -> 96 channels on the split-precision path");
         a.acc_scale = c.w_scale_inv;
         a.W2h = c.W2h; a.W2l = c.W2l; a.acc_scale2 = c.w2_scale_inv; a.bias2 = c.bias2; a.s1_alpha = c.mid_alpha; a.s1_beta = c.mid_beta; a.s1_pre = c.mid_pre;
+        if (c.W2fh && c.W2fl && !knob("Q3TTS_CONV_ROWMAJOR_W")) { a.W2fh = c.W2fh; a.W2fl = c.W2fl; }
+        use_cm();
         const int extra = (halo + 31) / 32, tiles = (rows + 255) / 256;
         if (nb > 1) a.batch_tiles = tiles;
         const dim3 g((unsigned)(tiles * nb), 1, 1);
@@ -1157,13 +1171,15 @@ void launch_conv(const ConvArgs& c, hipStream_t s) {
                 else if (extra == 0) Q3_CS(g, s, a, 2, 1, 1, 4, 2, 128, 1, false, false, false);
                 else if (extra == 1) Q3_CS(g, s, a, 2, 1, 1, 4, 3, 128, 1, false, false, false);
                 else Q3_CS(g, s, a, 2, 1, 1, 4, 4, 128, 1, false, false, false);
-            } else launch_split_in<2, 1, 1, 4>(a, g, extra, s);
+            } else { use_cm(); launch_split_in<2, 1, 1, 4>(a, g, extra, s); }
         }
         else if (!deep || n_big < 1024) {
+            use_cm();
             const dim3 g2 = bgrid((rows + 127) / 128, ntile, z);
             if (n96) launch_split_in<1, 3, 4, 1>(a, g2, extra, s);
             else launch_split_pa<1, 4, 4, 1>(a, g2, extra, s);
         } else {
+            use_cm();
             const dim3 g2 = bgrid((rows + 255) / 256, ntile, z);
             if (n96) launch_split_in<2, 3, 4, 1>(a, g2, extra, s);
             else launch_split_pa<2, 4, 4, 1>(a, g2, extra, s);
@@ -1174,6 +1190,41 @@ void launch_conv(const ConvArgs& c, hipStream_t s) {
     }
     if (nb > 1) throw Error("conv: a batched launch needs the split-precision path (or C_out == 1)");
     hipLaunchKernelGGL(k_conv_mfma, grid, dim3(256), 0, s, a);
+}
+
+// ---- line-friendly copies of the split-precision weight planes (ConvArgs::Whc, W2fh / W2fl) ----
+// planes [2][taps][cout][cin] -> [2][taps][cin / 32][cout][32]; plane_elems = the distance between the two planes (both layouts)
+__global__ void k_repack_planes_cm(const bf16_t* in, bf16_t* out, int taps, int cout, int cin, size_t plane_elems) {
+    const size_t n8 = (size_t)taps * cout * cin / 8;                  // 16-byte pieces per plane
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < 2 * n8; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t plane = i / n8, r = i % n8;
+        const int seg = (int)(r % 4);                                 // 8 halves of the 32-channel chunk
+        const size_t q = r / 4;
+        const int co = (int)(q % cout);
+        const size_t q2 = q / cout;
+        const int ch = (int)(q2 % (cin / 32)), tap = (int)(q2 / (cin / 32));
+        const uint4 v = *reinterpret_cast<const uint4*>(in + plane * plane_elems + ((size_t)tap * cout + co) * cin + ch * 32 + seg * 8);
+        *reinterpret_cast<uint4*>(out + plane * plane_elems + r * 8) = v;
+    }
+}
+void launch_repack_planes_cm(const bf16_t* planes, bf16_t* out, int taps, int cout, int cin, size_t plane_elems, hipStream_t s) {
+    if (cin % 32 != 0) throw Error("repack_planes_cm: C_in must be a multiple of 32");
+    hipLaunchKernelGGL(k_repack_planes_cm, dim3(1024), dim3(256), 0, s, planes, out, taps, cout, cin, plane_elems);
+}
+// plane [C][C] (row = output channel) -> B fragments of v_mfma_f32_32x32x16_f16: [k-step st][32-column block j][lane][8],
+// lane (col0 = lane & 31, rsel = lane >> 5) holds W[j 32 + col0][st 16 + 8 rsel .. + 7]
+__global__ void k_pack_w2_frags(const bf16_t* in, bf16_t* out, int C) {
+    const int NB = C / 32, KS = C / 16;
+    const int n = KS * NB * 64;
+    for (int f = blockIdx.x * blockDim.x + threadIdx.x; f < n; f += gridDim.x * blockDim.x) {
+        const int lane = f & 63, j = (f >> 6) % NB, st = (f >> 6) / NB;
+        const uint4 v = *reinterpret_cast<const uint4*>(in + (size_t)(j * 32 + (lane & 31)) * C + st * 16 + 8 * (lane >> 5));
+        *reinterpret_cast<uint4*>(out + (size_t)f * 8) = v;
+    }
+}
+void launch_pack_w2_frags(const bf16_t* plane, bf16_t* out, int C, hipStream_t s) {
+    if (C % 32 != 0) throw Error("pack_w2_frags: C must be a multiple of 32");
+    hipLaunchKernelGGL(k_pack_w2_frags, dim3(16), dim3(256), 0, s, plane, out, C);
 }
 
 // ---- weight repack: PyTorch Conv1d [co][ci][k] / ConvTranspose1d [ci][co][k] -> [k][co][ci] ----

@@ -284,6 +284,13 @@ struct ConvArgs { // out[t][co] = epi(bias[co] + sum_{tap,ci} W[tap][co][ci] * i
     // fused residual unit (96-channel decoder block): out = res + bias2 + W2 . snake_mid(bias + W . in) — the 7-tap conv, the SnakeBeta
     // between, the 1x1 conv and the residual add in ONE launch; the intermediate never leaves the CU.  W2 = the 1x1 conv's [1][C_out][C_out]
     const float* W2 = nullptr; const bf16_t* W2h = nullptr; const bf16_t* W2l = nullptr; float w2_scale_inv = 1.0f;
+    // Round 5, line-friendly copies of the weight planes (same values; launch_repack_planes_cm / launch_pack_w2_frags at finalize):
+    // Whc = the (hi, lo) planes CHUNK-major, [plane][tap][C_in / 32][C_out][32]: a workgroup's weight tile of one (tap, 32-channel chunk)
+    // is contiguous (96 rows x 64 B = 6 KB) instead of 96 separate 64-byte row pieces — k_conv_split's 32-wide-chunk kernels stage it with
+    // whole-line loads (the 128-wide-chunk kernels of the short GEMMs keep the row-major planes: their rows are 256 B already);
+    // W2fh / W2fl = the fused unit's 96 x 96 second conv in MFMA B-fragment order, [k-step][32-column block][lane][8]: the unit's weight
+    // fragments come straight from global memory, one contiguous KB per load instead of 32 rows x 32 bytes.
+    const bf16_t* Whc = nullptr; const bf16_t* W2fh = nullptr; const bf16_t* W2fl = nullptr;
     const float* bias2 = nullptr; const float* mid_alpha = nullptr; const float* mid_beta = nullptr; const float* mid_pre = nullptr;
     int batch = 1;               // independent sequences of the same shape: sequence u at in + u * in_ustride, out / out2 / res / mul at + u * T_out * C_out
     size_t in_ustride = 0;       // floats between the sequences' inputs (0: T_in * C_in, i.e. densely packed)
@@ -291,6 +298,8 @@ struct ConvArgs { // out[t][co] = epi(bias[co] + sum_{tap,ci} W[tap][co][ci] * i
 void launch_conv(const ConvArgs& a, hipStream_t s);
 void launch_split_planes(const float* w, bf16_t* hi, bf16_t* lo, size_t n, float scale, hipStream_t s);
 void launch_snake_pre(const float* alpha, const float* beta, float* pre /* [2][C] */, int C, hipStream_t s);
+void launch_repack_planes_cm(const bf16_t* planes /* [2][taps][cout][cin] */, bf16_t* out /* [2][taps][cin/32][cout][32] */, int taps, int cout, int cin, size_t plane_elems, hipStream_t s);
+void launch_pack_w2_frags(const bf16_t* plane /* [C][C] */, bf16_t* out /* [C/16][C/32][64][8] */, int C, hipStream_t s);
 void launch_absmax(const float* w, size_t n, unsigned* out, hipStream_t s);
 void launch_or_mag16(const bf16_t* p, size_t n, unsigned* out /* |= magnitude bits */, hipStream_t s);
 void launch_repack_conv(const float* w, float* out, int cin, int cout, int k, int transposed, hipStream_t s);
