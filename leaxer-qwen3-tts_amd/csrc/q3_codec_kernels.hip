@@ -99,7 +99,6 @@ struct ConvKArgs {
     // fused residual unit (k_conv_split<..., F2 = true>): second (1x1) conv behind a SnakeBeta on the first conv's output
     const bf16_t* W2h; const bf16_t* W2l; float acc_scale2; const float* bias2; const float* s1_alpha; const float* s1_beta;
     int wlo;                            // 0: every weight plane `lo` of this launch is identically zero (bf16- / fp16-origin weights) -> the WLO = false kernels
-    int w_cm;                           // Wh / Wl are the CHUNK-major planes [tap][C_in / 32][C_out][32] (ConvArgs::Whc): a (tap, chunk) tile is contiguous
     const bf16_t* W2fh; const bf16_t* W2fl;   // fused unit: W2's planes in B-fragment order (ConvArgs::W2fh), or null
 };
 
@@ -493,7 +492,10 @@ void k_conv_split(ConvKArgs a0) {
     // behind the hi plane in one allocation (launch_conv checks the distance)
     const char* const w_bytes = reinterpret_cast<const char*>(a.Wh);
     const unsigned w_lo = (unsigned)(reinterpret_cast<const char*>(a.Wl) - reinterpret_cast<const char*>(a.Wh));
-    const bool w_cm = KC == 32 && a.w_cm != 0;                         // chunk-major planes: a weight row of the tile is 64 bytes, rows back to back
+    // 32-wide-chunk kernels read the CHUNK-major planes (launch_conv hands them ConvArgs::Whc): a weight row of a (tap, chunk) tile is 64
+    // bytes and the tile's rows lie back to back; the 128-wide-chunk kernels read the row-major planes.  Compile-time: a run-time choice
+    // cost the peeled 7-tap kernels 12-20 bytes of scratch.
+    constexpr bool w_cm = KC == 32;
     const unsigned w_rowb = w_cm ? 64u : (unsigned)a.C_in * 2u;        // bytes between the tile's consecutive weight rows
     unsigned boff[PB];
 #pragma unroll
@@ -1079,10 +1081,12 @@ void launch_conv(const ConvArgs& c, hipStream_t s) {
             throw Error("conv: (hi, lo)-plane activations need a 96-multiple decoder conv on the split-precision path");
     }
     a.W2h = nullptr; a.W2l = nullptr; a.acc_scale2 = 1.0f; a.bias2 = nullptr; a.s1_alpha = nullptr; a.s1_beta = nullptr;
-    a.w_cm = 0; a.W2fh = nullptr; a.W2fl = nullptr;
-    // the 32-wide-chunk kernels take the chunk-major planes when the layer has them (Q3TTS_CONV_ROWMAJOR_W=1: the A/B knob)
-    const bool cm_ok = c.Whc != nullptr && c.Wh != nullptr && c.Wl != nullptr && c.C_in % 32 == 0 && !knob("Q3TTS_CONV_ROWMAJOR_W");
-    auto use_cm = [&]() { if (cm_ok) { a.Wl = c.Whc + (c.Wl - c.Wh); a.Wh = c.Whc; a.w_cm = 1; } };
+    a.W2fh = nullptr; a.W2fl = nullptr;
+    // the 32-wide-chunk kernels read the chunk-major planes (k_conv_split: w_cm), the 128-wide-chunk kernels the row-major ones
+    auto use_cm = [&]() {
+        if (c.Whc == nullptr || c.Wh == nullptr || c.Wl == nullptr) throw Error("conv: the 32-wide-chunk kernels need the chunk-major weight planes (ConvArgs::Whc)");
+        a.Wl = c.Whc + (c.Wl - c.Wh); a.Wh = c.Whc;
+    };
     a.in_ustride = c.in_ustride ? c.in_ustride : (size_t)c.T_in * c.C_in;
     const int nb = c.batch > 1 ? c.batch : 1;
     if (c.transposed && c.taps % c.stride != 0) throw Error("conv: transposed kernel must be a multiple of the stride");
@@ -1119,7 +1123,7 @@ void launch_conv(const ConvArgs& c, hipStream_t s) {
             throw Error("conv: fused residual unit needs 96 -> 96 channels on the split-precision path");
         a.acc_scale = c.w_scale_inv;
         a.W2h = c.W2h; a.W2l = c.W2l; a.acc_scale2 = c.w2_scale_inv; a.bias2 = c.bias2; a.s1_alpha = c.mid_alpha; a.s1_beta = c.mid_beta; a.s1_pre = c.mid_pre;
-        if (c.W2fh && c.W2fl && !knob("Q3TTS_CONV_ROWMAJOR_W")) { a.W2fh = c.W2fh; a.W2fl = c.W2fl; }
+        if (c.W2fh && c.W2fl && !knob("Q3TTS_CONV_W2_ROWMAJOR")) { a.W2fh = c.W2fh; a.W2fl = c.W2fl; }   // A/B knob: the second conv's fragments from the row-major planes
         use_cm();
         const int extra = (halo + 31) / 32, tiles = (rows + 255) / 256;
         if (nb > 1) a.batch_tiles = tiles;

@@ -242,8 +242,8 @@ def test_conv_ab_switches_reproduce_the_default_bit_for_bit():
         return [ln for ln in r.stdout.splitlines() if ln.startswith("PCM")][-1]
 
     base = run({})
-    # Q3TTS_CONV_ROWMAJOR_W (round 5): the row-major weight planes instead of the chunk-major / B-fragment copies — the same values
-    for knob in ("Q3TTS_CONV_NO_XCD_MAP", "Q3TTS_CONV_GENERIC_EPILOGUE", "Q3TTS_CONV_NO_PEEL", "Q3TTS_CONV_FP32_ACT", "Q3TTS_CONV_ROWMAJOR_W"):
+    # Q3TTS_CONV_W2_ROWMAJOR (round 5): the fused unit's second conv from the row-major planes instead of the B-fragment copy — the same values
+    for knob in ("Q3TTS_CONV_NO_XCD_MAP", "Q3TTS_CONV_GENERIC_EPILOGUE", "Q3TTS_CONV_NO_PEEL", "Q3TTS_CONV_FP32_ACT", "Q3TTS_CONV_W2_ROWMAJOR"):
         assert run({knob: "1"}) == base, knob
 
 
