@@ -1,5 +1,8 @@
 // q3_capi.cpp — extern "C" surface declared in include/q3tts.h.  No exception crosses the ABI.
+#include <algorithm>
+#include <climits>
 #include <cstddef>
+#include <cstdint>
 #include <cstdlib>
 #include <cstring>
 #include <deque>
@@ -26,6 +29,71 @@ static std::string g_create_err;
     catch (const q3::Error& ex) { (h)->err = ex.msg; return -1; } \
     catch (const std::exception& ex) { (h)->err = ex.what(); return -1; } \
     catch (...) { (h)->err = "unknown error"; return -1; }
+
+// The vocoder phase of a job: utterance u's codes are row u of the engine's job buffer (Engine::codec_job_codes, stride row_frames frames),
+// got_frames[u] of them valid.  Shared by the scheduler (below) and q3tts_codec_decode_batch_host.
+static void vocoder_job(q3::Engine& e, int n_utt, const std::vector<int32_t>& got_frames, int row_frames, float* const* pcm_out, int64_t pcm_cap,
+                        int64_t* pcm_len) {
+    // Vocoder, once the decode queue is empty.  Utterances are taken longest first, in blocks of similar length (the shortest at least half
+    // the longest, at most 2^16 padded frames): a block's pre-transformer and upsampling stages run as one batched pass, its conv decoder in
+    // groups of up to 32 utterances per set of launches (about 4.7 MB of workspace per frame: groups sized to ~8 GB), each group padded to its
+    // own longest member.  Padding is exact: every layer is causal.  Single utterances, the exact-fp32 codec and configs whose decoder the
+    // batched kernels do not cover go one utterance at a time over the side lanes.
+    // A failure in here (arena / pinned-buffer allocation, a launch error) must not leave lanes holding this job's pcm_out / pcm_len
+    // pointers: the next job's drain would write through them.  codec_async_abort() waits for the lanes and forgets their items.
+    try {
+    std::vector<int> order((size_t)n_utt);
+    for (int u = 0; u < n_utt; ++u) { order[(size_t)u] = u; if (pcm_len) pcm_len[u] = 0; }
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return got_frames[(size_t)x] > got_frames[(size_t)y]; });
+    const bool batchable = e.codec_batchable();
+    std::vector<int> nf;
+    std::vector<float*> up;
+    std::vector<int64_t*> lp;
+    for (int y0 = 0; y0 < n_utt;) {
+        const int F0 = got_frames[(size_t)order[(size_t)y0]];
+        if (F0 <= 0) break;                                            // sorted: the rest of the job produced no frame
+        int y1 = y0 + 1;
+        // a block is a batch dimension of the batched kernels (gridDim.y / .z <= 65535): at most 4096 sequences and 2^16 padded frames, and
+        // no activation matrix of its batched front may reach 4 GB (k_conv_split addresses rows with 32-bit byte offsets): the widest is
+        // the ConvNeXt hidden [frames x upsampling][4 x cd_hidden] — at 0.6B dims exactly 4 GB at 2^16 frames, hence the strict bound
+        int64_t up_front = 1;
+        for (int i = 0; i < e.c.cd_n_up; ++i) up_front *= e.c.cd_up_ratios[i];
+        const int64_t widest = std::max<int64_t>((int64_t)4 * e.c.cd_hidden * up_front, std::max<int64_t>(e.c.cd_ffn, (int64_t)3 * e.c.cd_hidden));
+        const int64_t frame_cap = std::min<int64_t>((int64_t)1 << 16, (((int64_t)1 << 32) - 1) / ((int64_t)sizeof(float) * widest));
+        while (y1 < n_utt && y1 - y0 < 4096 && (int64_t)(y1 - y0 + 1) * F0 <= frame_cap && got_frames[(size_t)order[(size_t)y1]] * 2 >= F0) ++y1;
+        const int nblk = y1 - y0;
+        if (nblk >= 2 && batchable && F0 <= frame_cap / 2) {
+            int rows = 0;
+            e.codec_lanes_join();                                      // the previous block's groups still read the batched buffers
+            const float* hb = e.codec_pre_batch(e.codec_job_codes(0, row_frames), row_frames, nblk, F0, true, &rows, order.data() + y0);
+            const size_t ustride = (size_t)rows * e.c.cd_hidden;
+            const int group = (int)std::max<int64_t>(1, std::min<int64_t>(32, ((int64_t)8 << 30) / ((int64_t)4700000 * F0)));
+            for (int g0 = 0; g0 < nblk; g0 += group) {
+                const int g = std::min(group, nblk - g0);
+                nf.assign((size_t)g, 0); up.assign((size_t)g, nullptr); lp.assign((size_t)g, nullptr);
+                for (int k = 0; k < g; ++k) {
+                    const int u = order[(size_t)(y0 + g0 + k)];
+                    nf[(size_t)k] = got_frames[(size_t)u];
+                    if (pcm_len) lp[(size_t)k] = pcm_len + u;
+                    if (pcm_out) up[(size_t)k] = pcm_out[u];
+                }
+                e.codec_async_submit_group(hb + (size_t)g0 * ustride, ustride, nf[0], g, nf.data(), up.data(), pcm_cap, lp.data());
+            }
+        } else {
+            for (int y = y0; y < y1; ++y) {
+                const int u = order[(size_t)y];
+                e.codec_async_submit_dev(e.codec_job_codes(u, row_frames), got_frames[(size_t)u], pcm_out ? pcm_out[u] : nullptr, pcm_cap, pcm_len ? pcm_len + u : nullptr);
+            }
+        }
+        y0 = y1;
+    }
+    e.codec_async_drain();
+    } catch (...) {
+        e.codec_async_abort();
+        for (int u = 0; u < n_utt; ++u) if (pcm_len) pcm_len[u] = 0;
+        throw;
+    }
+}
 
 extern "C" {
 
@@ -150,6 +218,35 @@ int q3tts_codec_decode_host(q3tts_engine* h, const int64_t* codes, int F, float*
     Q3_API_BEGIN(h)
     const int64_t n = h->e->codec_decode_host(codes, F, pcm, cap);
     if (out_len) *out_len = n;
+    return 0;
+    Q3_API_END(h)
+}
+
+int q3tts_codec_decode_batch_host(q3tts_engine* h, int n_utt, const int64_t* codes, const int32_t* frame_offsets, float* const* pcm_out, int64_t pcm_cap,
+                                  int64_t* pcm_len) {
+    Q3_API_BEGIN(h)
+    Engine& e = *h->e;
+    if (n_utt <= 0) return 0;
+    if (!codes || !frame_offsets) throw q3::Error("codec_decode_batch: null argument");
+    if (pcm_cap < 0) throw q3::Error("codec_decode_batch: negative pcm_cap");
+    const int G = e.c.n_groups;
+    int row_frames = 1;
+    std::vector<int32_t> nf((size_t)n_utt);
+    for (int u = 0; u < n_utt; ++u) {
+        const int64_t f = (int64_t)frame_offsets[u + 1] - frame_offsets[u];
+        if (f < 0) throw q3::Error("codec_decode_batch: frame_offsets must not decrease");
+        nf[(size_t)u] = (int32_t)f;
+        row_frames = std::max(row_frames, (int)f);
+    }
+    e.codec_async_prepare(row_frames, n_utt);
+    std::vector<int32_t> rows((size_t)n_utt * row_frames * G, 0);
+    for (int u = 0; u < n_utt; ++u) {
+        const int64_t* src = codes + (size_t)frame_offsets[u] * G;
+        int32_t* dst = rows.data() + (size_t)u * row_frames * G;
+        for (size_t i = 0; i < (size_t)nf[(size_t)u] * G; ++i) dst[i] = (int32_t)std::min<int64_t>(std::max<int64_t>(src[i], INT32_MIN), INT32_MAX);
+    }
+    e.codec_job_upload(rows.data(), n_utt, row_frames);
+    vocoder_job(e, n_utt, nf, row_frames, pcm_out, pcm_cap, pcm_len);
     return 0;
     Q3_API_END(h)
 }
@@ -447,65 +544,7 @@ int q3tts_synthesize_schedule_host(q3tts_engine* h, int n_utt, const int64_t* id
         for (int b = 0; b < B; ++b) { try { e.slot_release(b); } catch (...) { } }
         throw;
     }
-    // Vocoder, once the decode queue is empty.  Utterances are taken longest first, in blocks of similar length (the shortest at least half
-    // the longest, at most 2^16 padded frames): a block's pre-transformer and upsampling stages run as one batched pass, its conv decoder in
-    // groups of up to 32 utterances per set of launches (about 4.7 MB of workspace per frame: groups sized to ~8 GB), each group padded to its
-    // own longest member.  Padding is exact: every layer is causal.  Single utterances, the exact-fp32 codec and configs whose decoder the
-    // batched kernels do not cover go one utterance at a time over the side lanes.
-    // A failure in here (arena / pinned-buffer allocation, a launch error) must not leave lanes holding this job's pcm_out / pcm_len
-    // pointers: the next job's drain would write through them.  codec_async_abort() waits for the lanes and forgets their items.
-    try {
-    std::vector<int> order((size_t)n_utt);
-    for (int u = 0; u < n_utt; ++u) { order[(size_t)u] = u; if (pcm_len) pcm_len[u] = 0; }
-    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return got_frames[(size_t)x] > got_frames[(size_t)y]; });
-    const bool batchable = e.codec_batchable();
-    std::vector<int> nf;
-    std::vector<float*> up;
-    std::vector<int64_t*> lp;
-    for (int y0 = 0; y0 < n_utt;) {
-        const int F0 = got_frames[(size_t)order[(size_t)y0]];
-        if (F0 <= 0) break;                                            // sorted: the rest of the job produced no frame
-        int y1 = y0 + 1;
-        // a block is a batch dimension of the batched kernels (gridDim.y / .z <= 65535): at most 4096 sequences and 2^16 padded frames, and
-        // no activation matrix of its batched front may reach 4 GB (k_conv_split addresses rows with 32-bit byte offsets): the widest is
-        // the ConvNeXt hidden [frames x upsampling][4 x cd_hidden] — at 0.6B dims exactly 4 GB at 2^16 frames, hence the strict bound
-        int64_t up_front = 1;
-        for (int i = 0; i < e.c.cd_n_up; ++i) up_front *= e.c.cd_up_ratios[i];
-        const int64_t widest = std::max<int64_t>((int64_t)4 * e.c.cd_hidden * up_front, std::max<int64_t>(e.c.cd_ffn, (int64_t)3 * e.c.cd_hidden));
-        const int64_t frame_cap = std::min<int64_t>((int64_t)1 << 16, (((int64_t)1 << 32) - 1) / ((int64_t)sizeof(float) * widest));
-        while (y1 < n_utt && y1 - y0 < 4096 && (int64_t)(y1 - y0 + 1) * F0 <= frame_cap && got_frames[(size_t)order[(size_t)y1]] * 2 >= F0) ++y1;
-        const int nblk = y1 - y0;
-        if (nblk >= 2 && batchable && F0 <= frame_cap / 2) {
-            int rows = 0;
-            e.codec_lanes_join();                                      // the previous block's groups still read the batched buffers
-            const float* hb = e.codec_pre_batch(e.codec_job_codes(0, row_frames), row_frames, nblk, F0, true, &rows, order.data() + y0);
-            const size_t ustride = (size_t)rows * e.c.cd_hidden;
-            const int group = (int)std::max<int64_t>(1, std::min<int64_t>(32, ((int64_t)8 << 30) / ((int64_t)4700000 * F0)));
-            for (int g0 = 0; g0 < nblk; g0 += group) {
-                const int g = std::min(group, nblk - g0);
-                nf.assign((size_t)g, 0); up.assign((size_t)g, nullptr); lp.assign((size_t)g, nullptr);
-                for (int k = 0; k < g; ++k) {
-                    const int u = order[(size_t)(y0 + g0 + k)];
-                    nf[(size_t)k] = got_frames[(size_t)u];
-                    if (pcm_len) lp[(size_t)k] = pcm_len + u;
-                    if (pcm_out) up[(size_t)k] = pcm_out[u];
-                }
-                e.codec_async_submit_group(hb + (size_t)g0 * ustride, ustride, nf[0], g, nf.data(), up.data(), pcm_cap, lp.data());
-            }
-        } else {
-            for (int y = y0; y < y1; ++y) {
-                const int u = order[(size_t)y];
-                e.codec_async_submit_dev(e.codec_job_codes(u, row_frames), got_frames[(size_t)u], pcm_out ? pcm_out[u] : nullptr, pcm_cap, pcm_len ? pcm_len + u : nullptr);
-            }
-        }
-        y0 = y1;
-    }
-    e.codec_async_drain();
-    } catch (...) {
-        e.codec_async_abort();
-        for (int u = 0; u < n_utt; ++u) if (pcm_len) pcm_len[u] = 0;
-        throw;
-    }
+    vocoder_job(e, n_utt, got_frames, row_frames, pcm_out, pcm_cap, pcm_len);
     return 0;
     Q3_API_END(h)
 }
@@ -635,6 +674,18 @@ int q3tts_measure_skip_frames(q3tts_engine* h, int n_frames) {
     h->e->measure_skip_frames(n_frames);
     return 0;
     Q3_API_END(h)
+}
+int q3tts_test_group_final_conv(q3tts_engine* h, float* sx_out, float* pcm_out, int64_t cap_floats, int32_t* T, int32_t* C, int32_t* nb) {
+    Q3_API_BEGIN(h)
+    int t = 0, c = 0, n = 0;
+    h->e->codec_debug_group(sx_out, pcm_out, cap_floats, &t, &c, &n);
+    if (T) *T = t; if (C) *C = c; if (nb) *nb = n;
+    return 0;
+    Q3_API_END(h)
+}
+int64_t q3tts_test_final_conv_partials(q3tts_engine* h, float* out, int64_t cap_floats) {
+    if (!h || !h->e) return -1;
+    try { return h->e->codec_debug_partials(out, cap_floats); } catch (...) { return -1; }
 }
 int q3tts_test_poison_workspace(q3tts_engine* h) {
     Q3_API_BEGIN(h)

@@ -52,6 +52,7 @@ struct CodecW {
     struct Pending { std::vector<Item> items; int frames = 0; bool busy = false; };
     Pending pend[NLANE];
     int32_t* job_codes = nullptr; size_t job_codes_n = 0;
+    const float* dbg_sx = nullptr; const float* dbg_pcm = nullptr; int dbg_T = 0, dbg_C = 0, dbg_nb = 0;   // test hook: the last batched group's final conv
     char* batch_arena = nullptr; size_t batch_arena_bytes = 0;   // batched pre-transformer of a job (codec_pre_batch)
     int* batch_pages = nullptr; int batch_pages_n = 0;           // identity page table, one cache block per utterance   // codes of a scheduler job's finished utterances, [utterance][max_new][groups]
     hipEvent_t lane_done[NLANE] = {};
@@ -409,6 +410,7 @@ int64_t Engine::codec_run(const int32_t* codes_dev, int F, float** pcm_dev, int 
         pcm = take(nbz * Tc);
         { ConvArgs a; a.in = sx; a.T_in = Tc; a.C_in = C; a.out = pcm; a.T_out = Tc; a.C_out = 1; a.W = W.conv_out.w; a.bias = W.conv_out.b;
           a.taps = 7; a.clamp = 1; conv(a); }
+        if (!plan && nbatch > 1) { W.dbg_sx = sx; W.dbg_pcm = pcm; W.dbg_T = Tc; W.dbg_C = C; W.dbg_nb = nbatch; }
         n_pcm = Tc;
         if (plan && off > W.arena_bytes[lane]) {
             Q3_HIP_CHECK(hipStreamSynchronize(stream));
@@ -595,6 +597,15 @@ const int32_t* Engine::codec_stash(int slot, int nf, int utt, int row_frames) {
     int32_t* dst = W.job_codes + (size_t)utt * row_frames * G;
     if (nf > 0) Q3_HIP_CHECK(hipMemcpyAsync(dst, codes_d + (size_t)slot * max_frames_cap * G, (size_t)nf * G * sizeof(int32_t), hipMemcpyDeviceToDevice, stream));
     return dst;
+}
+
+// host codes [n_utt][row_frames][n_groups] -> the job buffer (after codec_async_prepare(row_frames, n_utt)); returns once they are in HBM
+void Engine::codec_job_upload(const int32_t* host, int n_utt, int row_frames) {
+    CodecW& W = *codec;
+    const size_t n = (size_t)n_utt * row_frames * c.n_groups;
+    if (n > W.job_codes_n) throw Error("codec_job_upload: job buffer not prepared");
+    Q3_HIP_CHECK(hipMemcpyAsync(W.job_codes, host, n * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+    sync();
 }
 
 const int32_t* Engine::codec_job_codes(int utt, int row_frames) { return codec->job_codes + (size_t)utt * row_frames * c.n_groups; }
@@ -897,6 +908,24 @@ void Engine::codec_poison() {
     if (W.stream_arena) Q3_HIP_CHECK(hipMemset(W.stream_arena, 0xFF, W.stream_arena_bytes));
     if (W.job_codes) Q3_HIP_CHECK(hipMemset(W.job_codes, 0xFF, W.job_codes_n * sizeof(int32_t)));   // -1: clamped to code 0 by the gather, never out of the table
     Q3_HIP_CHECK(hipDeviceSynchronize());
+}
+
+// Test hook: input rows [nb][T][C] and output [nb][T] of the last batched group's final conv, as they lie in the lane's arena now
+void Engine::codec_debug_group(float* sx_out, float* pcm_out, int64_t cap_floats, int* T, int* C, int* nb) {
+    if (!(flags & Q3TTS_FLAG_TEST_HOOKS)) throw Error("codec_debug_group needs Q3TTS_FLAG_TEST_HOOKS");
+    CodecW& W = *codec;
+    *T = W.dbg_T; *C = W.dbg_C; *nb = W.dbg_nb;
+    if (!W.dbg_sx) return;
+    Q3_HIP_CHECK(hipDeviceSynchronize());
+    const int64_t n = (int64_t)W.dbg_nb * W.dbg_T * W.dbg_C;
+    if (sx_out && n <= cap_floats) Q3_HIP_CHECK(hipMemcpy(sx_out, W.dbg_sx, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+    if (pcm_out) Q3_HIP_CHECK(hipMemcpy(pcm_out, W.dbg_pcm, (size_t)W.dbg_nb * W.dbg_T * sizeof(float), hipMemcpyDeviceToHost));
+}
+int64_t Engine::codec_debug_partials(float* out, int64_t cap_floats) {
+    const float* p = nullptr; size_t n = 0;
+    cout1_debug_buffer(&p, &n);
+    if (out && p && (int64_t)n <= cap_floats) { Q3_HIP_CHECK(hipDeviceSynchronize()); Q3_HIP_CHECK(hipMemcpy(out, p, n * sizeof(float), hipMemcpyDeviceToHost)); }
+    return (int64_t)n;
 }
 
 bool Engine::codec_batchable() const {

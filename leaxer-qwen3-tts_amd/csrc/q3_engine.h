@@ -116,6 +116,8 @@ public:
     int64_t codec_decode_chunked_host(const int64_t* codes, int F, int chunk, int left_context, float* pcm, int64_t cap);
     // streaming decode with carried state (q3_codec.cpp): a stream keeps the pre-transformer's K / V rows and output rows, a push decodes
     // n new frames in O(n + stage_b_context) work, exactly
+    void codec_debug_group(float* sx_out, float* pcm_out, int64_t cap_floats, int* T, int* C, int* nb);
+    int64_t codec_debug_partials(float* out, int64_t cap_floats);
     void codec_poison();                                // test hook: the vocoder's reusable workspace filled with NaN bytes
     int codec_stream_begin(int max_frames);
     void codec_stream_fit(int sid, int n);              // room for a push of n frames in the stream's sliding K / V and row buffers
@@ -189,6 +191,7 @@ public:
     void codec_async_prepare(int max_frames, int n_utt);
     const int32_t* codec_stash(int slot, int nf, int utt, int row_frames);
     const int32_t* codec_job_codes(int utt, int row_frames);
+    void codec_job_upload(const int32_t* host, int n_utt, int row_frames);
     void codec_async_submit_dev(const int32_t* codes_dev, int nf, float* user_pcm, int64_t cap, int64_t* len_out, const float* h_in = nullptr, int h_stage = 1);
     void codec_async_drain_lane(int lane);
     void codec_async_drain();

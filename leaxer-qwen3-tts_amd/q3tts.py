@@ -79,11 +79,11 @@ EXPORTS = [
     "q3tts_default_config", "q3tts_create", "q3tts_create_pooled", "q3tts_kv_pool_info", "q3tts_sched_stats", "q3tts_destroy", "q3tts_last_error", "q3tts_num_tensors",
     "q3tts_tensor_info", "q3tts_set_tensor_host", "q3tts_get_tensor_host", "q3tts_fill_synthetic", "q3tts_finalize",
     "q3tts_text_project_host", "q3tts_codec_embed_host", "q3tts_cp_embed_host", "q3tts_talker_prefill_host",
-    "q3tts_talker_decode_host", "q3tts_code_predictor_host", "q3tts_codec_decode_host", "q3tts_codec_decode_len",
+    "q3tts_talker_decode_host", "q3tts_code_predictor_host", "q3tts_codec_decode_host", "q3tts_codec_decode_batch_host", "q3tts_codec_decode_len",
     "q3tts_sample_host", "q3tts_rng_uniform", "q3tts_build_prompt_host", "q3tts_slot_begin", "q3tts_decode_steps",
     "q3tts_slot_status", "q3tts_slot_codes_host", "q3tts_slot_codec_decode_host", "q3tts_slot_release",
     "q3tts_synthesize_batch_host", "q3tts_last_decode_ms", "q3tts_last_codec_ms", "q3tts_decode_step_bytes",
-    "q3tts_codec_decode_dev", "q3tts_stream", "q3tts_counters", "q3tts_stage_profile", "q3tts_prefill_profile", "q3tts_codec_plane_stats", "q3tts_measure_skip_frames", "q3tts_test_poison_workspace", "q3tts_codec_stream_begin", "q3tts_codec_stream_push_host", "q3tts_codec_stream_end", "q3tts_talker_prefill_dev", "q3tts_talker_decode_dev", "q3tts_code_predictor_dev", "q3tts_sample_dev", "q3tts_config_num_tensors", "q3tts_config_tensor_info", "q3tts_read_weights_config", "q3tts_load_weights_file", "q3tts_save_weights_file",
+    "q3tts_codec_decode_dev", "q3tts_stream", "q3tts_counters", "q3tts_stage_profile", "q3tts_prefill_profile", "q3tts_codec_plane_stats", "q3tts_measure_skip_frames", "q3tts_test_poison_workspace", "q3tts_test_group_final_conv", "q3tts_test_final_conv_partials", "q3tts_codec_stream_begin", "q3tts_codec_stream_push_host", "q3tts_codec_stream_end", "q3tts_talker_prefill_dev", "q3tts_talker_decode_dev", "q3tts_code_predictor_dev", "q3tts_sample_dev", "q3tts_config_num_tensors", "q3tts_config_tensor_info", "q3tts_read_weights_config", "q3tts_load_weights_file", "q3tts_save_weights_file",
     "q3tts_tokenizer_create", "q3tts_tokenizer_destroy", "q3tts_tokenizer_load_vocab", "q3tts_tokenizer_load_merges",
     "q3tts_tokenizer_ready", "q3tts_tokenize",
     "q3tts_synthesize_clone_batch_host", "q3tts_synthesize_schedule_host", "q3tts_read_wav_host", "q3tts_resample_host", "q3tts_mel_host",
@@ -126,6 +126,7 @@ def lib():
     L.q3tts_talker_decode_host.argtypes = [vp, i32, vp, vp, vp]
     L.q3tts_code_predictor_host.argtypes = [vp, vp, i32, i32, vp]
     L.q3tts_codec_decode_host.argtypes = [vp, vp, i32, vp, i64, C.POINTER(i64)]
+    L.q3tts_codec_decode_batch_host.argtypes = [vp, i32, vp, vp, vp, i64, vp]
     L.q3tts_codec_decode_len.restype = i64
     L.q3tts_codec_decode_len.argtypes = [C.POINTER(Config), i32]
     L.q3tts_sample_host.argtypes = [vp, vp, i32, C.POINTER(Sampling), f32, i32, C.POINTER(i64)]
@@ -334,6 +335,23 @@ class Engine:
         out_len = C.c_int64(0)
         self._ck(self.L.q3tts_codec_decode_host(self.h, _p(c), c.shape[0], _p(pcm), n, C.byref(out_len)))
         return pcm[: out_len.value]
+
+    def codec_decode_batch(self, codes_list):
+        """the vocoder phase of a job on its own: one [F_u][n_groups] code array per utterance -> one PCM array each (batched blocks of
+        similar length + single utterances over the side lanes, exactly as synthesize_batch vocodes its results)"""
+        n = len(codes_list)
+        if n == 0:
+            return []
+        cs = [np.ascontiguousarray(c_, np.int64).reshape(-1, self.cfg.n_groups) for c_ in codes_list]
+        offs = np.zeros(n + 1, np.int32)
+        offs[1:] = np.cumsum([c_.shape[0] for c_ in cs])
+        flat = np.ascontiguousarray(np.concatenate(cs)) if offs[-1] else np.zeros((1, self.cfg.n_groups), np.int64)
+        cap = max(self.codec_decode_len(max(c_.shape[0] for c_ in cs)), 1)
+        pcm = [np.zeros(cap, np.float32) for _ in range(n)]
+        ptrs = (C.c_void_p * n)(*[a.ctypes.data for a in pcm])
+        pcm_len = np.zeros(n, np.int64)
+        self._ck(self.L.q3tts_codec_decode_batch_host(self.h, n, _p(flat), _p(offs), C.cast(ptrs, C.c_void_p), cap, _p(pcm_len)))
+        return [pcm[i][: pcm_len[i]] for i in range(n)]
 
     def codec_decode_chunked(self, codes, chunk_frames, left_context):
         """exact chunked decode: equals codec_decode(codes) when left_context covers the history"""
@@ -553,6 +571,28 @@ class Engine:
         """test hook (FLAG_TEST_HOOKS engines): NaN bytes over the vocoder's reusable workspace (q3tts_test_poison_workspace)"""
         self.L.q3tts_test_poison_workspace.argtypes = [C.c_void_p]
         self._ck(self.L.q3tts_test_poison_workspace(self.h))
+
+    def group_final_conv(self):
+        """test hook: (sx [nb][T][C], pcm [nb][T]) of the last batched vocoder group's final conv, read back from its lane's workspace"""
+        T, Cc, nb = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        self.L.q3tts_test_group_final_conv.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+        self._ck(self.L.q3tts_test_group_final_conv(self.h, None, None, 0, C.byref(T), C.byref(Cc), C.byref(nb)))
+        sx = np.empty((nb.value, T.value, Cc.value), np.float32)
+        pcm = np.empty((nb.value, T.value), np.float32)
+        self._ck(self.L.q3tts_test_group_final_conv(self.h, _p(sx), _p(pcm), sx.size, C.byref(T), C.byref(Cc), C.byref(nb)))
+        return sx, pcm
+
+    def final_conv_partials(self):
+        """test hook: [tiles][256][8] partial sums of the last batched group's final conv (Q3TTS_COUT1_VAR=6 only), or None"""
+        f = self.L.q3tts_test_final_conv_partials
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+        f.restype = C.c_int64
+        n = f(self.h, None, 0)
+        if n <= 0:
+            return None
+        out = np.empty(n, np.float32)
+        f(self.h, _p(out), n)
+        return out.reshape(-1, 256, 8)
 
     def measure_skip_frames(self, n):
         """measurement aid (FLAG_TEST_HOOKS engines): armed slots jump n frames ahead over a synthetic KV cache (q3tts_measure_skip_frames)"""
