@@ -131,7 +131,8 @@ int64_t q3tts_codec_decode_len(const q3tts_config* cfg, int F);
  * vocoder phase of q3tts_synthesize_schedule_host on its own): utterance u's codes are codes[frame_offsets[u] .. frame_offsets[u+1])
  * frames of n_groups ids each.  Utterances of similar length share one batched pass, the rest go one at a time over the side lanes;
  * pcm_out[u] receives up to pcm_cap samples, pcm_len[u] the utterance's sample count (q3tts_codec_decode_len of its frames; 0 for an
- * utterance without frames).  Each result equals q3tts_codec_decode_host of the same utterance to fp32 rounding. */
+ * utterance without frames).  Each result equals q3tts_codec_decode_host of the same utterance to fp32 rounding; ids outside
+ * [0, codebook) and utterances beyond the engine's frame capacity are rejected like there. */
 int q3tts_codec_decode_batch_host(q3tts_engine* e, int n_utt, const int64_t* codes, const int32_t* frame_offsets, float* const* pcm_out,
                                   int64_t pcm_cap, int64_t* pcm_len);
 /* the same with both ends in HBM: codes_dev int32 [F][n_groups] and pcm_dev float [cap] are DEVICE pointers on the engine's GPU (any
@@ -302,7 +303,7 @@ int q3tts_test_poison_workspace(q3tts_engine* e);
 /* Test hook (Q3TTS_FLAG_TEST_HOOKS engines): the last batched vocoder group's final conv as it lies in its lane's workspace — input rows
  * sx_out[nb][T][C] (cap_floats >= nb*T*C, else skipped) and output pcm_out[nb][T]; either may be NULL.  tools/vocoder_stress.py uses it to
  * tell a wrong input from a wrong conv when a job's PCM differs from the utterance's own decode. */
-/* ... and, when the A/B knob Q3TTS_COUT1_VAR=6 selected the dumping variant of that conv, the per-row per-tap partial sums each tile's
+/* ... and, when the A/B knob Q3TTS_COUT1_PACKED=2 selected the dumping variant of that conv, the per-row per-tap partial sums each tile's
  * output phase read from LDS: out[tile][256][8]; returns the float count (call with out == NULL to size). */
 int64_t q3tts_test_final_conv_partials(q3tts_engine* e, float* out, int64_t cap_floats);
 int q3tts_test_group_final_conv(q3tts_engine* e, float* sx_out, float* pcm_out, int64_t cap_floats, int32_t* T, int32_t* C, int32_t* nb);

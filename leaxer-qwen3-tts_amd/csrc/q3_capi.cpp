@@ -229,12 +229,14 @@ int q3tts_codec_decode_batch_host(q3tts_engine* h, int n_utt, const int64_t* cod
     if (n_utt <= 0) return 0;
     if (!codes || !frame_offsets) throw q3::Error("codec_decode_batch: null argument");
     if (pcm_cap < 0) throw q3::Error("codec_decode_batch: negative pcm_cap");
+    if (!e.finalized) throw q3::Error("weights not finalized");
     const int G = e.c.n_groups;
     int row_frames = 1;
     std::vector<int32_t> nf((size_t)n_utt);
     for (int u = 0; u < n_utt; ++u) {
         const int64_t f = (int64_t)frame_offsets[u + 1] - frame_offsets[u];
         if (f < 0) throw q3::Error("codec_decode_batch: frame_offsets must not decrease");
+        if (f > e.max_frames_cap) throw q3::Error("codec_decode: F out of range");   // the single-utterance entry point's bound and message
         nf[(size_t)u] = (int32_t)f;
         row_frames = std::max(row_frames, (int)f);
     }
@@ -243,7 +245,10 @@ int q3tts_codec_decode_batch_host(q3tts_engine* h, int n_utt, const int64_t* cod
     for (int u = 0; u < n_utt; ++u) {
         const int64_t* src = codes + (size_t)frame_offsets[u] * G;
         int32_t* dst = rows.data() + (size_t)u * row_frames * G;
-        for (size_t i = 0; i < (size_t)nf[(size_t)u] * G; ++i) dst[i] = (int32_t)std::min<int64_t>(std::max<int64_t>(src[i], INT32_MIN), INT32_MAX);
+        for (size_t i = 0; i < (size_t)nf[(size_t)u] * G; ++i) {
+            if (src[i] < 0 || src[i] >= e.c.cd_codebook) throw q3::Error("codec_decode: code out of range");   // as q3tts_codec_decode_host
+            dst[i] = (int32_t)src[i];
+        }
     }
     e.codec_job_upload(rows.data(), n_utt, row_frames);
     vocoder_job(e, n_utt, nf, row_frames, pcm_out, pcm_cap, pcm_len);

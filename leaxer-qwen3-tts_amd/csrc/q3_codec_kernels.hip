@@ -987,15 +987,24 @@ __global__ __launch_bounds__(CO1_T) void k_conv_cout1(ConvKArgs a0) {
 // workgroup walks 256 rows in 8 passes of 32 (every load of the tile issued up front), each lane forms its slice of the row's per-tap
 // dot products d[tap] = sum_c W[tap][c] x[row][c], the eight slices meet by DPP (quad sums, then the half-row mirror), and the partial sums
 // change hands through LDS: output j adds d[tap] of rows j + tap * dil.  Causal taps, optional clamp.  A tile yields 256 - halo outputs.
+//
+// Round 5: every sum here is a SCALAR fp32 instruction (opaque() below keeps the compiler from pairing two taps into v_pk_fma_f32 /
+// v_pk_add_f32).  With the packed form — what the compiler emits by itself, and what rounds 4-5 shipped until this fix — the kernel
+// returned a wrong partial sum now and then: the low half of a packed pair (an even tap), in lanes 48..63 of a wave (the rows 8w + 6 and
+// 8w + 7 of a pass, 9 times in 10 of the first pass), the input rows bit-identical to a clean run's — two adjacent PCM samples off by up
+// to 1.5e-2 in 12-28 % of the jobs whose last batched group is small enough to run one workgroup per CU while other lanes keep the chip
+// busy (round 4's "one-off" 3.8e-3).  Of twelve variants of this kernel the six with v_pk_fma_f32 fail at that rate and the six without
+// never do (0 of 1000-1200 jobs each; LDS layout, DPP vs ds_bpermute, wait states before the DPP reads, launching it twice do not
+// matter): profiles/r05_hunt/, tools/vocoder_stress.py, DESIGN.md section 8.  PACKED = the old code, kept as the reproducer behind the A/B
+// knob Q3TTS_COUT1_PACKED (=2: also dumps each tile's LDS partial sums, DUMP).
 #define CO1R_ROWS 256
-template <int CPT, int VAR = 0>
+static __device__ __forceinline__ float opaque(float v) { asm volatile("" : "+v"(v)); return v; }
+template <int CPT, bool PACKED = false, bool DUMP = false>
 __global__ __launch_bounds__(256) void k_conv_cout1_reg(ConvKArgs a0) {
     constexpr int MAXT = 8, NP = CO1R_ROWS / 32;
-    constexpr int LDR = VAR == 3 ? 10 : 9, LDT = CO1R_ROWS + 8;     // experiment layouts: VAR 3 = row-major with 8-byte-aligned tap pairs, VAR 4 = tap-major
-    __shared__ float dsf[VAR == 4 ? MAXT * LDT : CO1R_ROWS * LDR];
-    auto ds = [&](int row, int tap) -> float& { return VAR == 4 ? dsf[tap * LDT + row] : dsf[row * LDR + tap]; };
+    __shared__ float ds[CO1R_ROWS][MAXT + 1];
     ConvKArgs a = a0;
-    if constexpr (VAR == 6) a.out2 = nullptr;
+    if constexpr (DUMP) a.out2 = nullptr;   // a0.out2 carries the dump buffer: not a second output
     const int bx = conv_batch_rebase(a, blockIdx.x);
     const int tid = threadIdx.x, s8 = tid & 7, rl = tid >> 3;
     const int halo = (a.taps - 1) * a.dil, TO = CO1R_ROWS - halo, t0 = bx * TO;
@@ -1035,35 +1044,18 @@ __global__ __launch_bounds__(256) void k_conv_cout1_reg(ConvKArgs a0) {
 #pragma unroll
             for (int c = 0; c < CPT; ++c) acc = fmaf(w[tap][c], x[p][c], acc);
             acc = inr ? acc : 0.f;
-            if constexpr (VAR == 8) asm volatile("s_nop 4" : "+v"(acc));   // experiment: >= 5 wait states between the VALU write of acc and its first DPP read
-            if constexpr (VAR == 9) asm volatile("s_nop 0" : "+v"(acc));   // experiment: one more than the compiler's two
-            if constexpr (VAR == 10) asm volatile("" : "+v"(acc));         // experiment: the same opaque point without a wait state
-            if constexpr (VAR == 12) { d[tap] = acc; continue; }           // experiment: every tap's masked sum first, the DPP steps in a second loop
-            if constexpr (VAR == 1) {   // experiment: the same sums over ds_bpermute instead of DPP
-                acc += __shfl_xor(acc, 1); acc += __shfl_xor(acc, 2); acc += __shfl_xor(acc, 4);
-                d[tap] = acc;
-                continue;
-            }
+            if constexpr (!PACKED) acc = opaque(acc);   // one tap's chain is one value to the vectoriser: v_fmac_f32, never v_pk_fma_f32
             // the row's eight channel slices: quad sums, then lanes 0..3 take lanes 4..7 (lane s8 == 0 ends up with the row's sum)
             acc += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+            if constexpr (!PACKED) acc = opaque(acc);
             acc += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]: every lane holds its quad's sum
+            if constexpr (!PACKED) acc = opaque(acc);
             acc += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc), 0x141, 0xF, 0xF, true));   // row_half_mirror: lane i <-> lane 7 - i of its 8 lanes = the other quad
-            d[tap] = acc;
-        }
-        if constexpr (VAR == 12) {
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int tap = 0; tap < MAXT; ++tap) {
-                float acc = d[tap];
-                acc += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc), 0xB1, 0xF, 0xF, true));
-                acc += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc), 0x4E, 0xF, 0xF, true));
-                acc += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc), 0x141, 0xF, 0xF, true));
-                d[tap] = acc;
-            }
+            d[tap] = PACKED ? acc : opaque(acc);
         }
         if (s8 == 0) {
 #pragma unroll
-            for (int tap = 0; tap < MAXT; ++tap) ds(p * 32 + rl, tap) = d[tap];
+            for (int tap = 0; tap < MAXT; ++tap) ds[p * 32 + rl][tap] = d[tap];
         }
     }
     __syncthreads();
@@ -1072,17 +1064,18 @@ __global__ __launch_bounds__(256) void k_conv_cout1_reg(ConvKArgs a0) {
         float acc = 0.f;
 #pragma unroll
         for (int tap = 0; tap < MAXT; ++tap)
-            if (tap < a.taps) acc += ds(tid + tap * a.dil, tap);   // row t - (taps - 1 - tap) * dil
+            if (tap < a.taps) acc += ds[tid + tap * a.dil][tap];   // row t - (taps - 1 - tap) * dil
         float v = acc + (a.bias ? a.bias[0] : 0.f);
         if (a.clamp) v = v < -1.f ? -1.f : (v > 1.f ? 1.f : v);
         a.out[t] = v;
     }
-    if constexpr (VAR == 6) {   // experiment: the tile's partial sums as the output phase saw them -> a0.out2[blockIdx.x][row][tap]
+    if constexpr (DUMP) {   // the tile's partial sums as its output phase read them -> a0.out2[blockIdx.x][row][tap]
         float* dbg = a0.out2 + (size_t)blockIdx.x * CO1R_ROWS * MAXT;
-        for (int i = tid; i < CO1R_ROWS * MAXT; i += 256) dbg[i] = ds(i / MAXT, i % MAXT);
+        for (int i = tid; i < CO1R_ROWS * MAXT; i += 256) dbg[i] = ds[i / MAXT][i % MAXT];
     }
 }
 
+// dump buffer of the DUMP variant (Q3TTS_COUT1_PACKED=2 on a test-hook engine): one allocation, owned by the last batched launch
 static float* g_cout1_dbg = nullptr;
 static size_t g_cout1_dbg_floats = 0, g_cout1_dbg_used = 0;
 void cout1_debug_buffer(const float** p, size_t* n) { *p = g_cout1_dbg; *n = g_cout1_dbg_used; }
@@ -1129,22 +1122,14 @@ void launch_conv(const ConvArgs& c, hipStream_t s) {
         const int to1 = CO1R_ROWS - (c.taps - 1) * c.dil, tiles = (c.T_out + to1 - 1) / to1;
         if (nb > 1) a.batch_tiles = tiles;
         const dim3 g1((unsigned)(tiles * nb));
-        if (const char* v = knob("Q3TTS_COUT1_VAR")) {   // experiment knobs of the two-sample hunt
-            if (atoi(v) == 1) hipLaunchKernelGGL((k_conv_cout1_reg<12, 1>), g1, dim3(256), 0, s, a);
-            else if (atoi(v) == 3) hipLaunchKernelGGL((k_conv_cout1_reg<12, 3>), g1, dim3(256), 0, s, a);
-            else if (atoi(v) == 4) hipLaunchKernelGGL((k_conv_cout1_reg<12, 4>), g1, dim3(256), 0, s, a);
-            else if (atoi(v) == 8) hipLaunchKernelGGL((k_conv_cout1_reg<12, 8>), g1, dim3(256), 0, s, a);
-            else if (atoi(v) == 10) hipLaunchKernelGGL((k_conv_cout1_reg<12, 10>), g1, dim3(256), 0, s, a);
-            else if (atoi(v) == 12) hipLaunchKernelGGL((k_conv_cout1_reg<12, 12>), g1, dim3(256), 0, s, a);
-            else if (atoi(v) == 9) hipLaunchKernelGGL((k_conv_cout1_reg<12, 9>), g1, dim3(256), 0, s, a);
-            else if (atoi(v) == 6 && nb > 1) {   // batched groups only: one debug buffer, the last group's launch owns it
+        if (const char* v = knob("Q3TTS_COUT1_PACKED")) {   // A/B knob: the packed-fp32 code of rounds 4-5 (the reproducer of the two-sample mismatch)
+            if (atoi(v) == 2 && nb > 1) {
                 const size_t need = (size_t)tiles * nb * CO1R_ROWS * 8;
-                if (need > g_cout1_dbg_floats) { Q3_HIP_CHECK(hipDeviceSynchronize()); if (g_cout1_dbg) (void)hipFree(g_cout1_dbg); Q3_HIP_CHECK(hipMalloc((void**)&g_cout1_dbg, need * sizeof(float))); g_cout1_dbg_floats = need; }
+                if (need > g_cout1_dbg_floats) { Q3_HIP_CHECK(hipDeviceSynchronize()); if (g_cout1_dbg) (void)hipFree(g_cout1_dbg); g_cout1_dbg = nullptr; g_cout1_dbg_floats = 0; Q3_HIP_CHECK(hipMalloc((void**)&g_cout1_dbg, need * sizeof(float))); g_cout1_dbg_floats = need; }
                 g_cout1_dbg_used = need;
                 a.out2 = g_cout1_dbg;
-                hipLaunchKernelGGL((k_conv_cout1_reg<12, 6>), g1, dim3(256), 0, s, a);
-            }
-            else { hipLaunchKernelGGL(k_conv_cout1_reg<12>, g1, dim3(256), 0, s, a); hipLaunchKernelGGL(k_conv_cout1_reg<12>, g1, dim3(256), 0, s, a); }
+                hipLaunchKernelGGL((k_conv_cout1_reg<12, true, true>), g1, dim3(256), 0, s, a);
+            } else hipLaunchKernelGGL((k_conv_cout1_reg<12, true, false>), g1, dim3(256), 0, s, a);
             Q3_HIP_CHECK(hipGetLastError());
             return;
         }

@@ -296,7 +296,7 @@ struct ConvArgs { // out[t][co] = epi(bias[co] + sum_{tap,ci} W[tap][co][ci] * i
     size_t in_ustride = 0;       // floats between the sequences' inputs (0: T_in * C_in, i.e. densely packed)
 };
 void launch_conv(const ConvArgs& a, hipStream_t s);
-void cout1_debug_buffer(const float** p, size_t* n);   // experiment hook (Q3TTS_COUT1_VAR=6)
+void cout1_debug_buffer(const float** p, size_t* n);   // experiment hook (Q3TTS_COUT1_PACKED=2)
 void launch_split_planes(const float* w, bf16_t* hi, bf16_t* lo, size_t n, float scale, hipStream_t s);
 void launch_snake_pre(const float* alpha, const float* beta, float* pre /* [2][C] */, int C, hipStream_t s);
 void launch_repack_planes_cm(const bf16_t* planes /* [2][taps][cout][cin] */, bf16_t* out /* [2][taps][cin/32][cout][32] */, int taps, int cout, int cin, size_t plane_elems, hipStream_t s);

@@ -583,7 +583,7 @@ class Engine:
         return sx, pcm
 
     def final_conv_partials(self):
-        """test hook: [tiles][256][8] partial sums of the last batched group's final conv (Q3TTS_COUT1_VAR=6 only), or None"""
+        """test hook: [tiles][256][8] partial sums of the last batched group's final conv (Q3TTS_COUT1_PACKED=2 only), or None"""
         f = self.L.q3tts_test_final_conv_partials
         f.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
         f.restype = C.c_int64

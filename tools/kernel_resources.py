@@ -43,6 +43,33 @@ def kernel_table(obj):
     return [(re.sub(r"\(.*", "", d.replace("void q3::", "")),) + r[1:] for r, d in zip(rows, dem)]
 
 
+def kernel_disassembly(obj, name_substr):
+    """{demangled name: instruction text} of every gfx950 kernel of `obj` whose demangled name contains name_substr."""
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        fat = os.path.join(tmp, "k.fat")
+        subprocess.run([LLVM + "llvm-objcopy", "-O", "binary", "--only-section=.hip_fatbin", obj, fat], check=True)
+        blob = open(fat, "rb").read()
+        magic = b"__CLANG_OFFLOAD_BUNDLE__"
+        starts = [m.start() for m in re.finditer(re.escape(magic), blob)]
+        for n, (a, b) in enumerate(zip(starts, starts[1:] + [len(blob)])):
+            one, co = os.path.join(tmp, "b%d.fat" % n), os.path.join(tmp, "b%d.co" % n)
+            open(one, "wb").write(blob[a:b])
+            lst = subprocess.run([LLVM + "clang-offload-bundler", "--list", "--type=o", "--input=" + one], capture_output=True, text=True, check=True)
+            tgts = [l for l in lst.stdout.split() if "gfx950" in l]
+            if not tgts:
+                continue
+            subprocess.run([LLVM + "clang-offload-bundler", "--unbundle", "--type=o", "--input=" + one, "--targets=" + tgts[0], "--output=" + co], check=True)
+            syms = subprocess.run([LLVM + "llvm-readelf", "-s", "-W", co], capture_output=True, text=True, check=True).stdout
+            mangled = sorted(set(re.findall(r"FUNC\s+\w+\s+\w+\s+\d+\s+(\S+)", syms)))
+            dem = subprocess.run(["c++filt"], input="\n".join(mangled), capture_output=True, text=True).stdout.split("\n")
+            for m_, d_ in zip(mangled, dem):
+                if name_substr in d_:
+                    txt = subprocess.run([LLVM + "llvm-objdump", "-d", "--disassemble-symbols=" + m_, co], capture_output=True, text=True, check=True).stdout
+                    out[re.sub(r"\(.*", "", d_.replace("void q3::", ""))] = txt
+    return out
+
+
 if __name__ == "__main__":
     pat = sys.argv[2] if len(sys.argv) > 2 else ""
     for name, vgpr, agpr, sgpr, scratch, lds in kernel_table(sys.argv[1]):

@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--tol", type=float, default=2e-5)
     ap.add_argument("--model", default="0.6b")
     ap.add_argument("--no-poison", action="store_true")
+    ap.add_argument("--check-input", action="store_true", help="every repetition: the last batched group's final-conv input must equal the first clean job's, bit for bit (all upstream kernels of that group under the same stress)")
     ap.add_argument("--diag", type=int, default=0, help="for the first N mismatching jobs read back the last batched group's final-conv input and output and say which is wrong")
     ap.add_argument("--phase", action="append", default=[], help="NAME:KNOB=V,KNOB=V (repeatable); default: one phase without knobs")
     a = ap.parse_args()
@@ -61,7 +62,7 @@ def main():
         knobs = dict(x.split("=", 1) for x in kv.split(",") if x)
         for k, v in knobs.items():
             os.environ[k] = v
-        bad, worst, t0, alone_bad = 0, 0.0, time.time(), 0
+        bad, worst, t0, alone_bad, n_in, in_bad = 0, 0.0, time.time(), 0, 0, 0
         for rep in range(a.reps):
             if not a.no_poison:
                 eng.poison_workspace()
@@ -85,7 +86,14 @@ def main():
                     print("%s rep %d utterance %d (%d frames, %d samples): %d samples off in [%d, %d], max %.3g" % (name, rep, u, caps[u], pcm[u].size, off.size, lo, hi, d))
                     print("   job  ", np.array2string(pcm[u][w0:w1], precision=6, max_line_width=250))
                     print("   alone", np.array2string(alone0[u][w0:w1], precision=6, max_line_width=250), flush=True)
-            if a.diag and (sx_good is None or (diag_left > 0 and bad > bad_before)):
+            if a.check_input and sx_good is not None:
+                sx_now, _ = eng.group_final_conv()
+                n_in += 1
+                if not np.array_equal(sx_now, sx_good):
+                    in_bad += 1
+                    dx = np.argwhere(sx_now != sx_good)
+                    print("%s rep %d: final-conv INPUT differs from the clean job's at %d elements: %s" % (name, rep, len(dx), dx[:8].tolist()), flush=True)
+            if (a.diag or a.check_input) and (sx_good is None or (diag_left > 0 and bad > bad_before)):
                 sx, gp = eng.group_final_conv()
                 if sx.size:
                     ref = np.stack([host_conv(sx[i]) for i in range(sx.shape[0])])
@@ -164,9 +172,10 @@ def main():
                         print("%s rep %d utterance %d: SINGLE decode moved: %d samples in [%d, %d], max %.3g" % (name, rep, u, off.size, off[0], off[-1], float(dd.max())), flush=True)
         for k in knobs:
             os.environ.pop(k, None)
-        print("phase %-24s knobs %-40s reps %d: %d mismatching utterances, %d moved single decodes, worst |job - alone| %.3g, %.1f s"
-              % (name, kv or "-", a.reps, bad, alone_bad, worst, time.time() - t0), flush=True)
-        total_bad += bad + alone_bad
+        print("phase %-24s knobs %-40s reps %d: %d mismatching utterances, %d moved single decodes, worst |job - alone| %.3g, %.1f s%s"
+              % (name, kv or "-", a.reps, bad, alone_bad, worst, time.time() - t0,
+                 "; final-conv input checked on %d jobs: %d differ" % (n_in, in_bad) if a.check_input else ""), flush=True)
+        total_bad += bad + alone_bad + in_bad
     eng.close()
     return 1 if total_bad else 0
 
