@@ -991,12 +991,13 @@ __global__ __launch_bounds__(CO1_T) void k_conv_cout1(ConvKArgs a0) {
 // Round 5: every sum here is a SCALAR fp32 instruction (opaque() below keeps the compiler from pairing two taps into v_pk_fma_f32 /
 // v_pk_add_f32).  With the packed form — what the compiler emits by itself, and what rounds 4-5 shipped until this fix — the kernel
 // returned a wrong partial sum now and then: the low half of a packed pair (an even tap), in lanes 48..63 of a wave (the rows 8w + 6 and
-// 8w + 7 of a pass, 9 times in 10 of the first pass), the input rows bit-identical to a clean run's — two adjacent PCM samples off by up
-// to 1.5e-2 in 12-28 % of the jobs whose last batched group is small enough to run one workgroup per CU while other lanes keep the chip
-// busy (round 4's "one-off" 3.8e-3).  Of twelve variants of this kernel the six with v_pk_fma_f32 fail at that rate and the six without
-// never do (0 of 1000-1200 jobs each; LDS layout, DPP vs ds_bpermute, wait states before the DPP reads, launching it twice do not
-// matter): profiles/r05_hunt/, tools/vocoder_stress.py, DESIGN.md section 8.  PACKED = the old code, kept as the reproducer behind the A/B
-// knob Q3TTS_COUT1_PACKED (=2: also dumps each tile's LDS partial sums, DUMP).
+// 8w + 7 of a pass, 9 times in 10 of the first pass, i.e. at the onset of the FMA burst behind the kernel's one memory wait), the input
+// rows bit-identical to a clean run's — two adjacent PCM samples off by up to 1.7e-2 (round 4's "one-off" 3.8e-3).  Which launch of a
+// job it hits depends on the job's composition (0 % to 90 % of the jobs: profiles/r05_hunt/README.txt); a decode on its own never
+// fails.  Of twelve variants of this kernel the six with v_pk_fma_f32 fail and the six without never do (0 of 1000-3000 jobs each; LDS
+// layout, DPP vs ds_bpermute, wait states before the DPP reads, launching it twice do not matter): tools/vocoder_stress.py, DESIGN.md
+// section 8.  PACKED = the old code, kept as the reproducer behind the A/B knob Q3TTS_COUT1_PACKED (=2: also dumps each tile's LDS
+// partial sums, DUMP).
 #define CO1R_ROWS 256
 static __device__ __forceinline__ float opaque(float v) { asm volatile("" : "+v"(v)); return v; }
 template <int CPT, bool PACKED = false, bool DUMP = false>
