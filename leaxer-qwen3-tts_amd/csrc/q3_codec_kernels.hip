@@ -1076,6 +1076,12 @@ __global__ __launch_bounds__(256) void k_conv_cout1_reg(ConvKArgs a0) {
     }
 }
 
+// experiment of the packed-FMA hunt (Q3TTS_COUT1_DELAY_US, with Q3TTS_COUT1_PACKED): one wave that idles for `us` microseconds in front of the conv
+__global__ void k_idle_us(int us) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();   // 100 MHz wall clock
+    while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)us * 100ull) __builtin_amdgcn_s_sleep(8);
+}
+
 // dump buffer of the DUMP variant (Q3TTS_COUT1_PACKED=2 on a test-hook engine): one allocation, owned by the last batched launch
 static float* g_cout1_dbg = nullptr;
 static size_t g_cout1_dbg_floats = 0, g_cout1_dbg_used = 0;
@@ -1124,6 +1130,7 @@ void launch_conv(const ConvArgs& c, hipStream_t s) {
         if (nb > 1) a.batch_tiles = tiles;
         const dim3 g1((unsigned)(tiles * nb));
         if (const char* v = knob("Q3TTS_COUT1_PACKED")) {   // A/B knob: the packed-fp32 code of rounds 4-5 (the reproducer of the two-sample mismatch)
+            if (const char* d = knob("Q3TTS_COUT1_DELAY_US")) hipLaunchKernelGGL(k_idle_us, dim3(1), dim3(64), 0, s, atoi(d));
             if (atoi(v) == 2 && nb > 1) {
                 const size_t need = (size_t)tiles * nb * CO1R_ROWS * 8;
                 if (need > g_cout1_dbg_floats) { Q3_HIP_CHECK(hipDeviceSynchronize()); if (g_cout1_dbg) (void)hipFree(g_cout1_dbg); g_cout1_dbg = nullptr; g_cout1_dbg_floats = 0; Q3_HIP_CHECK(hipMalloc((void**)&g_cout1_dbg, need * sizeof(float))); g_cout1_dbg_floats = need; }
