@@ -1034,6 +1034,11 @@ __global__ __launch_bounds__(256) void k_conv_cout1_reg(ConvKArgs a0) {
         }
     }
     __builtin_amdgcn_sched_barrier(0);
+    unsigned long long clk0 = 0, rt0 = 0;
+    if constexpr (DUMP) {   // shader clock over the FMA passes: s_memtime ticks per s_memrealtime tick (100 MHz), both taken behind the loads
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        clk0 = __builtin_amdgcn_s_memtime(); rt0 = __builtin_amdgcn_s_memrealtime();
+    }
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
         const int src = t0 - halo + p * 32 + rl;
@@ -1071,8 +1076,12 @@ __global__ __launch_bounds__(256) void k_conv_cout1_reg(ConvKArgs a0) {
         a.out[t] = v;
     }
     if constexpr (DUMP) {   // the tile's partial sums as its output phase read them -> a0.out2[blockIdx.x][row][tap]
+        const unsigned long long clk1 = __builtin_amdgcn_s_memtime(), rt1 = __builtin_amdgcn_s_memrealtime();
         float* dbg = a0.out2 + (size_t)blockIdx.x * CO1R_ROWS * MAXT;
         for (int i = tid; i < CO1R_ROWS * MAXT; i += 256) dbg[i] = ds[i / MAXT][i % MAXT];
+        __syncthreads();
+        // tap 7 does not exist (its sums are 0): rows 0..2 of that column carry wave 0's shader ticks, 100 MHz ticks and the start time
+        if (tid == 0) { dbg[0 * MAXT + 7] = (float)(clk1 - clk0); dbg[1 * MAXT + 7] = (float)(rt1 - rt0); dbg[2 * MAXT + 7] = (float)(rt0 & 0xFFFFFF); }
     }
 }
 

@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--model", default="0.6b")
     ap.add_argument("--no-poison", action="store_true")
     ap.add_argument("--check-input", action="store_true", help="every repetition: the last batched group's final-conv input must equal the first clean job's, bit for bit (all upstream kernels of that group under the same stress)")
+    ap.add_argument("--clock", type=int, default=0, help="with Q3TTS_COUT1_PACKED=2: print the conv's shader clock for the first N jobs of each phase, wrong or not")
     ap.add_argument("--diag", type=int, default=0, help="for the first N mismatching jobs read back the last batched group's final-conv input and output and say which is wrong")
     ap.add_argument("--phase", action="append", default=[], help="NAME:KNOB=V,KNOB=V (repeatable); default: one phase without knobs")
     a = ap.parse_args()
@@ -86,6 +87,13 @@ def main():
                     print("%s rep %d utterance %d (%d frames, %d samples): %d samples off in [%d, %d], max %.3g" % (name, rep, u, caps[u], pcm[u].size, off.size, lo, hi, d))
                     print("   job  ", np.array2string(pcm[u][w0:w1], precision=6, max_line_width=250))
                     print("   alone", np.array2string(alone0[u][w0:w1], precision=6, max_line_width=250), flush=True)
+            if a.clock and rep < a.clock:
+                part_c = eng.final_conv_partials()
+                if part_c is not None:
+                    ticks, rt = part_c[:, 0, 7].astype(np.float64), part_c[:, 1, 7].astype(np.float64)
+                    mhz = ticks / np.maximum(rt, 1.0) * 100.0
+                    print("%s rep %d: %s; conv shader clock median %.0f MHz (min %.0f, max %.0f), FMA passes median %.2f us" % (
+                        name, rep, "WRONG" if bad > bad_before else "clean", np.median(mhz), mhz.min(), mhz.max(), np.median(rt) / 100.0), flush=True)
             if a.check_input and sx_good is not None:
                 sx_now, _ = eng.group_final_conv()
                 n_in += 1
@@ -123,6 +131,12 @@ def main():
                                         q, t, pr - 6, k + 1, k, [(int(r_) + lo_r - 6, int(k_)) for r_, k_ in m1[:4]], [(int(r_) + lo_r - 6, int(k_)) for r_, k_ in m0[:4]],
                                         "; zero too" if abs(x1) < 2e-6 and abs(x0) < 2e-6 else ""))
                         part = eng.final_conv_partials()
+                        if part is not None:
+                            ticks, rt = part[:, 0, 7].astype(np.float64), part[:, 1, 7].astype(np.float64)
+                            mhz = ticks / np.maximum(rt, 1.0) * 100.0
+                            print("      shader clock over the FMA passes, per tile: median %.0f MHz (min %.0f, max %.0f); passes take median %.2f us" % (
+                                np.median(mhz), mhz.min(), mhz.max(), np.median(rt) / 100.0))
+                            part = part.copy(); part[:, :3, 7] = 0.0
                         if part is not None:   # [tile][row][tap]: tile b of sequence q covers padded rows 250 b .. 250 b + 255
                             tiles = part.shape[0] // sx.shape[0]
                             for q in sorted(set(int(x) for x in wrong[:, 0])):
