@@ -15,10 +15,16 @@ SOURCES = ["q3_decode_kernels.hip", "q3_gemm_kernels.hip", "q3_codec_kernels.hip
 HEADERS = ["q3_common.h", "q3_engine.h", "q3_kvpool.h", "q3_bpe.h", "q3_audio.h", os.path.join("..", "..", "include", "q3tts.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall", "-Wno-unused-function",
          "-Wno-unused-variable", "-Wno-unused-but-set-variable"]
+# Kernels are built WITHOUT packed fp32 instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32): on this hardware they return wrong
+# results now and then while other kernels keep the chip loaded — the vocoder's last conv (two PCM samples off by up to 1.7e-2 in up to
+# 91 % of stressed jobs) and the decode step's logits (~1e-6, enough to move marginal sampled ids) beside a busy vocoder — and never with
+# scalar fp32 (profiles/r05_hunt/README.txt; tests/test_kernel_resources.py checks the built code objects).  Cost: nothing on the codec
+# and the batched step, 2 % on the b=1 step.  Q3TTS_BUILD_PACKED_FP32=1 builds the old way (tools/build_pk_lib.sh: the reproducer).
+NO_PK = [] if os.environ.get("Q3TTS_BUILD_PACKED_FP32") == "1" else ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 
 
 def _digest(paths):
-    h = hashlib.sha1(" ".join(FLAGS).encode())
+    h = hashlib.sha1(" ".join(FLAGS + NO_PK).encode())
     for p in paths:
         with open(p, "rb") as f:
             h.update(f.read())
@@ -33,6 +39,8 @@ def _compile(src, hdr_digest, force):
     if not force and os.path.exists(obj) and os.path.exists(tag) and open(tag).read() == dg:
         return obj, False
     extra = ["-mllvm", "-amdgpu-kernarg-preload-count=16"] if src in ("q3_decode_kernels.hip", "q3_gemm_kernels.hip") else []   # leading scalar kernel args arrive in SGPRs
+    if src.endswith(".hip"):
+        extra = extra + NO_PK
     cmd = ["hipcc"] + FLAGS + extra + ["-x", "hip", "-c", path, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:

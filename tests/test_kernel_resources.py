@@ -23,14 +23,18 @@ def test_no_product_kernel_uses_scratch():
     assert all(lds <= 160 * 1024 for *_, lds in rows)   # gfx950: 160 KB of LDS per workgroup
 
 
-def test_last_conv_kernel_has_no_packed_fp32_instruction():
-    """k_conv_cout1_reg (the vocoder's C_out = 1 conv) must be scalar fp32: with v_pk_fma_f32 it returned wrong partial sums in 12-28 %
-    of the jobs of tools/vocoder_stress.py (round 5); the packed form survives only as the A/B reproducer."""
+def test_no_product_kernel_contains_a_packed_fp32_instruction():
+    """Round 5: v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 return wrong results now and then on this hardware while other kernels load the
+    chip — the vocoder's last conv (two PCM samples off by up to 1.7e-2 in up to 91 % of stressed jobs) and the decode step's logits beside
+    a busy vocoder (~1e-6: marginal sampled ids move) — and scalar fp32 never does (profiles/r05_hunt/README.txt).  The library is built
+    without them (build.py: NO_PK, plus opaque() in k_conv_cout1_reg); this checks the built code objects."""
+    import re
     import q3tts
     from kernel_resources import kernel_disassembly
-    ks = kernel_disassembly(q3tts.LIB_PATH, "k_conv_cout1_reg<")
-    prod = [n for n in ks if "false, false" in n]
-    repro = [n for n in ks if "true, false" in n]
-    assert len(prod) == 1 and len(repro) == 1, sorted(ks)
-    assert "v_pk_" not in ks[prod[0]] and ks[prod[0]].count("v_fmac_f32") + ks[prod[0]].count("v_fma_f32") >= 96 * 8
-    assert "v_pk_fma_f32" in ks[repro[0]]      # the reproducer still is what it claims to be
+    ks = kernel_disassembly(q3tts.LIB_PATH, "")
+    assert len(ks) > 100, len(ks)
+    bad = {n: len(re.findall(r"\bv_pk_(?:fma|mul|add)_f32\b", t)) for n, t in ks.items()}
+    bad = {n: c for n, c in bad.items() if c}
+    assert not bad, "kernels with packed fp32 instructions: %s" % sorted(bad.items())[:10]
+    prod = [n for n in ks if n.startswith("k_conv_cout1_reg<") and "false, false" in n]
+    assert len(prod) == 1 and ks[prod[0]].count("v_fmac_f32") + ks[prod[0]].count("v_fma_f32") >= 96 * 8

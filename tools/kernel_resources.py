@@ -44,7 +44,8 @@ def kernel_table(obj):
 
 
 def kernel_disassembly(obj, name_substr):
-    """{demangled name: instruction text} of every gfx950 kernel of `obj` whose demangled name contains name_substr."""
+    """{demangled name: instruction text} of every gfx950 kernel of `obj` whose demangled name contains name_substr (one llvm-objdump
+    pass per offload bundle, split at the symbol headers)."""
     out = {}
     with tempfile.TemporaryDirectory() as tmp:
         fat = os.path.join(tmp, "k.fat")
@@ -60,13 +61,16 @@ def kernel_disassembly(obj, name_substr):
             if not tgts:
                 continue
             subprocess.run([LLVM + "clang-offload-bundler", "--unbundle", "--type=o", "--input=" + one, "--targets=" + tgts[0], "--output=" + co], check=True)
-            syms = subprocess.run([LLVM + "llvm-readelf", "-s", "-W", co], capture_output=True, text=True, check=True).stdout
-            mangled = sorted(set(re.findall(r"FUNC\s+\w+\s+\w+\s+\d+\s+(\S+)", syms)))
-            dem = subprocess.run(["c++filt"], input="\n".join(mangled), capture_output=True, text=True).stdout.split("\n")
-            for m_, d_ in zip(mangled, dem):
+            md = subprocess.run([LLVM + "llvm-readelf", "--notes", co], capture_output=True, text=True, check=True).stdout
+            kernels = set(re.findall(r"\.name:\s+(\S+)", md))          # kernel entry points (device functions are not in the notes)
+            txt = subprocess.run([LLVM + "llvm-objdump", "-d", co], capture_output=True, text=True, check=True).stdout
+            parts = re.split(r"^[0-9a-f]+ <([^>]+)>:\n", txt, flags=re.M)
+            syms, bodies = parts[1::2], parts[2::2]
+            keep = [(m_, t_) for m_, t_ in zip(syms, bodies) if m_ in kernels]
+            dem = subprocess.run(["c++filt"], input="\n".join(m_ for m_, _ in keep), capture_output=True, text=True).stdout.split("\n")
+            for (m_, t_), d_ in zip(keep, dem):
                 if name_substr in d_:
-                    txt = subprocess.run([LLVM + "llvm-objdump", "-d", "--disassemble-symbols=" + m_, co], capture_output=True, text=True, check=True).stdout
-                    out[re.sub(r"\(.*", "", d_.replace("void q3::", ""))] = txt
+                    out[re.sub(r"\(.*", "", d_.replace("void q3::", ""))] = t_
     return out
 
 
