@@ -11,7 +11,8 @@ batched front's arena re-use all occur.  tests/test_kernel_resources.py holds th
 Round 5: that block-sequence job reproduced the anomaly (2 of 12 repetitions in one run, none in five others), and the vocoder-only
 repetition of it (q3tts_codec_decode_batch_host, tools/vocoder_stress.py) in 12-28 % of the jobs: two adjacent samples of an utterance of
 the small batched group {9, 8, 6} off by up to 1.5e-2, the wrong value a partial sum of the last conv (k_conv_cout1_reg) computed with
-packed fp32 FMAs — fixed by keeping that kernel scalar (profiles/r05_hunt/).  The last test below repeats the
+packed fp32 FMAs — fixed by keeping that kernel scalar, and, once the decode step showed the same fault beside a busy vocoder, by building
+the whole library without packed fp32 (DESIGN.md sections 2 and 8, profiles/r05_hunt/).  The last test below repeats the
 vocoder-only job 400 times: at the old failure rate it cannot pass by luck."""
 import os
 

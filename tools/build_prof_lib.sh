@@ -7,7 +7,7 @@ PROF_DEFS=("$@")
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 mkdir -p "$ROOT/tools/exp" /tmp/q3prof
 cd /tmp/q3prof
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -DQ3_SAMPLE_PROF -mllvm -amdgpu-kernarg-preload-count=16 -x hip -c "$ROOT/leaxer-qwen3-tts_amd/csrc/q3_decode_kernels.hip" -o dk_prof.o
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -Xclang -target-feature -Xclang -packed-fp32-ops -DQ3_SAMPLE_PROF -mllvm -amdgpu-kernarg-preload-count=16 -x hip -c "$ROOT/leaxer-qwen3-tts_amd/csrc/q3_decode_kernels.hip" -o dk_prof.o
 # the codec kernels take minutes to compile: SKIP_CODEC=1 links the regular object (no stamps inside k_conv_split) and stubs the accessor
 CK=ck_prof.o
 if [ "$SKIP_CODEC" = "1" ]; then
@@ -15,9 +15,9 @@ if [ "$SKIP_CODEC" = "1" ]; then
   echo 'namespace q3 { void conv_prof_read(long long* out) { for (int i = 0; i < 64; ++i) out[i] = 0; } }' > conv_stub.cpp
   g++ -O2 -fPIC -c conv_stub.cpp -o conv_stub.o
 else
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -DQ3_SAMPLE_PROF "${PROF_DEFS[@]}" -x hip -c "$ROOT/leaxer-qwen3-tts_amd/csrc/q3_codec_kernels.hip" -o ck_prof.o
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -Xclang -target-feature -Xclang -packed-fp32-ops -DQ3_SAMPLE_PROF "${PROF_DEFS[@]}" -x hip -c "$ROOT/leaxer-qwen3-tts_amd/csrc/q3_codec_kernels.hip" -o ck_prof.o
 fi
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -DQ3_SAMPLE_PROF -mllvm -amdgpu-kernarg-preload-count=16 -x hip -c "$ROOT/leaxer-qwen3-tts_amd/csrc/q3_gemm_kernels.hip" -o gk_prof.o
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -Xclang -target-feature -Xclang -packed-fp32-ops -DQ3_SAMPLE_PROF -mllvm -amdgpu-kernarg-preload-count=16 -x hip -c "$ROOT/leaxer-qwen3-tts_amd/csrc/q3_gemm_kernels.hip" -o gk_prof.o
 cat > prof_api.cpp <<'EOC'
 namespace q3 { void sample_prof_read(long long* out); void conv_prof_read(long long* out); void gemm_prof_read(long long* out); void seam_prof_read(long long* out); }
 extern "C" void q3_seam_prof(long long* out) { q3::seam_prof_read(out); }

@@ -9,7 +9,7 @@ set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 mkdir -p "$ROOT/tools/exp" /tmp/q3spill
 cd /tmp/q3spill
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -DQ3_FORCE_SPILL -x hip -c "$ROOT/leaxer-qwen3-tts_amd/csrc/q3_codec_kernels.hip" -o ck_spill.o
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -Xclang -target-feature -Xclang -packed-fp32-ops -DQ3_FORCE_SPILL -x hip -c "$ROOT/leaxer-qwen3-tts_amd/csrc/q3_codec_kernels.hip" -o ck_spill.o
 B="$ROOT/leaxer-qwen3-tts_amd/build"
 hipcc --offload-arch=gfx950 -shared -fPIC -o "$ROOT/tools/exp/libspill.so" ck_spill.o "$B/q3_decode_kernels.hip.o" "$B/q3_gemm_kernels.hip.o" \
     "$B/q3_speaker_kernels.hip.o" "$B/q3_engine.cpp.o" "$B/q3_codec.cpp.o" "$B/q3_speaker.cpp.o" "$B/q3_audio.cpp.o" "$B/q3_bpe.cpp.o" "$B/q3_capi.cpp.o"
