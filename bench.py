@@ -666,6 +666,10 @@ def main():
             "codec_decode_ms_per_frame": round(ctr["codec_ms"] / max(ctr["codec_frames"], 1), 5),
             "first_2s_audio_latency_ms": first_audio,
             "roofline": roofline_record(cfg, B, F, step_ms, args.model, args.kv_bf16),
+            # round 5: kernels are compiled without packed fp32 instructions — with them results depended on what else the GPU was running
+            # (profiles/r05_hunt/README.txt); costs 2-3 % of the b=1 step, nothing at batch 64 or in the codec
+            "build": {"library": os.path.basename(q3tts.LIB_PATH),
+                      "packed_fp32_instructions": "none in the default build (tests/test_kernel_resources.py checks the code objects)"},
         }
         if HOOKS:
             out["ab_knobs"] = {k: v for k, v in os.environ.items() if k.startswith("Q3TTS_")}   # an A/B run: which knobs were set
